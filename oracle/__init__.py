@@ -1,0 +1,234 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes wrapper over ``oracle/liboracle.so`` (the CPU restatement of the reference algorithms, see the
+headers of ``oracle/*.hpp``).  Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg
+of ``bench.py`` may import this package; the product (``libiop_amd``) never does.
+
+Field elements travel as ``numpy.uint64`` arrays of shape ``(count, words)`` — the raw little-endian
+word layout of libff's binary fields (gf64: 1 word, gf128: 2, gf192: 3, gf256: 4).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_szp = ctypes.POINTER(ctypes.c_size_t)
+
+
+def build(force=False):
+    """Compile oracle/liboracle.so with the Makefile next to this file."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".hpp", ".cpp")) or f == "Makefile"]
+    stale = (not os.path.exists(_LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.oracle_localization_array.restype = ctypes.c_size_t
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_u64p)
+
+
+def _c(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a
+
+
+def _words(a):
+    return int(a.shape[-1])
+
+
+def has_pclmul():
+    return bool(lib().oracle_has_pclmul())
+
+
+def clmul64(a, b, portable=False):
+    lo, hi = ctypes.c_uint64(), ctypes.c_uint64()
+    f = lib().oracle_clmul64_portable if portable else lib().oracle_clmul64
+    f(ctypes.c_uint64(a), ctypes.c_uint64(b), ctypes.byref(lo), ctypes.byref(hi))
+    return lo.value, hi.value
+
+
+def gf_mul(a, b):
+    a, b = _c(a), _c(b)
+    out = np.empty_like(a)
+    rc = lib().oracle_gf_mul(_words(a), _p(a), _p(b), _p(out), ctypes.c_size_t(a.shape[0]))
+    assert rc == 0
+    return out
+
+
+def gf_inv(a):
+    a = _c(a)
+    out = np.empty_like(a)
+    rc = lib().oracle_gf_inv(_words(a), _p(a), _p(out), ctypes.c_size_t(a.shape[0]))
+    assert rc == 0
+    return out
+
+
+def standard_basis(m, words):
+    """libiop/algebra/field_subset/subspace.tcc:93-108 — basis element i is FieldT(1 << i)."""
+    b = np.zeros((m, words), dtype=np.uint64)
+    for i in range(m):
+        b[i, 0] = np.uint64(1) << np.uint64(i)
+    return b
+
+
+def all_subset_sums(basis, shift):
+    basis, shift = _c(basis), _c(shift)
+    m, w = basis.shape
+    out = np.empty((1 << m, w), dtype=np.uint64)
+    rc = lib().oracle_all_subset_sums(w, _p(basis), ctypes.c_size_t(m), _p(shift), _p(out))
+    assert rc == 0
+    return out
+
+
+def naive_fft(coeffs, basis, shift):
+    coeffs, basis, shift = _c(coeffs), _c(basis), _c(shift)
+    m, w = basis.shape
+    out = np.empty((1 << m, w), dtype=np.uint64)
+    rc = lib().oracle_naive_fft(w, _p(coeffs), ctypes.c_size_t(coeffs.shape[0]), _p(basis), ctypes.c_size_t(m), _p(shift), _p(out))
+    assert rc == 0
+    return out
+
+
+def additive_fft(coeffs, basis, shift):
+    coeffs, basis, shift = _c(coeffs), _c(basis), _c(shift)
+    m, w = basis.shape
+    out = np.empty((1 << m, w), dtype=np.uint64)
+    rc = lib().oracle_additive_fft(w, _p(coeffs), ctypes.c_size_t(coeffs.shape[0]), _p(basis), ctypes.c_size_t(m), _p(shift), _p(out))
+    if rc != 0:
+        raise ValueError("oracle_additive_fft rc=%d" % rc)
+    return out
+
+
+def additive_ifft(evals, basis, shift):
+    evals, basis, shift = _c(evals), _c(basis), _c(shift)
+    m, w = basis.shape
+    assert evals.shape[0] == 1 << m
+    out = np.empty((1 << m, w), dtype=np.uint64)
+    rc = lib().oracle_additive_ifft(w, _p(evals), _p(basis), ctypes.c_size_t(m), _p(shift), _p(out))
+    assert rc == 0
+    return out
+
+
+def additive_ifft_known_degree(evals, degree, basis, shift):
+    evals, basis, shift = _c(evals), _c(basis), _c(shift)
+    m, w = basis.shape
+    k = max(degree - 1, 0).bit_length()
+    out = np.empty((1 << k, w), dtype=np.uint64)
+    rc = lib().oracle_additive_ifft_known_degree(w, _p(evals), ctypes.c_size_t(degree), _p(basis), ctypes.c_size_t(m), _p(shift), _p(out))
+    assert rc == 0
+    return out
+
+
+def fri_fold_additive(f_i, basis, shift, coset_size, x_i):
+    f_i, basis, shift, x_i = _c(f_i), _c(basis), _c(shift), _c(x_i)
+    m, w = basis.shape
+    out = np.empty(((1 << m) // coset_size, w), dtype=np.uint64)
+    rc = lib().oracle_fri_fold_additive(w, _p(f_i), _p(basis), ctypes.c_size_t(m), _p(shift), ctypes.c_size_t(coset_size), _p(x_i), _p(out))
+    assert rc == 0
+    return out
+
+
+def fri_domains_additive(basis, shift, loc_params):
+    """Returns [(basis_i, shift_i)] for L^(1).. following fri_ldt.tcc:310-338."""
+    basis, shift = _c(basis), _c(shift)
+    m, w = basis.shape
+    dims, d = [], m
+    for eta in loc_params:
+        d -= eta
+        dims.append(d)
+    out_b = np.zeros((sum(dims), w), dtype=np.uint64)
+    out_s = np.zeros((len(dims), w), dtype=np.uint64)
+    loc = (ctypes.c_size_t * len(loc_params))(*loc_params)
+    rc = lib().oracle_fri_domains_additive(w, _p(basis), ctypes.c_size_t(m), _p(shift), loc, ctypes.c_size_t(len(loc_params)), _p(out_b), _p(out_s))
+    assert rc == 0
+    res, off = [], 0
+    for i, dd in enumerate(dims):
+        res.append((out_b[off:off + dd].copy(), out_s[i].copy()))
+        off += dd
+    return res
+
+
+def localization_array(loc_param, codeword_dim, rs_extra):
+    buf = (ctypes.c_size_t * 64)()
+    n = lib().oracle_localization_array(ctypes.c_size_t(loc_param), ctypes.c_size_t(codeword_dim), ctypes.c_size_t(rs_extra), buf, ctypes.c_size_t(64))
+    return [int(buf[i]) for i in range(n)]
+
+
+def next_coset_query_positions(additive, non_localized_n, localized_n, seed_position, prev_loc, cur_loc):
+    buf = (ctypes.c_size_t * (1 << cur_loc))()
+    lib().oracle_next_coset_query_positions(int(additive), ctypes.c_size_t(non_localized_n), ctypes.c_size_t(localized_n),
+                                            ctypes.c_size_t(seed_position), ctypes.c_size_t(prev_loc), ctypes.c_size_t(cur_loc), buf)
+    return [int(v) for v in buf]
+
+
+def blake2b(data, outlen=32, key=b""):
+    out = (ctypes.c_uint8 * outlen)()
+    d = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) if len(data) else b"\0")
+    k = (ctypes.c_uint8 * max(len(key), 1)).from_buffer_copy(bytes(key) if len(key) else b"\0")
+    lib().oracle_blake2b(out, ctypes.c_size_t(outlen), d, ctypes.c_size_t(len(data)), k, ctypes.c_size_t(len(key)))
+    return bytes(out)
+
+
+def merkle_build(oracles, coset_size, additive=True, salts=None):
+    """oracles: list of (n, words) uint64 arrays.  Returns (2L-1, 32) uint8 node array in heap order."""
+    oracles = [_c(o) for o in oracles]
+    n, w = oracles[0].shape
+    L = n // coset_size
+    nodes = np.zeros((2 * L - 1, 32), dtype=np.uint8)
+    ptrs = (ctypes.c_void_p * len(oracles))(*[o.ctypes.data for o in oracles])
+    if salts is not None:
+        salts = np.ascontiguousarray(salts, dtype=np.uint8)
+        sp, sb = salts.ctypes.data_as(_u8p), salts.shape[1]
+    else:
+        sp, sb = None, 0
+    rc = lib().oracle_merkle_build(ptrs, ctypes.c_size_t(len(oracles)), ctypes.c_size_t(8 * w), ctypes.c_size_t(n),
+                                   ctypes.c_size_t(coset_size), int(additive), sp, ctypes.c_size_t(sb),
+                                   nodes.ctypes.data_as(_u8p))
+    if rc != 0:
+        raise ValueError("Merkle tree size must be a power of two, and at least 2.")
+    return nodes
+
+
+class Hashchain:
+    """libiop/bcs/hashing/blake2b.tcc:10-110 restated (see oracle/merkle.hpp)."""
+
+    def __init__(self):
+        self.state = (ctypes.c_uint8 * 32)()
+        self.idx = ctypes.c_uint64(0)
+        lib().oracle_hashchain_init(self.state, ctypes.byref(self.idx))
+
+    def absorb(self, digest):
+        d = (ctypes.c_uint8 * 32).from_buffer_copy(bytes(digest))
+        lib().oracle_hashchain_absorb(self.state, d)
+
+    def squeeze(self, num_elements, words):
+        out = np.zeros((num_elements, words), dtype=np.uint64)
+        lib().oracle_hashchain_squeeze_binary(self.state, ctypes.byref(self.idx), ctypes.c_size_t(num_elements),
+                                              ctypes.c_size_t(8 * words), out.ctypes.data_as(_u8p))
+        return out
+
+    def squeeze_query_positions(self, num_positions, rng):
+        buf = (ctypes.c_size_t * num_positions)()
+        rc = lib().oracle_hashchain_squeeze_positions(self.state, ctypes.byref(self.idx), ctypes.c_size_t(num_positions), ctypes.c_size_t(rng), buf)
+        if rc != 0:
+            raise ValueError("upper_bound must be a power of two.")
+        return [int(v) for v in buf]

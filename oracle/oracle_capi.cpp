@@ -1,0 +1,198 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/field.hpp header).
+// extern "C" surface over the templated restatement, for ctypes (tests/, smoke(), bench cpu_baseline).
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "field.hpp"
+#include "algebra.hpp"
+#include "fri.hpp"
+#include "merkle.hpp"
+
+using namespace oracle;
+
+namespace {
+
+template<typename F>
+std::vector<F> load(const uint64_t *p, size_t count)
+{
+    std::vector<F> v(count);
+    if (count) memcpy((void *)v.data(), p, count * sizeof(F));
+    return v;
+}
+template<typename F>
+void store(uint64_t *p, const std::vector<F> &v) { if (!v.empty()) memcpy(p, (const void *)v.data(), v.size() * sizeof(F)); }
+
+template<typename F>
+affine_subspace<F> load_domain(const uint64_t *basis, size_t m, const uint64_t *shift)
+{
+    F s; memcpy((void *)&s, shift, sizeof(F));
+    return affine_subspace<F>(load<F>(basis, m), s);
+}
+
+#define DISPATCH(words, CALL)                         \
+    switch (words) {                                  \
+    case 1: { typedef gf64 F; CALL; } break;          \
+    case 2: { typedef gf128 F; CALL; } break;         \
+    case 3: { typedef gf192 F; CALL; } break;         \
+    case 4: { typedef gf256 F; CALL; } break;         \
+    default: return -1;                               \
+    }
+
+} // namespace
+
+extern "C" {
+
+int oracle_has_pclmul(void)
+{
+#if defined(__PCLMUL__)
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+void oracle_clmul64(uint64_t a, uint64_t b, uint64_t *lo, uint64_t *hi) { clmul64(a, b, *lo, *hi); }
+void oracle_clmul64_portable(uint64_t a, uint64_t b, uint64_t *lo, uint64_t *hi) { clmul64_portable(a, b, *lo, *hi); }
+
+int oracle_gf_mul(int words, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t count)
+{
+    DISPATCH(words, {
+        const F *x = (const F *)a; const F *y = (const F *)b; F *o = (F *)out;
+        for (size_t i = 0; i < count; ++i) o[i] = x[i] * y[i];
+    });
+    return 0;
+}
+
+int oracle_gf_inv(int words, const uint64_t *a, uint64_t *out, size_t count)
+{
+    DISPATCH(words, {
+        const F *x = (const F *)a; F *o = (F *)out;
+        for (size_t i = 0; i < count; ++i) o[i] = x[i].inverse();
+    });
+    return 0;
+}
+
+int oracle_all_subset_sums(int words, const uint64_t *basis, size_t m, const uint64_t *shift, uint64_t *out)
+{
+    DISPATCH(words, { store<F>(out, load_domain<F>(basis, m, shift).all_elements()); });
+    return 0;
+}
+
+int oracle_naive_fft(int words, const uint64_t *coeffs, size_t n_coeffs, const uint64_t *basis, size_t m,
+                     const uint64_t *shift, uint64_t *out)
+{
+    DISPATCH(words, {
+        const affine_subspace<F> d = load_domain<F>(basis, m, shift);
+        store<F>(out, naive_FFT<F>(load<F>(coeffs, n_coeffs), d.all_elements()));
+    });
+    return 0;
+}
+
+int oracle_additive_fft(int words, const uint64_t *coeffs, size_t n_coeffs, const uint64_t *basis, size_t m,
+                        const uint64_t *shift, uint64_t *out)
+{
+    if (n_coeffs > ((size_t)1 << m)) return -2;
+    DISPATCH(words, { store<F>(out, additive_FFT<F>(load<F>(coeffs, n_coeffs), load_domain<F>(basis, m, shift))); });
+    return 0;
+}
+
+int oracle_additive_ifft(int words, const uint64_t *evals, const uint64_t *basis, size_t m, const uint64_t *shift,
+                         uint64_t *out)
+{
+    DISPATCH(words, { store<F>(out, additive_IFFT<F>(load<F>(evals, (size_t)1 << m), load_domain<F>(basis, m, shift))); });
+    return 0;
+}
+
+// out receives 2^ceil(log2 degree) coefficients
+int oracle_additive_ifft_known_degree(int words, const uint64_t *evals, size_t degree, const uint64_t *basis, size_t m,
+                                      const uint64_t *shift, uint64_t *out)
+{
+    DISPATCH(words, {
+        store<F>(out, additive_IFFT_of_known_degree<F>(load<F>(evals, (size_t)1 << m), degree, load_domain<F>(basis, m, shift)));
+    });
+    return 0;
+}
+
+int oracle_fri_fold_additive(int words, const uint64_t *f_i, const uint64_t *basis, size_t m, const uint64_t *shift,
+                             size_t coset_size, const uint64_t *x_i, uint64_t *out)
+{
+    DISPATCH(words, {
+        F x; memcpy((void *)&x, x_i, sizeof(F));
+        store<F>(out, additive_evaluate_next_f_i_over_entire_domain<F>(load<F>(f_i, (size_t)1 << m),
+                                                                      load_domain<F>(basis, m, shift), coset_size, x));
+    });
+    return 0;
+}
+
+// Domain chain: out_bases holds the bases of L^(1), L^(2), ... concatenated (dims m - eta_0, ...),
+// out_shifts one shift per derived domain.
+int oracle_fri_domains_additive(int words, const uint64_t *basis, size_t m, const uint64_t *shift,
+                                const size_t *loc, size_t num_loc, uint64_t *out_bases, uint64_t *out_shifts)
+{
+    DISPATCH(words, {
+        const std::vector<affine_subspace<F>> doms =
+            fri_additive_domains<F>(load_domain<F>(basis, m, shift), std::vector<size_t>(loc, loc + num_loc));
+        size_t off = 0;
+        for (size_t i = 1; i < doms.size(); ++i) {
+            memcpy(out_bases + off, (const void *)doms[i].basis.data(), doms[i].basis.size() * sizeof(F));
+            off += doms[i].basis.size() * (sizeof(F) / 8);
+            memcpy(out_shifts + (i - 1) * (sizeof(F) / 8), (const void *)&doms[i].shift, sizeof(F));
+        }
+    });
+    return 0;
+}
+
+size_t oracle_localization_array(size_t loc_param, size_t codeword_dim, size_t rs_extra, size_t *out, size_t cap)
+{
+    const std::vector<size_t> v = localization_parameter_to_array(loc_param, codeword_dim, rs_extra);
+    for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
+    return v.size();
+}
+
+void oracle_next_coset_query_positions(int additive, size_t non_localized_n, size_t localized_n, size_t seed_position,
+                                       size_t prev_loc, size_t cur_loc, size_t *out)
+{
+    const std::vector<size_t> v = next_coset_query_positions(additive != 0, non_localized_n, localized_n, seed_position, prev_loc, cur_loc);
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+}
+
+void oracle_blake2b(uint8_t *out, size_t outlen, const uint8_t *in, size_t inlen, const uint8_t *key, size_t keylen)
+{
+    blake2b(out, outlen, in, inlen, key, keylen);
+}
+
+int oracle_merkle_build(const uint8_t *const *oracles, size_t num_oracles, size_t elem_bytes, size_t n, size_t coset_size,
+                        int additive, const uint8_t *salts, size_t salt_bytes, uint8_t *nodes)
+{
+    try {
+        merkle_build(oracles, num_oracles, elem_bytes, n, coset_size, additive != 0, salts, salt_bytes, nodes);
+    } catch (const std::invalid_argument &) { return -3; }
+    return 0;
+}
+
+// hashchain, functional form: state (32 B) and squeeze index are caller-held
+void oracle_hashchain_init(uint8_t *state, uint64_t *squeeze_index)
+{
+    blake2b_hashchain hc; memcpy(state, hc.state, DIGEST_LEN); *squeeze_index = 0;
+}
+void oracle_hashchain_absorb(uint8_t *state, const uint8_t *digest)
+{
+    blake2b_hashchain hc; memcpy(hc.state, state, DIGEST_LEN); hc.absorb_digest(digest); memcpy(state, hc.state, DIGEST_LEN);
+}
+void oracle_hashchain_squeeze_binary(const uint8_t *state, uint64_t *squeeze_index, size_t num_elements, size_t elem_bytes, uint8_t *out)
+{
+    blake2b_hashchain hc; memcpy(hc.state, state, DIGEST_LEN); hc.squeeze_index = *squeeze_index;
+    hc.squeeze_binary_field(num_elements, elem_bytes, out); *squeeze_index = hc.squeeze_index;
+}
+int oracle_hashchain_squeeze_positions(const uint8_t *state, uint64_t *squeeze_index, size_t num_positions, size_t range, size_t *out)
+{
+    blake2b_hashchain hc; memcpy(hc.state, state, DIGEST_LEN); hc.squeeze_index = *squeeze_index;
+    try {
+        const std::vector<size_t> v = hc.squeeze_query_positions(num_positions, range);
+        for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    } catch (const std::invalid_argument &) { return -3; }
+    *squeeze_index = hc.squeeze_index;
+    return 0;
+}
+
+} // extern "C"
