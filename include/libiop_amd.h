@@ -1,0 +1,114 @@
+/*
+ * libiop_amd — C ABI of the MI355X (gfx950) prover hot path for libiop-style IOP SNARKs.
+ *
+ * The reference (scipr-lab/libiop) has no FFI boundary: its seams are C++ templates.  Each entry point
+ * below replaces one of those templates for FieldT = libff::gf192 and is what a thin header shim in
+ * libiop would bind.  Paths are relative to the reference tree.
+ *
+ * Conventions
+ *   - A field element is 3 little-endian uint64 words (24 bytes): libff::gf192's in-memory layout.
+ *   - `basis` (m elements) and `shift` (1 element) always live in HOST memory: they are O(m) metadata
+ *     (libiop/algebra/field_subset/subspace.tcc:47-108).  Evaluation order is the reference's:
+ *     output index i is the point shift + sum_{bit k of i} basis[k] (libiop/algebra/utils.tcc:8-30).
+ *   - `*_dev` entry points take DEVICE pointers for codeword-sized buffers and enqueue work on the
+ *     library's current stream (iopx_set_stream); they do not synchronise.  The variants without the
+ *     suffix take HOST pointers, copy in/out and synchronise: drop-in for std::vector callers.
+ *   - Every function returns IOPX_OK or a negative code; iopx_last_error() gives the message.  The C++
+ *     shim rethrows: INVALID_ARGUMENT -> std::invalid_argument, LOGIC -> std::logic_error,
+ *     RUNTIME / NO_DEVICE -> std::runtime_error (the exception types used at fft.tcc:333,368,
+ *     merkle_tree.tcc:27-31,98-108, blake2b.tcc:153-156).
+ *   - There is no CPU fallback: without a usable HIP device every compute entry point fails with
+ *     IOPX_ERR_NO_DEVICE.
+ */
+#ifndef LIBIOP_AMD_H
+#define LIBIOP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IOPX_OK                     0
+#define IOPX_ERR_INVALID_ARGUMENT  (-1)
+#define IOPX_ERR_LOGIC             (-2)
+#define IOPX_ERR_RUNTIME           (-3)
+#define IOPX_ERR_NO_DEVICE         (-4)
+
+#define IOPX_DOMAIN_ADDITIVE        0   /* affine_subspace_type   (field_subset.hpp) */
+#define IOPX_DOMAIN_MULTIPLICATIVE  1   /* multiplicative_coset_type */
+
+/* ---- runtime ------------------------------------------------------------------------------------ */
+int         iopx_version(void);
+const char *iopx_last_error(void);
+/* Number of visible HIP devices (0 on a CPU-only host; never fails). */
+int         iopx_device_count(void);
+/* Bind the calling process to a device (one process per GPU). */
+int         iopx_init(int device);
+/* Use the caller's hipStream_t for all subsequent work (NULL = the library's own stream). */
+int         iopx_set_stream(void *hip_stream);
+int         iopx_synchronize(void);
+int         iopx_malloc(void **dptr, size_t bytes);
+int         iopx_free(void *dptr);
+int         iopx_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int         iopx_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+/* Drop every cached per-domain plan (twist-power tables, twiddle tables). */
+int         iopx_clear_plans(void);
+
+/* ---- additive FFT / IFFT over GF(2^192) --------------------------------------------------------- */
+/* additive_FFT(poly_coeffs, domain): libiop/algebra/fft.tcc:39-124 (dispatch :414-419).
+ * Evaluates the polynomial with n_coeffs <= 2^m coefficients (zero padded, fft.tcc:43-44) on the
+ * affine subspace (basis[m], shift); writes 2^m evaluations. */
+int iopx_add_fft_gf192_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *basis, size_t m,
+                           const uint64_t *shift, uint64_t *d_out);
+int iopx_add_fft_gf192(const uint64_t *coeffs, size_t n_coeffs, const uint64_t *basis, size_t m,
+                       const uint64_t *shift, uint64_t *out);
+/* additive_IFFT(evals, domain): libiop/algebra/fft.tcc:126-204 (dispatch :428-433).  2^m in, 2^m out.
+ * IFFT_of_known_degree_over_field_subset (fft.tcc:458-475) is this call on the first
+ * 2^ceil(log2 degree) evaluations with the first ceil(log2 degree) basis vectors. */
+int iopx_add_ifft_gf192_dev(const uint64_t *d_evals, const uint64_t *basis, size_t m, const uint64_t *shift,
+                            uint64_t *d_out);
+int iopx_add_ifft_gf192(const uint64_t *evals, const uint64_t *basis, size_t m, const uint64_t *shift,
+                        uint64_t *out);
+
+/* ---- FRI fold over GF(2^192) -------------------------------------------------------------------- */
+/* evaluate_next_f_i_over_entire_domain for affine subspaces:
+ * libiop/protocols/ldt/fri/fri_aux.tcc:5-34 -> :36-103.  f_i has 2^m evaluations over (basis, shift);
+ * coset_size = 2^eta (contiguous cosets, subspace.tcc:73-91); writes 2^m / coset_size values. */
+int iopx_fri_fold_add_gf192_dev(const uint64_t *d_f_i, const uint64_t *basis, size_t m, const uint64_t *shift,
+                                size_t coset_size, const uint64_t *x_i, uint64_t *d_next);
+int iopx_fri_fold_add_gf192(const uint64_t *f_i, const uint64_t *basis, size_t m, const uint64_t *shift,
+                            size_t coset_size, const uint64_t *x_i, uint64_t *next);
+
+/* ---- BCS Merkle tree, BLAKE2b ------------------------------------------------------------------- */
+/* merkle_tree::construct_with_leaves_serialized_by_cosets + compute_inner_nodes:
+ * libiop/bcs/merkle_tree.tcc:92-151, 200-229 with blake2b_leafhash / blake2b_two_to_one_hash
+ * (libiop/bcs/hashing/blake2b.tcc:120-160, blake2b.cpp:28-48), 32-byte digests.
+ *   oracles      host array of num_oracles pointers, each to n elements of elem_bytes raw bytes
+ *   domain_type  position map of the default domain of size n (IOPX_DOMAIN_*)
+ *   salts        NULL, or num_leaves * salt_bytes zk salts: leaf = H(H(slice) || salt)
+ *   nodes        (2 L - 1) * 32 bytes, heap order, L = n / coset_size leaves at index (L - 1) + i;
+ *                nodes[0..32) is the root (merkle_tree::get_root, merkle_tree.tcc:231-240). */
+int iopx_merkle_blake2b_dev(const void *const *d_oracles, size_t num_oracles, size_t elem_bytes, size_t n,
+                            size_t coset_size, int domain_type, const uint8_t *d_salts, size_t salt_bytes,
+                            uint8_t *d_nodes);
+int iopx_merkle_blake2b(const void *const *oracles, size_t num_oracles, size_t elem_bytes, size_t n,
+                        size_t coset_size, int domain_type, const uint8_t *salts, size_t salt_bytes,
+                        uint8_t *nodes);
+
+/* ---- measurement hooks -------------------------------------------------------------------------- */
+/* Per-kernel timing with HIP events recorded on the library's stream around every kernel launch.
+ * iopx_profile_begin() starts recording; iopx_profile_report() synchronises, stops recording and writes
+ * one text line per kernel: "<kernel> <launches> <total_ms>\n" (used by bench.py for the roofline line). */
+int iopx_profile_begin(void);
+int iopx_profile_report(char *buf, size_t cap);
+
+/* Elementwise GF(2^192) product on the device (d_out[i] = d_a[i] * d_b[i]); used by the parity tests of
+ * the field arithmetic itself and by the field-multiplication micro-benchmark. */
+int iopx_gf192_mul_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIBIOP_AMD_H */

@@ -1,0 +1,267 @@
+"""libiop_amd — MI355X (gfx950) prover hot path for libiop-style IOP SNARKs.
+
+Python binding (ctypes) over the C ABI declared in ``include/libiop_amd.h``.  The shared library
+``libiop_amd/lib/libiop_amd.so`` is built from the HIP sources in ``libiop_amd/csrc`` by
+``libiop_amd.build.build()`` (``hipcc --offload-arch=gfx950``).  There is no CPU fallback: if the
+library is missing, or no HIP device is visible, every compute call raises.
+
+Field elements travel as ``numpy.uint64`` arrays of shape ``(count, 3)`` — libff::gf192's raw words.
+The function names mirror the reference's operator API for this path:
+
+    additive_FFT / additive_IFFT                         libiop/algebra/fft.hpp:28-38
+    IFFT_of_known_degree_over_field_subset (additive)    libiop/algebra/fft.tcc:458-475
+    evaluate_next_f_i_over_entire_domain                 libiop/protocols/ldt/fri/fri_aux.hpp:23-28
+    merkle_tree::construct_with_leaves_serialized_by_cosets / get_root   libiop/bcs/merkle_tree.hpp:88-104
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libiop_amd.so")
+
+IOPX_OK = 0
+IOPX_ERR_INVALID_ARGUMENT = -1
+IOPX_ERR_LOGIC = -2
+IOPX_ERR_RUNTIME = -3
+IOPX_ERR_NO_DEVICE = -4
+
+DOMAIN_ADDITIVE = 0
+DOMAIN_MULTIPLICATIVE = 1
+
+# every symbol include/libiop_amd.h declares (checked by tests/test_abi.py)
+EXPORTED_SYMBOLS = [
+    "iopx_version", "iopx_last_error", "iopx_device_count", "iopx_init", "iopx_set_stream", "iopx_synchronize",
+    "iopx_malloc", "iopx_free", "iopx_memcpy_h2d", "iopx_memcpy_d2h", "iopx_clear_plans",
+    "iopx_add_fft_gf192_dev", "iopx_add_fft_gf192", "iopx_add_ifft_gf192_dev", "iopx_add_ifft_gf192",
+    "iopx_fri_fold_add_gf192_dev", "iopx_fri_fold_add_gf192",
+    "iopx_merkle_blake2b_dev", "iopx_merkle_blake2b",
+    "iopx_gf192_mul_dev", "iopx_profile_begin", "iopx_profile_report",
+]
+
+
+class NoDeviceError(RuntimeError):
+    pass
+
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_sz = ctypes.c_size_t
+_vp = ctypes.c_void_p
+
+
+def _as_u64(a, cols=3):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.ndim == 1:
+        a = a.reshape(-1, cols)
+    if a.shape[-1] != cols:
+        raise ValueError("expected (count, %d) uint64 words" % cols)
+    return a
+
+
+class Library:
+    """One loaded instance of the C ABI.  ``Library()`` loads the product library."""
+
+    def __init__(self, path=None):
+        path = path or LIB_PATH
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "libiop_amd: %s is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        self.path = path
+        self.c = ctypes.CDLL(path)
+        c = self.c
+        c.iopx_last_error.restype = ctypes.c_char_p
+        c.iopx_malloc.argtypes = [ctypes.POINTER(_vp), _sz]
+        c.iopx_free.argtypes = [_vp]
+        c.iopx_memcpy_h2d.argtypes = [_vp, _vp, _sz]
+        c.iopx_memcpy_d2h.argtypes = [_vp, _vp, _sz]
+        c.iopx_set_stream.argtypes = [_vp]
+        c.iopx_add_fft_gf192_dev.argtypes = [_vp, _sz, _u64p, _sz, _u64p, _vp]
+        c.iopx_add_fft_gf192.argtypes = [_u64p, _sz, _u64p, _sz, _u64p, _u64p]
+        c.iopx_add_ifft_gf192_dev.argtypes = [_vp, _u64p, _sz, _u64p, _vp]
+        c.iopx_add_ifft_gf192.argtypes = [_u64p, _u64p, _sz, _u64p, _u64p]
+        c.iopx_fri_fold_add_gf192_dev.argtypes = [_vp, _u64p, _sz, _u64p, _sz, _u64p, _vp]
+        c.iopx_fri_fold_add_gf192.argtypes = [_u64p, _u64p, _sz, _u64p, _sz, _u64p, _u64p]
+        c.iopx_merkle_blake2b_dev.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _sz, _sz, ctypes.c_int, _vp, _sz, _vp]
+        c.iopx_merkle_blake2b.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _sz, _sz, ctypes.c_int, _vp, _sz, _vp]
+        c.iopx_gf192_mul_dev.argtypes = [_vp, _vp, _vp, _sz]
+
+    # ---- error translation (the exception types the reference throws) ----
+    def _check(self, rc):
+        if rc == IOPX_OK:
+            return
+        msg = (self.c.iopx_last_error() or b"").decode()
+        if rc == IOPX_ERR_INVALID_ARGUMENT:
+            raise ValueError(msg)                 # std::invalid_argument
+        if rc == IOPX_ERR_LOGIC:
+            raise AssertionError(msg)             # std::logic_error
+        if rc == IOPX_ERR_NO_DEVICE:
+            raise NoDeviceError(msg)
+        raise RuntimeError(msg)                   # std::runtime_error
+
+    # ---- runtime ----
+    def version(self):
+        return self.c.iopx_version()
+
+    def device_count(self):
+        return self.c.iopx_device_count()
+
+    def init(self, device=0):
+        self._check(self.c.iopx_init(device))
+
+    def set_stream(self, hip_stream):
+        self._check(self.c.iopx_set_stream(_vp(hip_stream)))
+
+    def synchronize(self):
+        self._check(self.c.iopx_synchronize())
+
+    def clear_plans(self):
+        self._check(self.c.iopx_clear_plans())
+
+    def malloc(self, nbytes):
+        p = _vp()
+        self._check(self.c.iopx_malloc(ctypes.byref(p), nbytes))
+        return p.value
+
+    def free(self, dptr):
+        self._check(self.c.iopx_free(_vp(dptr)))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._check(self.c.iopx_memcpy_h2d(_vp(dptr), _vp(arr.ctypes.data), arr.nbytes))
+
+    def d2h(self, arr, dptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        self._check(self.c.iopx_memcpy_d2h(_vp(arr.ctypes.data), _vp(dptr), arr.nbytes))
+
+    # ---- host-pointer operators (std::vector in / out, like the reference templates) ----
+    def additive_FFT(self, poly_coeffs, basis, shift):
+        """additive_FFT(poly_coeffs, affine_subspace(basis, shift)) — fft.tcc:39-124."""
+        coeffs, basis, shift = _as_u64(poly_coeffs), _as_u64(basis), _as_u64(shift)
+        m = basis.shape[0]
+        out = np.empty((1 << m, 3), dtype=np.uint64)
+        self._check(self.c.iopx_add_fft_gf192(coeffs.ctypes.data_as(_u64p), coeffs.shape[0], basis.ctypes.data_as(_u64p), m,
+                                              shift.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p)))
+        return out
+
+    def additive_IFFT(self, evals, basis, shift):
+        """additive_IFFT(evals, affine_subspace(basis, shift)) — fft.tcc:126-204."""
+        evals, basis, shift = _as_u64(evals), _as_u64(basis), _as_u64(shift)
+        m = basis.shape[0]
+        if evals.shape[0] != 1 << m:
+            raise ValueError("additive IFFT: %d evaluations for a domain of size %d" % (evals.shape[0], 1 << m))
+        out = np.empty((1 << m, 3), dtype=np.uint64)
+        self._check(self.c.iopx_add_ifft_gf192(evals.ctypes.data_as(_u64p), basis.ctypes.data_as(_u64p), m,
+                                               shift.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p)))
+        return out
+
+    def IFFT_of_known_degree(self, evals, degree, basis, shift):
+        """IFFT_of_known_degree_over_field_subset, additive overload — fft.tcc:458-475."""
+        evals, basis = _as_u64(evals), _as_u64(basis)
+        k = max(int(degree) - 1, 0).bit_length()
+        return self.additive_IFFT(evals[: 1 << k], basis[:k], shift)
+
+    def evaluate_next_f_i_over_entire_domain(self, f_i_evals, basis, shift, coset_size, x_i):
+        """fri_aux.tcc:5-34 -> additive_evaluate_next_f_i_over_entire_domain (:36-103)."""
+        f, basis, shift, x = _as_u64(f_i_evals), _as_u64(basis), _as_u64(shift), _as_u64(x_i)
+        m = basis.shape[0]
+        if f.shape[0] != 1 << m:
+            raise ValueError("f_i has %d evaluations for a domain of size %d" % (f.shape[0], 1 << m))
+        out = np.empty(((1 << m) // max(int(coset_size), 1), 3), dtype=np.uint64)
+        self._check(self.c.iopx_fri_fold_add_gf192(f.ctypes.data_as(_u64p), basis.ctypes.data_as(_u64p), m,
+                                                   shift.ctypes.data_as(_u64p), int(coset_size), x.ctypes.data_as(_u64p),
+                                                   out.ctypes.data_as(_u64p)))
+        return out
+
+    def merkle_tree(self, oracles, coset_size, domain_type=DOMAIN_ADDITIVE, salts=None):
+        """construct_with_leaves_serialized_by_cosets + compute_inner_nodes (merkle_tree.tcc:92-229).
+        Returns the (2L-1, 32) uint8 node array in heap order; row 0 is get_root()."""
+        oracles = [np.ascontiguousarray(o, dtype=np.uint64) for o in oracles]
+        n, w = oracles[0].shape
+        for o in oracles:
+            if o.shape != (n, w):
+                raise AssertionError("Attempting to construct a Merkle tree with a constituent vector of wrong size")
+        cs = int(coset_size)
+        L = n // cs if cs > 0 else 0
+        nodes = np.zeros((max(2 * L - 1, 1), 32), dtype=np.uint8)
+        ptrs = (_vp * len(oracles))(*[o.ctypes.data for o in oracles])
+        if salts is not None:
+            salts = np.ascontiguousarray(salts, dtype=np.uint8)
+            sp, sb = _vp(salts.ctypes.data), salts.shape[1]
+        else:
+            sp, sb = _vp(0), 0
+        self._check(self.c.iopx_merkle_blake2b(ptrs, len(oracles), 8 * w, n, cs, int(domain_type), sp, sb, _vp(nodes.ctypes.data)))
+        return nodes
+
+    # ---- device-pointer operators (integers are raw device addresses, e.g. torch.Tensor.data_ptr()) ----
+    def additive_FFT_dev(self, d_coeffs, n_coeffs, basis, shift, d_out):
+        basis, shift = _as_u64(basis), _as_u64(shift)
+        self._check(self.c.iopx_add_fft_gf192_dev(_vp(d_coeffs), n_coeffs, basis.ctypes.data_as(_u64p), basis.shape[0],
+                                                  shift.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def additive_IFFT_dev(self, d_evals, basis, shift, d_out):
+        basis, shift = _as_u64(basis), _as_u64(shift)
+        self._check(self.c.iopx_add_ifft_gf192_dev(_vp(d_evals), basis.ctypes.data_as(_u64p), basis.shape[0],
+                                                   shift.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def fri_fold_dev(self, d_f, basis, shift, coset_size, x_i, d_next):
+        basis, shift, x = _as_u64(basis), _as_u64(shift), _as_u64(x_i)
+        self._check(self.c.iopx_fri_fold_add_gf192_dev(_vp(d_f), basis.ctypes.data_as(_u64p), basis.shape[0],
+                                                       shift.ctypes.data_as(_u64p), int(coset_size), x.ctypes.data_as(_u64p), _vp(d_next)))
+
+    def merkle_tree_dev(self, d_oracles, elem_bytes, n, coset_size, d_nodes, domain_type=DOMAIN_ADDITIVE, d_salts=0, salt_bytes=0):
+        ptrs = (_vp * len(d_oracles))(*d_oracles)
+        self._check(self.c.iopx_merkle_blake2b_dev(ptrs, len(d_oracles), elem_bytes, n, int(coset_size), int(domain_type),
+                                                   _vp(d_salts), salt_bytes, _vp(d_nodes)))
+
+    def profile_begin(self):
+        self._check(self.c.iopx_profile_begin())
+
+    def profile_report(self):
+        """Returns {kernel: (launches, total_ms)} for the launches since profile_begin()."""
+        buf = ctypes.create_string_buffer(1 << 16)
+        self._check(self.c.iopx_profile_report(buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            out[name] = (int(cnt), float(ms))
+        return out
+
+    def gf192_mul_dev(self, d_a, d_b, d_out, count):
+        self._check(self.c.iopx_gf192_mul_dev(_vp(d_a), _vp(d_b), _vp(d_out), count))
+
+    def gf192_mul(self, a, b):
+        a, b = _as_u64(a), _as_u64(b)
+        n = a.shape[0]
+        da, db, do = self.malloc(a.nbytes), self.malloc(a.nbytes), self.malloc(a.nbytes)
+        try:
+            self.h2d(da, a)
+            self.h2d(db, b)
+            self.gf192_mul_dev(da, db, do, n)
+            out = np.empty_like(a)
+            self.d2h(out, do)
+        finally:
+            for p in (da, db, do):
+                self.free(p)
+        return out
+
+
+_default = None
+
+
+def lib():
+    """The product library (HIP, gfx950).  Raises if it has not been built."""
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default
+
+
+def standard_basis(m):
+    """affine_subspace default basis: element i is FieldT(1ull << i) (subspace.tcc:93-108)."""
+    b = np.zeros((m, 3), dtype=np.uint64)
+    for i in range(m):
+        b[i, 0] = np.uint64(1) << np.uint64(i)
+    return b

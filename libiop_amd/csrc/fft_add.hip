@@ -1,0 +1,872 @@
+// Additive (Gao–Mateer-equivalent) FFT / IFFT over GF(2^192) for gfx950.
+//
+// Replaces additive_FFT / additive_IFFT of the reference (libiop/algebra/fft.tcc:39-124, 126-204).  The
+// outputs are the unique evaluations / coefficients, so the kernel schedule is free to differ:
+//
+//   phase 1  (coefficients -> Gao–Mateer basis), in place on 2^d elements, d = ceil(log2 n_coeffs):
+//            for each level j: twist by beta_j^(idx >> j) (power table in HBM, built once per domain),
+//            then the Taylor-expansion XOR network on index bits (k+1,k), k = d-2 .. j (fft.tcc:62-83).
+//            The XOR network runs in LDS tiles: a pass loads 2^(c+A) elements (2^c contiguous columns x
+//            2^A rows on A consecutive index bits) and performs every operation whose two index bits
+//            lie inside the tile; the last pass fuses all remaining levels.
+//   phase 2  (the "unwind" butterflies, fft.tcc:102-120) is run WITHOUT the bit reversal of fft.tcc:99,
+//            i.e. in the order where the 2^(d-1-l) butterflies of one block share one twiddle and are
+//            contiguous in memory; the bit reversal is folded into the addressing of the last pass.
+//            For n_coeffs << 2^m (the prover's low-degree extension) phase 1 runs once on 2^d elements
+//            and phase 2 runs once per coset of span(basis[0..d)) — 2^(m-d) independent transforms whose
+//            twiddles differ only by a per-level additive constant (the recursed shift is GF(2)-linear
+//            in the coset shift).
+//
+// The IFFT runs the exact inverse schedule.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+#include "gf192_dev.h"
+#include "gf192_host.h"
+#include "runtime.h"
+
+namespace iopx {
+
+// Tile geometry.  Defaults: 4096-element tiles (96 KiB of LDS per workgroup).  The IOPX_TILE_BITS /
+// IOPX_P1_COLS / IOPX_P2_COLS / IOPX_P2_TOP environment variables override them (read once): used for
+// tuning, and by the tests to exercise the multi-pass schedules at small transform sizes.
+struct Tuning { int tile_bits, p1_cols, p2_cols, p2_top; };
+static int env_int(const char *name, int dflt, int lo, int hi)
+{
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    const int x = atoi(v);
+    return x < lo ? lo : (x > hi ? hi : x);
+}
+static const Tuning &tuning()
+{
+    static const Tuning t = [] {
+        Tuning u;
+        u.tile_bits = env_int("IOPX_TILE_BITS", 12, 4, 12);
+        u.p1_cols = env_int("IOPX_P1_COLS", 2, 0, u.tile_bits - 3);     // strided phase-1 tiles: 2^c contiguous columns
+        u.p2_cols = env_int("IOPX_P2_COLS", 4, 0, u.tile_bits - 2);     // phase-2 upper passes: 2^c contiguous columns
+        u.p2_top = env_int("IOPX_P2_TOP", 4, 0, u.tile_bits - 2);       // last pass: 2^c natural-order runs
+        return u;
+    }();
+    return t;
+}
+#define TILE_BITS (tuning().tile_bits)
+#define P1_COLS (tuning().p1_cols)
+#define P2_COLS (tuning().p2_cols)
+#define P2_TOP (tuning().p2_top)
+static const int BLOCK_THREADS = 512;
+static const size_t SCRATCH_BYTES = (size_t)256 << 20;   // block-order staging for a group of LDE cosets
+
+// ---------------------------------------------------------------------------------------------
+// LDS tile: three planes of 64-bit words (conflict-free for consecutive element indices)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ gf192 lds_get(const uint64_t *s, int E, int li)
+{
+    const uint64_t a = s[li], b = s[E + li], c = s[2 * E + li];
+    gf192 r;
+    r.w[0] = (uint32_t)a; r.w[1] = (uint32_t)(a >> 32);
+    r.w[2] = (uint32_t)b; r.w[3] = (uint32_t)(b >> 32);
+    r.w[4] = (uint32_t)c; r.w[5] = (uint32_t)(c >> 32);
+    return r;
+}
+
+__device__ __forceinline__ void lds_put(uint64_t *s, int E, int li, const gf192 &v)
+{
+    s[li] = (uint64_t)v.w[0] | ((uint64_t)v.w[1] << 32);
+    s[E + li] = (uint64_t)v.w[2] | ((uint64_t)v.w[3] << 32);
+    s[2 * E + li] = (uint64_t)v.w[4] | ((uint64_t)v.w[5] << 32);
+}
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, int bits)
+{
+    return bits == 0 ? 0u : (__brev(x) >> (32 - bits));
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan construction kernels
+// ---------------------------------------------------------------------------------------------
+// out[q] = prod_{k : bit k of q} sq[k]  for q < count   (sq[k] = beta^(2^k))
+__global__ void k_pow_direct(uint64_t *out, const uint64_t *sq, int nbits, size_t count)
+{
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (size_t)gridDim.x * blockDim.x) {
+        gf192 acc = gf_zero();
+        acc.w[0] = 1;
+        for (int k = 0; k < nbits; ++k) {
+            if ((q >> k) & 1) acc = gf_mul(acc, gf_load(sq, k));
+        }
+        gf_store(out, q, acc);
+    }
+}
+
+// out[q] = out[q & 255] * hi[q >> 8]  for 256 <= q < count
+__global__ void k_pow_expand(uint64_t *out, const uint64_t *hi, size_t count)
+{
+    for (size_t q = 256 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (size_t)gridDim.x * blockDim.x) {
+        gf_store(out, q, gf_mul(gf_load(out, q & 255), gf_load(hi, q >> 8)));
+    }
+}
+
+// Twiddle table in block order: entry (2^l - 1) + b, b < 2^l, is sum_k bit_{l-1-k}(b) * B_l[k] where
+// B_l = the l recursed basis vectors popped by unwind level l (fft.tcc:104-110), i.e. sums[rev_l(b)]
+// without the shift term.
+__global__ void k_build_ltab(uint64_t *ltab, const uint64_t *rec_betas, int d, size_t count)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
+        int l = 0;
+        while (((size_t)2 << l) <= e + 1) ++l;          // l = floor(log2(e + 1))
+        const size_t b = e + 1 - ((size_t)1 << l);
+        const int j = d - 1 - l;                        // recursion level that produced B_l
+        // rec_betas[j] has d-1-j entries, levels stored back to back
+        const size_t off = (size_t)j * (d - 1) - (size_t)j * (j - 1) / 2;
+        gf192 acc = gf_zero();
+        for (int k = 0; k < l; ++k) {
+            if ((b >> (l - 1 - k)) & 1) gf_add_to(acc, gf_load(rec_betas, off + k));
+        }
+        gf_store(ltab, e, acc);
+    }
+}
+
+__global__ void k_pad_copy(uint64_t *dst, const uint64_t *src, size_t n_src, size_t n_dst)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n_dst; i += (size_t)gridDim.x * blockDim.x) {
+        dst[i] = i < 3 * n_src ? src[i] : 0;
+    }
+}
+
+// out[i] = c for every i (degree-0 polynomial: n_coeffs <= 1)
+__global__ void k_fill(uint64_t *dst, const uint64_t *src, int have_src, size_t n)
+{
+    const uint64_t a = have_src ? src[0] : 0, b = have_src ? src[1] : 0, c = have_src ? src[2] : 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        dst[3 * i] = a; dst[3 * i + 1] = b; dst[3 * i + 2] = c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// phase 1: twist + Taylor-expansion network on an LDS tile
+// ---------------------------------------------------------------------------------------------
+struct P1Params {
+    uint64_t *S;            // 2^d elements, updated in place
+    const uint64_t *pow;    // power tables, level j at offset 2^(d+1) - 2^(d+1-j), 2^(d-j) entries
+    int d;
+    int c, h, A;            // tile = columns on bits [0,c) x rows on bits [h, h+A)
+    int j0, j1;             // levels handled by this pass
+    int k_start, k_end;     // first op of level j0, last op of level j1 (ops run k = d-2 .. j)
+};
+
+template<bool INV>
+__global__ void k_phase1(P1Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
+    uint64_t *s = iopx_smem;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int E = 1 << (p.c + p.A);
+    const int midbits = p.h - p.c;
+    const size_t o = blockIdx.x;
+    const size_t mid = o & (((size_t)1 << midbits) - 1), hi = o >> midbits;
+    const size_t base = (hi << (p.h + p.A)) | (mid << p.c);
+    const int cmask = (1 << p.c) - 1;
+
+    for (int li = tid; li < E; li += nt) {
+        const size_t gi = base | ((size_t)(li >> p.c) << p.h) | (size_t)(li & cmask);
+        lds_put(s, E, li, gf_load(p.S, gi));
+    }
+    __syncthreads();
+
+    const int jb = INV ? p.j1 : p.j0, je = INV ? p.j0 - 1 : p.j1 + 1, js = INV ? -1 : 1;
+    for (int j = jb; j != je; j += js) {
+        const int ks = (j == p.j0) ? p.k_start : p.d - 2;
+        const int ke = (j == p.j1) ? p.k_end : j;
+        const bool twist = (ks == p.d - 2);
+        const uint64_t *powj = p.pow + 3 * ((((size_t)2) << p.d) - (((size_t)2) << (p.d - j)));
+        if (!INV && twist) {
+            for (int li = tid; li < E; li += nt) {
+                const size_t gi = base | ((size_t)(li >> p.c) << p.h) | (size_t)(li & cmask);
+                const size_t q = gi >> j;
+                if (q) lds_put(s, E, li, gf_mul(lds_get(s, E, li), gf_load(powj, q)));
+            }
+            __syncthreads();
+        }
+        // forward: k = ks down to ke; inverse: k = ke up to ks
+        const int nops = ks - ke + 1;
+        for (int t = 0; t < nops; ++t) {
+            const int k = INV ? ke + t : ks - t;
+            const int kl = k - p.h + p.c;               // tile-local bit of global bit k
+            for (int qd = tid; qd < (E >> 2); qd += nt) {
+                const int low = qd & ((1 << kl) - 1), high = qd >> kl;
+                const int b0 = (high << (kl + 2)) | low;
+                const int e1 = b0 | (1 << kl), e2 = b0 | (2 << kl), e3 = b0 | (3 << kl);
+                if (!INV) {
+                    // S[2s+i] += S[3s+i]; S[s+i] += S[2s+i]            (fft.tcc:79-80)
+                    const gf192 v2 = gf_add(lds_get(s, E, e2), lds_get(s, E, e3));
+                    lds_put(s, E, e2, v2);
+                    lds_put(s, E, e1, gf_add(lds_get(s, E, e1), v2));
+                } else {
+                    // S[q+i] += S[2q+i]; S[2q+i] += S[3q+i]            (fft.tcc:182-183)
+                    const gf192 v2 = lds_get(s, E, e2);
+                    lds_put(s, E, e1, gf_add(lds_get(s, E, e1), v2));
+                    lds_put(s, E, e2, gf_add(v2, lds_get(s, E, e3)));
+                }
+            }
+            __syncthreads();
+        }
+        if (INV && twist) {
+            for (int li = tid; li < E; li += nt) {
+                const size_t gi = base | ((size_t)(li >> p.c) << p.h) | (size_t)(li & cmask);
+                const size_t q = gi >> j;
+                if (q) lds_put(s, E, li, gf_mul(lds_get(s, E, li), gf_load(powj, q)));
+            }
+            __syncthreads();
+        }
+    }
+
+    for (int li = tid; li < E; li += nt) {
+        const size_t gi = base | ((size_t)(li >> p.c) << p.h) | (size_t)(li & cmask);
+        gf_store(p.S, gi, lds_get(s, E, li));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// phase 2: butterflies in block order
+// ---------------------------------------------------------------------------------------------
+struct BfParams {
+    const uint64_t *src;    // forward: W (2^d, shared by all cosets) when src_shared, else = dst layout
+    uint64_t *dst;          // cosets * 2^d elements
+    const uint64_t *ltab;   // 2^d - 1 twiddles (no shift term)
+    const uint64_t *rs;     // (1 + nhi) * d shift terms: rs[v * d + l]
+    int src_shared;
+    int d, nhi;
+    int c, h, A;            // upper pass tile geometry
+    int p_hi, p_lo;         // pair bits handled (forward: p_hi down to p_lo)
+    int a_low, c_top;       // last/first pass tile: low a_low bits x top c_top bits
+    int g_bits;             // last/first pass: 2^g_bits tiles per workgroup
+    size_t total_units;     // cosets (of this launch) * tiles per coset
+    size_t coset_base;      // global index of the first coset of this launch (src/dst are pre-offset)
+};
+
+// twiddle of the block that contains in-coset index u at the level with pair bit pbit
+__device__ __forceinline__ gf192 bf_twiddle(const BfParams &p, size_t coset, size_t u, int pbit)
+{
+    const int l = p.d - 1 - pbit;
+    gf192 tw = gf_load(p.ltab, (((size_t)1) << l) - 1 + (u >> (pbit + 1)));
+    gf_add_to(tw, gf_load(p.rs, (size_t)l));
+    const size_t gc = p.coset_base + coset;
+    for (int v = 0; v < p.nhi; ++v) {
+        if ((gc >> v) & 1) gf_add_to(tw, gf_load(p.rs, (size_t)(1 + v) * p.d + l));
+    }
+    return tw;
+}
+
+template<bool INV>
+__device__ __forceinline__ void bf_apply(uint64_t *s, int E, int ia, int ib, const gf192 &tw)
+{
+    gf192 a = lds_get(s, E, ia), b = lds_get(s, E, ib);
+    if (!INV) {
+        gf_add_to(a, gf_mul(b, tw));        // S[a] += S[b] * t ; S[b] += S[a]     (fft.tcc:116-117)
+        gf_add_to(b, a);
+    } else {
+        gf_add_to(b, a);                    // S[b] += S[a] ; S[a] += S[b] * t     (fft.tcc:164-165)
+        gf_add_to(a, gf_mul(b, tw));
+    }
+    lds_put(s, E, ia, a);
+    lds_put(s, E, ib, b);
+}
+
+template<bool INV>
+__global__ void k_bfly_upper(BfParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
+    uint64_t *s = iopx_smem;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int E = 1 << (p.c + p.A);
+    const int tpc_bits = p.d - p.c - p.A;
+    const size_t unit = blockIdx.x;
+    const size_t coset = unit >> tpc_bits, o = unit & (((size_t)1 << tpc_bits) - 1);
+    const int midbits = p.h - p.c;
+    const size_t mid = o & (((size_t)1 << midbits) - 1), hi = o >> midbits;
+    const size_t base = (hi << (p.h + p.A)) | (mid << p.c);
+    const int cmask = (1 << p.c) - 1;
+    const uint64_t *src = p.src_shared ? p.src : p.src + 3 * (coset << p.d);
+    uint64_t *dst = p.dst + 3 * (coset << p.d);
+
+    for (int li = tid; li < E; li += nt) {
+        const size_t u = base | ((size_t)(li >> p.c) << p.h) | (size_t)(li & cmask);
+        lds_put(s, E, li, gf_load(src, u));
+    }
+    __syncthreads();
+
+    const int nlev = p.p_hi - p.p_lo + 1;
+    for (int t = 0; t < nlev; ++t) {
+        const int pbit = INV ? p.p_lo + t : p.p_hi - t;
+        const int pl = pbit - p.h + p.c;
+        for (int bf = tid; bf < (E >> 1); bf += nt) {
+            const int low = bf & ((1 << pl) - 1), high = bf >> pl;
+            const int ia = (high << (pl + 1)) | low, ib = ia | (1 << pl);
+            const size_t u = base | ((size_t)(ia >> p.c) << p.h) | (size_t)(ia & cmask);
+            bf_apply<INV>(s, E, ia, ib, bf_twiddle(p, coset, u, pbit));
+        }
+        __syncthreads();
+    }
+
+    for (int li = tid; li < E; li += nt) {
+        const size_t u = base | ((size_t)(li >> p.c) << p.h) | (size_t)(li & cmask);
+        gf_store(dst, u, lds_get(s, E, li));
+    }
+}
+
+// Forward: last pass — pair bits a_low-1 .. 0, then natural-order (bit-reversed) store.
+// Inverse: first pass — natural-order load, pair bits 0 .. a_low-1, block-order store.
+template<bool INV>
+__global__ void k_bfly_edge(BfParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
+    uint64_t *s = iopx_smem;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tb = p.a_low + p.c_top;                   // bits of one tile
+    const int E = 1 << (tb + p.g_bits);                 // elements in LDS (2^g_bits tiles)
+    const int midbits = p.d - tb;                       // tile index bits inside a coset
+    const size_t unit0 = (size_t)blockIdx.x << p.g_bits;
+    const int lomask = (1 << p.a_low) - 1, tmask = (1 << p.c_top) - 1;
+
+    // natural-order side: slot sidx -> (tile g, lo, t' = rev(top)); consecutive sidx = consecutive addresses
+    // block-order side  : slot e    -> (tile g, top, lo)
+    if (!INV) {
+        for (int e = tid; e < E; e += nt) {
+            const size_t unit = unit0 + (size_t)(e >> tb);
+            if (unit >= p.total_units) continue;
+            const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
+            const int li = e & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
+            const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
+            const uint64_t *src = p.src_shared ? p.src : p.src + 3 * (coset << p.d);
+            lds_put(s, E, e, gf_load(src, u));
+        }
+    } else {
+        for (int sidx = tid; sidx < E; sidx += nt) {
+            const size_t unit = unit0 + (size_t)(sidx >> tb);
+            if (unit >= p.total_units) continue;
+            const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
+            const int tp = sidx & tmask, lo = (sidx >> p.c_top) & lomask;
+            const int top = (int)bitrev((uint32_t)tp, p.c_top);
+            const size_t v = ((size_t)bitrev((uint32_t)lo, p.a_low) << (p.d - p.a_low)) |
+                             ((size_t)bitrev((uint32_t)mid, midbits) << p.c_top) | (size_t)tp;
+            const int e = ((sidx >> tb) << tb) | (top << p.a_low) | lo;
+            lds_put(s, E, e, gf_load(p.src + 3 * (coset << p.d), v));
+        }
+    }
+    __syncthreads();
+
+    for (int t = 0; t < p.a_low; ++t) {
+        const int pbit = INV ? t : p.a_low - 1 - t;
+        for (int bf = tid; bf < (E >> 1); bf += nt) {
+            const int low = bf & ((1 << pbit) - 1), high = bf >> pbit;
+            const int ia = (high << (pbit + 1)) | low, ib = ia | (1 << pbit);
+            const size_t unit = unit0 + (size_t)(ia >> tb);
+            if (unit >= p.total_units) continue;
+            const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
+            const int li = ia & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
+            const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
+            bf_apply<INV>(s, E, ia, ib, bf_twiddle(p, coset, u, pbit));
+        }
+        __syncthreads();
+    }
+
+    if (!INV) {
+        for (int sidx = tid; sidx < E; sidx += nt) {
+            const size_t unit = unit0 + (size_t)(sidx >> tb);
+            if (unit >= p.total_units) continue;
+            const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
+            const int tp = sidx & tmask, lo = (sidx >> p.c_top) & lomask;
+            const int top = (int)bitrev((uint32_t)tp, p.c_top);
+            const size_t v = ((size_t)bitrev((uint32_t)lo, p.a_low) << (p.d - p.a_low)) |
+                             ((size_t)bitrev((uint32_t)mid, midbits) << p.c_top) | (size_t)tp;
+            const int e = ((sidx >> tb) << tb) | (top << p.a_low) | lo;
+            gf_store(p.dst + 3 * (coset << p.d), v, lds_get(s, E, e));
+        }
+    } else {
+        for (int e = tid; e < E; e += nt) {
+            const size_t unit = unit0 + (size_t)(e >> tb);
+            if (unit >= p.total_units) continue;
+            const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
+            const int li = e & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
+            const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
+            gf_store(p.dst + 3 * (coset << p.d), u, lds_get(s, E, e));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: plans
+// ---------------------------------------------------------------------------------------------
+struct AddPlan {
+    int d = 0;
+    std::vector<hgf192> basis;                  // basis[0..d)
+    std::vector<hgf192> beta, betainv;          // per level j
+    DevBuf ltab;                                // 2^d - 1 twiddles
+    DevBuf pow_fwd, pow_inv;                    // 2^(d+1) - 2 entries each, built on first use
+    bool have_fwd = false, have_inv = false;
+    DevBuf rs;                                  // per-call shift terms (stream ordered)
+    size_t rs_cap = 0;
+
+    // recursed shift of an arbitrary element: GF(2)-linear in s (fft.tcc:93-95 / :153-154)
+    void recursed_shifts(const hgf192 &s, hgf192 *out_by_unwind_level) const
+    {
+        hgf192 s2 = s;
+        for (int j = 0; j < d; ++j) {
+            const hgf192 ns = s2 * betainv[j];
+            out_by_unwind_level[d - 1 - j] = ns;        // unwind level l pops recursed_shifts[d-1-l]
+            s2 = ns.squared() + ns;
+        }
+    }
+};
+
+static std::mutex g_plan_mu;
+static std::map<std::vector<uint64_t>, std::unique_ptr<AddPlan>> g_plans;
+
+static int grid_for(size_t work, int threads)
+{
+    size_t g = (work + threads - 1) / threads;
+    if (g < 1) g = 1;
+    if (g > 8192) g = 8192;
+    return (int)g;
+}
+
+static int build_pow_table(uint64_t *out, const uint64_t *d_sq, int nb)
+{
+    const size_t count = (size_t)1 << nb;
+    if (nb <= 8) {
+        { ProfScope ps_("k_pow_direct"); hipLaunchKernelGGL(k_pow_direct, dim3(grid_for(count, 256)), dim3(256), 0, stream(), out, d_sq, nb, count); }
+        return IOPX_OK;
+    }
+    DevBuf tmp;
+    int rc = tmp.alloc(((size_t)1 << (nb - 8)) * 24);
+    if (rc != IOPX_OK) return rc;
+    rc = build_pow_table(tmp.u64(), d_sq + 3 * 8, nb - 8);
+    if (rc != IOPX_OK) return rc;
+    { ProfScope ps_("k_pow_direct"); hipLaunchKernelGGL(k_pow_direct, dim3(1), dim3(256), 0, stream(), out, d_sq, 8, (size_t)256); }
+    { ProfScope ps_("k_pow_expand"); hipLaunchKernelGGL(k_pow_expand, dim3(grid_for(count - 256, 256)), dim3(256), 0, stream(), out, (const uint64_t *)tmp.u64(), count); }
+    IOPX_HIP(hipStreamSynchronize(stream()));           // tmp is freed on return
+    return IOPX_OK;
+}
+
+static int build_pow_tables(AddPlan &pl, bool inverse)
+{
+    const int d = pl.d;
+    DevBuf &buf = inverse ? pl.pow_inv : pl.pow_fwd;
+    int rc = buf.alloc(((((size_t)2) << d) - 2) * 24);
+    if (rc != IOPX_OK) return rc;
+    // squares beta_j^(2^k), k < d - j, all levels back to back
+    std::vector<uint64_t> sq;
+    std::vector<size_t> off(d);
+    for (int j = 0; j < d; ++j) {
+        off[j] = sq.size();
+        hgf192 x = inverse ? pl.betainv[j] : pl.beta[j];
+        for (int k = 0; k < d - j; ++k) {
+            sq.insert(sq.end(), x.w, x.w + 3);
+            x = x.squared();
+        }
+    }
+    DevBuf dsq;
+    rc = dsq.alloc(sq.size() * 8);
+    if (rc != IOPX_OK) return rc;
+    IOPX_HIP(hipMemcpyAsync(dsq.p, sq.data(), sq.size() * 8, hipMemcpyHostToDevice, stream()));
+    for (int j = 0; j < d; ++j) {
+        uint64_t *out = buf.u64() + 3 * ((((size_t)2) << d) - (((size_t)2) << (d - j)));
+        rc = build_pow_table(out, dsq.u64() + off[j], d - j);
+        if (rc != IOPX_OK) return rc;
+    }
+    IOPX_HIP(hipStreamSynchronize(stream()));
+    (inverse ? pl.have_inv : pl.have_fwd) = true;
+    return IOPX_OK;
+}
+
+static int get_plan(const uint64_t *basis, int d, AddPlan **out)
+{
+    std::vector<uint64_t> key(basis, basis + 3 * (size_t)d);
+    key.push_back((uint64_t)d);
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) { *out = it->second.get(); return IOPX_OK; }
+
+    std::unique_ptr<AddPlan> pl(new AddPlan());
+    pl->d = d;
+    for (int i = 0; i < d; ++i) pl->basis.push_back(hgf192::from_words(basis + 3 * i));
+    // recursed bases (fft.tcc:55-96); rec[j] = newbetas of level j (d-1-j entries)
+    std::vector<hgf192> betas2(pl->basis);
+    std::vector<uint64_t> rec_flat;
+    for (int j = 0; j < d; ++j) {
+        const hgf192 beta = betas2[d - 1 - j];
+        if (beta.is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "additive FFT: basis vectors are linearly dependent");
+        const hgf192 binv = beta.inverse();
+        pl->beta.push_back(beta);
+        pl->betainv.push_back(binv);
+        for (int i = 0; i < d - 1 - j; ++i) {
+            const hgf192 nb = betas2[i] * binv;
+            rec_flat.insert(rec_flat.end(), nb.w, nb.w + 3);
+            betas2[i] = nb.squared() + nb;
+        }
+    }
+    if (d >= 1) {
+        const size_t count = ((size_t)1 << d) - 1;
+        int rc = pl->ltab.alloc(count * 24);
+        if (rc != IOPX_OK) return rc;
+        DevBuf drec;
+        rc = drec.alloc(rec_flat.size() * 8);
+        if (rc != IOPX_OK) return rc;
+        if (!rec_flat.empty()) IOPX_HIP(hipMemcpyAsync(drec.p, rec_flat.data(), rec_flat.size() * 8, hipMemcpyHostToDevice, stream()));
+        { ProfScope ps_("k_build_ltab"); hipLaunchKernelGGL(k_build_ltab, dim3(grid_for(count, 256)), dim3(256), 0, stream(), pl->ltab.u64(), (const uint64_t *)drec.u64(), d, count); }
+        IOPX_HIP(hipStreamSynchronize(stream()));
+    }
+    *out = pl.get();
+    g_plans[key] = std::move(pl);
+    return IOPX_OK;
+}
+
+static int upload_rs(AddPlan &pl, const hgf192 &shift, const uint64_t *hi_basis, int nhi)
+{
+    const int d = pl.d;
+    std::vector<hgf192> rs((size_t)(1 + nhi) * d);
+    pl.recursed_shifts(shift, rs.data());
+    for (int v = 0; v < nhi; ++v) pl.recursed_shifts(hgf192::from_words(hi_basis + 3 * v), rs.data() + (size_t)(1 + v) * d);
+    const size_t bytes = rs.size() * 24;
+    if (bytes > pl.rs_cap) {
+        IOPX_HIP(hipStreamSynchronize(stream()));
+        int rc = pl.rs.alloc(bytes);
+        if (rc != IOPX_OK) return rc;
+        pl.rs_cap = bytes;
+    }
+    if (bytes) IOPX_HIP(hipMemcpyAsync(pl.rs.p, rs.data(), bytes, hipMemcpyHostToDevice, stream()));
+    return IOPX_OK;
+}
+
+template<typename K>
+static int set_lds(K kernel, size_t bytes)
+{
+    if (bytes > 64 * 1024) IOPX_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return IOPX_OK;
+}
+
+// ---- phase-1 schedule --------------------------------------------------------------------------
+struct P1Pass { int c, h, A, j0, j1, k_start, k_end; };
+
+static std::vector<P1Pass> phase1_schedule(int d)
+{
+    std::vector<P1Pass> sched;
+    if (d <= TILE_BITS) {
+        sched.push_back({0, 0, d, 0, d - 1, d - 2, d - 1});
+        return sched;
+    }
+    const int A = TILE_BITS - P1_COLS;
+    const int hfin = d - A;                 // levels >= hfin live entirely in the top A bits
+    for (int j = 0; j < hfin; ++j) {
+        int k = d - 2;
+        while (k >= j) {
+            if (k + 1 <= TILE_BITS - 1) {   // the rest of this level fits a contiguous tile
+                sched.push_back({0, 0, TILE_BITS, j, j, k, j});
+                break;
+            }
+            const int h = k + 2 - A;
+            const int ke = h > j ? h : j;
+            sched.push_back({P1_COLS, h, A, j, j, k, ke});
+            k = ke - 1;
+        }
+    }
+    sched.push_back({P1_COLS, hfin, A, hfin, d - 1, d - 2, d - 1});
+    return sched;
+}
+
+template<bool INV>
+static int run_phase1(AddPlan &pl, uint64_t *S)
+{
+    const int d = pl.d;
+    if (d == 0) return IOPX_OK;
+    if (!(INV ? pl.have_inv : pl.have_fwd)) {
+        int rc = build_pow_tables(pl, INV);
+        if (rc != IOPX_OK) return rc;
+    }
+    std::vector<P1Pass> sched = phase1_schedule(d);
+    const int n = (int)sched.size();
+    for (int i = 0; i < n; ++i) {
+        const P1Pass &ps = sched[INV ? n - 1 - i : i];
+        P1Params p;
+        p.S = S;
+        p.pow = INV ? pl.pow_inv.u64() : pl.pow_fwd.u64();
+        p.d = d; p.c = ps.c; p.h = ps.h; p.A = ps.A;
+        p.j0 = ps.j0; p.j1 = ps.j1; p.k_start = ps.k_start; p.k_end = ps.k_end;
+        const int tbits = ps.c + ps.A;
+        const size_t lds = ((size_t)24) << tbits;
+        const size_t blocks = (size_t)1 << (d - tbits);
+        const int threads = (1 << tbits) >= 4 * BLOCK_THREADS ? BLOCK_THREADS : ((1 << tbits) >= 256 ? 64 * ((1 << tbits) / 256) : 64);
+        int rc = set_lds(k_phase1<INV>, lds);
+        if (rc != IOPX_OK) return rc;
+        { ProfScope ps_("k_phase1"); hipLaunchKernelGGL(k_phase1<INV>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+    }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+// ---- phase-2 schedule --------------------------------------------------------------------------
+struct P2Geom { int a_low, c_top; };
+
+static P2Geom phase2_geom(int d)
+{
+    if (d < TILE_BITS) return {d, 0};
+    return {TILE_BITS - P2_TOP, P2_TOP};
+}
+
+// forward: W (2^d, block order after phase 1) -> dst (2^nhi cosets * 2^d, natural order);
+// inverse: single coset, natural-order src -> block-order dst (src != dst).
+// The edge pass permutes (bit reversal), so it never runs in place across workgroups: the forward
+// transform keeps the upper passes in W (one coset) or in a scratch buffer holding a group of cosets.
+template<bool INV>
+static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi)
+{
+    const int d = pl.d;
+    const P2Geom g = phase2_geom(d);
+    const size_t cosets = (size_t)1 << nhi;
+    const size_t nd = (size_t)1 << d;
+    BfParams p;
+    memset(&p, 0, sizeof(p));
+    p.ltab = pl.ltab.u64();
+    p.rs = pl.rs.u64();
+    p.d = d; p.nhi = nhi;
+    p.a_low = g.a_low; p.c_top = g.c_top;
+
+    // upper passes over pair bits [a_low, d): chunks of up to A bits, from the top (forward order)
+    struct Up { int h, A, c; };
+    std::vector<Up> ups;
+    {
+        int top = d;                        // exclusive
+        while (top > g.a_low) {
+            int A = TILE_BITS - P2_COLS;
+            if (top - A < g.a_low) A = top - g.a_low;
+            const int c = TILE_BITS - A > g.a_low ? g.a_low : TILE_BITS - A;
+            ups.push_back({top - A, A, c});
+            top -= A;
+        }
+    }
+    const int tb = g.a_low + g.c_top;
+
+    auto launch_edge = [&](const uint64_t *s, uint64_t *dd, int shared, size_t ncos, size_t cbase) -> int {
+        int g_bits = TILE_BITS - tb;
+        const size_t units = ncos << (d - tb);
+        while (g_bits > 0 && ((size_t)1 << g_bits) > units) --g_bits;
+        const size_t lds = ((size_t)24) << (tb + g_bits);
+        const size_t blocks = (units + ((size_t)1 << g_bits) - 1) >> g_bits;
+        const int elems = 1 << (tb + g_bits);
+        const int threads = elems >= 2 * BLOCK_THREADS ? BLOCK_THREADS : (elems >= 128 ? elems / 2 : 64);
+        p.src = s; p.dst = dd; p.src_shared = shared;
+        p.g_bits = g_bits; p.total_units = units; p.coset_base = cbase;
+        int rc = set_lds(k_bfly_edge<INV>, lds);
+        if (rc != IOPX_OK) return rc;
+        { ProfScope ps_("k_bfly_edge"); hipLaunchKernelGGL(k_bfly_edge<INV>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        return IOPX_OK;
+    };
+    auto launch_upper = [&](const Up &u, const uint64_t *s, uint64_t *dd, int shared, size_t ncos, size_t cbase) -> int {
+        p.src = s; p.dst = dd; p.src_shared = shared;
+        p.c = u.c; p.h = u.h; p.A = u.A;
+        p.p_hi = u.h + u.A - 1; p.p_lo = u.h;
+        const int tbits = u.c + u.A;
+        const size_t lds = ((size_t)24) << tbits;
+        const size_t blocks = ncos << (d - tbits);
+        p.total_units = blocks; p.coset_base = cbase;
+        const int threads = (1 << tbits) >= 2 * BLOCK_THREADS ? BLOCK_THREADS : ((1 << tbits) >= 128 ? (1 << tbits) / 2 : 64);
+        int rc = set_lds(k_bfly_upper<INV>, lds);
+        if (rc != IOPX_OK) return rc;
+        { ProfScope ps_("k_bfly_upper"); hipLaunchKernelGGL(k_bfly_upper<INV>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        return IOPX_OK;
+    };
+
+    int rc;
+    if (INV) {
+        rc = launch_edge(src, dst, 0, 1, 0);
+        if (rc != IOPX_OK) return rc;
+        for (size_t i = ups.size(); i-- > 0; ) {
+            rc = launch_upper(ups[i], dst, dst, 0, 1, 0);
+            if (rc != IOPX_OK) return rc;
+        }
+    } else if (ups.empty()) {
+        rc = launch_edge(src, dst, 1, cosets, 0);
+        if (rc != IOPX_OK) return rc;
+    } else if (nhi == 0) {
+        uint64_t *W = const_cast<uint64_t *>(src);
+        for (size_t i = 0; i < ups.size(); ++i) {
+            rc = launch_upper(ups[i], W, W, 1, 1, 0);
+            if (rc != IOPX_OK) return rc;
+        }
+        rc = launch_edge(W, dst, 1, 1, 0);
+        if (rc != IOPX_OK) return rc;
+    } else {
+        size_t group = SCRATCH_BYTES / (nd * 24);
+        if (group < 1) group = 1;
+        if (group > cosets) group = cosets;
+        DevBuf scratch;
+        rc = scratch.alloc(group * nd * 24);
+        if (rc != IOPX_OK) return rc;
+        for (size_t c0 = 0; c0 < cosets; c0 += group) {
+            const size_t nc = cosets - c0 < group ? cosets - c0 : group;
+            for (size_t i = 0; i < ups.size(); ++i) {
+                rc = launch_upper(ups[i], i == 0 ? src : scratch.u64(), scratch.u64(), i == 0 ? 1 : 0, nc, c0);
+                if (rc != IOPX_OK) return rc;
+            }
+            rc = launch_edge(scratch.u64(), dst + 3 * c0 * nd, 0, nc, c0);
+            if (rc != IOPX_OK) return rc;
+        }
+        IOPX_HIP(hipStreamSynchronize(stream()));       // scratch is freed on return
+    }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+static int check_basis_args(const uint64_t *basis, size_t m, const uint64_t *shift)
+{
+    if (m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "domain dimension %zu too large", m);
+    if ((m > 0 && !basis) || !shift) return fail(IOPX_ERR_INVALID_ARGUMENT, "null basis/shift");
+    return IOPX_OK;
+}
+
+} // namespace iopx
+
+using namespace iopx;
+
+extern "C" {
+
+int iopx_clear_plans(void)
+{
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (!g_plans.empty()) (void)hipDeviceSynchronize();
+    g_plans.clear();
+    return IOPX_OK;
+}
+
+int iopx_add_fft_gf192_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *basis, size_t m,
+                           const uint64_t *shift, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    rc = check_basis_args(basis, m, shift);
+    if (rc != IOPX_OK) return rc;
+    const size_t n = (size_t)1 << m;
+    if (n_coeffs > n) return fail(IOPX_ERR_INVALID_ARGUMENT, "additive FFT: %zu coefficients exceed the domain size %zu", n_coeffs, n);
+    if (!d_out || (n_coeffs && !d_coeffs)) return fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
+    if (n_coeffs <= 1) {
+        { ProfScope ps_("k_fill"); hipLaunchKernelGGL(k_fill, dim3(grid_for(n, 256)), dim3(256), 0, stream(), d_out, d_coeffs, (int)(n_coeffs == 1), n); }
+        IOPX_HIP(hipGetLastError());
+        return IOPX_OK;
+    }
+    const int d = (int)ceil_log2(n_coeffs);
+    const int nhi = (int)m - d;
+    AddPlan *pl = nullptr;
+    rc = get_plan(basis, d, &pl);
+    if (rc != IOPX_OK) return rc;
+    rc = upload_rs(*pl, hgf192::from_words(shift), basis + 3 * (size_t)d, nhi);
+    if (rc != IOPX_OK) return rc;
+
+    // phase 1 (and, for a full-size transform, the upper butterfly passes) run in a work buffer: the
+    // last pass permutes into natural order and therefore writes out of place
+    const size_t nd = (size_t)1 << d;
+    DevBuf work;
+    rc = work.alloc(nd * 24);
+    if (rc != IOPX_OK) return rc;
+    uint64_t *W = work.u64();
+    { ProfScope ps_("k_pad_copy"); hipLaunchKernelGGL(k_pad_copy, dim3(grid_for(3 * nd, 256)), dim3(256), 0, stream(), W, d_coeffs, n_coeffs, nd); }
+    rc = run_phase1<false>(*pl, W);
+    if (rc != IOPX_OK) return rc;
+    rc = run_phase2<false>(*pl, W, d_out, nhi);
+    if (rc != IOPX_OK) return rc;
+    IOPX_HIP(hipStreamSynchronize(stream()));           // work buffer is freed on return
+    return IOPX_OK;
+}
+
+int iopx_add_ifft_gf192_dev(const uint64_t *d_evals, const uint64_t *basis, size_t m, const uint64_t *shift,
+                            uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    rc = check_basis_args(basis, m, shift);
+    if (rc != IOPX_OK) return rc;
+    if (!d_evals || !d_out) return fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
+    if (m == 0) {
+        IOPX_HIP(hipMemcpyAsync(d_out, d_evals, 24, hipMemcpyDeviceToDevice, stream()));
+        return IOPX_OK;
+    }
+    AddPlan *pl = nullptr;
+    rc = get_plan(basis, (int)m, &pl);
+    if (rc != IOPX_OK) return rc;
+    rc = upload_rs(*pl, hgf192::from_words(shift), nullptr, 0);
+    if (rc != IOPX_OK) return rc;
+    const uint64_t *src = d_evals;
+    DevBuf tmp;
+    if (d_evals == d_out) {     // the first pass permutes: it cannot run in place
+        rc = tmp.alloc(((size_t)24) << m);
+        if (rc != IOPX_OK) return rc;
+        IOPX_HIP(hipMemcpyAsync(tmp.p, d_evals, ((size_t)24) << m, hipMemcpyDeviceToDevice, stream()));
+        src = tmp.u64();
+    }
+    rc = run_phase2<true>(*pl, src, d_out, 0);
+    if (rc != IOPX_OK) return rc;
+    rc = run_phase1<true>(*pl, d_out);
+    if (rc != IOPX_OK) return rc;
+    if (tmp.p) IOPX_HIP(hipStreamSynchronize(stream()));
+    return IOPX_OK;
+}
+
+int iopx_add_fft_gf192(const uint64_t *coeffs, size_t n_coeffs, const uint64_t *basis, size_t m,
+                       const uint64_t *shift, uint64_t *out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "domain dimension %zu too large", m);
+    const size_t n = (size_t)1 << m;
+    if (n_coeffs > n) return fail(IOPX_ERR_INVALID_ARGUMENT, "additive FFT: %zu coefficients exceed the domain size %zu", n_coeffs, n);
+    DevBuf din, dout;
+    if ((rc = din.alloc(n_coeffs * 24)) != IOPX_OK) return rc;
+    if ((rc = dout.alloc(n * 24)) != IOPX_OK) return rc;
+    if (n_coeffs) IOPX_HIP(hipMemcpyAsync(din.p, coeffs, n_coeffs * 24, hipMemcpyHostToDevice, stream()));
+    rc = iopx_add_fft_gf192_dev(din.u64(), n_coeffs, basis, m, shift, dout.u64());
+    if (rc != IOPX_OK) return rc;
+    IOPX_HIP(hipMemcpyAsync(out, dout.p, n * 24, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(hipStreamSynchronize(stream()));
+    return IOPX_OK;
+}
+
+int iopx_add_ifft_gf192(const uint64_t *evals, const uint64_t *basis, size_t m, const uint64_t *shift,
+                        uint64_t *out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "domain dimension %zu too large", m);
+    const size_t n = (size_t)1 << m;
+    DevBuf din, dout;
+    if ((rc = din.alloc(n * 24)) != IOPX_OK) return rc;
+    if ((rc = dout.alloc(n * 24)) != IOPX_OK) return rc;
+    IOPX_HIP(hipMemcpyAsync(din.p, evals, n * 24, hipMemcpyHostToDevice, stream()));
+    rc = iopx_add_ifft_gf192_dev(din.u64(), basis, m, shift, dout.u64());
+    if (rc != IOPX_OK) return rc;
+    IOPX_HIP(hipMemcpyAsync(out, dout.p, n * 24, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(hipStreamSynchronize(stream()));
+    return IOPX_OK;
+}
+
+// d_out[i] = d_a[i] * d_b[i]
+__global__ void k_gf192_mul(const uint64_t *a, const uint64_t *b, uint64_t *out, size_t count)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        gf_store(out, i, gf_mul(gf_load(a, i), gf_load(b, i)));
+    }
+}
+
+int iopx_gf192_mul_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (count == 0) return IOPX_OK;
+    { ProfScope ps_("k_gf192_mul"); hipLaunchKernelGGL(k_gf192_mul, dim3(grid_for(count, 256)), dim3(256), 0, stream(), d_a, d_b, d_out, count); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,138 @@
+// FRI prover fold over GF(2^192) for affine-subspace domains on gfx950.
+//
+// Replaces additive_evaluate_next_f_i_over_entire_domain (libiop/protocols/ldt/fri/fri_aux.tcc:36-103):
+// next[j] = P_j(x_i), P_j the interpolant of f_i on the j-th contiguous coset of size 2^eta.
+// The reference computes P_j(x_i) with one field inversion per coset (:92-99).  The value is unique, so
+// this kernel uses the inversion-free nested form instead: a coset of size 2^eta is folded eta times
+// by two,
+//     g[J] = f[2J] + (f[2J] + f[2J+1]) * (x + v_{2J}) / b_0 ,
+// each time over the domain derived by q(X) = X^2 + b_0 X (basis q(b_1..), shift q(s), point q(x)).
+// (x + v_{2J}) / b_0 is GF(2)-affine in the bits of J, so the per-pair multiplier is a subset sum of
+// m-1 host-prepared constants.  When x lies in the coset the formula returns f at x, which is what
+// the reference's special case (:77-86) returns.
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "gf192_dev.h"
+#include "gf192_host.h"
+#include "runtime.h"
+
+namespace iopx {
+
+struct FoldParams {
+    const uint64_t *src;    // 2 * n_out elements
+    uint64_t *dst;          // n_out elements
+    const uint64_t *consts; // [0] = (x + s) / b0, [1 + k] = b_{k+1} / b0, k < nbits
+    int nbits;              // log2(n_out)
+    size_t n_out;
+};
+
+__global__ void k_fri_fold2(FoldParams p)
+{
+    for (size_t J = (size_t)blockIdx.x * blockDim.x + threadIdx.x; J < p.n_out; J += (size_t)gridDim.x * blockDim.x) {
+        gf192 mult = gf_load(p.consts, 0);
+        for (int k = 0; k < p.nbits; ++k) {
+            if ((J >> k) & 1) gf_add_to(mult, gf_load(p.consts, 1 + k));
+        }
+        const gf192 f0 = gf_load(p.src, 2 * J), f1 = gf_load(p.src, 2 * J + 1);
+        gf192 r = gf_mul(gf_add(f0, f1), mult);
+        gf_add_to(r, f0);
+        gf_store(p.dst, J, r);
+    }
+}
+
+} // namespace iopx
+
+using namespace iopx;
+
+extern "C" {
+
+int iopx_fri_fold_add_gf192_dev(const uint64_t *d_f_i, const uint64_t *basis, size_t m, const uint64_t *shift,
+                                size_t coset_size, const uint64_t *x_i, uint64_t *d_next)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "domain dimension %zu too large", m);
+    if (!d_f_i || !d_next || !shift || !x_i || (m && !basis)) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (coset_size == 0 || (coset_size & (coset_size - 1))) return fail(IOPX_ERR_INVALID_ARGUMENT, "coset size %zu is not a power of two", coset_size);
+    const int eta = (int)ceil_log2(coset_size);
+    if ((size_t)eta > m) return fail(IOPX_ERR_INVALID_ARGUMENT, "coset size %zu exceeds the domain size", coset_size);
+    const size_t n = (size_t)1 << m;
+    if (eta == 0) {     // cosets of one element: the interpolant is the constant f(v)
+        IOPX_HIP(hipMemcpyAsync(d_next, d_f_i, n * 24, hipMemcpyDeviceToDevice, stream()));
+        return IOPX_OK;
+    }
+
+    std::vector<hgf192> b(m);
+    for (size_t i = 0; i < m; ++i) b[i] = hgf192::from_words(basis + 3 * i);
+    hgf192 s = hgf192::from_words(shift), x = hgf192::from_words(x_i);
+
+    // constants of all eta levels, uploaded once
+    std::vector<uint64_t> hc;
+    std::vector<size_t> off(eta);
+    for (int e = 0; e < eta; ++e) {
+        if (b[0].is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "FRI fold: basis vectors are linearly dependent");
+        const hgf192 b0 = b[0], b0inv = b0.inverse();
+        off[e] = hc.size() / 3;
+        const hgf192 a = (x + s) * b0inv;
+        hc.insert(hc.end(), a.w, a.w + 3);
+        for (size_t k = 1; k < b.size(); ++k) {
+            const hgf192 dk = b[k] * b0inv;
+            hc.insert(hc.end(), dk.w, dk.w + 3);
+        }
+        // derived domain: q(X) = X^2 + b0 X
+        std::vector<hgf192> nb;
+        for (size_t k = 1; k < b.size(); ++k) nb.push_back(b[k].squared() + b0 * b[k]);
+        s = s.squared() + b0 * s;
+        x = x.squared() + b0 * x;
+        b.swap(nb);
+    }
+    DevBuf dc;
+    if ((rc = dc.alloc(hc.size() * 8)) != IOPX_OK) return rc;
+    IOPX_HIP(hipMemcpyAsync(dc.p, hc.data(), hc.size() * 8, hipMemcpyHostToDevice, stream()));
+
+    DevBuf tmp[2];
+    const uint64_t *src = d_f_i;
+    size_t cur = n;
+    for (int e = 0; e < eta; ++e) {
+        const size_t n_out = cur >> 1;
+        uint64_t *dst = d_next;
+        if (e != eta - 1) {
+            if ((rc = tmp[e & 1].alloc(n_out * 24)) != IOPX_OK) return rc;
+            dst = tmp[e & 1].u64();
+        }
+        FoldParams p;
+        p.src = src; p.dst = dst; p.consts = dc.u64() + 3 * off[e];
+        p.nbits = (int)m - 1 - e; p.n_out = n_out;
+        size_t grid = (n_out + 255) / 256;
+        if (grid > 16384) grid = 16384;
+        if (grid < 1) grid = 1;
+        { ProfScope ps_("k_fri_fold2"); hipLaunchKernelGGL(k_fri_fold2, dim3((unsigned)grid), dim3(256), 0, stream(), p); }
+        src = dst;
+        cur = n_out;
+    }
+    IOPX_HIP(hipGetLastError());
+    IOPX_HIP(hipStreamSynchronize(stream()));       // constants / temporaries are freed on return
+    return IOPX_OK;
+}
+
+int iopx_fri_fold_add_gf192(const uint64_t *f_i, const uint64_t *basis, size_t m, const uint64_t *shift,
+                            size_t coset_size, const uint64_t *x_i, uint64_t *next)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "domain dimension %zu too large", m);
+    if (coset_size == 0 || (coset_size & (coset_size - 1)) || coset_size > ((size_t)1 << m))
+        return fail(IOPX_ERR_INVALID_ARGUMENT, "bad coset size %zu", coset_size);
+    const size_t n = (size_t)1 << m, n_out = n / coset_size;
+    DevBuf din, dout;
+    if ((rc = din.alloc(n * 24)) != IOPX_OK) return rc;
+    if ((rc = dout.alloc(n_out * 24)) != IOPX_OK) return rc;
+    IOPX_HIP(hipMemcpyAsync(din.p, f_i, n * 24, hipMemcpyHostToDevice, stream()));
+    rc = iopx_fri_fold_add_gf192_dev(din.u64(), basis, m, shift, coset_size, x_i, dout.u64());
+    if (rc != IOPX_OK) return rc;
+    IOPX_HIP(hipMemcpyAsync(next, dout.p, n_out * 24, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(hipStreamSynchronize(stream()));
+    return IOPX_OK;
+}
+
+} // extern "C"

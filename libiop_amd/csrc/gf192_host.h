@@ -1,0 +1,79 @@
+// Host-side GF(2^192) arithmetic used only to prepare the per-domain constants (recursed bases,
+// shifts, fold multipliers: O(m^2) field operations per plan).  Portable C++ (no intrinsics): the
+// hot path runs on the GPU, this never touches codeword-sized data.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace iopx {
+
+struct hgf192 {
+    uint64_t w[3];
+
+    hgf192() { w[0] = w[1] = w[2] = 0; }
+    explicit hgf192(uint64_t v) { w[0] = v; w[1] = w[2] = 0; }
+    static hgf192 from_words(const uint64_t *p) { hgf192 r; r.w[0] = p[0]; r.w[1] = p[1]; r.w[2] = p[2]; return r; }
+    static hgf192 zero() { return hgf192(); }
+    static hgf192 one() { return hgf192(1); }
+
+    bool is_zero() const { return (w[0] | w[1] | w[2]) == 0; }
+    bool operator==(const hgf192 &o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2]; }
+    bool operator!=(const hgf192 &o) const { return !(*this == o); }
+    bool operator<(const hgf192 &o) const { return memcmp(w, o.w, sizeof(w)) < 0; }
+
+    hgf192 operator+(const hgf192 &o) const { hgf192 r; for (int i = 0; i < 3; ++i) r.w[i] = w[i] ^ o.w[i]; return r; }
+    hgf192 &operator+=(const hgf192 &o) { for (int i = 0; i < 3; ++i) w[i] ^= o.w[i]; return *this; }
+
+    hgf192 operator*(const hgf192 &o) const
+    {
+        // 4-bit window comb over the 48 nibbles of o; table of (*this) * u for u < 16 (195 bits each)
+        uint64_t tab[16][4];
+        memset(tab, 0, sizeof(tab));
+        for (int i = 0; i < 3; ++i) tab[1][i] = w[i];
+        for (int u = 2; u < 16; u += 2) {
+            for (int i = 3; i > 0; --i) tab[u][i] = (tab[u >> 1][i] << 1) | (tab[u >> 1][i - 1] >> 63);
+            tab[u][0] = tab[u >> 1][0] << 1;
+            for (int i = 0; i < 4; ++i) tab[u + 1][i] = tab[u][i] ^ tab[1][i];
+        }
+        uint64_t c[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int nib = 15; nib >= 0; --nib) {
+            for (int i = 6; i > 0; --i) c[i] = (c[i] << 4) | (c[i - 1] >> 60);
+            c[0] <<= 4;
+            for (int k = 0; k < 3; ++k) {
+                const uint64_t *t = tab[(o.w[k] >> (4 * nib)) & 15];
+                for (int i = 0; i < 4; ++i) c[k + i] ^= t[i];
+            }
+        }
+        // reduce modulo x^192 + x^7 + x^2 + x + 1 (c[6] is always zero: the product has 383 bits)
+        for (int i = 5; i >= 3; --i) {
+            const uint64_t t = c[i];
+            c[i - 3] ^= t ^ (t << 1) ^ (t << 2) ^ (t << 7);
+            c[i - 2] ^= (t >> 63) ^ (t >> 62) ^ (t >> 57);
+        }
+        hgf192 r; r.w[0] = c[0]; r.w[1] = c[1]; r.w[2] = c[2];
+        return r;
+    }
+    hgf192 &operator*=(const hgf192 &o) { *this = *this * o; return *this; }
+
+    hgf192 squared() const { return *this * *this; }
+
+    // a^(2^192 - 2)
+    hgf192 inverse() const
+    {
+        hgf192 r = *this;
+        for (int i = 0; i < 190; ++i) { r = r.squared(); r *= *this; }
+        return r.squared();
+    }
+};
+
+// coefficient i >= 1 multiplies X^(2^(i-1)); slot 0 is the constant term
+inline hgf192 linearized_eval(const std::vector<hgf192> &c, const hgf192 &x)
+{
+    hgf192 r = c.empty() ? hgf192::zero() : c[0];
+    hgf192 xp = x;
+    for (size_t i = 1; i < c.size(); ++i) { r += c[i] * xp; xp = xp.squared(); }
+    return r;
+}
+
+} // namespace iopx

@@ -1,0 +1,242 @@
+// BCS Merkle tree with BLAKE2b-256 leaves and nodes on gfx950.
+//
+// Replaces merkle_tree::construct_with_leaves_serialized_by_cosets + compute_inner_nodes
+// (libiop/bcs/merkle_tree.tcc:92-151, 200-229) with blake2b_leafhash / blake2b_two_to_one_hash
+// (libiop/bcs/hashing/blake2b.tcc:120-160, blake2b.cpp:28-48).  BLAKE2b follows RFC 7693; one lane
+// hashes one leaf (or one inner node), the message words are gathered straight from the oracle
+// buffers in the reference's serialisation order: oracle-major, then position within the coset
+// (merkle_tree.tcc:127-134).
+#include <hip/hip_runtime.h>
+#include <memory>
+#include <vector>
+#include "runtime.h"
+
+namespace iopx {
+
+__device__ static const uint64_t B2B_IV[8] = {
+    0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull,
+    0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull };
+
+__device__ __forceinline__ uint64_t rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+
+#define B2B_G(a, b, c, d, x, y)                                   \
+    do {                                                          \
+        v[a] = v[a] + v[b] + (x); v[d] = rotr64(v[d] ^ v[a], 32); \
+        v[c] = v[c] + v[d];       v[b] = rotr64(v[b] ^ v[c], 24); \
+        v[a] = v[a] + v[b] + (y); v[d] = rotr64(v[d] ^ v[a], 16); \
+        v[c] = v[c] + v[d];       v[b] = rotr64(v[b] ^ v[c], 63); \
+    } while (0)
+
+#define B2B_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
+    do {                                                                                \
+        B2B_G(0, 4,  8, 12, m[s0],  m[s1]);                                             \
+        B2B_G(1, 5,  9, 13, m[s2],  m[s3]);                                             \
+        B2B_G(2, 6, 10, 14, m[s4],  m[s5]);                                             \
+        B2B_G(3, 7, 11, 15, m[s6],  m[s7]);                                             \
+        B2B_G(0, 5, 10, 15, m[s8],  m[s9]);                                             \
+        B2B_G(1, 6, 11, 12, m[s10], m[s11]);                                            \
+        B2B_G(2, 7,  8, 13, m[s12], m[s13]);                                            \
+        B2B_G(3, 4,  9, 14, m[s14], m[s15]);                                            \
+    } while (0)
+
+// one compression: h <- F(h, m, t, last)    (RFC 7693 section 3.2; message length < 2^64)
+__device__ __forceinline__ void b2b_compress(uint64_t (&h)[8], const uint64_t (&m)[16], uint64_t t, bool last)
+{
+    uint64_t v[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = h[i]; v[i + 8] = B2B_IV[i]; }
+    v[12] ^= t;
+    if (last) v[14] = ~v[14];
+    B2B_ROUND( 0,  1,  2,  3,  4,  5,  6,  7,  8,  9, 10, 11, 12, 13, 14, 15);
+    B2B_ROUND(14, 10,  4,  8,  9, 15, 13,  6,  1, 12,  0,  2, 11,  7,  5,  3);
+    B2B_ROUND(11,  8, 12,  0,  5,  2, 15, 13, 10, 14,  3,  6,  7,  1,  9,  4);
+    B2B_ROUND( 7,  9,  3,  1, 13, 12, 11, 14,  2,  6,  5, 10,  4,  0, 15,  8);
+    B2B_ROUND( 9,  0,  5,  7,  2,  4, 10, 15, 14,  1, 11, 12,  6,  8,  3, 13);
+    B2B_ROUND( 2, 12,  6, 10,  0, 11,  8,  3,  4, 13,  7,  5, 15, 14,  1,  9);
+    B2B_ROUND(12,  5,  1, 15, 14, 13,  4, 10,  0,  7,  6,  3,  9,  2,  8, 11);
+    B2B_ROUND(13, 11,  7, 14, 12,  1,  3,  9,  5,  0, 15,  4,  8,  6,  2, 10);
+    B2B_ROUND( 6, 15, 14,  9, 11,  3,  0,  8, 12,  2, 13,  7,  1,  4, 10,  5);
+    B2B_ROUND(10,  2,  8,  4,  7,  6,  1,  5, 15, 11,  9, 14,  3, 12, 13,  0);
+    B2B_ROUND( 0,  1,  2,  3,  4,  5,  6,  7,  8,  9, 10, 11, 12, 13, 14, 15);
+    B2B_ROUND(14, 10,  4,  8,  9, 15, 13,  6,  1, 12,  0,  2, 11,  7,  5,  3);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+}
+
+__device__ __forceinline__ void b2b_init(uint64_t (&h)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = B2B_IV[i];
+    h[0] ^= 0x01010000ull ^ 32ull;         // unkeyed, 32-byte digest
+}
+
+struct LeafParams {
+    const uint64_t *const *oracles;     // device array of num_oracles device pointers
+    const uint64_t *salts;              // nullptr or num_leaves * salt_words words
+    uint64_t *nodes;                    // (2 L - 1) * 4 words
+    size_t num_oracles, elem_words, n, coset_size, num_leaves;
+    size_t salt_bytes;
+    int additive;
+};
+
+__global__ void k_merkle_leaves(LeafParams p)
+{
+    const size_t words_total = p.num_oracles * p.coset_size * p.elem_words;
+    const size_t bytes_total = words_total * 8;
+    const size_t cw = p.coset_size * p.elem_words;      // words contributed by one oracle
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.num_leaves; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t h[8];
+        b2b_init(h);
+        size_t done = 0;                                // words consumed
+        while (true) {
+            uint64_t m[16];
+#pragma unroll
+            for (int w = 0; w < 16; ++w) {
+                const size_t g = done + w;
+                uint64_t val = 0;
+                if (g < words_total) {
+                    const size_t k = g / cw, r = g % cw, j = r / p.elem_words, ww = r % p.elem_words;
+                    // position_by_coset_indices: subspace.tcc:86-91 / subgroup.tcc:191-197
+                    const size_t pos = p.additive ? i * p.coset_size + j : i + j * p.num_leaves;
+                    val = p.oracles[k][pos * p.elem_words + ww];
+                }
+                m[w] = val;
+            }
+            const bool last = (done + 16 >= words_total);
+            const uint64_t t = last ? bytes_total : (done + 16) * 8;
+            b2b_compress(h, m, t, last);
+            if (last) break;
+            done += 16;
+        }
+        if (p.salts) {
+            // zk leaf: H(H(slice) || salt)   (blake2b.tcc:126-136); 32 + salt_bytes <= 128
+            uint64_t m[16];
+#pragma unroll
+            for (int w = 0; w < 16; ++w) m[w] = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) m[w] = h[w];
+            const unsigned char *sp = (const unsigned char *)p.salts + i * p.salt_bytes;
+            for (size_t b = 0; b < p.salt_bytes; ++b) m[4 + (b >> 3)] |= (uint64_t)sp[b] << (8 * (b & 7));
+            b2b_init(h);
+            b2b_compress(h, m, 32 + p.salt_bytes, true);
+        }
+        uint64_t *out = p.nodes + 4 * (p.num_leaves - 1 + i);
+        out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = h[3];
+    }
+}
+
+__device__ __forceinline__ void node_hash(uint64_t *nodes, size_t j)
+{
+    uint64_t h[8], m[16];
+    b2b_init(h);
+    const uint64_t *l = nodes + 4 * (2 * j + 1);        // children are adjacent: 64 contiguous bytes
+#pragma unroll
+    for (int w = 0; w < 8; ++w) m[w] = l[w];
+#pragma unroll
+    for (int w = 8; w < 16; ++w) m[w] = 0;
+    b2b_compress(h, m, 64, true);
+    uint64_t *out = nodes + 4 * j;
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = h[3];
+}
+
+// one tree level: nodes first .. first + count - 1      (merkle_tree.tcc:208-218)
+__global__ void k_merkle_level(uint64_t *nodes, size_t first, size_t count)
+{
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (size_t)gridDim.x * blockDim.x) {
+        node_hash(nodes, first + j);
+    }
+}
+
+// the top of the tree in one workgroup: levels of `count`, count/2, ..., 1 nodes
+__global__ void k_merkle_top(uint64_t *nodes, size_t count)
+{
+    for (size_t c = count; c >= 1; c >>= 1) {
+        for (size_t j = threadIdx.x; j < c; j += blockDim.x) node_hash(nodes, (c - 1) + j);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+} // namespace iopx
+
+using namespace iopx;
+
+extern "C" {
+
+int iopx_merkle_blake2b_dev(const void *const *d_oracles, size_t num_oracles, size_t elem_bytes, size_t n,
+                            size_t coset_size, int domain_type, const uint8_t *d_salts, size_t salt_bytes,
+                            uint8_t *d_nodes)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_oracles || num_oracles == 0 || !d_nodes) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (elem_bytes == 0 || (elem_bytes & 7)) return fail(IOPX_ERR_INVALID_ARGUMENT, "element size %zu is not a multiple of 8 bytes", elem_bytes);
+    if (domain_type != IOPX_DOMAIN_ADDITIVE && domain_type != IOPX_DOMAIN_MULTIPLICATIVE)
+        return fail(IOPX_ERR_INVALID_ARGUMENT, "unsupported domain type %d", domain_type);
+    if (coset_size == 0 || n % coset_size) return fail(IOPX_ERR_LOGIC, "Attempting to construct a Merkle tree with a constituent vector of wrong size");
+    const size_t L = n / coset_size;
+    if (L < 2 || (L & (L - 1))) return fail(IOPX_ERR_INVALID_ARGUMENT, "Merkle tree size must be a power of two, and at least 2.");
+    if (d_salts && salt_bytes > 96) return fail(IOPX_ERR_INVALID_ARGUMENT, "zk salt of %zu bytes does not fit one BLAKE2b block", salt_bytes);
+
+    DevBuf dptrs;
+    if ((rc = dptrs.alloc(num_oracles * sizeof(void *))) != IOPX_OK) return rc;
+    IOPX_HIP(hipMemcpyAsync(dptrs.p, d_oracles, num_oracles * sizeof(void *), hipMemcpyHostToDevice, stream()));
+
+    LeafParams p;
+    p.oracles = (const uint64_t *const *)dptrs.p;
+    p.salts = (const uint64_t *)d_salts;
+    p.nodes = (uint64_t *)d_nodes;
+    p.num_oracles = num_oracles; p.elem_words = elem_bytes / 8; p.n = n; p.coset_size = coset_size; p.num_leaves = L;
+    p.salt_bytes = salt_bytes;
+    p.additive = (domain_type == IOPX_DOMAIN_ADDITIVE);
+    size_t grid = (L + 255) / 256;
+    if (grid > 65536) grid = 65536;
+    { ProfScope ps_("k_merkle_leaves"); hipLaunchKernelGGL(k_merkle_leaves, dim3((unsigned)grid), dim3(256), 0, stream(), p); }
+
+    // inner levels: L/2, L/4, ... nodes; the last levels (<= 1024 nodes) in one workgroup
+    size_t count = L / 2;
+    while (count > 1024) {
+        size_t g = (count + 255) / 256;
+        if (g > 65536) g = 65536;
+        { ProfScope ps_("k_merkle_level"); hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)g), dim3(256), 0, stream(), (uint64_t *)d_nodes, count - 1, count); }
+        count >>= 1;
+    }
+    { ProfScope ps_("k_merkle_top"); hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(count >= 256 ? 256 : 64), 0, stream(), (uint64_t *)d_nodes, count); }
+    IOPX_HIP(hipGetLastError());
+    IOPX_HIP(hipStreamSynchronize(stream()));       // pointer table is freed on return
+    return IOPX_OK;
+}
+
+int iopx_merkle_blake2b(const void *const *oracles, size_t num_oracles, size_t elem_bytes, size_t n,
+                        size_t coset_size, int domain_type, const uint8_t *salts, size_t salt_bytes,
+                        uint8_t *nodes)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!oracles || num_oracles == 0 || !nodes) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (coset_size == 0 || n % coset_size) return fail(IOPX_ERR_LOGIC, "Attempting to construct a Merkle tree with a constituent vector of wrong size");
+    const size_t L = n / coset_size;
+    if (L < 2 || (L & (L - 1))) return fail(IOPX_ERR_INVALID_ARGUMENT, "Merkle tree size must be a power of two, and at least 2.");
+    std::vector<std::unique_ptr<DevBuf>> bufs;
+    std::vector<const void *> dptrs;
+    for (size_t k = 0; k < num_oracles; ++k) {
+        bufs.emplace_back(new DevBuf());
+        if ((rc = bufs.back()->alloc(n * elem_bytes)) != IOPX_OK) return rc;
+        IOPX_HIP(hipMemcpyAsync(bufs.back()->p, oracles[k], n * elem_bytes, hipMemcpyHostToDevice, stream()));
+        dptrs.push_back(bufs.back()->p);
+    }
+    DevBuf dsalt, dnodes;
+    if (salts) {
+        if ((rc = dsalt.alloc(L * salt_bytes)) != IOPX_OK) return rc;
+        IOPX_HIP(hipMemcpyAsync(dsalt.p, salts, L * salt_bytes, hipMemcpyHostToDevice, stream()));
+    }
+    if ((rc = dnodes.alloc((2 * L - 1) * 32)) != IOPX_OK) return rc;
+    rc = iopx_merkle_blake2b_dev(dptrs.data(), num_oracles, elem_bytes, n, coset_size, domain_type,
+                                 salts ? (const uint8_t *)dsalt.p : nullptr, salt_bytes, (uint8_t *)dnodes.p);
+    if (rc != IOPX_OK) return rc;
+    IOPX_HIP(hipMemcpyAsync(nodes, dnodes.p, (2 * L - 1) * 32, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(hipStreamSynchronize(stream()));
+    return IOPX_OK;
+}
+
+} // extern "C"

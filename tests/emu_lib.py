@@ -1,0 +1,18 @@
+"""TEST INFRASTRUCTURE ONLY: builds and loads tests/emu/libiopx_emu.so — the product kernel sources compiled
+for the CPU with one thread per workgroup (see tests/emu/fakehip/hip/hip_runtime.h).  Wrapped by the
+same ctypes binding class as the product library so the tests call the C ABI exactly as on the GPU."""
+import os
+import subprocess
+
+import libiop_amd
+
+_EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+_emu = None
+
+
+def emu():
+    global _emu
+    if _emu is None:
+        subprocess.check_call(["make", "-s", "-C", _EMU_DIR])
+        _emu = libiop_amd.Library(os.path.join(_EMU_DIR, "libiopx_emu.so"))
+    return _emu

@@ -1,0 +1,177 @@
+"""Parity tests proper: the HIP path, called through the C ABI on a real MI355X, against the CPU oracle
+(bit-exact) on seeded inputs, plus size-independent properties at BASELINE.json's full sizes."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import rand_elems
+
+pytestmark = pytest.mark.gpu
+W = 3
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import libiop_amd
+    lib = libiop_amd.lib()          # raises if the HIP library is missing: no fallback
+    lib.init(0)
+    return lib
+
+
+def _dom(m, kind, seed):
+    if kind == "std0":
+        return oracle.standard_basis(m, W), np.zeros(W, dtype=np.uint64)
+    if kind == "aurora":
+        return oracle.standard_basis(m, W), np.array([1 << m, 0, 0], dtype=np.uint64)
+    return rand_elems(seed + 1, m, W), rand_elems(seed, 1, W)[0]
+
+
+def test_field_mul(gpu):
+    a, b = rand_elems(1, 1 << 16, W), rand_elems(2, 1 << 16, W)
+    a[0] = 0xFFFFFFFFFFFFFFFF
+    b[0] = 0xFFFFFFFFFFFFFFFF
+    a[1] = 0
+    a[2] = 0
+    a[2, 2] = 1 << 63
+    b[2] = 0
+    b[2, 0] = 2
+    assert np.array_equal(gpu.gf192_mul(a, b), oracle.gf_mul(a, b))
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 6, 10, 11, 12, 13, 16, 18])
+@pytest.mark.parametrize("kind", ["std0", "aurora", "general"])
+def test_fft_full_size(gpu, m, kind):
+    basis, shift = _dom(m, kind, 100 + m)
+    coeffs = rand_elems(m, 1 << m, W)
+    assert np.array_equal(gpu.additive_FFT(coeffs, basis, shift), oracle.additive_fft(coeffs, basis, shift))
+
+
+@pytest.mark.parametrize("m,ncoef", [(4, 0), (4, 1), (6, 5), (10, 255), (13, 300), (15, 4096), (17, 8195), (18, 1 << 13), (20, (1 << 15) - 1)])
+def test_fft_lde(gpu, m, ncoef):
+    basis, shift = _dom(m, "aurora", 7)
+    coeffs = rand_elems(m + ncoef, ncoef, W)
+    assert np.array_equal(gpu.additive_FFT(coeffs, basis, shift), oracle.additive_fft(coeffs, basis, shift))
+
+
+@pytest.mark.parametrize("m", [1, 2, 5, 11, 12, 13, 16, 18])
+@pytest.mark.parametrize("kind", ["std0", "general"])
+def test_ifft(gpu, m, kind):
+    basis, shift = _dom(m, kind, 200 + m)
+    evals = rand_elems(300 + m, 1 << m, W)
+    assert np.array_equal(gpu.additive_IFFT(evals, basis, shift), oracle.additive_ifft(evals, basis, shift))
+
+
+def test_ifft_known_degree(gpu):
+    m, deg = 14, 3000
+    basis, shift = _dom(m, "aurora", 5)
+    evals = oracle.additive_fft(rand_elems(1, deg, W), basis, shift)
+    assert np.array_equal(gpu.IFFT_of_known_degree(evals, deg, basis, shift), oracle.additive_ifft_known_degree(evals, deg, basis, shift))
+
+
+@pytest.mark.parametrize("m,cs", [(1, 2), (3, 2), (6, 4), (8, 8), (14, 2), (14, 4), (7, 1), (16, 4)])
+@pytest.mark.parametrize("kind", ["std0", "general"])
+def test_fri_fold(gpu, m, cs, kind):
+    basis, shift = _dom(m, kind, 400 + m)
+    f = rand_elems(500 + m, 1 << m, W)
+    x = rand_elems(600 + m, 1, W)[0]
+    assert np.array_equal(gpu.evaluate_next_f_i_over_entire_domain(f, basis, shift, cs, x),
+                          oracle.fri_fold_additive(f, basis, shift, cs, x))
+
+
+def test_fri_fold_x_in_domain(gpu):
+    m, cs = 6, 4
+    basis, shift = _dom(m, "general", 9)
+    f = rand_elems(1, 1 << m, W)
+    pts = oracle.all_subset_sums(basis, shift)
+    for idx in (0, 13, 63):
+        assert np.array_equal(gpu.evaluate_next_f_i_over_entire_domain(f, basis, shift, cs, pts[idx]),
+                              oracle.fri_fold_additive(f, basis, shift, cs, pts[idx]))
+
+
+def test_fri_chain_cfg3_shape_small(gpu):
+    # the cfg3 round structure ([1,2,2,...], fri_ldt.tcc:132-146) on a dim-12 codeword, derived domains included
+    m, rs = 12, 2
+    loc = oracle.localization_array(2, m, rs)
+    basis, shift = _dom(m, "std0", 0)
+    doms = oracle.fri_domains_additive(basis, shift, loc)
+    cw_g = cw_o = oracle.additive_fft(rand_elems(3, 1 << (m - rs), W), basis, shift)
+    cb, cs_ = basis, shift
+    for i, eta in enumerate(loc):
+        x = rand_elems(900 + i, 1, W)[0]
+        cw_g = gpu.evaluate_next_f_i_over_entire_domain(cw_g, cb, cs_, 1 << eta, x)
+        cw_o = oracle.fri_fold_additive(cw_o, cb, cs_, 1 << eta, x)
+        assert np.array_equal(cw_g, cw_o)
+        cb, cs_ = doms[i]
+
+
+@pytest.mark.parametrize("additive", [True, False])
+@pytest.mark.parametrize("r,cs,L", [(1, 1, 2), (1, 2, 16), (4, 2, 64), (1, 4, 32), (12, 2, 8), (2, 8, 4), (4, 2, 1 << 15), (1, 2, 1 << 17)])
+def test_merkle(gpu, additive, r, cs, L):
+    n = L * cs
+    oracles = [rand_elems(700 + k, n, W) for k in range(r)]
+    got = gpu.merkle_tree(oracles, cs, 0 if additive else 1)
+    assert np.array_equal(got, oracle.merkle_build(oracles, cs, additive))
+
+
+def test_merkle_zk_and_errors(gpu):
+    oracles = [rand_elems(5, 64, W)]
+    salts = np.random.default_rng(3).integers(0, 256, size=(32, 32), dtype=np.uint8)
+    assert np.array_equal(gpu.merkle_tree(oracles, 2, 0, salts), oracle.merkle_build(oracles, 2, True, salts))
+    with pytest.raises(ValueError):
+        gpu.merkle_tree([rand_elems(1, 2, W)], 2)
+    with pytest.raises(ValueError):
+        gpu.additive_FFT(rand_elems(1, 9, W), oracle.standard_basis(3, W), np.zeros(W, dtype=np.uint64))
+
+
+# ---- full-size properties (BASELINE.json configs 2 / 3: sizes the oracle cannot sweep in seconds) --------
+def _horner_at(coeffs, x):
+    acc = np.zeros((1, W), dtype=np.uint64)
+    # Horner in chunks through the oracle's elementwise multiply would be slow; evaluate via powers instead
+    n = coeffs.shape[0]
+    pw = np.zeros((n, W), dtype=np.uint64)
+    pw[0, 0] = 1
+    cur = 1
+    xs = x[None, :]
+    step = xs.copy()
+    while cur < n:                      # pw[cur + i] = pw[i] * x^cur
+        k = min(cur, n - cur)
+        pw[cur:cur + k] = oracle.gf_mul(pw[:k], np.repeat(step, k, axis=0))
+        step = oracle.gf_mul(step, step)
+        cur *= 2
+    prod = oracle.gf_mul(coeffs, pw)
+    return np.bitwise_xor.reduce(prod, axis=0)
+
+
+def test_cfg2_full_size_properties(gpu):
+    m = 22
+    basis, shift = _dom(m, "std0", 0)
+    coeffs = rand_elems(0x2201, 1 << m, W)
+    ev = gpu.additive_FFT(coeffs, basis, shift)
+    # (1) spot values against Horner at the reference's point order (utils.tcc:8-30): index i <-> element i
+    for idx in (0, 1, 2, 12345, (1 << m) - 1, 1 << 21):
+        pt = np.array([idx, 0, 0], dtype=np.uint64)
+        assert np.array_equal(ev[idx], _horner_at(coeffs, pt)), idx
+    # (2) interpolate(evaluate) == id
+    assert np.array_equal(gpu.additive_IFFT(ev, basis, shift), coeffs)
+    # (3) GF(2)-linearity
+    c2 = rand_elems(7, 1 << m, W)
+    ev2 = gpu.additive_FFT(c2, basis, shift)
+    assert np.array_equal(gpu.additive_FFT(coeffs ^ c2, basis, shift), ev ^ ev2)
+
+
+def test_cfg3_fold_preserves_low_degree_at_full_size(gpu):
+    # degree-2^20 codeword over 2^22 points, first two FRI rounds (eta = 1, 2): the folded word must again be
+    # a codeword of the halved / quartered degree over the derived domain (checked by GPU IFFT: high coeffs zero)
+    m, d = 22, 20
+    basis, shift = _dom(m, "std0", 0)
+    cw = gpu.additive_FFT(rand_elems(0x2203, 1 << d, W), basis, shift)
+    loc = [1, 2]
+    doms = oracle.fri_domains_additive(basis, shift, loc)
+    cb, cs_, deg = basis, shift, 1 << d
+    for i, eta in enumerate(loc):
+        x = rand_elems(50 + i, 1, W)[0]
+        cw = gpu.evaluate_next_f_i_over_entire_domain(cw, cb, cs_, 1 << eta, x)
+        cb, cs_ = doms[i]
+        deg >>= eta
+        co = gpu.additive_IFFT(cw, cb, cs_)
+        assert not co[deg:].any()

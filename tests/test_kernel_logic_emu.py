@@ -1,0 +1,101 @@
+"""Kernel logic of the product sources, executed on the CPU (one thread per workgroup, tests/emu) and
+compared bit-for-bit with the oracle.  The same comparisons run on the real GPU in tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import oracle
+from emu_lib import emu
+from helpers import rand_elems
+
+W = 3
+
+
+def test_field_mul():
+    a, b = rand_elems(1, 500, W), rand_elems(2, 500, W)
+    a[0] = 0xFFFFFFFFFFFFFFFF
+    b[0] = 0xFFFFFFFFFFFFFFFF
+    a[1] = 0
+    assert np.array_equal(emu().gf192_mul(a, b), oracle.gf_mul(a, b))
+
+
+def _dom(m, kind, seed):
+    if kind == "std0":
+        return oracle.standard_basis(m, W), np.zeros(W, dtype=np.uint64)
+    if kind == "aurora":      # standard basis, shift x^m (aurora_iop.tcc:282-287)
+        return oracle.standard_basis(m, W), np.array([1 << m, 0, 0], dtype=np.uint64)
+    if kind == "stdrand":
+        return oracle.standard_basis(m, W), rand_elems(seed, 1, W)[0]
+    return rand_elems(seed + 1, m, W), rand_elems(seed, 1, W)[0]      # general basis (FRI-derived style)
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 5, 8, 11, 12, 13])
+@pytest.mark.parametrize("kind", ["std0", "aurora", "stdrand", "general"])
+def test_fft_full_size(m, kind):
+    if m >= 12 and kind in ("aurora", "stdrand"):
+        pytest.skip("covered by std0/general at this size")
+    basis, shift = _dom(m, kind, 100 + m)
+    coeffs = rand_elems(m, 1 << m, W)
+    assert np.array_equal(emu().additive_FFT(coeffs, basis, shift), oracle.additive_fft(coeffs, basis, shift))
+
+
+@pytest.mark.parametrize("m,ncoef", [(4, 0), (4, 1), (6, 2), (6, 5), (8, 16), (8, 100), (10, 255), (13, 300), (14, 4096), (15, 4097 * 2)])
+def test_fft_lde(m, ncoef):
+    basis, shift = _dom(m, "aurora", 7)
+    coeffs = rand_elems(m + ncoef, ncoef, W)
+    assert np.array_equal(emu().additive_FFT(coeffs, basis, shift), oracle.additive_fft(coeffs, basis, shift))
+
+
+@pytest.mark.parametrize("m", [1, 2, 4, 7, 11, 12, 13])
+@pytest.mark.parametrize("kind", ["std0", "general"])
+def test_ifft(m, kind):
+    basis, shift = _dom(m, kind, 200 + m)
+    evals = rand_elems(300 + m, 1 << m, W)
+    assert np.array_equal(emu().additive_IFFT(evals, basis, shift), oracle.additive_ifft(evals, basis, shift))
+
+
+def test_ifft_known_degree():
+    m, deg = 9, 70
+    basis, shift = _dom(m, "stdrand", 5)
+    evals = oracle.additive_fft(rand_elems(1, deg, W), basis, shift)
+    assert np.array_equal(emu().IFFT_of_known_degree(evals, deg, basis, shift), oracle.additive_ifft_known_degree(evals, deg, basis, shift))
+
+
+@pytest.mark.parametrize("m,cs", [(1, 2), (3, 2), (6, 4), (8, 8), (10, 2), (10, 4), (7, 1)])
+@pytest.mark.parametrize("kind", ["std0", "general"])
+def test_fri_fold(m, cs, kind):
+    basis, shift = _dom(m, kind, 400 + m)
+    f = rand_elems(500 + m, 1 << m, W)
+    x = rand_elems(600 + m, 1, W)[0]
+    assert np.array_equal(emu().evaluate_next_f_i_over_entire_domain(f, basis, shift, cs, x),
+                          oracle.fri_fold_additive(f, basis, shift, cs, x))
+
+
+def test_fri_fold_x_in_domain():
+    m, cs = 6, 4
+    basis, shift = _dom(m, "general", 9)
+    f = rand_elems(1, 1 << m, W)
+    pts = oracle.all_subset_sums(basis, shift)
+    for idx in (0, 13, 63):
+        assert np.array_equal(emu().evaluate_next_f_i_over_entire_domain(f, basis, shift, cs, pts[idx]),
+                              oracle.fri_fold_additive(f, basis, shift, cs, pts[idx]))
+
+
+@pytest.mark.parametrize("additive", [True, False])
+@pytest.mark.parametrize("r,cs,L", [(1, 1, 2), (1, 2, 16), (4, 2, 64), (1, 4, 32), (12, 2, 8), (2, 8, 4), (3, 2, 4096)])
+def test_merkle(additive, r, cs, L):
+    n = L * cs
+    oracles = [rand_elems(700 + k, n, W) for k in range(r)]
+    got = emu().merkle_tree(oracles, cs, 0 if additive else 1)
+    assert np.array_equal(got, oracle.merkle_build(oracles, cs, additive))
+
+
+def test_merkle_zk_and_errors():
+    oracles = [rand_elems(5, 64, W)]
+    salts = np.random.default_rng(3).integers(0, 256, size=(32, 32), dtype=np.uint8)
+    assert np.array_equal(emu().merkle_tree(oracles, 2, 0, salts), oracle.merkle_build(oracles, 2, True, salts))
+    with pytest.raises(ValueError):             # merkle_tree.tcc:27-31 -> std::invalid_argument
+        emu().merkle_tree([rand_elems(1, 2, W)], 2)
+    with pytest.raises(ValueError):
+        emu().merkle_tree([rand_elems(1, 12, W)], 2)
+    with pytest.raises(ValueError):             # more coefficients than the domain holds
+        emu().additive_FFT(rand_elems(1, 9, W), oracle.standard_basis(3, W), np.zeros(W, dtype=np.uint64))
