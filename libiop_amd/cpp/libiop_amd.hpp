@@ -1,0 +1,249 @@
+// Host-side C++ mirror of the reference's template API for the accelerated path.
+//
+// The reference is header-only C++14 templates over FieldT (no FFI).  This header restates the
+// signatures of the seams that the hot path sits behind — same names, argument meaning and exception
+// types — and forwards them to the C ABI of include/libiop_amd.h for any FieldT whose in-memory
+// layout is libff::gf192's (three little-endian uint64 words; checked with static_assert):
+//
+//   affine_subspace<FieldT>, field_subset<FieldT>          libiop/algebra/field_subset/{subspace,field_subset}.hpp
+//   additive_FFT / additive_IFFT                           libiop/algebra/fft.hpp:28-38   (fft.tcc:39-204)
+//   FFT_over_field_subset / IFFT_over_field_subset /
+//   IFFT_of_known_degree_over_field_subset                 libiop/algebra/fft.hpp:62-88   (fft.tcc:407-475)
+//   evaluate_next_f_i_over_entire_domain                   libiop/protocols/ldt/fri/fri_aux.hpp:23-28
+//   merkle_tree<FieldT, binary_hash_digest>                libiop/bcs/merkle_tree.hpp:67-104 (construct*, get_root)
+//
+// INTEGRATION.md shows how libiop's own headers bind to this instead of their CPU bodies.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/libiop_amd.h"
+
+namespace libiop_amd {
+
+inline void check(int rc)
+{
+    if (rc == IOPX_OK) return;
+    const std::string msg = iopx_last_error();
+    if (rc == IOPX_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
+    if (rc == IOPX_ERR_LOGIC) throw std::logic_error(msg);
+    throw std::runtime_error(msg);
+}
+
+template<typename FieldT>
+struct is_gf192_layout {
+    static const bool value = (sizeof(FieldT) == 24);
+};
+
+enum field_subset_type { affine_subspace_type = 1, multiplicative_coset_type = 2 };
+
+// libiop/algebra/field_subset/subspace.hpp — basis + shift; index i <-> shift + sum_{bit k of i} basis[k]
+template<typename FieldT>
+class affine_subspace {
+    std::vector<FieldT> basis_;
+    FieldT shift_;
+public:
+    affine_subspace() : shift_(FieldT(0)) {}
+    affine_subspace(const std::vector<FieldT> &basis, const FieldT &shift = FieldT(0)) : basis_(basis), shift_(shift) {}
+
+    std::size_t dimension() const { return basis_.size(); }
+    std::size_t num_elements() const { return (std::size_t)1 << basis_.size(); }
+    const std::vector<FieldT> &basis() const { return basis_; }
+    const FieldT &shift() const { return shift_; }
+
+    // subspace.tcc:93-108 — default (standard) basis FieldT(1ull << i)
+    static affine_subspace shifted_standard_basis(std::size_t dimension, const FieldT &shift)
+    {
+        std::vector<FieldT> b;
+        for (std::size_t i = 0; i < dimension; ++i) b.emplace_back(FieldT((uint64_t)1 << i));
+        return affine_subspace(b, shift);
+    }
+
+    FieldT element_by_index(std::size_t index) const
+    {
+        if (index >= num_elements()) throw std::invalid_argument("element index out of bounds");
+        FieldT r = shift_;
+        for (std::size_t i = 0; i < basis_.size(); ++i) if (index & ((std::size_t)1 << i)) r += basis_[i];
+        return r;
+    }
+    // subspace.tcc:73-91
+    std::size_t coset_index(std::size_t position, std::size_t coset_size) const { return position / coset_size; }
+    std::size_t intra_coset_index(std::size_t position, std::size_t coset_size) const { return position % coset_size; }
+    std::size_t position_by_coset_indices(std::size_t ci, std::size_t ici, std::size_t coset_size) const { return ci * coset_size + ici; }
+};
+
+// libiop/algebra/field_subset/field_subset.hpp — tagged union; only the additive arm is accelerated so far
+template<typename FieldT>
+class field_subset {
+    field_subset_type type_;
+    std::shared_ptr<affine_subspace<FieldT>> subspace_;
+public:
+    field_subset() : type_(affine_subspace_type) {}
+    field_subset(const affine_subspace<FieldT> &s) : type_(affine_subspace_type), subspace_(std::make_shared<affine_subspace<FieldT>>(s)) {}
+    // field_subset.tcc:3-22 (additive fields): default domain of that size = standard basis, given shift
+    field_subset(std::size_t num_elements, const FieldT &shift = FieldT(0)) : type_(affine_subspace_type)
+    {
+        std::size_t d = 0;
+        while (((std::size_t)1 << d) < num_elements) ++d;
+        if (((std::size_t)1 << d) != num_elements) throw std::invalid_argument("field_subset: size must be a power of two");
+        subspace_ = std::make_shared<affine_subspace<FieldT>>(affine_subspace<FieldT>::shifted_standard_basis(d, shift));
+    }
+
+    field_subset_type type() const { return type_; }
+    const affine_subspace<FieldT> &subspace() const { return *subspace_; }
+    std::size_t dimension() const { return subspace_->dimension(); }
+    std::size_t num_elements() const { return subspace_->num_elements(); }
+    const std::vector<FieldT> &basis() const { return subspace_->basis(); }
+    const FieldT &shift() const { return subspace_->shift(); }
+    FieldT element_by_index(std::size_t i) const { return subspace_->element_by_index(i); }
+
+    // field_subset.tcc:217-237: first log2(order) basis vectors, same shift
+    field_subset get_subset_of_order(std::size_t order) const
+    {
+        std::size_t d = 0;
+        while (((std::size_t)1 << d) < order) ++d;
+        if (d > dimension()) throw std::invalid_argument("subset order exceeds the domain");
+        return field_subset(affine_subspace<FieldT>(std::vector<FieldT>(basis().begin(), basis().begin() + d), shift()));
+    }
+    std::size_t coset_index(std::size_t p, std::size_t cs) const { return subspace_->coset_index(p, cs); }
+    std::size_t intra_coset_index(std::size_t p, std::size_t cs) const { return subspace_->intra_coset_index(p, cs); }
+    std::size_t position_by_coset_indices(std::size_t ci, std::size_t ici, std::size_t cs) const { return subspace_->position_by_coset_indices(ci, ici, cs); }
+    std::vector<std::size_t> all_positions_in_coset_i(std::size_t ci, std::size_t cs) const      // field_subset.tcc:187-198
+    {
+        std::vector<std::size_t> out;
+        for (std::size_t i = 0; i < cs; ++i) out.emplace_back(position_by_coset_indices(ci, i, cs));
+        return out;
+    }
+};
+
+namespace detail {
+template<typename FieldT>
+inline const uint64_t *words(const FieldT *p) { return reinterpret_cast<const uint64_t *>(p); }
+template<typename FieldT>
+inline uint64_t *words(FieldT *p) { return reinterpret_cast<uint64_t *>(p); }
+} // namespace detail
+
+// ---- FFT / IFFT (libiop/algebra/fft.hpp) ----------------------------------------------------------
+template<typename FieldT>
+std::vector<FieldT> additive_FFT(const std::vector<FieldT> &poly_coeffs, const affine_subspace<FieldT> &domain)
+{
+    static_assert(is_gf192_layout<FieldT>::value, "libiop_amd accelerates fields with libff::gf192's layout");
+    std::vector<FieldT> out(domain.num_elements(), FieldT(0));
+    check(iopx_add_fft_gf192(detail::words(poly_coeffs.data()), poly_coeffs.size(), detail::words(domain.basis().data()),
+                             domain.dimension(), detail::words(&domain.shift()), detail::words(out.data())));
+    return out;
+}
+
+template<typename FieldT>
+std::vector<FieldT> additive_IFFT(const std::vector<FieldT> &evals, const affine_subspace<FieldT> &domain)
+{
+    static_assert(is_gf192_layout<FieldT>::value, "libiop_amd accelerates fields with libff::gf192's layout");
+    if (evals.size() != domain.num_elements()) throw std::invalid_argument("additive_IFFT: evaluation count != domain size");
+    std::vector<FieldT> out(domain.num_elements(), FieldT(0));
+    check(iopx_add_ifft_gf192(detail::words(evals.data()), detail::words(domain.basis().data()), domain.dimension(),
+                              detail::words(&domain.shift()), detail::words(out.data())));
+    return out;
+}
+
+// fft.tcc:414-419, 428-433 — by-value signatures kept
+template<typename FieldT>
+std::vector<FieldT> FFT_over_field_subset(const std::vector<FieldT> coeffs, field_subset<FieldT> domain)
+{
+    return additive_FFT<FieldT>(coeffs, domain.subspace());
+}
+
+template<typename FieldT>
+std::vector<FieldT> IFFT_over_field_subset(const std::vector<FieldT> evals, field_subset<FieldT> domain)
+{
+    return additive_IFFT<FieldT>(evals, domain.subspace());
+}
+
+// fft.tcc:458-475
+template<typename FieldT>
+std::vector<FieldT> IFFT_of_known_degree_over_field_subset(const std::vector<FieldT> evals, std::size_t degree, field_subset<FieldT> domain)
+{
+    std::size_t pow2 = 1;
+    while (pow2 < degree) pow2 <<= 1;
+    const field_subset<FieldT> minimal = domain.get_subset_of_order(pow2);
+    const std::vector<FieldT> head(evals.begin(), evals.begin() + pow2);
+    return additive_IFFT<FieldT>(head, minimal.subspace());
+}
+
+// ---- FRI fold (libiop/protocols/ldt/fri/fri_aux.hpp:23-28) ----------------------------------------
+template<typename FieldT>
+std::shared_ptr<std::vector<FieldT>> evaluate_next_f_i_over_entire_domain(
+    const std::shared_ptr<std::vector<FieldT>> &f_i_evals, const field_subset<FieldT> &f_i_domain,
+    const std::size_t coset_size, const FieldT x_i)
+{
+    static_assert(is_gf192_layout<FieldT>::value, "libiop_amd accelerates fields with libff::gf192's layout");
+    if (f_i_domain.type() != affine_subspace_type) throw std::invalid_argument("f_i_domain is of unsupported domain type");
+    if (f_i_evals->size() != f_i_domain.num_elements()) throw std::invalid_argument("f_i size != domain size");
+    auto next = std::make_shared<std::vector<FieldT>>(f_i_domain.num_elements() / coset_size, FieldT(0));
+    check(iopx_fri_fold_add_gf192(detail::words(f_i_evals->data()), detail::words(f_i_domain.basis().data()), f_i_domain.dimension(),
+                                  detail::words(&f_i_domain.shift()), coset_size, detail::words(&x_i), detail::words(next->data())));
+    return next;
+}
+
+// ---- Merkle tree (libiop/bcs/merkle_tree.hpp) -----------------------------------------------------
+typedef std::string binary_hash_digest;       // libiop/bcs/hashing/hashing.hpp:21
+
+template<typename FieldT>
+class merkle_tree {
+    std::size_t num_leaves_;
+    std::size_t digest_len_bytes_;
+    bool make_zk_;
+    bool constructed_;
+    std::vector<uint8_t> nodes_;               // (2L-1) * 32, heap order (merkle_tree.tcc:114,145)
+    std::vector<uint8_t> zk_salts_;
+    std::size_t salt_bytes_;
+public:
+    // merkle_tree.tcc:12-33 (leaf / node hashers are BLAKE2b: hash_enum.tcc:112-165 with blake2b_type)
+    merkle_tree(std::size_t num_leaves, std::size_t digest_len_bytes = 32, bool make_zk = false, std::size_t security_parameter = 128)
+        : num_leaves_(num_leaves), digest_len_bytes_(digest_len_bytes), make_zk_(make_zk), constructed_(false),
+          salt_bytes_((security_parameter * 2 + 7) / 8)
+    {
+        if (num_leaves < 2 || (num_leaves & (num_leaves - 1)))
+            throw std::invalid_argument("Merkle tree size must be a power of two, and at least 2.");
+        if (digest_len_bytes != 32) throw std::invalid_argument("libiop_amd: only 32-byte BLAKE2b digests are supported");
+    }
+
+    // zk salts are sampled by the caller (merkle_tree.tcc:36-72 uses libsodium randombytes)
+    void set_leaf_randomness(const std::vector<uint8_t> &salts) { zk_salts_ = salts; }
+
+    void construct_with_leaves_serialized_by_cosets(const std::vector<std::shared_ptr<std::vector<FieldT>>> &leaf_contents,
+                                                    std::size_t coset_serialization_size)
+    {
+        if (constructed_) throw std::logic_error("Attempting to double-construct a Merkle tree.");
+        for (auto &v : leaf_contents)
+            if ((v->size() / coset_serialization_size) != num_leaves_)
+                throw std::logic_error("Attempting to construct a Merkle tree with a constituent vector of wrong size");
+        if (make_zk_ && zk_salts_.size() != num_leaves_ * salt_bytes_) throw std::logic_error("zk Merkle tree without leaf randomness");
+        std::vector<const void *> ptrs;
+        for (auto &v : leaf_contents) ptrs.push_back(v->data());
+        nodes_.assign((2 * num_leaves_ - 1) * 32, 0);
+        check(iopx_merkle_blake2b(ptrs.data(), ptrs.size(), sizeof(FieldT), leaf_contents[0]->size(), coset_serialization_size,
+                                  IOPX_DOMAIN_ADDITIVE, make_zk_ ? zk_salts_.data() : nullptr, make_zk_ ? salt_bytes_ : 0, nodes_.data()));
+        constructed_ = true;
+    }
+    void construct(const std::vector<std::shared_ptr<std::vector<FieldT>>> &leaf_contents)
+    {
+        construct_with_leaves_serialized_by_cosets(leaf_contents, 1);
+    }
+
+    binary_hash_digest get_root() const
+    {
+        if (!constructed_) throw std::logic_error("Attempting to obtain a Merkle tree root without constructing the tree first.");
+        return binary_hash_digest(reinterpret_cast<const char *>(nodes_.data()), 32);
+    }
+    binary_hash_digest node(std::size_t heap_index) const
+    {
+        return binary_hash_digest(reinterpret_cast<const char *>(nodes_.data()) + 32 * heap_index, 32);
+    }
+    std::size_t num_leaves() const { return num_leaves_; }
+};
+
+} // namespace libiop_amd

@@ -1,0 +1,88 @@
+// Drives the C++ mirror of the reference's template API (libiop_amd/cpp/libiop_amd.hpp) the way the
+// reference's own tests drive libiop (libiop/tests/algebra/test_fft.cpp:27-52,
+// tests/protocols/test_fri_aux.cpp:16-45, tests/bcs/test_merkle_tree.cpp:47-94), with FieldT = the
+// oracle's gf192 (same 24-byte layout as libff::gf192) and the oracle as the checker.
+//   test_shim nodevice : every operator must throw std::runtime_error on a host without a GPU
+//   test_shim gpu      : parity on a real MI355X
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <string>
+
+#include "../../libiop_amd/cpp/libiop_amd.hpp"
+#include "../../oracle/field.hpp"
+#include "../../oracle/algebra.hpp"
+#include "../../oracle/fri.hpp"
+#include "../../oracle/merkle.hpp"
+
+typedef oracle::gf192 FieldT;
+
+static std::mt19937_64 rng(12345);
+static FieldT rnd() { FieldT r; for (int i = 0; i < 3; ++i) r.w[i] = rng(); return r; }
+static std::vector<FieldT> rnd_vec(size_t n) { std::vector<FieldT> v; for (size_t i = 0; i < n; ++i) v.push_back(rnd()); return v; }
+
+#define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } } while (0)
+
+static int run_nodevice()
+{
+    const libiop_amd::affine_subspace<FieldT> dom = libiop_amd::affine_subspace<FieldT>::shifted_standard_basis(3, FieldT(0));
+    bool threw = false;
+    try { libiop_amd::additive_FFT<FieldT>(rnd_vec(8), dom); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+    threw = false;
+    try { libiop_amd::merkle_tree<FieldT> t(3); } catch (const std::invalid_argument &) { threw = true; }   // merkle_tree.tcc:27-31
+    CHECK(threw);
+    libiop_amd::merkle_tree<FieldT> t(4);
+    threw = false;
+    try { t.get_root(); } catch (const std::logic_error &) { threw = true; }                                 // merkle_tree.tcc:234-237
+    CHECK(threw);
+    printf("nodevice ok\n");
+    return 0;
+}
+
+static int run_gpu()
+{
+    for (size_t m = 1; m <= 11; ++m) {       // test_fft.cpp:27-52 (standard basis + random shift)
+        const FieldT shift = rnd();
+        const libiop_amd::field_subset<FieldT> domain(libiop_amd::affine_subspace<FieldT>::shifted_standard_basis(m, shift));
+        const oracle::affine_subspace<FieldT> odom = oracle::affine_subspace<FieldT>::standard(m, shift);
+        const std::vector<FieldT> coeffs = rnd_vec((size_t)1 << m);
+        const std::vector<FieldT> got = libiop_amd::FFT_over_field_subset<FieldT>(coeffs, domain);
+        CHECK(got == oracle::naive_FFT<FieldT>(coeffs, odom.all_elements()));
+        CHECK(libiop_amd::IFFT_over_field_subset<FieldT>(got, domain) == coeffs);
+    }
+    {   // test_fri_aux.cpp:16-45: fold of a degree<4 polynomial is P(x) on every coset
+        const size_t m = 12, cs = 4;
+        const FieldT shift = rnd(), x = rnd();
+        const libiop_amd::field_subset<FieldT> domain(libiop_amd::affine_subspace<FieldT>::shifted_standard_basis(m, shift));
+        const std::vector<FieldT> poly = rnd_vec(cs);
+        auto evals = std::make_shared<std::vector<FieldT>>(libiop_amd::FFT_over_field_subset<FieldT>(poly, domain));
+        FieldT px = FieldT::zero();
+        for (size_t i = cs; i--; ) { px *= x; px += poly[i]; }
+        auto next = libiop_amd::evaluate_next_f_i_over_entire_domain<FieldT>(evals, domain, cs, x);
+        CHECK(next->size() == domain.num_elements() / cs);
+        for (const FieldT &v : *next) CHECK(v == px);
+    }
+    {   // Merkle root == oracle's root; double construct throws (merkle_tree.tcc:98-101)
+        const size_t n = 1 << 10, cs = 2;
+        std::vector<std::shared_ptr<std::vector<FieldT>>> cols;
+        std::vector<const uint8_t *> raw;
+        for (int k = 0; k < 4; ++k) { cols.push_back(std::make_shared<std::vector<FieldT>>(rnd_vec(n))); raw.push_back((const uint8_t *)cols.back()->data()); }
+        libiop_amd::merkle_tree<FieldT> tree(n / cs);
+        tree.construct_with_leaves_serialized_by_cosets(cols, cs);
+        std::vector<uint8_t> nodes((2 * (n / cs) - 1) * 32);
+        oracle::merkle_build(raw.data(), raw.size(), sizeof(FieldT), n, cs, true, nullptr, 0, nodes.data());
+        CHECK(tree.get_root() == std::string((const char *)nodes.data(), 32));
+        bool threw = false;
+        try { tree.construct_with_leaves_serialized_by_cosets(cols, cs); } catch (const std::logic_error &) { threw = true; }
+        CHECK(threw);
+    }
+    printf("gpu ok\n");
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    const std::string mode = argc > 1 ? argv[1] : "nodevice";
+    return mode == "gpu" ? run_gpu() : run_nodevice();
+}

@@ -1,0 +1,37 @@
+"""Builds tests/cpp/test_shim.cpp (the C++ mirror of the reference's template API driven like the reference's
+own gtest files) against the product library; runs the no-device half here and the parity half on the GPU."""
+import os
+import subprocess
+
+import pytest
+
+from libiop_amd import build as iopx_build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "test_shim")
+
+
+def _build():
+    lib = iopx_build.build()
+    src = os.path.join(ROOT, "tests", "cpp", "test_shim.cpp")
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src), os.path.getmtime(lib)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-mpclmul", "-msse4.1", src, "-o", EXE,
+                               "-L" + os.path.dirname(lib), "-liop_amd", "-Wl,-rpath," + os.path.dirname(lib),
+                               "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return EXE
+
+
+def test_cpp_shim_without_device():
+    import libiop_amd
+    exe = _build()
+    if libiop_amd.Library().device_count() > 0:
+        pytest.skip("a GPU is visible")
+    r = subprocess.run([exe, "nodevice"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "nodevice ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_shim_parity_on_gpu():
+    exe = _build()
+    r = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "gpu ok" in r.stdout, r.stdout + r.stderr
