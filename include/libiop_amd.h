@@ -107,6 +107,8 @@ int iopx_profile_report(char *buf, size_t cap);
 /* Elementwise GF(2^192) product on the device (d_out[i] = d_a[i] * d_b[i]); used by the parity tests of
  * the field arithmetic itself and by the field-multiplication micro-benchmark. */
 int iopx_gf192_mul_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count);
+/* d_out[i] = d_a[i] * d_c[0]: the wave-uniform-multiplier path the butterfly kernels use. */
+int iopx_gf192_mul_uniform_dev(const uint64_t *d_a, const uint64_t *d_c, uint64_t *d_out, size_t count);
 
 #ifdef __cplusplus
 }

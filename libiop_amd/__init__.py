@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "iopx_add_fft_gf192_dev", "iopx_add_fft_gf192", "iopx_add_ifft_gf192_dev", "iopx_add_ifft_gf192",
     "iopx_fri_fold_add_gf192_dev", "iopx_fri_fold_add_gf192",
     "iopx_merkle_blake2b_dev", "iopx_merkle_blake2b",
-    "iopx_gf192_mul_dev", "iopx_profile_begin", "iopx_profile_report",
+    "iopx_gf192_mul_dev", "iopx_gf192_mul_uniform_dev", "iopx_profile_begin", "iopx_profile_report",
 ]
 
 
@@ -87,6 +87,7 @@ class Library:
         c.iopx_merkle_blake2b_dev.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _sz, _sz, ctypes.c_int, _vp, _sz, _vp]
         c.iopx_merkle_blake2b.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _sz, _sz, ctypes.c_int, _vp, _sz, _vp]
         c.iopx_gf192_mul_dev.argtypes = [_vp, _vp, _vp, _sz]
+        c.iopx_gf192_mul_uniform_dev.argtypes = [_vp, _vp, _vp, _sz]
 
     # ---- error translation (the exception types the reference throws) ----
     def _check(self, rc):
@@ -233,8 +234,21 @@ class Library:
         self._check(self.c.iopx_gf192_mul_dev(_vp(d_a), _vp(d_b), _vp(d_out), count))
 
     def gf192_mul(self, a, b):
+        """Elementwise a[i] * b[i]; a single-row b selects the wave-uniform multiplier kernel."""
         a, b = _as_u64(a), _as_u64(b)
         n = a.shape[0]
+        if b.shape[0] == 1 and n != 1:
+            da, db, do = self.malloc(a.nbytes), self.malloc(24), self.malloc(a.nbytes)
+            try:
+                self.h2d(da, a)
+                self.h2d(db, b)
+                self._check(self.c.iopx_gf192_mul_uniform_dev(_vp(da), _vp(db), _vp(do), n))
+                out = np.empty_like(a)
+                self.d2h(out, do)
+            finally:
+                for p in (da, db, do):
+                    self.free(p)
+            return out
         da, db, do = self.malloc(a.nbytes), self.malloc(a.nbytes), self.malloc(a.nbytes)
         try:
             self.h2d(da, a)

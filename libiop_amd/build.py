@@ -9,7 +9,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libiop_amd.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-               "-fgpu-rdc" if False else "-fno-gpu-rdc"]
+               "-fno-gpu-rdc", "-I" + os.path.join(CSRC, "include")]
 
 
 def sources():
@@ -20,7 +20,7 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "libiop_amd.h")]
+    deps = [os.path.join(dp, f) for dp, _, fs in os.walk(CSRC) for f in fs] + [os.path.join(_HERE, "..", "include", "libiop_amd.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -159,7 +159,7 @@ struct P1Params {
 };
 
 template<bool INV>
-__global__ void k_phase1(P1Params p)
+__global__ void __launch_bounds__(512) k_phase1(P1Params p)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
     uint64_t *s = iopx_smem;
@@ -261,23 +261,24 @@ __device__ __forceinline__ gf192 bf_twiddle(const BfParams &p, size_t coset, siz
     return tw;
 }
 
+// `uniform`: every lane of the wavefront has the same twiddle (64 consecutive butterflies of one block)
 template<bool INV>
-__device__ __forceinline__ void bf_apply(uint64_t *s, int E, int ia, int ib, const gf192 &tw)
+__device__ __forceinline__ void bf_apply(uint64_t *s, int E, int ia, int ib, const gf192 &tw, bool uniform)
 {
     gf192 a = lds_get(s, E, ia), b = lds_get(s, E, ib);
     if (!INV) {
-        gf_add_to(a, gf_mul(b, tw));        // S[a] += S[b] * t ; S[b] += S[a]     (fft.tcc:116-117)
+        gf_add_to(a, uniform ? gf_mul_uniform(b, tw) : gf_mul(b, tw));  // S[a] += S[b] * t ; S[b] += S[a]  (fft.tcc:116-117)
         gf_add_to(b, a);
     } else {
         gf_add_to(b, a);                    // S[b] += S[a] ; S[a] += S[b] * t     (fft.tcc:164-165)
-        gf_add_to(a, gf_mul(b, tw));
+        gf_add_to(a, uniform ? gf_mul_uniform(b, tw) : gf_mul(b, tw));
     }
     lds_put(s, E, ia, a);
     lds_put(s, E, ib, b);
 }
 
 template<bool INV>
-__global__ void k_bfly_upper(BfParams p)
+__global__ void __launch_bounds__(512) k_bfly_upper(BfParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
     uint64_t *s = iopx_smem;
@@ -307,7 +308,7 @@ __global__ void k_bfly_upper(BfParams p)
             const int low = bf & ((1 << pl) - 1), high = bf >> pl;
             const int ia = (high << (pl + 1)) | low, ib = ia | (1 << pl);
             const size_t u = base | ((size_t)(ia >> p.c) << p.h) | (size_t)(ia & cmask);
-            bf_apply<INV>(s, E, ia, ib, bf_twiddle(p, coset, u, pbit));
+            bf_apply<INV>(s, E, ia, ib, bf_twiddle(p, coset, u, pbit), pl >= 6);
         }
         __syncthreads();
     }
@@ -321,7 +322,7 @@ __global__ void k_bfly_upper(BfParams p)
 // Forward: last pass — pair bits a_low-1 .. 0, then natural-order (bit-reversed) store.
 // Inverse: first pass — natural-order load, pair bits 0 .. a_low-1, block-order store.
 template<bool INV>
-__global__ void k_bfly_edge(BfParams p)
+__global__ void __launch_bounds__(512) k_bfly_edge(BfParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
     uint64_t *s = iopx_smem;
@@ -369,7 +370,7 @@ __global__ void k_bfly_edge(BfParams p)
             const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
             const int li = ia & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
             const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
-            bf_apply<INV>(s, E, ia, ib, bf_twiddle(p, coset, u, pbit));
+            bf_apply<INV>(s, E, ia, ib, bf_twiddle(p, coset, u, pbit), pbit >= 6);
         }
         __syncthreads();
     }
@@ -857,6 +858,25 @@ __global__ void k_gf192_mul(const uint64_t *a, const uint64_t *b, uint64_t *out,
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
         gf_store(out, i, gf_mul(gf_load(a, i), gf_load(b, i)));
     }
+}
+
+// d_out[i] = d_a[i] * c, c the same for every element (exercises the wave-uniform comb multiplier)
+__global__ void __launch_bounds__(256) k_gf192_mul_uniform(const uint64_t *a, const uint64_t *c, uint64_t *out, size_t count)
+{
+    const gf192 cc = gf_load(c, 0);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        gf_store(out, i, gf_mul_uniform(gf_load(a, i), cc));
+    }
+}
+
+int iopx_gf192_mul_uniform_dev(const uint64_t *d_a, const uint64_t *d_c, uint64_t *d_out, size_t count)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (count == 0) return IOPX_OK;
+    { ProfScope ps_("k_gf192_mul_uniform"); hipLaunchKernelGGL(k_gf192_mul_uniform, dim3(grid_for(count, 256)), dim3(256), 0, stream(), d_a, d_c, d_out, count); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
 }
 
 int iopx_gf192_mul_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count)

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <iopx/gfx950_comb.h>
 
 struct gf192 {
     uint32_t w[6];
@@ -80,26 +81,120 @@ __device__ __forceinline__ uint32_t xor_and(uint32_t c, uint32_t m, uint32_t b)
     return __builtin_amdgcn_bitop3_b32(c, m, b, 0x78);
 }
 
-// General product, both operands per-lane.  Horner over the bit position inside a word: the 12-word
-// accumulator is shifted left by one per step and, for each of the six words of a, the bit at that
-// position (sign-extended by v_bfe_i32) conditionally adds b at that word offset with one v_bitop3
-// per word: 32 x (12 + 6 + 36) = ~1.7k VALU ops.
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
+// bitwise select: (a & m) | (b & ~m)
+__device__ __forceinline__ uint32_t bsel(uint32_t a, uint32_t b, uint32_t m)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, m, 0xE4);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// General product, both operands per-lane: integer multiplication "with holes" + Karatsuba.
+//
+// Measured on MI355X (tools/ubench/valu_rates.hip): v_xor/v_and/v_bitop3 57 T lane-ops/s, shifts /
+// v_alignbit / v_bfe 36 T, v_mad_u64_u32 32 T — a 32x32->64 integer multiply costs about as much as two
+// logic ops, so the carry-less 32x32 product is built from 16 integer multiplies of operands that keep
+// only every 4th bit (at most 8 terms meet in a 4-bit slot, so no carry crosses a slot; BearSSL's
+// ctmul technique) instead of 32 shift/mask steps.  192x192 = 18 such products (Karatsuba 2-way over
+// 96-bit halves, 3-way inside each half).  ~1.0k VALU ops against ~1.7k for the bit-serial form.
+// ---------------------------------------------------------------------------------------------------
+struct holes4 {
+    uint32_t s[4];          // s[i] = x & (0x11111111 << i)
+};
+
+__device__ __forceinline__ holes4 holes_split(uint32_t x)
+{
+    holes4 r;
+    r.s[0] = x & 0x11111111u; r.s[1] = x & 0x22222222u; r.s[2] = x & 0x44444444u; r.s[3] = x & 0x88888888u;
+    return r;
+}
+
+__device__ __forceinline__ holes4 holes_add(const holes4 &a, const holes4 &b)
+{
+    holes4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.s[i] = a.s[i] ^ b.s[i];
+    return r;
+}
+
+// carry-less x * y (32x32 -> 64) from the hole-split operands; lo/hi receive the two result words
+__device__ __forceinline__ void clmul32_holes(const holes4 &x, const holes4 &y, uint32_t &lo, uint32_t &hi)
+{
+    uint64_t p[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[i][j] = (uint64_t)x.s[i] * (uint64_t)y.s[j];
+    uint32_t zl[4], zh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // slot class k collects the products with i + j = k (mod 4)
+        const uint64_t a = p[0][k], b = p[1][(k + 3) & 3], c = p[2][(k + 2) & 3], d = p[3][(k + 1) & 3];
+        zl[k] = xor3((uint32_t)a, (uint32_t)b, (uint32_t)c) ^ (uint32_t)d;
+        zh[k] = xor3((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32)) ^ (uint32_t)(d >> 32);
+    }
+    // take class k at bit positions = k (mod 4)
+    lo = bsel(bsel(zl[0], zl[1], 0x55555555u), bsel(zl[2], zl[3], 0x55555555u), 0x33333333u);
+    hi = bsel(bsel(zh[0], zh[1], 0x55555555u), bsel(zh[2], zh[3], 0x55555555u), 0x33333333u);
+}
+
+// 3 x 3 words -> 6 words (Karatsuba with 6 word products); a, b are hole-split words
+__device__ __forceinline__ void clmul96(const holes4 (&a)[3], const holes4 (&b)[3], uint32_t (&c)[6])
+{
+    uint32_t d0l, d0h, d1l, d1h, d2l, d2h, e01l, e01h, e02l, e02h, e12l, e12h;
+    clmul32_holes(a[0], b[0], d0l, d0h);
+    clmul32_holes(a[1], b[1], d1l, d1h);
+    clmul32_holes(a[2], b[2], d2l, d2h);
+    clmul32_holes(holes_add(a[0], a[1]), holes_add(b[0], b[1]), e01l, e01h);
+    clmul32_holes(holes_add(a[0], a[2]), holes_add(b[0], b[2]), e02l, e02h);
+    clmul32_holes(holes_add(a[1], a[2]), holes_add(b[1], b[2]), e12l, e12h);
+    // c = d0 + X (e01 + d0 + d1) + X^2 (e02 + d0 + d1 + d2) + X^3 (e12 + d1 + d2) + X^4 d2,  X = x^32
+    const uint32_t m1l = xor3(e01l, d0l, d1l), m1h = xor3(e01h, d0h, d1h);
+    const uint32_t m2l = xor3(e02l, d0l, d2l) ^ d1l, m2h = xor3(e02h, d0h, d2h) ^ d1h;
+    const uint32_t m3l = xor3(e12l, d1l, d2l), m3h = xor3(e12h, d1h, d2h);
+    c[0] = d0l;
+    c[1] = d0h ^ m1l;
+    c[2] = xor3(m1h, m2l, 0u);
+    c[3] = xor3(m2h, m3l, 0u);
+    c[4] = xor3(m3h, d2l, 0u);
+    c[5] = d2h;
+}
+
 __device__ __forceinline__ gf192 gf_mul(const gf192 &a, const gf192 &b)
 {
+    holes4 al[3], ah[3], bl[3], bh[3], am[3], bm[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        al[i] = holes_split(a.w[i]); ah[i] = holes_split(a.w[3 + i]);
+        bl[i] = holes_split(b.w[i]); bh[i] = holes_split(b.w[3 + i]);
+        am[i] = holes_add(al[i], ah[i]); bm[i] = holes_add(bl[i], bh[i]);
+    }
+    uint32_t p0[6], p1[6], p2[6];
+    clmul96(al, bl, p0);
+    clmul96(ah, bh, p2);
+    clmul96(am, bm, p1);
     uint32_t c[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) c[i] = 0;
-#pragma unroll 4
-    for (int t = 31; t >= 0; --t) {
+    for (int i = 0; i < 6; ++i) { c[i] = p0[i]; c[6 + i] = p2[i]; }
 #pragma unroll
-        for (int i = 11; i > 0; --i) c[i] = (c[i] << 1) | (c[i - 1] >> 31);
-        c[0] <<= 1;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)a.w[k], t, 1);
-#pragma unroll
-            for (int w = 0; w < 6; ++w) c[k + w] = xor_and(c[k + w], m, b.w[w]);
-        }
-    }
+    for (int i = 0; i < 6; ++i) c[3 + i] ^= xor3(p1[i], p0[i], p2[i]);
     return gf_reduce(c);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Product by a WAVE-UNIFORM multiplier c (every active lane of the wavefront holds the same c): the
+// carry-less product is one hand-written asm block (iopx/gfx950_comb.h, 4-bit-window comb, table selected
+// by S_SET_GPR_IDX): ~0.57k VALU ops against ~1.7k for gf_mul.  The caller guarantees uniformity of c.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ gf192 gf_mul_uniform(const gf192 &a, const gf192 &c_uniform)
+{
+    uint32_t c[6], r[12];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c[i] = __builtin_amdgcn_readfirstlane(c_uniform.w[i]);
+    comb_clmul_192_uniform(r, a.w, c);
+    return gf_reduce(r);
 }

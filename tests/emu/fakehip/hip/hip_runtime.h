@@ -42,6 +42,7 @@ static inline uint32_t __builtin_amdgcn_bitop3_b32(uint32_t a, uint32_t b, uint3
 {
     if (tt == 0x78) return a ^ (b & c);      // fast path for the form the field multiply uses
     if (tt == 0x96) return a ^ b ^ c;
+    if (tt == 0xE4) return (a & c) | (b & ~c);
     uint32_t r = 0;
     for (int i = 0; i < 32; ++i) {
         const uint32_t idx = (((a >> i) & 1) << 2) | (((b >> i) & 1) << 1) | ((c >> i) & 1);
@@ -55,6 +56,8 @@ static inline int __builtin_amdgcn_sbfe(int v, unsigned off, unsigned width)
     const uint32_t sign = 1u << (width - 1);
     return (int)((x ^ sign) - sign);
 }
+
+static inline uint32_t __builtin_amdgcn_readfirstlane(uint32_t x) { return x; }
 
 typedef int hipError_t;
 typedef void *hipStream_t;

@@ -38,6 +38,14 @@ def test_field_mul(gpu):
     assert np.array_equal(gpu.gf192_mul(a, b), oracle.gf_mul(a, b))
 
 
+def test_field_mul_uniform(gpu):
+    a = rand_elems(3, 1 << 14, W)
+    a[0] = 0xFFFFFFFFFFFFFFFF
+    for c in (rand_elems(4, 1, W), np.full((1, W), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64), np.array([[1, 0, 0]], dtype=np.uint64),
+              np.array([[0, 0, 1 << 63]], dtype=np.uint64)):
+        assert np.array_equal(gpu.gf192_mul(a, c), oracle.gf_mul(a, np.repeat(c, a.shape[0], axis=0)))
+
+
 @pytest.mark.parametrize("m", [1, 2, 3, 6, 10, 11, 12, 13, 16, 18])
 @pytest.mark.parametrize("kind", ["std0", "aurora", "general"])
 def test_fft_full_size(gpu, m, kind):

@@ -18,6 +18,14 @@ def test_field_mul():
     assert np.array_equal(emu().gf192_mul(a, b), oracle.gf_mul(a, b))
 
 
+def test_field_mul_uniform():
+    a = rand_elems(3, 300, W)
+    a[0] = 0xFFFFFFFFFFFFFFFF
+    for c in (rand_elems(4, 1, W), np.full((1, W), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64), np.array([[1, 0, 0]], dtype=np.uint64),
+              np.array([[0, 0, 1 << 63]], dtype=np.uint64)):
+        assert np.array_equal(emu().gf192_mul(a, c), oracle.gf_mul(a, np.repeat(c, 300, axis=0)))
+
+
 def _dom(m, kind, seed):
     if kind == "std0":
         return oracle.standard_basis(m, W), np.zeros(W, dtype=np.uint64)
