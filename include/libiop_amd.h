@@ -64,6 +64,12 @@ int iopx_add_fft_gf192_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint
                            const uint64_t *shift, uint64_t *d_out);
 int iopx_add_fft_gf192(const uint64_t *coeffs, size_t n_coeffs, const uint64_t *basis, size_t m,
                        const uint64_t *shift, uint64_t *out);
+/* One shard of the same transform (multi-GPU low-degree extension): with
+ * d = ceil(log2 n_coeffs) the output splits into 2^(m-d) contiguous blocks of 2^d evaluations (the cosets of
+ * span(basis[0..d))); this computes blocks [coset_begin, coset_begin + coset_count) into d_out
+ * (coset_count * 2^d elements), i.e. elements [coset_begin * 2^d, ...) of iopx_add_fft_gf192_dev's output. */
+int iopx_add_lde_gf192_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *basis, size_t m,
+                           const uint64_t *shift, size_t coset_begin, size_t coset_count, uint64_t *d_out);
 /* additive_IFFT(evals, domain): libiop/algebra/fft.tcc:126-204 (dispatch :428-433).  2^m in, 2^m out.
  * IFFT_of_known_degree_over_field_subset (fft.tcc:458-475) is this call on the first
  * 2^ceil(log2 degree) evaluations with the first ceil(log2 degree) basis vectors. */
@@ -71,6 +77,33 @@ int iopx_add_ifft_gf192_dev(const uint64_t *d_evals, const uint64_t *basis, size
                             uint64_t *d_out);
 int iopx_add_ifft_gf192(const uint64_t *evals, const uint64_t *basis, size_t m, const uint64_t *shift,
                         uint64_t *out);
+
+/* ---- multiplicative-coset FFT / IFFT / FRI fold over the 181-bit prime field (libff edwards_Fr) --- */
+/* Elements are libff Fp_model Montgomery words (3 x uint64, R = 2^192), exactly the bytes libiop hashes.
+ * `gen` is the generator of the order-2^log_n subgroup (multiplicative_coset::generator(), subgroup.tcc:55-59),
+ * `shift` the coset shift; evaluation order is natural: index i <-> shift * gen^i.
+ *   iopx_mul_fft_fp3      multiplicative_FFT_degree_aware, libiop/algebra/fft.tcc:236-317 (n_coeffs <= 2^log_n,
+ *                         any length; only ceil(log2 n_coeffs) butterfly levels run)
+ *   iopx_mul_ifft_fp3     multiplicative_IFFT_internal, fft.tcc:343-361 (libfqfft iFFT / icosetFFT)
+ *   iopx_mul_ifft_known_degree_fp3_dev   IFFT_of_known_degree_over_field_subset, fft.tcc:435-456: every
+ *                         (2^log_n / 2^ceil(log2 degree))-th evaluation, IFFT over that sub-coset; writes
+ *                         2^ceil(log2 degree) coefficients
+ *   iopx_fri_fold_mul_fp3 multiplicative_evaluate_next_f_i_over_entire_domain, fri_aux.tcc:106-249
+ *                         (cosets {j + k * n / coset_size}, subgroup.tcc:175-197) */
+int iopx_mul_fft_fp3_dev(const uint64_t *d_coeffs, size_t n_coeffs, size_t log_n, const uint64_t *gen,
+                         const uint64_t *shift, uint64_t *d_out);
+int iopx_mul_fft_fp3(const uint64_t *coeffs, size_t n_coeffs, size_t log_n, const uint64_t *gen,
+                     const uint64_t *shift, uint64_t *out);
+int iopx_mul_ifft_fp3_dev(const uint64_t *d_evals, size_t log_n, const uint64_t *gen, const uint64_t *shift,
+                          uint64_t *d_out);
+int iopx_mul_ifft_fp3(const uint64_t *evals, size_t log_n, const uint64_t *gen, const uint64_t *shift,
+                      uint64_t *out);
+int iopx_mul_ifft_known_degree_fp3_dev(const uint64_t *d_evals, size_t degree, size_t log_n, const uint64_t *gen,
+                                       const uint64_t *shift, uint64_t *d_out);
+int iopx_fri_fold_mul_fp3_dev(const uint64_t *d_f_i, size_t log_n, const uint64_t *gen, const uint64_t *shift,
+                              size_t coset_size, const uint64_t *x_i, uint64_t *d_next);
+int iopx_fri_fold_mul_fp3(const uint64_t *f_i, size_t log_n, const uint64_t *gen, const uint64_t *shift,
+                          size_t coset_size, const uint64_t *x_i, uint64_t *next);
 
 /* ---- FRI fold over GF(2^192) -------------------------------------------------------------------- */
 /* evaluate_next_f_i_over_entire_domain for affine subspaces:

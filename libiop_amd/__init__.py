@@ -34,8 +34,10 @@ DOMAIN_MULTIPLICATIVE = 1
 EXPORTED_SYMBOLS = [
     "iopx_version", "iopx_last_error", "iopx_device_count", "iopx_init", "iopx_set_stream", "iopx_synchronize",
     "iopx_malloc", "iopx_free", "iopx_memcpy_h2d", "iopx_memcpy_d2h", "iopx_clear_plans",
-    "iopx_add_fft_gf192_dev", "iopx_add_fft_gf192", "iopx_add_ifft_gf192_dev", "iopx_add_ifft_gf192",
+    "iopx_add_fft_gf192_dev", "iopx_add_fft_gf192", "iopx_add_lde_gf192_dev", "iopx_add_ifft_gf192_dev", "iopx_add_ifft_gf192",
     "iopx_fri_fold_add_gf192_dev", "iopx_fri_fold_add_gf192",
+    "iopx_mul_fft_fp3_dev", "iopx_mul_fft_fp3", "iopx_mul_ifft_fp3_dev", "iopx_mul_ifft_fp3",
+    "iopx_mul_ifft_known_degree_fp3_dev", "iopx_fri_fold_mul_fp3_dev", "iopx_fri_fold_mul_fp3",
     "iopx_merkle_blake2b_dev", "iopx_merkle_blake2b",
     "iopx_gf192_mul_dev", "iopx_gf192_mul_uniform_dev", "iopx_profile_begin", "iopx_profile_report",
 ]
@@ -80,10 +82,18 @@ class Library:
         c.iopx_set_stream.argtypes = [_vp]
         c.iopx_add_fft_gf192_dev.argtypes = [_vp, _sz, _u64p, _sz, _u64p, _vp]
         c.iopx_add_fft_gf192.argtypes = [_u64p, _sz, _u64p, _sz, _u64p, _u64p]
+        c.iopx_add_lde_gf192_dev.argtypes = [_vp, _sz, _u64p, _sz, _u64p, _sz, _sz, _vp]
         c.iopx_add_ifft_gf192_dev.argtypes = [_vp, _u64p, _sz, _u64p, _vp]
         c.iopx_add_ifft_gf192.argtypes = [_u64p, _u64p, _sz, _u64p, _u64p]
         c.iopx_fri_fold_add_gf192_dev.argtypes = [_vp, _u64p, _sz, _u64p, _sz, _u64p, _vp]
         c.iopx_fri_fold_add_gf192.argtypes = [_u64p, _u64p, _sz, _u64p, _sz, _u64p, _u64p]
+        c.iopx_mul_fft_fp3_dev.argtypes = [_vp, _sz, _sz, _u64p, _u64p, _vp]
+        c.iopx_mul_fft_fp3.argtypes = [_u64p, _sz, _sz, _u64p, _u64p, _u64p]
+        c.iopx_mul_ifft_fp3_dev.argtypes = [_vp, _sz, _u64p, _u64p, _vp]
+        c.iopx_mul_ifft_fp3.argtypes = [_u64p, _sz, _u64p, _u64p, _u64p]
+        c.iopx_mul_ifft_known_degree_fp3_dev.argtypes = [_vp, _sz, _sz, _u64p, _u64p, _vp]
+        c.iopx_fri_fold_mul_fp3_dev.argtypes = [_vp, _sz, _u64p, _u64p, _sz, _u64p, _vp]
+        c.iopx_fri_fold_mul_fp3.argtypes = [_u64p, _sz, _u64p, _u64p, _sz, _u64p, _u64p]
         c.iopx_merkle_blake2b_dev.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _sz, _sz, ctypes.c_int, _vp, _sz, _vp]
         c.iopx_merkle_blake2b.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _sz, _sz, ctypes.c_int, _vp, _sz, _vp]
         c.iopx_gf192_mul_dev.argtypes = [_vp, _vp, _vp, _sz]
@@ -176,6 +186,59 @@ class Library:
                                                    out.ctypes.data_as(_u64p)))
         return out
 
+    # ---- multiplicative cosets over the 181-bit prime field (Montgomery words) ----
+    def multiplicative_FFT(self, poly_coeffs, log_n, shift, gen=None):
+        """multiplicative_FFT(poly_coeffs, multiplicative_coset(2^log_n, shift)) — fft.tcc:236-317."""
+        coeffs, shift = _as_u64(poly_coeffs), _as_u64(shift)
+        gen = _as_u64(edwards_subgroup_generator(log_n) if gen is None else gen)
+        out = np.empty((1 << log_n, 3), dtype=np.uint64)
+        self._check(self.c.iopx_mul_fft_fp3(coeffs.ctypes.data_as(_u64p), coeffs.shape[0], log_n, gen.ctypes.data_as(_u64p),
+                                            shift.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p)))
+        return out
+
+    def multiplicative_IFFT(self, evals, shift, gen=None):
+        """multiplicative_IFFT(evals, coset) — fft.tcc:343-361 over libfqfft iFFT / icosetFFT."""
+        evals, shift = _as_u64(evals), _as_u64(shift)
+        n = evals.shape[0]
+        log_n = n.bit_length() - 1
+        if n != 1 << log_n:
+            raise ValueError("multiplicative IFFT: %d evaluations is not a power of two" % n)
+        gen = _as_u64(edwards_subgroup_generator(log_n) if gen is None else gen)
+        out = np.empty_like(evals)
+        self._check(self.c.iopx_mul_ifft_fp3(evals.ctypes.data_as(_u64p), log_n, gen.ctypes.data_as(_u64p),
+                                             shift.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p)))
+        return out
+
+    def multiplicative_IFFT_of_known_degree(self, evals, degree, shift):
+        """IFFT_of_known_degree_over_field_subset, multiplicative overload — fft.tcc:435-456."""
+        evals, shift = _as_u64(evals), _as_u64(shift)
+        n = evals.shape[0]
+        log_n = n.bit_length() - 1
+        k = max(int(degree) - 1, 0).bit_length()
+        gen = _as_u64(edwards_subgroup_generator(log_n))
+        d_in, d_out = self.malloc(evals.nbytes), self.malloc(24 << k)
+        try:
+            self.h2d(d_in, evals)
+            self._check(self.c.iopx_mul_ifft_known_degree_fp3_dev(_vp(d_in), int(degree), log_n, gen.ctypes.data_as(_u64p),
+                                                                  shift.ctypes.data_as(_u64p), _vp(d_out)))
+            out = np.empty((1 << k, 3), dtype=np.uint64)
+            self.d2h(out, d_out)
+        finally:
+            self.free(d_in)
+            self.free(d_out)
+        return out
+
+    def multiplicative_evaluate_next_f_i(self, f_i_evals, shift, coset_size, x_i, gen=None):
+        """multiplicative_evaluate_next_f_i_over_entire_domain — fri_aux.tcc:106-249."""
+        f, shift, x = _as_u64(f_i_evals), _as_u64(shift), _as_u64(x_i)
+        n = f.shape[0]
+        log_n = n.bit_length() - 1
+        gen = _as_u64(edwards_subgroup_generator(log_n) if gen is None else gen)
+        out = np.empty((n // max(int(coset_size), 1), 3), dtype=np.uint64)
+        self._check(self.c.iopx_fri_fold_mul_fp3(f.ctypes.data_as(_u64p), log_n, gen.ctypes.data_as(_u64p), shift.ctypes.data_as(_u64p),
+                                                 int(coset_size), x.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p)))
+        return out
+
     def merkle_tree(self, oracles, coset_size, domain_type=DOMAIN_ADDITIVE, salts=None):
         """construct_with_leaves_serialized_by_cosets + compute_inner_nodes (merkle_tree.tcc:92-229).
         Returns the (2L-1, 32) uint8 node array in heap order; row 0 is get_root()."""
@@ -201,6 +264,12 @@ class Library:
         basis, shift = _as_u64(basis), _as_u64(shift)
         self._check(self.c.iopx_add_fft_gf192_dev(_vp(d_coeffs), n_coeffs, basis.ctypes.data_as(_u64p), basis.shape[0],
                                                   shift.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def additive_LDE_dev(self, d_coeffs, n_coeffs, basis, shift, coset_begin, coset_count, d_out):
+        """Cosets [coset_begin, +coset_count) of the transform (one GPU's shard of a codeword)."""
+        basis, shift = _as_u64(basis), _as_u64(shift)
+        self._check(self.c.iopx_add_lde_gf192_dev(_vp(d_coeffs), n_coeffs, basis.ctypes.data_as(_u64p), basis.shape[0],
+                                                  shift.ctypes.data_as(_u64p), coset_begin, coset_count, _vp(d_out)))
 
     def additive_IFFT_dev(self, d_evals, basis, shift, d_out):
         basis, shift = _as_u64(basis), _as_u64(shift)
@@ -271,6 +340,25 @@ def lib():
     if _default is None:
         _default = Library()
     return _default
+
+
+EDWARDS_FR_MODULUS = 1552511030102430251236801561344621993261920897571225601    # libff edwards_Fr, 181 bits
+EDWARDS_FR_GENERATOR = 19                                                        # multiplicative_generator
+
+
+def edwards_to_montgomery(values):
+    """canonical ints -> libff Fp_model `mont_repr` words (x * 2^192 mod p), shape (count, 3)."""
+    out = np.empty((len(values), 3), dtype=np.uint64)
+    for i, v in enumerate(values):
+        mv = (int(v) % EDWARDS_FR_MODULUS) * (1 << 192) % EDWARDS_FR_MODULUS
+        out[i] = [(mv >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(3)]
+    return out
+
+
+def edwards_subgroup_generator(log_n):
+    """multiplicative_generator^((p-1)/2^log_n) — multiplicative_subgroup_base::construct_internal, subgroup.tcc:55-59."""
+    g = pow(EDWARDS_FR_GENERATOR, (EDWARDS_FR_MODULUS - 1) >> log_n, EDWARDS_FR_MODULUS)
+    return edwards_to_montgomery([g])[0]
 
 
 def standard_basis(m):

@@ -623,11 +623,11 @@ static P2Geom phase2_geom(int d)
 // The edge pass permutes (bit reversal), so it never runs in place across workgroups: the forward
 // transform keeps the upper passes in W (one coset) or in a scratch buffer holding a group of cosets.
 template<bool INV>
-static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi)
+static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, size_t coset_begin = 0, size_t coset_count = 0)
 {
     const int d = pl.d;
     const P2Geom g = phase2_geom(d);
-    const size_t cosets = (size_t)1 << nhi;
+    const size_t cosets = coset_count ? coset_count : ((size_t)1 << nhi);
     const size_t nd = (size_t)1 << d;
     BfParams p;
     memset(&p, 0, sizeof(p));
@@ -690,7 +690,7 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi)
             if (rc != IOPX_OK) return rc;
         }
     } else if (ups.empty()) {
-        rc = launch_edge(src, dst, 1, cosets, 0);
+        rc = launch_edge(src, dst, 1, cosets, coset_begin);
         if (rc != IOPX_OK) return rc;
     } else if (nhi == 0) {
         uint64_t *W = const_cast<uint64_t *>(src);
@@ -710,10 +710,10 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi)
         for (size_t c0 = 0; c0 < cosets; c0 += group) {
             const size_t nc = cosets - c0 < group ? cosets - c0 : group;
             for (size_t i = 0; i < ups.size(); ++i) {
-                rc = launch_upper(ups[i], i == 0 ? src : scratch.u64(), scratch.u64(), i == 0 ? 1 : 0, nc, c0);
+                rc = launch_upper(ups[i], i == 0 ? src : scratch.u64(), scratch.u64(), i == 0 ? 1 : 0, nc, coset_begin + c0);
                 if (rc != IOPX_OK) return rc;
             }
-            rc = launch_edge(scratch.u64(), dst + 3 * c0 * nd, 0, nc, c0);
+            rc = launch_edge(scratch.u64(), dst + 3 * c0 * nd, 0, nc, coset_begin + c0);
             if (rc != IOPX_OK) return rc;
         }
         IOPX_HIP(hipStreamSynchronize(stream()));       // scratch is freed on return
@@ -743,8 +743,10 @@ int iopx_clear_plans(void)
     return IOPX_OK;
 }
 
-int iopx_add_fft_gf192_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *basis, size_t m,
-                           const uint64_t *shift, uint64_t *d_out)
+// Cosets [coset_begin, coset_begin + coset_count) of span(basis[0..d)), d = ceil(log2 n_coeffs): the
+// contiguous output block [coset_begin * 2^d, (coset_begin + coset_count) * 2^d) of the full transform.
+int iopx_add_lde_gf192_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *basis, size_t m,
+                           const uint64_t *shift, size_t coset_begin, size_t coset_count, uint64_t *d_out)
 {
     int rc = ensure_device();
     if (rc != IOPX_OK) return rc;
@@ -753,13 +755,16 @@ int iopx_add_fft_gf192_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint
     const size_t n = (size_t)1 << m;
     if (n_coeffs > n) return fail(IOPX_ERR_INVALID_ARGUMENT, "additive FFT: %zu coefficients exceed the domain size %zu", n_coeffs, n);
     if (!d_out || (n_coeffs && !d_coeffs)) return fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
+    const int d = n_coeffs <= 1 ? 0 : (int)ceil_log2(n_coeffs);
+    const int nhi = (int)m - d;
+    const size_t all_cosets = (size_t)1 << nhi;
+    if (coset_count == 0 || coset_begin >= all_cosets || coset_count > all_cosets - coset_begin)
+        return fail(IOPX_ERR_INVALID_ARGUMENT, "coset range [%zu, +%zu) outside the %zu cosets of the transform", coset_begin, coset_count, all_cosets);
     if (n_coeffs <= 1) {
-        { ProfScope ps_("k_fill"); hipLaunchKernelGGL(k_fill, dim3(grid_for(n, 256)), dim3(256), 0, stream(), d_out, d_coeffs, (int)(n_coeffs == 1), n); }
+        { ProfScope ps_("k_fill"); hipLaunchKernelGGL(k_fill, dim3(grid_for(coset_count, 256)), dim3(256), 0, stream(), d_out, d_coeffs, (int)(n_coeffs == 1), coset_count); }
         IOPX_HIP(hipGetLastError());
         return IOPX_OK;
     }
-    const int d = (int)ceil_log2(n_coeffs);
-    const int nhi = (int)m - d;
     AddPlan *pl = nullptr;
     rc = get_plan(basis, d, &pl);
     if (rc != IOPX_OK) return rc;
@@ -776,10 +781,20 @@ int iopx_add_fft_gf192_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint
     { ProfScope ps_("k_pad_copy"); hipLaunchKernelGGL(k_pad_copy, dim3(grid_for(3 * nd, 256)), dim3(256), 0, stream(), W, d_coeffs, n_coeffs, nd); }
     rc = run_phase1<false>(*pl, W);
     if (rc != IOPX_OK) return rc;
-    rc = run_phase2<false>(*pl, W, d_out, nhi);
+    rc = run_phase2<false>(*pl, W, d_out, nhi, coset_begin, coset_count);
     if (rc != IOPX_OK) return rc;
     IOPX_HIP(hipStreamSynchronize(stream()));           // work buffer is freed on return
     return IOPX_OK;
+}
+
+int iopx_add_fft_gf192_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *basis, size_t m,
+                           const uint64_t *shift, uint64_t *d_out)
+{
+    if (m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "domain dimension %zu too large", m);
+    const size_t n = (size_t)1 << m;
+    if (n_coeffs > n) return fail(IOPX_ERR_INVALID_ARGUMENT, "additive FFT: %zu coefficients exceed the domain size %zu", n_coeffs, n);
+    const int d = n_coeffs <= 1 ? 0 : (int)ceil_log2(n_coeffs);
+    return iopx_add_lde_gf192_dev(d_coeffs, n_coeffs, basis, m, shift, 0, (size_t)1 << ((int)m - d), d_out);
 }
 
 int iopx_add_ifft_gf192_dev(const uint64_t *d_evals, const uint64_t *basis, size_t m, const uint64_t *shift,

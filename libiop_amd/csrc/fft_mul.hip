@@ -1,0 +1,549 @@
+// Multiplicative-coset FFT / IFFT and FRI fold over the 181-bit prime field (libff edwards_Fr) for gfx950.
+//
+// Replaces, for multiplicative domains (reference paths relative to /root/reference):
+//   multiplicative_FFT_degree_aware      libiop/algebra/fft.tcc:236-317   (a[i] = P(shift * g^i), natural order)
+//   multiplicative_IFFT_internal         libiop/algebra/fft.tcc:343-361   -> libfqfft basic_radix2_domain::iFFT / icosetFFT
+//   IFFT_of_known_degree (mult.)         libiop/algebra/fft.tcc:435-456   (strided gather + IFFT on the sub-coset)
+//   multiplicative_evaluate_next_f_i_... libiop/protocols/ldt/fri/fri_aux.tcc:106-249
+//
+// Forward transform = the reference's structure: coefficients (pre-scaled by shift^k, fft.tcc:246-249) are read in
+// bit-reversed order, each value is replicated over the 2^(log n - ceil(log2 len)) low index bits (:263-289), and
+// only the last ceil(log2 len) radix-2 levels run (:293-315), in LDS tiles of up to 12 index bits per HBM sweep,
+// with the reference's twiddle cache layout (subgroup.tcc:117-144) kept in HBM per domain.
+// Inverse = radix-2 FFT with g^-1 on the bit-reversed evaluations, scaled by n^-1 (and shift^-i for a coset) in the
+// last pass.  The fold uses the inversion-free nested form: a coset {j + k n/c} is folded log2(c) times by two,
+//     g[j] = ((a + b) + (a - b) * x / (shift * g^j)) / 2,   a = f[j], b = f[j + n/2],
+// each time over the squared domain (shift^2, g^2, x^2) — the unique interpolant value the reference computes with
+// one global batch inversion (:230-231).
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+#include "fp3_dev.h"
+#include "fp3_host.h"
+#include "runtime.h"
+
+namespace iopx {
+
+static const int MF_TILE_BITS = 12;
+static const int MF_COLS = 4;
+static const int MF_THREADS = 512;
+
+__device__ __forceinline__ fp3 mlds_get(const uint64_t *s, int E, int li)
+{
+    const uint64_t a = s[li], b = s[E + li], c = s[2 * E + li];
+    fp3 r;
+    r.w[0] = (uint32_t)a; r.w[1] = (uint32_t)(a >> 32);
+    r.w[2] = (uint32_t)b; r.w[3] = (uint32_t)(b >> 32);
+    r.w[4] = (uint32_t)c; r.w[5] = (uint32_t)(c >> 32);
+    return r;
+}
+
+__device__ __forceinline__ void mlds_put(uint64_t *s, int E, int li, const fp3 &v)
+{
+    s[li] = (uint64_t)v.w[0] | ((uint64_t)v.w[1] << 32);
+    s[E + li] = (uint64_t)v.w[2] | ((uint64_t)v.w[3] << 32);
+    s[2 * E + li] = (uint64_t)v.w[4] | ((uint64_t)v.w[5] << 32);
+}
+
+// out[q] = init * prod_{k : bit k of q} sq[k]   (sq[k] = base^(2^k)), q < count
+__global__ void k_fp_pow_direct(uint64_t *out, const uint64_t *sq, const uint64_t *init, int nbits, size_t count)
+{
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (size_t)gridDim.x * blockDim.x) {
+        fp3 acc = fp_load(init, 0);
+        for (int k = 0; k < nbits; ++k) {
+            if ((q >> k) & 1) acc = fp_mul(acc, fp_load(sq, k));
+        }
+        fp_store(out, q, acc);
+    }
+}
+
+// out[q] = out[q & 255] * hi[q >> 8]  for 256 <= q < count
+__global__ void k_fp_pow_expand(uint64_t *out, const uint64_t *hi, size_t count)
+{
+    for (size_t q = 256 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (size_t)gridDim.x * blockDim.x) {
+        fp_store(out, q, fp_mul(fp_load(out, q & 255), fp_load(hi, q >> 8)));
+    }
+}
+
+// cache level with m = 2^b entries at offset m - 1: entry j = top[j << (logn - 1 - b)]   (subgroup.tcc:117-144)
+__global__ void k_fp_cache_level(uint64_t *cache, int logn, int b)
+{
+    const size_t m = (size_t)1 << b;
+    const uint64_t *top = cache + 3 * ((((size_t)1) << (logn - 1)) - 1);
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (size_t)gridDim.x * blockDim.x) {
+        fp_store(cache, m - 1 + j, fp_load(top, j << (logn - 1 - b)));
+    }
+}
+
+// dst[k] = src[k] * hi[k >> 12] * lo[k & 4095]      (coset pre-scaling a[k] *= shift^k, fft.tcc:246-249)
+__global__ void k_fp_scale_pow(uint64_t *dst, const uint64_t *src, const uint64_t *hi, const uint64_t *lo, size_t count)
+{
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (size_t)gridDim.x * blockDim.x) {
+        fp_store(dst, k, fp_mul(fp_mul(fp_load(src, k), fp_load(hi, k >> 12)), fp_load(lo, k & 4095)));
+    }
+}
+
+__global__ void k_fp_gather_stride(uint64_t *dst, const uint64_t *src, size_t stride, size_t count)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * count; i += (size_t)gridDim.x * blockDim.x) {
+        dst[i] = src[3 * ((i / 3) * stride) + (i % 3)];
+    }
+}
+
+struct MfParams {
+    const uint64_t *src;    // first pass: coefficient / evaluation array of n_src elements (gathered bit-reversed)
+    uint64_t *dst;
+    const uint64_t *cache;  // n - 1 twiddles, level b at offset 2^b - 1
+    const uint64_t *sc_hi, *sc_lo;  // last pass: out[i] *= sc_hi[i >> 12] * sc_lo[i & 4095]   (null: no scaling)
+    size_t n_src;
+    int logn, logrho;       // index bits [logrho, logn) are active; the low logrho bits replicate
+    int gather;
+    int c, h, A;            // tile: columns on bits [0,c), rows on bits [h, h+A)
+    int b_lo, b_hi;         // butterfly bits of this pass (ascending)
+    int scale;              // 0 none, 1 sc_hi[0] only (n^-1), 2 two-level table
+};
+
+__global__ void __launch_bounds__(512) k_mfft_pass(MfParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
+    uint64_t *s = iopx_smem;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int E = 1 << (p.c + p.A);
+    const int midbits = p.h - p.c;
+    const size_t o = blockIdx.x;
+    const size_t mid = o & (((size_t)1 << midbits) - 1), hi = o >> midbits;
+    const size_t base = (hi << (p.h + p.A)) | (mid << p.c);
+    const int cmask = (1 << p.c) - 1;
+    const int logd = p.logn - p.logrho;
+
+    for (int li = tid; li < E; li += nt) {
+        const size_t gi = base | ((size_t)(li >> p.c) << p.h) | (size_t)(li & cmask);
+        fp3 v;
+        if (p.gather) {
+            const size_t t = gi >> p.logrho;
+            const size_t k = logd == 0 ? 0 : (size_t)(__brevll((unsigned long long)t) >> (64 - logd));
+            v = k < p.n_src ? fp_load(p.src, k) : fp_zero();
+        } else {
+            v = fp_load(p.src, gi);
+        }
+        mlds_put(s, E, li, v);
+    }
+    __syncthreads();
+
+    for (int b = p.b_lo; b <= p.b_hi; ++b) {
+        const int bl = b - p.h + p.c;                       // tile-local bit
+        const uint64_t *lvl = p.cache + 3 * ((((size_t)1) << b) - 1);
+        for (int bf = tid; bf < (E >> 1); bf += nt) {
+            const int low = bf & ((1 << bl) - 1), high = bf >> bl;
+            const int ia = (high << (bl + 1)) | low, ib = ia | (1 << bl);
+            const size_t gi = base | ((size_t)(ia >> p.c) << p.h) | (size_t)(ia & cmask);
+            const fp3 w = fp_load(lvl, gi & ((((size_t)1) << b) - 1));
+            const fp3 x = mlds_get(s, E, ia);
+            const fp3 t = fp_mul(w, mlds_get(s, E, ib));       // t = w * a[k+j+m]; a[k+j+m] = a[k+j] - t; a[k+j] += t
+            mlds_put(s, E, ib, fp_sub(x, t));
+            mlds_put(s, E, ia, fp_add(x, t));
+        }
+        __syncthreads();
+    }
+
+    for (int li = tid; li < E; li += nt) {
+        const size_t gi = base | ((size_t)(li >> p.c) << p.h) | (size_t)(li & cmask);
+        fp3 v = mlds_get(s, E, li);
+        if (p.scale == 1) v = fp_mul(v, fp_load(p.sc_hi, 0));
+        if (p.scale == 2) v = fp_mul(fp_mul(v, fp_load(p.sc_hi, gi >> 12)), fp_load(p.sc_lo, gi & 4095));
+        fp_store(p.dst, gi, v);
+    }
+}
+
+struct MfoldParams {
+    const uint64_t *src;
+    uint64_t *dst;
+    const uint64_t *ginv;   // g^-j for j < n0/2 (top level of the inverse cache)
+    const uint64_t *consts; // [0] = x / shift, [1] = 1/2    (of this level)
+    size_t half;            // outputs = pairs (j, j + half)
+    int stride_log;         // ginv index = j << stride_log
+};
+
+// g[j] = ((a + b) + (a - b) * (x / shift) * g^-j) / 2
+__global__ void k_fri_fold2_mul(MfoldParams p)
+{
+    const fp3 xs = fp_load(p.consts, 0), inv2 = fp_load(p.consts, 1);
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < p.half; j += (size_t)gridDim.x * blockDim.x) {
+        const fp3 a = fp_load(p.src, j), b = fp_load(p.src, j + p.half);
+        const fp3 c = fp_mul(xs, fp_load(p.ginv, j << p.stride_log));
+        const fp3 r = fp_add(fp_add(a, b), fp_mul(fp_sub(a, b), c));
+        fp_store(p.dst, j, fp_mul(r, inv2));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct MulPlan {
+    int logn = 0;
+    hfp3 g, ginv;
+    DevBuf cache_fwd, cache_inv;        // n - 1 twiddles each, built on first use
+    bool have_fwd = false, have_inv = false;
+};
+
+static std::mutex g_mplan_mu;
+static std::map<std::vector<uint64_t>, std::unique_ptr<MulPlan>> g_mplans;
+
+static int mgrid(size_t work, int threads)
+{
+    size_t g = (work + threads - 1) / threads;
+    if (g < 1) g = 1;
+    if (g > 8192) g = 8192;
+    return (int)g;
+}
+
+// out[q] = init * base^q for q < 2^nb
+static int fp_build_pow(uint64_t *out, const hfp3 &base, const hfp3 &init, int nb)
+{
+    std::vector<uint64_t> sq;
+    hfp3 x = base;
+    for (int k = 0; k < nb; ++k) { sq.insert(sq.end(), x.w, x.w + 3); x = x.squared(); }
+    const hfp3 one = hfp3::one();
+    DevBuf dsq, dinit, done;
+    int rc;
+    if ((rc = dsq.alloc(sq.size() * 8 + 8)) != IOPX_OK) return rc;
+    if ((rc = dinit.alloc(24)) != IOPX_OK) return rc;
+    if ((rc = done.alloc(24)) != IOPX_OK) return rc;
+    if (!sq.empty()) IOPX_HIP(hipMemcpyAsync(dsq.p, sq.data(), sq.size() * 8, hipMemcpyHostToDevice, stream()));
+    IOPX_HIP(hipMemcpyAsync(dinit.p, init.w, 24, hipMemcpyHostToDevice, stream()));
+    IOPX_HIP(hipMemcpyAsync(done.p, one.w, 24, hipMemcpyHostToDevice, stream()));
+    const size_t count = (size_t)1 << nb;
+    if (nb <= 8) {
+        { ProfScope ps_("k_fp_pow_direct"); hipLaunchKernelGGL(k_fp_pow_direct, dim3(mgrid(count, 256)), dim3(256), 0, stream(), out, (const uint64_t *)dsq.u64(), (const uint64_t *)dinit.u64(), nb, count); }
+    } else {
+        // out[0..256) = init * base^q ; hi[r] = (base^256)^r ; out[q] = out[q & 255] * hi[q >> 8]
+        DevBuf hi;
+        if ((rc = hi.alloc((((size_t)1) << (nb - 8)) * 24)) != IOPX_OK) return rc;
+        hfp3 b256 = base;
+        for (int k = 0; k < 8; ++k) b256 = b256.squared();
+        rc = fp_build_pow(hi.u64(), b256, one, nb - 8);
+        if (rc != IOPX_OK) return rc;
+        { ProfScope ps_("k_fp_pow_direct"); hipLaunchKernelGGL(k_fp_pow_direct, dim3(1), dim3(256), 0, stream(), out, (const uint64_t *)dsq.u64(), (const uint64_t *)dinit.u64(), 8, (size_t)256); }
+        { ProfScope ps_("k_fp_pow_expand"); hipLaunchKernelGGL(k_fp_pow_expand, dim3(mgrid(count - 256, 256)), dim3(256), 0, stream(), out, (const uint64_t *)hi.u64(), count); }
+        IOPX_HIP(hipStreamSynchronize(stream()));
+    }
+    IOPX_HIP(hipStreamSynchronize(stream()));
+    return IOPX_OK;
+}
+
+static int build_cache(MulPlan &pl, bool inverse)
+{
+    const int logn = pl.logn;
+    DevBuf &buf = inverse ? pl.cache_inv : pl.cache_fwd;
+    const size_t n = (size_t)1 << logn;
+    int rc = buf.alloc((n > 1 ? n - 1 : 1) * 24);
+    if (rc != IOPX_OK) return rc;
+    if (logn >= 1) {
+        uint64_t *top = buf.u64() + 3 * ((n >> 1) - 1);
+        rc = fp_build_pow(top, inverse ? pl.ginv : pl.g, hfp3::one(), logn - 1);
+        if (rc != IOPX_OK) return rc;
+        for (int b = 0; b < logn - 1; ++b) {
+            { ProfScope ps_("k_fp_cache_level"); hipLaunchKernelGGL(k_fp_cache_level, dim3(mgrid((size_t)1 << b, 256)), dim3(256), 0, stream(), buf.u64(), logn, b); }
+        }
+        IOPX_HIP(hipStreamSynchronize(stream()));
+    }
+    (inverse ? pl.have_inv : pl.have_fwd) = true;
+    return IOPX_OK;
+}
+
+static int get_mplan(int logn, const uint64_t *gen, MulPlan **out)
+{
+    std::vector<uint64_t> key(gen, gen + 3);
+    key.push_back((uint64_t)logn);
+    std::lock_guard<std::mutex> lk(g_mplan_mu);
+    auto it = g_mplans.find(key);
+    if (it != g_mplans.end()) { *out = it->second.get(); return IOPX_OK; }
+    std::unique_ptr<MulPlan> pl(new MulPlan());
+    pl->logn = logn;
+    pl->g = hfp3::from_words(gen);
+    if (pl->g.is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "multiplicative FFT: zero generator");
+    // the generator must have order exactly 2^logn
+    if (!(pl->g.pow((uint64_t)1 << logn) == hfp3::one()) || (logn > 0 && pl->g.pow((uint64_t)1 << (logn - 1)) == hfp3::one()))
+        return fail(IOPX_ERR_INVALID_ARGUMENT, "multiplicative FFT: generator does not have order 2^%d", logn);
+    pl->ginv = pl->g.inverse();
+    *out = pl.get();
+    g_mplans[key] = std::move(pl);
+    return IOPX_OK;
+}
+
+// two-level power tables: hi[q] = init * base^(4096 q) (q < 2^max(logc-12,0)), lo[r] = base^r (r < 4096)
+static int build_two_level(const hfp3 &base, const hfp3 &init, int logc, DevBuf &hi, DevBuf &lo)
+{
+    const int lo_bits = logc < 12 ? logc : 12, hi_bits = logc > 12 ? logc - 12 : 0;
+    int rc;
+    if ((rc = lo.alloc(((size_t)4096) * 24)) != IOPX_OK) return rc;
+    if ((rc = hi.alloc((((size_t)1) << hi_bits) * 24)) != IOPX_OK) return rc;
+    rc = fp_build_pow(lo.u64(), base, hfp3::one(), lo_bits);
+    if (rc != IOPX_OK) return rc;
+    hfp3 b4096 = base;
+    for (int k = 0; k < 12; ++k) b4096 = b4096.squared();
+    return fp_build_pow(hi.u64(), b4096, init, hi_bits);
+}
+
+// runs the radix-2 levels on index bits [logrho, logn) (first pass gathers src bit-reversed), natural-order dst
+static int run_mfft(const uint64_t *cache, const uint64_t *src, size_t n_src, uint64_t *dst, int logn, int logrho,
+                    int scale, const uint64_t *sc_hi, const uint64_t *sc_lo)
+{
+    struct Pass { int c, h, A, b_lo, b_hi; };
+    std::vector<Pass> passes;
+    int b = logrho;
+    if (logn <= MF_TILE_BITS) {
+        passes.push_back({0, 0, logn, b, logn - 1});
+        b = logn;
+    } else if (logrho < MF_TILE_BITS) {
+        passes.push_back({0, 0, MF_TILE_BITS, b, MF_TILE_BITS - 1});
+        b = MF_TILE_BITS;
+    }
+    while (b < logn) {
+        int A = MF_TILE_BITS - MF_COLS;
+        if (b + A > logn) A = logn - b;
+        int c = MF_TILE_BITS - A;
+        if (c > b) c = b;
+        passes.push_back({c, b, A, b, b + A - 1});
+        b += A;
+    }
+    if (passes.empty()) passes.push_back({0, 0, logn < MF_TILE_BITS ? logn : MF_TILE_BITS, 1, 0});     // replication only
+    for (size_t i = 0; i < passes.size(); ++i) {
+        const Pass &ps = passes[i];
+        MfParams p;
+        memset(&p, 0, sizeof(p));
+        p.src = i == 0 ? src : dst;
+        p.dst = dst;
+        p.cache = cache;
+        p.n_src = n_src;
+        p.logn = logn; p.logrho = logrho;
+        p.gather = (i == 0);
+        p.c = ps.c; p.h = ps.h; p.A = ps.A; p.b_lo = ps.b_lo; p.b_hi = ps.b_hi;
+        if (i + 1 == passes.size()) { p.scale = scale; p.sc_hi = sc_hi; p.sc_lo = sc_lo; }
+        const int tbits = ps.c + ps.A;
+        const size_t lds = ((size_t)24) << tbits;
+        const size_t blocks = (size_t)1 << (logn - tbits);
+        const int threads = (1 << tbits) >= 2 * MF_THREADS ? MF_THREADS : ((1 << tbits) >= 128 ? (1 << tbits) / 2 : 64);
+        if (lds > 64 * 1024) IOPX_HIP(hipFuncSetAttribute((const void *)k_mfft_pass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { ProfScope ps_("k_mfft_pass"); hipLaunchKernelGGL(k_mfft_pass, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+    }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+} // namespace iopx
+
+using namespace iopx;
+
+extern "C" {
+
+int iopx_mul_fft_fp3_dev(const uint64_t *d_coeffs, size_t n_coeffs, size_t log_n, const uint64_t *gen,
+                         const uint64_t *shift, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (log_n > 31) return fail(IOPX_ERR_INVALID_ARGUMENT, "log_n %zu exceeds the 2-adicity of the field", log_n);
+    if (!gen || !shift || !d_out || (n_coeffs && !d_coeffs)) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    const size_t n = (size_t)1 << log_n;
+    if (n_coeffs > n) return fail(IOPX_ERR_INVALID_ARGUMENT, "multiplicative FFT: %zu coefficients exceed the domain size %zu", n_coeffs, n);
+    if (n_coeffs == 0) {
+        IOPX_HIP(hipMemsetAsync(d_out, 0, n * 24, stream()));
+        return IOPX_OK;
+    }
+    MulPlan *pl = nullptr;
+    rc = get_mplan((int)log_n, gen, &pl);
+    if (rc != IOPX_OK) return rc;
+    if (!pl->have_fwd && (rc = build_cache(*pl, false)) != IOPX_OK) return rc;
+    const int logd = (int)ceil_log2(n_coeffs);
+    const hfp3 sh = hfp3::from_words(shift);
+    if (sh.is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "multiplicative FFT: zero coset shift");
+    DevBuf scaled, hi, lo;
+    const uint64_t *src = d_coeffs;
+    if (d_coeffs == d_out) {    // the first pass permutes: it cannot run in place
+        if ((rc = scaled.alloc(n_coeffs * 24)) != IOPX_OK) return rc;
+        IOPX_HIP(hipMemcpyAsync(scaled.p, d_coeffs, n_coeffs * 24, hipMemcpyDeviceToDevice, stream()));
+        src = scaled.u64();
+    }
+    if (!(sh == hfp3::one()) && n_coeffs > 1) {
+        if (!scaled.p && (rc = scaled.alloc(n_coeffs * 24)) != IOPX_OK) return rc;
+        if ((rc = build_two_level(sh, hfp3::one(), logd, hi, lo)) != IOPX_OK) return rc;
+        { ProfScope ps_("k_fp_scale_pow"); hipLaunchKernelGGL(k_fp_scale_pow, dim3(mgrid(n_coeffs, 256)), dim3(256), 0, stream(), scaled.u64(), src, (const uint64_t *)hi.u64(), (const uint64_t *)lo.u64(), n_coeffs); }
+        src = scaled.u64();
+    }
+    rc = run_mfft(pl->cache_fwd.u64(), src, n_coeffs, d_out, (int)log_n, (int)log_n - logd, 0, nullptr, nullptr);
+    if (rc != IOPX_OK) return rc;
+    IOPX_HIP(hipStreamSynchronize(stream()));           // per-call tables are freed on return
+    return IOPX_OK;
+}
+
+int iopx_mul_ifft_fp3_dev(const uint64_t *d_evals, size_t log_n, const uint64_t *gen, const uint64_t *shift, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (log_n > 31) return fail(IOPX_ERR_INVALID_ARGUMENT, "log_n %zu exceeds the 2-adicity of the field", log_n);
+    if (!gen || !shift || !d_out || !d_evals) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    const size_t n = (size_t)1 << log_n;
+    if (log_n == 0) {       // multiplicative_IFFT_wrapper returns {v[0]} for size 1 (fft.tcc:397-401)
+        IOPX_HIP(hipMemcpyAsync(d_out, d_evals, 24, hipMemcpyDeviceToDevice, stream()));
+        return IOPX_OK;
+    }
+    MulPlan *pl = nullptr;
+    rc = get_mplan((int)log_n, gen, &pl);
+    if (rc != IOPX_OK) return rc;
+    if (!pl->have_inv && (rc = build_cache(*pl, true)) != IOPX_OK) return rc;
+    const hfp3 sh = hfp3::from_words(shift);
+    if (sh.is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "multiplicative IFFT: zero coset shift");
+    const hfp3 ninv = hfp3::from_uint((uint64_t)n).inverse();
+    DevBuf hi, lo, tmp;
+    int scale = 1;
+    if (sh == hfp3::one()) {
+        if ((rc = hi.alloc(24)) != IOPX_OK) return rc;
+        IOPX_HIP(hipMemcpyAsync(hi.p, ninv.w, 24, hipMemcpyHostToDevice, stream()));
+    } else {
+        scale = 2;
+        if ((rc = build_two_level(sh.inverse(), ninv, (int)log_n, hi, lo)) != IOPX_OK) return rc;
+    }
+    const uint64_t *src = d_evals;
+    if (d_evals == d_out) {     // the first pass permutes: it cannot run in place
+        if ((rc = tmp.alloc(n * 24)) != IOPX_OK) return rc;
+        IOPX_HIP(hipMemcpyAsync(tmp.p, d_evals, n * 24, hipMemcpyDeviceToDevice, stream()));
+        src = tmp.u64();
+    }
+    rc = run_mfft(pl->cache_inv.u64(), src, n, d_out, (int)log_n, 0, scale, hi.u64(), lo.p ? lo.u64() : nullptr);
+    if (rc != IOPX_OK) return rc;
+    IOPX_HIP(hipStreamSynchronize(stream()));
+    return IOPX_OK;
+}
+
+int iopx_mul_ifft_known_degree_fp3_dev(const uint64_t *d_evals, size_t degree, size_t log_n, const uint64_t *gen,
+                                       const uint64_t *shift, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (log_n > 31 || degree == 0 || degree > ((size_t)1 << log_n)) return fail(IOPX_ERR_INVALID_ARGUMENT, "bad degree / domain size");
+    const int k = (int)ceil_log2(degree);
+    const size_t pow2 = (size_t)1 << k, stride = ((size_t)1 << log_n) >> k;
+    DevBuf sub;
+    if ((rc = sub.alloc(pow2 * 24)) != IOPX_OK) return rc;
+    { ProfScope ps_("k_fp_gather_stride"); hipLaunchKernelGGL(k_fp_gather_stride, dim3(mgrid(3 * pow2, 256)), dim3(256), 0, stream(), sub.u64(), d_evals, stride, pow2); }
+    // generator of the sub-coset: g^(n / pow2)
+    hfp3 gs = hfp3::from_words(gen);
+    for (size_t s = stride; s > 1; s >>= 1) gs = gs.squared();
+    rc = iopx_mul_ifft_fp3_dev(sub.u64(), (size_t)k, gs.w, shift, d_out);
+    if (rc != IOPX_OK) return rc;
+    IOPX_HIP(hipStreamSynchronize(stream()));
+    return IOPX_OK;
+}
+
+int iopx_fri_fold_mul_fp3_dev(const uint64_t *d_f_i, size_t log_n, const uint64_t *gen, const uint64_t *shift,
+                              size_t coset_size, const uint64_t *x_i, uint64_t *d_next)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (log_n > 31) return fail(IOPX_ERR_INVALID_ARGUMENT, "log_n %zu exceeds the 2-adicity of the field", log_n);
+    if (!d_f_i || !d_next || !gen || !shift || !x_i) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (coset_size == 0 || (coset_size & (coset_size - 1))) return fail(IOPX_ERR_INVALID_ARGUMENT, "coset size %zu is not a power of two", coset_size);
+    const int eta = (int)ceil_log2(coset_size);
+    if ((size_t)eta > log_n) return fail(IOPX_ERR_INVALID_ARGUMENT, "coset size %zu exceeds the domain size", coset_size);
+    const size_t n = (size_t)1 << log_n;
+    if (eta == 0) {
+        IOPX_HIP(hipMemcpyAsync(d_next, d_f_i, n * 24, hipMemcpyDeviceToDevice, stream()));
+        return IOPX_OK;
+    }
+    MulPlan *pl = nullptr;
+    rc = get_mplan((int)log_n, gen, &pl);
+    if (rc != IOPX_OK) return rc;
+    if (!pl->have_inv && (rc = build_cache(*pl, true)) != IOPX_OK) return rc;
+    hfp3 sh = hfp3::from_words(shift), x = hfp3::from_words(x_i);
+    if (sh.is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "FRI fold: zero coset shift");
+    const hfp3 inv2 = hfp3::from_uint(2).inverse();
+    std::vector<uint64_t> hc;
+    for (int e = 0; e < eta; ++e) {
+        const hfp3 xs = x * sh.inverse();
+        hc.insert(hc.end(), xs.w, xs.w + 3);
+        hc.insert(hc.end(), inv2.w, inv2.w + 3);
+        sh = sh.squared();
+        x = x.squared();
+    }
+    DevBuf dc;
+    if ((rc = dc.alloc(hc.size() * 8)) != IOPX_OK) return rc;
+    IOPX_HIP(hipMemcpyAsync(dc.p, hc.data(), hc.size() * 8, hipMemcpyHostToDevice, stream()));
+    const uint64_t *ginv_top = pl->cache_inv.u64() + 3 * ((n >> 1) - 1);
+    DevBuf tmp[2];
+    const uint64_t *src = d_f_i;
+    size_t cur = n;
+    for (int e = 0; e < eta; ++e) {
+        const size_t half = cur >> 1;
+        uint64_t *dst = d_next;
+        if (e != eta - 1) {
+            if ((rc = tmp[e & 1].alloc(half * 24)) != IOPX_OK) return rc;
+            dst = tmp[e & 1].u64();
+        }
+        MfoldParams p;
+        p.src = src; p.dst = dst; p.ginv = ginv_top; p.consts = dc.u64() + 6 * e; p.half = half; p.stride_log = e;
+        { ProfScope ps_("k_fri_fold2_mul"); hipLaunchKernelGGL(k_fri_fold2_mul, dim3(mgrid(half, 256)), dim3(256), 0, stream(), p); }
+        src = dst;
+        cur = half;
+    }
+    IOPX_HIP(hipGetLastError());
+    IOPX_HIP(hipStreamSynchronize(stream()));
+    return IOPX_OK;
+}
+
+// ---- host-pointer variants ---------------------------------------------------------------------
+int iopx_mul_fft_fp3(const uint64_t *coeffs, size_t n_coeffs, size_t log_n, const uint64_t *gen, const uint64_t *shift, uint64_t *out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (log_n > 31) return fail(IOPX_ERR_INVALID_ARGUMENT, "log_n %zu exceeds the 2-adicity of the field", log_n);
+    const size_t n = (size_t)1 << log_n;
+    if (n_coeffs > n) return fail(IOPX_ERR_INVALID_ARGUMENT, "multiplicative FFT: %zu coefficients exceed the domain size %zu", n_coeffs, n);
+    DevBuf din, dout;
+    if ((rc = din.alloc(n_coeffs * 24)) != IOPX_OK) return rc;
+    if ((rc = dout.alloc(n * 24)) != IOPX_OK) return rc;
+    if (n_coeffs) IOPX_HIP(hipMemcpyAsync(din.p, coeffs, n_coeffs * 24, hipMemcpyHostToDevice, stream()));
+    if ((rc = iopx_mul_fft_fp3_dev(din.u64(), n_coeffs, log_n, gen, shift, dout.u64())) != IOPX_OK) return rc;
+    IOPX_HIP(hipMemcpyAsync(out, dout.p, n * 24, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(hipStreamSynchronize(stream()));
+    return IOPX_OK;
+}
+
+int iopx_mul_ifft_fp3(const uint64_t *evals, size_t log_n, const uint64_t *gen, const uint64_t *shift, uint64_t *out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (log_n > 31) return fail(IOPX_ERR_INVALID_ARGUMENT, "log_n %zu exceeds the 2-adicity of the field", log_n);
+    const size_t n = (size_t)1 << log_n;
+    DevBuf din, dout;
+    if ((rc = din.alloc(n * 24)) != IOPX_OK) return rc;
+    if ((rc = dout.alloc(n * 24)) != IOPX_OK) return rc;
+    IOPX_HIP(hipMemcpyAsync(din.p, evals, n * 24, hipMemcpyHostToDevice, stream()));
+    if ((rc = iopx_mul_ifft_fp3_dev(din.u64(), log_n, gen, shift, dout.u64())) != IOPX_OK) return rc;
+    IOPX_HIP(hipMemcpyAsync(out, dout.p, n * 24, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(hipStreamSynchronize(stream()));
+    return IOPX_OK;
+}
+
+int iopx_fri_fold_mul_fp3(const uint64_t *f_i, size_t log_n, const uint64_t *gen, const uint64_t *shift, size_t coset_size,
+                          const uint64_t *x_i, uint64_t *next)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (log_n > 31) return fail(IOPX_ERR_INVALID_ARGUMENT, "log_n %zu exceeds the 2-adicity of the field", log_n);
+    if (coset_size == 0 || (coset_size & (coset_size - 1)) || coset_size > ((size_t)1 << log_n))
+        return fail(IOPX_ERR_INVALID_ARGUMENT, "bad coset size %zu", coset_size);
+    const size_t n = (size_t)1 << log_n, n_out = n / coset_size;
+    DevBuf din, dout;
+    if ((rc = din.alloc(n * 24)) != IOPX_OK) return rc;
+    if ((rc = dout.alloc(n_out * 24)) != IOPX_OK) return rc;
+    IOPX_HIP(hipMemcpyAsync(din.p, f_i, n * 24, hipMemcpyHostToDevice, stream()));
+    if ((rc = iopx_fri_fold_mul_fp3_dev(din.u64(), log_n, gen, shift, coset_size, x_i, dout.u64())) != IOPX_OK) return rc;
+    IOPX_HIP(hipMemcpyAsync(next, dout.p, n_out * 24, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(hipStreamSynchronize(stream()));
+    return IOPX_OK;
+}
+
+} // extern "C"

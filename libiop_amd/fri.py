@@ -1,0 +1,55 @@
+"""FRI prover commit phase on device-resident codewords (additive domains, GF(2^192)).
+
+Host-side mirror of FRI_protocol::calculate_and_submit_proof (libiop/protocols/ldt/fri/fri_ldt.tcc:475-548)
+together with the per-round work bcs_prover::signal_prover_round_done does for it (bcs_prover.tcc:23-60: one
+Merkle tree per round over the round's oracle, leaves serialised by cosets of size 2^eta_i; bcs_common.tcc:550-614:
+absorb the root, absorb the round's prover messages, squeeze the verifier challenge).  The codeword never leaves
+HBM: Merkle build, fold and the final IFFT run through the C ABI's *_dev entry points on torch-owned buffers."""
+import numpy as np
+
+from . import host
+
+
+class FRICommitResult:
+    def __init__(self):
+        self.roots = []             # one 32-byte root per round
+        self.challenges = []        # x_i, (3,) uint64 each
+        self.trees = []             # device node buffers (torch uint8 tensors), heap order
+        self.codewords = []         # f_i device buffers (torch int64 tensors, (n_i, 3))
+        self.final_polynomial = None
+
+
+def fri_commit(lib, torch, d_codeword, basis, shift, localization_parameters, final_degree_bound, hashchain=None,
+               keep_codewords=False):
+    """Runs the FRI reductions on `d_codeword` ((2^m, 3) int64 torch tensor on the device `lib` is bound to).
+    Returns FRICommitResult.  `hashchain` defaults to a fresh Blake2bHashchain."""
+    hc = hashchain or host.Blake2bHashchain()
+    doms = host.fri_additive_domains(basis, shift, localization_parameters)
+    res = FRICommitResult()
+    f = d_codeword
+    for i, eta in enumerate(localization_parameters):
+        b_i, s_i = doms[i]
+        n_i = f.shape[0]
+        cs = 1 << eta
+        leaves = n_i // cs
+        nodes = torch.empty((2 * leaves - 1, 32), dtype=torch.uint8, device=f.device)
+        # signal_prover_round_done: Merkle tree over f_i with cosets of size 2^eta_i (bcs_prover.tcc:36-46)
+        lib.merkle_tree_dev([f.data_ptr()], 24, n_i, cs, nodes.data_ptr())
+        root = bytes(nodes[0].cpu().numpy())
+        res.roots.append(root)
+        res.trees.append(nodes)
+        if keep_codewords:
+            res.codewords.append(f)
+        hc.absorb(root)             # run_hashchain_for_round: roots, then the (empty) prover messages
+        hc.absorb(None)
+        x_i = hc.squeeze_gf192(1)[0]
+        res.challenges.append(x_i)
+        nxt = torch.empty((n_i // cs, 3), dtype=torch.int64, device=f.device)
+        lib.fri_fold_dev(f.data_ptr(), b_i, s_i, cs, x_i, nxt.data_ptr())     # fri_ldt.tcc:522-526
+        f = nxt
+    b_l, s_l = doms[len(localization_parameters)]
+    coeffs = torch.empty_like(f)
+    lib.additive_IFFT_dev(f.data_ptr(), b_l, s_l, coeffs.data_ptr())          # fri_ldt.tcc:538
+    lib.synchronize()
+    res.final_polynomial = coeffs.cpu().numpy().view(np.uint64)[:final_degree_bound].copy()   # :540 resize
+    return res

@@ -232,3 +232,109 @@ class Hashchain:
         if rc != 0:
             raise ValueError("upper_bound must be a power of two.")
         return [int(v) for v in buf]
+
+
+# ---- prime field edwards_Fr (Montgomery words, (count, 3) uint64) and the multiplicative-domain path ----------
+EDWARDS_R = 1552511030102430251236801561344621993261920897571225601
+
+
+def fp_from_ints(values):
+    """canonical Python ints -> Montgomery words"""
+    c = np.array([[(int(v) >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(3)] for v in values], dtype=np.uint64).reshape(-1, 3)
+    out = np.empty_like(c)
+    lib().oracle_fp_from_canonical(_p(c), _p(out), ctypes.c_size_t(c.shape[0]))
+    return out
+
+
+def fp_to_ints(m):
+    m = _c(m).reshape(-1, 3)
+    out = np.empty_like(m)
+    lib().oracle_fp_to_canonical(_p(m), _p(out), ctypes.c_size_t(m.shape[0]))
+    return [int(r[0]) | (int(r[1]) << 64) | (int(r[2]) << 128) for r in out]
+
+
+def fp_rand(seed, count):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    vals = [int.from_bytes(rng.bytes(32), "little") % EDWARDS_R for _ in range(count)]
+    return fp_from_ints(vals)
+
+
+def _fp_bin(op, a, b):
+    a, b = _c(a), _c(b)
+    out = np.empty_like(a)
+    lib().oracle_fp_binop(op, _p(a), _p(b), _p(out), ctypes.c_size_t(a.shape[0]))
+    return out
+
+
+def fp_mul(a, b):
+    return _fp_bin(0, a, b)
+
+
+def fp_add(a, b):
+    return _fp_bin(1, a, b)
+
+
+def fp_sub(a, b):
+    return _fp_bin(2, a, b)
+
+
+def fp_inv(a):
+    a = _c(a)
+    out = np.empty_like(a)
+    lib().oracle_fp_inv(_p(a), _p(out), ctypes.c_size_t(a.shape[0]))
+    return out
+
+
+def fp_subgroup_generator(order):
+    out = np.empty(3, dtype=np.uint64)
+    lib().oracle_fp_subgroup_generator(ctypes.c_size_t(order), _p(out))
+    return out
+
+
+def fp_one():
+    return fp_from_ints([1])[0]
+
+
+def fp_all_elements(order, shift):
+    shift = _c(shift)
+    out = np.empty((order, 3), dtype=np.uint64)
+    lib().oracle_fp_all_elements(ctypes.c_size_t(order), _p(shift), _p(out))
+    return out
+
+
+def fp_naive_fft(coeffs, order, shift):
+    coeffs, shift = _c(coeffs), _c(shift)
+    out = np.empty((order, 3), dtype=np.uint64)
+    lib().oracle_fp_naive_fft(_p(coeffs), ctypes.c_size_t(coeffs.shape[0]), ctypes.c_size_t(order), _p(shift), _p(out))
+    return out
+
+
+def multiplicative_fft(coeffs, order, shift):
+    coeffs, shift = _c(coeffs), _c(shift)
+    out = np.empty((order, 3), dtype=np.uint64)
+    rc = lib().oracle_fp_fft(_p(coeffs), ctypes.c_size_t(coeffs.shape[0]), ctypes.c_size_t(order), _p(shift), _p(out))
+    if rc != 0:
+        raise ValueError("oracle_fp_fft rc=%d" % rc)
+    return out
+
+
+def multiplicative_ifft(evals, shift):
+    evals, shift = _c(evals), _c(shift)
+    out = np.empty_like(evals)
+    lib().oracle_fp_ifft(_p(evals), ctypes.c_size_t(evals.shape[0]), _p(shift), _p(out))
+    return out
+
+
+def multiplicative_ifft_known_degree(evals, degree, shift):
+    evals, shift = _c(evals), _c(shift)
+    k = max(degree - 1, 0).bit_length()
+    out = np.empty((1 << k, 3), dtype=np.uint64)
+    lib().oracle_fp_ifft_known_degree(_p(evals), ctypes.c_size_t(degree), ctypes.c_size_t(evals.shape[0]), _p(shift), _p(out))
+    return out
+
+
+def fri_fold_multiplicative(f_i, shift, coset_size, x_i):
+    f_i, shift, x_i = _c(f_i), _c(shift), _c(x_i)
+    out = np.empty((f_i.shape[0] // coset_size, 3), dtype=np.uint64)
+    lib().oracle_fp_fri_fold(_p(f_i), ctypes.c_size_t(f_i.shape[0]), _p(shift), ctypes.c_size_t(coset_size), _p(x_i), _p(out))
+    return out

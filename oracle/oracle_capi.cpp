@@ -7,6 +7,7 @@
 #include "algebra.hpp"
 #include "fri.hpp"
 #include "merkle.hpp"
+#include "mult.hpp"
 
 using namespace oracle;
 
@@ -193,6 +194,60 @@ int oracle_hashchain_squeeze_positions(const uint8_t *state, uint64_t *squeeze_i
     } catch (const std::invalid_argument &) { return -3; }
     *squeeze_index = hc.squeeze_index;
     return 0;
+}
+
+
+// ---- prime field edwards_Fr (3 limbs, Montgomery words) and the multiplicative-domain path ----------------
+typedef edwards_Fr FP;
+
+void oracle_fp_from_canonical(const uint64_t *c, uint64_t *out, size_t count)
+{
+    for (size_t i = 0; i < count; ++i) { const FP x = FP::from_canonical(c + 3 * i); memcpy(out + 3 * i, x.mont, 24); }
+}
+void oracle_fp_to_canonical(const uint64_t *m, uint64_t *out, size_t count)
+{
+    for (size_t i = 0; i < count; ++i) { FP x; memcpy(x.mont, m + 3 * i, 24); x.to_canonical(out + 3 * i); }
+}
+void oracle_fp_binop(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t count)
+{
+    const FP *x = (const FP *)a; const FP *y = (const FP *)b; FP *o = (FP *)out;
+    for (size_t i = 0; i < count; ++i) o[i] = op == 0 ? x[i] * y[i] : (op == 1 ? x[i] + y[i] : x[i] - y[i]);
+}
+void oracle_fp_inv(const uint64_t *a, uint64_t *out, size_t count)
+{
+    const FP *x = (const FP *)a; FP *o = (FP *)out;
+    for (size_t i = 0; i < count; ++i) o[i] = x[i].inverse();
+}
+void oracle_fp_subgroup_generator(size_t order, uint64_t *out) { const FP g = FP::subgroup_generator(order); memcpy(out, g.mont, 24); }
+
+static mult_coset<FP> load_coset(size_t order, const uint64_t *shift)
+{
+    FP s; memcpy(s.mont, shift, 24);
+    return mult_coset<FP>(order, s);
+}
+void oracle_fp_all_elements(size_t order, const uint64_t *shift, uint64_t *out) { store<FP>(out, load_coset(order, shift).all_elements()); }
+void oracle_fp_naive_fft(const uint64_t *coeffs, size_t n_coeffs, size_t order, const uint64_t *shift, uint64_t *out)
+{
+    store<FP>(out, naive_FFT<FP>(load<FP>(coeffs, n_coeffs), load_coset(order, shift).all_elements()));
+}
+int oracle_fp_fft(const uint64_t *coeffs, size_t n_coeffs, size_t order, const uint64_t *shift, uint64_t *out)
+{
+    if (n_coeffs > order || n_coeffs == 0) return -2;
+    store<FP>(out, multiplicative_FFT_degree_aware<FP>(load<FP>(coeffs, n_coeffs), load_coset(order, shift)));
+    return 0;
+}
+void oracle_fp_ifft(const uint64_t *evals, size_t order, const uint64_t *shift, uint64_t *out)
+{
+    store<FP>(out, multiplicative_IFFT<FP>(load<FP>(evals, order), load_coset(order, shift)));
+}
+void oracle_fp_ifft_known_degree(const uint64_t *evals, size_t degree, size_t order, const uint64_t *shift, uint64_t *out)
+{
+    store<FP>(out, multiplicative_IFFT_of_known_degree<FP>(load<FP>(evals, order), degree, load_coset(order, shift)));
+}
+void oracle_fp_fri_fold(const uint64_t *f_i, size_t order, const uint64_t *shift, size_t coset_size, const uint64_t *x_i, uint64_t *out)
+{
+    FP x; memcpy(x.mont, x_i, 24);
+    store<FP>(out, multiplicative_evaluate_next_f_i_over_entire_domain<FP>(load<FP>(f_i, order), load_coset(order, shift), coset_size, x));
 }
 
 } // extern "C"

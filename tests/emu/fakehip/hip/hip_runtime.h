@@ -59,6 +59,13 @@ static inline int __builtin_amdgcn_sbfe(int v, unsigned off, unsigned width)
 
 static inline uint32_t __builtin_amdgcn_readfirstlane(uint32_t x) { return x; }
 
+static inline unsigned long long __brevll(unsigned long long x)
+{
+    unsigned long long r = 0;
+    for (int i = 0; i < 64; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+
 typedef int hipError_t;
 typedef void *hipStream_t;
 enum { hipSuccess = 0, hipErrorUnknown = 999 };

@@ -183,3 +183,64 @@ def test_cfg3_fold_preserves_low_degree_at_full_size(gpu):
         deg >>= eta
         co = gpu.additive_IFFT(cw, cb, cs_)
         assert not co[deg:].any()
+
+
+# ---- multiplicative cosets over the 181-bit prime field (BASELINE config 5's field) ----------------------------
+def _fp_shifts():
+    return [oracle.fp_one(), oracle.fp_from_ints([19])[0], oracle.fp_rand(5, 1)[0]]
+
+
+@pytest.mark.parametrize("logn", [1, 2, 3, 6, 9, 12, 13, 16])
+def test_mult_fft(gpu, logn):
+    n = 1 << logn
+    for ncoef in sorted({1, 2, 3, n // 2 + 1, n - 1, n}):
+        if ncoef > n or ncoef < 1:
+            continue
+        coeffs = oracle.fp_rand(logn * 10 + ncoef, ncoef)
+        for shift in _fp_shifts()[: (3 if logn < 12 else 2)]:
+            assert np.array_equal(gpu.multiplicative_FFT(coeffs, logn, shift), oracle.multiplicative_fft(coeffs, n, shift)), (logn, ncoef)
+
+
+def test_mult_fft_lde_shapes(gpu):
+    shift = oracle.fp_from_ints([19])[0]            # Fractal's codeword coset shift = multiplicative_generator
+    for logn, ncoef in [(14, 16), (18, 1 << 13), (18, (1 << 13) - 5), (20, 1 << 15)]:
+        coeffs = oracle.fp_rand(ncoef, ncoef)
+        assert np.array_equal(gpu.multiplicative_FFT(coeffs, logn, shift), oracle.multiplicative_fft(coeffs, 1 << logn, shift))
+    assert not gpu.multiplicative_FFT(np.zeros((0, 3), dtype=np.uint64), 5, shift).any()
+
+
+@pytest.mark.parametrize("logn", [1, 2, 5, 9, 12, 13, 17])
+def test_mult_ifft(gpu, logn):
+    ev = oracle.fp_rand(logn, 1 << logn)
+    for shift in _fp_shifts()[:2]:
+        assert np.array_equal(gpu.multiplicative_IFFT(ev, shift), oracle.multiplicative_ifft(ev, shift))
+
+
+def test_mult_ifft_known_degree(gpu):
+    n, deg = 1 << 15, 3000
+    shift = oracle.fp_from_ints([19])[0]
+    ev = oracle.multiplicative_fft(oracle.fp_rand(1, deg), n, shift)
+    assert np.array_equal(gpu.multiplicative_IFFT_of_known_degree(ev, deg, shift), oracle.multiplicative_ifft_known_degree(ev, deg, shift))
+
+
+@pytest.mark.parametrize("logn,cs", [(1, 2), (4, 2), (6, 4), (8, 8), (14, 2), (14, 4), (5, 1)])
+def test_mult_fri_fold(gpu, logn, cs):
+    f = oracle.fp_rand(logn + cs, 1 << logn)
+    x = oracle.fp_rand(99, 1)[0]
+    for shift in _fp_shifts()[:2]:
+        assert np.array_equal(gpu.multiplicative_evaluate_next_f_i(f, shift, cs, x), oracle.fri_fold_multiplicative(f, shift, cs, x))
+
+
+def test_cfg5_shape_properties(gpu):
+    # 2^22-point coset (Fractal codeword coset shift), degree-2^19 polynomial: round trip through the strided
+    # IFFT of known degree, and the fold keeps the codeword low-degree over the squared coset
+    logn, d = 22, 19
+    shift = oracle.fp_from_ints([19])[0]
+    coeffs = oracle.fp_rand(0x2205, 1 << d)
+    cw = gpu.multiplicative_FFT(coeffs, logn, shift)
+    assert np.array_equal(gpu.multiplicative_IFFT_of_known_degree(cw, 1 << d, shift), coeffs)
+    x = oracle.fp_rand(7, 1)[0]
+    nxt = gpu.multiplicative_evaluate_next_f_i(cw, shift, 4, x)
+    shift4 = oracle.fp_mul(oracle.fp_mul(shift[None, :], shift[None, :]), oracle.fp_mul(shift[None, :], shift[None, :]))[0]
+    co = gpu.multiplicative_IFFT(nxt, shift4)
+    assert not co[1 << (d - 2):].any()

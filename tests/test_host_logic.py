@@ -1,0 +1,73 @@
+"""Host-side logic of the product (libiop_amd/host.py, fri.py) against the oracle; device work runs on the CPU
+emulation of the kernels (tests/emu)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from emu_lib import emu
+from helpers import rand_elems
+from libiop_amd import fri, host
+
+W = 3
+
+
+def test_gf192_int_helpers_match_oracle():
+    a, b = rand_elems(1, 50, W), rand_elems(2, 50, W)
+    exp = oracle.gf_mul(a, b)
+    for i in range(50):
+        assert host.gf_mul(host.gf_from_words(a[i]), host.gf_from_words(b[i])) == host.gf_from_words(exp[i])
+    inv = oracle.gf_inv(a[:5])
+    for i in range(5):
+        assert host.gf_inv(host.gf_from_words(a[i])) == host.gf_from_words(inv[i])
+
+
+def test_localization_array_and_domain_chain():
+    assert host.localization_parameter_to_array(2, 22, 2) == oracle.localization_array(2, 22, 2) == [1] + [2] * 9
+    assert host.localization_parameter_to_array(3, 15, 2) == oracle.localization_array(3, 15, 2)
+    basis, shift = rand_elems(3, 10, W), rand_elems(4, 1, W)[0]
+    loc = [1, 2, 3]
+    got = host.fri_additive_domains(basis, shift, loc)
+    exp = oracle.fri_domains_additive(basis, shift, loc)
+    assert np.array_equal(got[0][0], basis) and np.array_equal(got[0][1], shift)
+    for (gb, gs), (eb, es) in zip(got[1:], exp):
+        assert np.array_equal(gb, eb) and np.array_equal(gs, es)
+
+
+def test_hashchain_matches_oracle():
+    a, b = host.Blake2bHashchain(), oracle.Hashchain()
+    for r in range(3):
+        a.absorb(bytes([r]) * 32)
+        b.absorb(bytes([r]) * 32)
+        assert a.state == bytes(b.state)
+        assert np.array_equal(a.squeeze_gf192(2), b.squeeze(2, 3))
+    assert a.squeeze_query_positions(5, 1 << 12) == b.squeeze_query_positions(5, 1 << 12)
+    with pytest.raises(ValueError):
+        a.squeeze_query_positions(1, 12)
+
+
+def test_fri_commit_matches_oracle_composition():
+    # dim-10 codeword of a degree-<2^8 polynomial, array [1,2,2] (fri_ldt.tcc:132-146 with eta = 2, RS extra 2 -> [1,2,2,2];
+    # one reduction fewer keeps the CPU emulation short)
+    m, d = 10, 8
+    basis, shift = oracle.standard_basis(m, W), np.zeros(W, dtype=np.uint64)
+    loc = [1, 2, 2]
+    cw = oracle.additive_fft(rand_elems(7, 1 << d, W), basis, shift)
+    d_cw = torch.from_numpy(cw.view(np.int64).copy())
+    res = fri.fri_commit(emu(), torch, d_cw, basis, shift, loc, final_degree_bound=1 << (d - sum(loc)))
+
+    hc = oracle.Hashchain()
+    doms = [(basis, shift)] + oracle.fri_domains_additive(basis, shift, loc)
+    f = cw
+    for i, eta in enumerate(loc):
+        nodes = oracle.merkle_build([f], 1 << eta, True)
+        assert res.roots[i] == bytes(nodes[0])
+        assert np.array_equal(res.trees[i].numpy(), nodes)
+        hc.absorb(bytes(nodes[0]))
+        hc.absorb(b"\0" * 32)
+        x = hc.squeeze(1, 3)[0]
+        assert np.array_equal(res.challenges[i], x)
+        f = oracle.fri_fold_additive(f, doms[i][0], doms[i][1], 1 << eta, x)
+    final = oracle.additive_ifft(f, doms[-1][0], doms[-1][1])
+    assert not final[1 << (d - sum(loc)):].any()            # the folded word is low degree
+    assert np.array_equal(res.final_polynomial, final[: 1 << (d - sum(loc))])

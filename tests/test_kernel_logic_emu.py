@@ -107,3 +107,56 @@ def test_merkle_zk_and_errors():
         emu().merkle_tree([rand_elems(1, 12, W)], 2)
     with pytest.raises(ValueError):             # more coefficients than the domain holds
         emu().additive_FFT(rand_elems(1, 9, W), oracle.standard_basis(3, W), np.zeros(W, dtype=np.uint64))
+
+
+# ---- multiplicative cosets over the 181-bit prime field --------------------------------------------------------
+def _shifts():
+    return [oracle.fp_one(), oracle.fp_from_ints([19])[0], oracle.fp_rand(5, 1)[0]]
+
+
+def test_fp_generator_matches_oracle():
+    import libiop_amd
+    for k in (1, 5, 20, 31):
+        assert np.array_equal(libiop_amd.edwards_subgroup_generator(k), oracle.fp_subgroup_generator(1 << k))
+
+
+@pytest.mark.parametrize("logn", [1, 2, 3, 6, 9, 12, 13])
+def test_mult_fft(logn):
+    n = 1 << logn
+    for ncoef in sorted({1, 2, 3, n // 2 + 1, n - 1, n}):
+        if ncoef > n or ncoef < 1:
+            continue
+        coeffs = oracle.fp_rand(logn * 10 + ncoef, ncoef)
+        for shift in _shifts()[: (3 if logn < 12 else 2)]:
+            assert np.array_equal(emu().multiplicative_FFT(coeffs, logn, shift), oracle.multiplicative_fft(coeffs, n, shift)), (logn, ncoef)
+
+
+def test_mult_fft_small_degree_large_domain():
+    # 16 coefficients onto 2^14 points: only the top 4 index bits are active (Aurora's f_1v shape)
+    coeffs = oracle.fp_rand(3, 16)
+    shift = oracle.fp_from_ints([19])[0]
+    assert np.array_equal(emu().multiplicative_FFT(coeffs, 14, shift), oracle.multiplicative_fft(coeffs, 1 << 14, shift))
+    assert not emu().multiplicative_FFT(np.zeros((0, 3), dtype=np.uint64), 5, shift).any()
+
+
+@pytest.mark.parametrize("logn", [1, 2, 5, 9, 12, 13])
+def test_mult_ifft(logn):
+    n = 1 << logn
+    ev = oracle.fp_rand(logn, n)
+    for shift in _shifts()[:2]:
+        assert np.array_equal(emu().multiplicative_IFFT(ev, shift), oracle.multiplicative_ifft(ev, shift))
+
+
+def test_mult_ifft_known_degree():
+    n, deg = 1 << 10, 100
+    shift = oracle.fp_from_ints([19])[0]
+    ev = oracle.multiplicative_fft(oracle.fp_rand(1, deg), n, shift)
+    assert np.array_equal(emu().multiplicative_IFFT_of_known_degree(ev, deg, shift), oracle.multiplicative_ifft_known_degree(ev, deg, shift))
+
+
+@pytest.mark.parametrize("logn,cs", [(1, 2), (4, 2), (6, 4), (8, 8), (10, 2), (10, 4), (5, 1)])
+def test_mult_fri_fold(logn, cs):
+    f = oracle.fp_rand(logn + cs, 1 << logn)
+    x = oracle.fp_rand(99, 1)[0]
+    for shift in _shifts()[:2]:
+        assert np.array_equal(emu().multiplicative_evaluate_next_f_i(f, shift, cs, x), oracle.fri_fold_multiplicative(f, shift, cs, x))
