@@ -11,6 +11,9 @@
 //   IFFT_of_known_degree_over_field_subset                 libiop/algebra/fft.hpp:62-88   (fft.tcc:407-475)
 //   evaluate_next_f_i_over_entire_domain                   libiop/protocols/ldt/fri/fri_aux.hpp:23-28
 //   merkle_tree<FieldT, binary_hash_digest>                libiop/bcs/merkle_tree.hpp:67-104 (construct*, get_root)
+//   multiplicative_coset<FieldT>, multiplicative_FFT / _IFFT,
+//   multiplicative_evaluate_next_f_i_over_entire_domain    field_subset/subgroup.hpp, fft.hpp:40-52, fri_aux.tcc:106-249
+//                                                          (FieldT with libff::edwards_Fr's layout)
 //
 // INTEGRATION.md shows how libiop's own headers bind to this instead of their CPU bodies.
 #pragma once
@@ -173,6 +176,65 @@ std::vector<FieldT> IFFT_of_known_degree_over_field_subset(const std::vector<Fie
     return additive_IFFT<FieldT>(head, minimal.subspace());
 }
 
+// ---- multiplicative cosets over the 181-bit prime field ------------------------------------------------
+// libiop/algebra/field_subset/subgroup.hpp — multiplicative_coset: order 2^k, generator g, shift; index i <-> shift * g^i.
+// FieldT must have libff::edwards_Fr's layout (three uint64 Montgomery words).  The generator is supplied by the caller's
+// field type (subgroup.tcc:55-59: multiplicative_generator^((p-1)/order)).
+template<typename FieldT>
+class multiplicative_coset {
+    std::size_t order_;
+    FieldT g_, shift_;
+public:
+    multiplicative_coset(std::size_t order, const FieldT &generator, const FieldT &shift) : order_(order), g_(generator), shift_(shift)
+    {
+        if (order == 0 || (order & (order - 1))) throw std::invalid_argument("The order of the subgroup must be a power of two.");
+    }
+    std::size_t num_elements() const { return order_; }
+    std::size_t dimension() const { std::size_t d = 0; while (((std::size_t)1 << d) < order_) ++d; return d; }
+    const FieldT &generator() const { return g_; }
+    const FieldT &shift() const { return shift_; }
+    // subgroup.tcc:175-197
+    std::size_t coset_index(std::size_t position, std::size_t coset_size) const { return position % (order_ / coset_size); }
+    std::size_t intra_coset_index(std::size_t position, std::size_t coset_size) const { return position / (order_ / coset_size); }
+    std::size_t position_by_coset_indices(std::size_t ci, std::size_t ici, std::size_t coset_size) const { return ci + ici * (order_ / coset_size); }
+};
+
+// multiplicative_FFT (fft.tcc:236-317, 336-341)
+template<typename FieldT>
+std::vector<FieldT> multiplicative_FFT(const std::vector<FieldT> &poly_coeffs, const multiplicative_coset<FieldT> &domain)
+{
+    static_assert(sizeof(FieldT) == 24, "libiop_amd accelerates prime fields with libff::edwards_Fr's layout");
+    std::vector<FieldT> out(domain.num_elements());
+    check(iopx_mul_fft_fp3(detail::words(poly_coeffs.data()), poly_coeffs.size(), domain.dimension(), detail::words(&domain.generator()),
+                           detail::words(&domain.shift()), detail::words(out.data())));
+    return out;
+}
+
+// multiplicative_IFFT (fft.tcc:343-376; size-1 early return :397-401)
+template<typename FieldT>
+std::vector<FieldT> multiplicative_IFFT(const std::vector<FieldT> &evals, const multiplicative_coset<FieldT> &domain)
+{
+    static_assert(sizeof(FieldT) == 24, "libiop_amd accelerates prime fields with libff::edwards_Fr's layout");
+    if (evals.size() != domain.num_elements()) throw std::invalid_argument("multiplicative_IFFT: evaluation count != domain size");
+    std::vector<FieldT> out(domain.num_elements());
+    check(iopx_mul_ifft_fp3(detail::words(evals.data()), domain.dimension(), detail::words(&domain.generator()),
+                            detail::words(&domain.shift()), detail::words(out.data())));
+    return out;
+}
+
+// multiplicative_evaluate_next_f_i_over_entire_domain (fri_aux.tcc:106-249)
+template<typename FieldT>
+std::shared_ptr<std::vector<FieldT>> multiplicative_evaluate_next_f_i_over_entire_domain(
+    const std::shared_ptr<std::vector<FieldT>> &f_i_evals, const multiplicative_coset<FieldT> &f_i_domain,
+    const std::size_t coset_size, const FieldT x_i)
+{
+    if (f_i_evals->size() != f_i_domain.num_elements()) throw std::invalid_argument("f_i size != domain size");
+    auto next = std::make_shared<std::vector<FieldT>>(f_i_domain.num_elements() / coset_size);
+    check(iopx_fri_fold_mul_fp3(detail::words(f_i_evals->data()), f_i_domain.dimension(), detail::words(&f_i_domain.generator()),
+                                detail::words(&f_i_domain.shift()), coset_size, detail::words(&x_i), detail::words(next->data())));
+    return next;
+}
+
 // ---- FRI fold (libiop/protocols/ldt/fri/fri_aux.hpp:23-28) ----------------------------------------
 template<typename FieldT>
 std::shared_ptr<std::vector<FieldT>> evaluate_next_f_i_over_entire_domain(
@@ -214,8 +276,10 @@ public:
     // zk salts are sampled by the caller (merkle_tree.tcc:36-72 uses libsodium randombytes)
     void set_leaf_randomness(const std::vector<uint8_t> &salts) { zk_salts_ = salts; }
 
+    // domain_type: position map of the default domain of the leaf_contents' size (field_subset<FieldT>(size), merkle_tree.tcc:118):
+    // IOPX_DOMAIN_ADDITIVE for binary fields, IOPX_DOMAIN_MULTIPLICATIVE for prime fields
     void construct_with_leaves_serialized_by_cosets(const std::vector<std::shared_ptr<std::vector<FieldT>>> &leaf_contents,
-                                                    std::size_t coset_serialization_size)
+                                                    std::size_t coset_serialization_size, int domain_type = IOPX_DOMAIN_ADDITIVE)
     {
         if (constructed_) throw std::logic_error("Attempting to double-construct a Merkle tree.");
         for (auto &v : leaf_contents)
@@ -226,7 +290,7 @@ public:
         for (auto &v : leaf_contents) ptrs.push_back(v->data());
         nodes_.assign((2 * num_leaves_ - 1) * 32, 0);
         check(iopx_merkle_blake2b(ptrs.data(), ptrs.size(), sizeof(FieldT), leaf_contents[0]->size(), coset_serialization_size,
-                                  IOPX_DOMAIN_ADDITIVE, make_zk_ ? zk_salts_.data() : nullptr, make_zk_ ? salt_bytes_ : 0, nodes_.data()));
+                                  domain_type, make_zk_ ? zk_salts_.data() : nullptr, make_zk_ ? salt_bytes_ : 0, nodes_.data()));
         constructed_ = true;
     }
     void construct(const std::vector<std::shared_ptr<std::vector<FieldT>>> &leaf_contents)

@@ -34,7 +34,7 @@ namespace iopx {
 // Tile geometry.  Defaults: 4096-element tiles (96 KiB of LDS per workgroup).  The IOPX_TILE_BITS /
 // IOPX_P1_COLS / IOPX_P2_COLS / IOPX_P2_TOP environment variables override them (read once): used for
 // tuning, and by the tests to exercise the multi-pass schedules at small transform sizes.
-struct Tuning { int tile_bits, p1_cols, p2_cols, p2_top; };
+struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads; };
 static int env_int(const char *name, int dflt, int lo, int hi)
 {
     const char *v = getenv(name);
@@ -47,15 +47,22 @@ static const Tuning &tuning()
     static const Tuning t = [] {
         Tuning u;
         u.tile_bits = env_int("IOPX_TILE_BITS", 12, 4, 12);
-        u.p1_cols = env_int("IOPX_P1_COLS", 2, 0, u.tile_bits - 3);     // strided phase-1 tiles: 2^c contiguous columns
+        u.p1_tile_bits = env_int("IOPX_P1_TILE_BITS", u.tile_bits < 10 ? u.tile_bits : 10, 4, 12);   // phase 1 is latency-bound: smaller tiles, more workgroups per CU
+        u.p1_cols = env_int("IOPX_P1_COLS", 3, 0, u.p1_tile_bits - 3);  // strided phase-1 tiles: 2^c contiguous columns
         u.p2_cols = env_int("IOPX_P2_COLS", 4, 0, u.tile_bits - 2);     // phase-2 upper passes: 2^c contiguous columns
-        u.p2_top = env_int("IOPX_P2_TOP", 4, 0, u.tile_bits - 2);       // last pass: 2^c natural-order runs
+        // the edge pass holds the levels whose twiddles are not wave-uniform (pair bits < 6): general multiplier,
+        // small tiles for occupancy; 2^p2_top natural-order runs
+        u.edge_tile_bits = env_int("IOPX_EDGE_TILE_BITS", u.tile_bits < 10 ? u.tile_bits : 10, 4, u.tile_bits);
+        u.p2_top = env_int("IOPX_P2_TOP", 4, 0, u.edge_tile_bits - 2);
+        u.comb = env_int("IOPX_COMB", 1, 0, 1);                         // 1: asm comb multiplier where the twiddle is wave-uniform
+        u.p2_threads = env_int("IOPX_P2_THREADS", u.comb ? 512 : 1024, 64, u.comb ? 512 : 1024);
         return u;
     }();
     return t;
 }
 #define TILE_BITS (tuning().tile_bits)
 #define P1_COLS (tuning().p1_cols)
+#define P1_TILE_BITS (tuning().p1_tile_bits)
 #define P2_COLS (tuning().p2_cols)
 #define P2_TOP (tuning().p2_top)
 static const int BLOCK_THREADS = 512;
@@ -238,6 +245,7 @@ struct BfParams {
     uint64_t *dst;          // cosets * 2^d elements
     const uint64_t *ltab;   // 2^d - 1 twiddles (no shift term)
     const uint64_t *rs;     // (1 + nhi) * d shift terms: rs[v * d + l]
+    const uint64_t *rs_comb;    // optional: per (local coset, level) combined shift term, [coset * d + l]
     int src_shared;
     int d, nhi;
     int c, h, A;            // upper pass tile geometry
@@ -253,6 +261,10 @@ __device__ __forceinline__ gf192 bf_twiddle(const BfParams &p, size_t coset, siz
 {
     const int l = p.d - 1 - pbit;
     gf192 tw = gf_load(p.ltab, (((size_t)1) << l) - 1 + (u >> (pbit + 1)));
+    if (p.rs_comb) {
+        gf_add_to(tw, gf_load(p.rs_comb, coset * p.d + l));
+        return tw;
+    }
     gf_add_to(tw, gf_load(p.rs, (size_t)l));
     const size_t gc = p.coset_base + coset;
     for (int v = 0; v < p.nhi; ++v) {
@@ -262,23 +274,36 @@ __device__ __forceinline__ gf192 bf_twiddle(const BfParams &p, size_t coset, siz
 }
 
 // `uniform`: every lane of the wavefront has the same twiddle (64 consecutive butterflies of one block)
-template<bool INV>
+// rs_comb[c * d + l] = rs[l] + sum_{bit v of (coset_base + c)} rs[(1 + v) * d + l]
+__global__ void k_rs_combine(uint64_t *out, const uint64_t *rs, int d, int nhi, size_t coset_base, size_t count)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t c = e / d, l = e % d, gc = coset_base + c;
+        gf192 acc = gf_load(rs, l);
+        for (int v = 0; v < nhi; ++v) {
+            if ((gc >> v) & 1) gf_add_to(acc, gf_load(rs, (size_t)(1 + v) * d + l));
+        }
+        gf_store(out, e, acc);
+    }
+}
+
+template<bool INV, bool COMB>
 __device__ __forceinline__ void bf_apply(uint64_t *s, int E, int ia, int ib, const gf192 &tw, bool uniform)
 {
     gf192 a = lds_get(s, E, ia), b = lds_get(s, E, ib);
     if (!INV) {
-        gf_add_to(a, uniform ? gf_mul_uniform(b, tw) : gf_mul(b, tw));  // S[a] += S[b] * t ; S[b] += S[a]  (fft.tcc:116-117)
+        gf_add_to(a, (COMB && uniform) ? gf_mul_uniform(b, tw) : gf_mul(b, tw));  // S[a] += S[b] * t ; S[b] += S[a]  (fft.tcc:116-117)
         gf_add_to(b, a);
     } else {
         gf_add_to(b, a);                    // S[b] += S[a] ; S[a] += S[b] * t     (fft.tcc:164-165)
-        gf_add_to(a, uniform ? gf_mul_uniform(b, tw) : gf_mul(b, tw));
+        gf_add_to(a, (COMB && uniform) ? gf_mul_uniform(b, tw) : gf_mul(b, tw));
     }
     lds_put(s, E, ia, a);
     lds_put(s, E, ib, b);
 }
 
-template<bool INV>
-__global__ void __launch_bounds__(512) k_bfly_upper(BfParams p)
+template<bool INV, bool COMB>
+__global__ void __launch_bounds__(COMB ? 512 : 1024) k_bfly_upper(BfParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
     uint64_t *s = iopx_smem;
@@ -304,11 +329,17 @@ __global__ void __launch_bounds__(512) k_bfly_upper(BfParams p)
     for (int t = 0; t < nlev; ++t) {
         const int pbit = INV ? p.p_lo + t : p.p_hi - t;
         const int pl = pbit - p.h + p.c;
-        for (int bf = tid; bf < (E >> 1); bf += nt) {
-            const int low = bf & ((1 << pl) - 1), high = bf >> pl;
-            const int ia = (high << (pl + 1)) | low, ib = ia | (1 << pl);
-            const size_t u = base | ((size_t)(ia >> p.c) << p.h) | (size_t)(ia & cmask);
-            bf_apply<INV>(s, E, ia, ib, bf_twiddle(p, coset, u, pbit), pl >= 6);
+        // two butterflies per trip: both twiddle loads are issued ahead of the multiplies
+        for (int bf0 = tid; bf0 < (E >> 1); bf0 += 2 * nt) {
+            const int bf1 = bf0 + nt;
+            const bool ok1 = bf1 < (E >> 1);
+            const int ia0 = ((bf0 >> pl) << (pl + 1)) | (bf0 & ((1 << pl) - 1));
+            const int ia1 = ((bf1 >> pl) << (pl + 1)) | (bf1 & ((1 << pl) - 1));
+            const gf192 tw0 = bf_twiddle(p, coset, base | ((size_t)(ia0 >> p.c) << p.h) | (size_t)(ia0 & cmask), pbit);
+            gf192 tw1 = tw0;
+            if (ok1) tw1 = bf_twiddle(p, coset, base | ((size_t)(ia1 >> p.c) << p.h) | (size_t)(ia1 & cmask), pbit);
+            bf_apply<INV, COMB>(s, E, ia0, ia0 | (1 << pl), tw0, pl >= 6);
+            if (ok1) bf_apply<INV, COMB>(s, E, ia1, ia1 | (1 << pl), tw1, pl >= 6);
         }
         __syncthreads();
     }
@@ -321,8 +352,8 @@ __global__ void __launch_bounds__(512) k_bfly_upper(BfParams p)
 
 // Forward: last pass — pair bits a_low-1 .. 0, then natural-order (bit-reversed) store.
 // Inverse: first pass — natural-order load, pair bits 0 .. a_low-1, block-order store.
-template<bool INV>
-__global__ void __launch_bounds__(512) k_bfly_edge(BfParams p)
+template<bool INV, bool COMB>
+__global__ void __launch_bounds__(COMB ? 512 : 1024) k_bfly_edge(BfParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
     uint64_t *s = iopx_smem;
@@ -370,7 +401,7 @@ __global__ void __launch_bounds__(512) k_bfly_edge(BfParams p)
             const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
             const int li = ia & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
             const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
-            bf_apply<INV>(s, E, ia, ib, bf_twiddle(p, coset, u, pbit), pbit >= 6);
+            bf_apply<INV, COMB>(s, E, ia, ib, bf_twiddle(p, coset, u, pbit), pbit >= 6);
         }
         __syncthreads();
     }
@@ -556,17 +587,17 @@ struct P1Pass { int c, h, A, j0, j1, k_start, k_end; };
 static std::vector<P1Pass> phase1_schedule(int d)
 {
     std::vector<P1Pass> sched;
-    if (d <= TILE_BITS) {
+    if (d <= P1_TILE_BITS) {
         sched.push_back({0, 0, d, 0, d - 1, d - 2, d - 1});
         return sched;
     }
-    const int A = TILE_BITS - P1_COLS;
+    const int A = P1_TILE_BITS - P1_COLS;
     const int hfin = d - A;                 // levels >= hfin live entirely in the top A bits
     for (int j = 0; j < hfin; ++j) {
         int k = d - 2;
         while (k >= j) {
-            if (k + 1 <= TILE_BITS - 1) {   // the rest of this level fits a contiguous tile
-                sched.push_back({0, 0, TILE_BITS, j, j, k, j});
+            if (k + 1 <= P1_TILE_BITS - 1) {   // the rest of this level fits a contiguous tile
+                sched.push_back({0, 0, P1_TILE_BITS, j, j, k, j});
                 break;
             }
             const int h = k + 2 - A;
@@ -612,10 +643,11 @@ static int run_phase1(AddPlan &pl, uint64_t *S)
 // ---- phase-2 schedule --------------------------------------------------------------------------
 struct P2Geom { int a_low, c_top; };
 
+#define EDGE_TILE_BITS (tuning().edge_tile_bits)
 static P2Geom phase2_geom(int d)
 {
-    if (d < TILE_BITS) return {d, 0};
-    return {TILE_BITS - P2_TOP, P2_TOP};
+    if (d < EDGE_TILE_BITS) return {d, 0};
+    return {EDGE_TILE_BITS - P2_TOP, P2_TOP};
 }
 
 // forward: W (2^d, block order after phase 1) -> dst (2^nhi cosets * 2^d, natural order);
@@ -635,6 +667,15 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
     p.rs = pl.rs.u64();
     p.d = d; p.nhi = nhi;
     p.a_low = g.a_low; p.c_top = g.c_top;
+    // combined per-coset shift terms (one load per twiddle instead of 1 + nhi); skipped for huge coset counts
+    DevBuf rs_comb;
+    size_t comb_base = 0, comb_count = 0;
+    if (!INV && nhi > 0 && cosets * (size_t)d <= ((size_t)1 << 22)) {
+        int rcc = rs_comb.alloc(cosets * d * 24);
+        if (rcc != IOPX_OK) return rcc;
+        comb_base = coset_begin; comb_count = cosets;
+        { ProfScope ps_("k_rs_combine"); hipLaunchKernelGGL(k_rs_combine, dim3(grid_for(cosets * d, 256)), dim3(256), 0, stream(), rs_comb.u64(), (const uint64_t *)pl.rs.u64(), d, nhi, coset_begin, cosets * (size_t)d); }
+    }
 
     // upper passes over pair bits [a_low, d): chunks of up to A bits, from the top (forward order)
     struct Up { int h, A, c; };
@@ -652,18 +693,20 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
     const int tb = g.a_low + g.c_top;
 
     auto launch_edge = [&](const uint64_t *s, uint64_t *dd, int shared, size_t ncos, size_t cbase) -> int {
-        int g_bits = TILE_BITS - tb;
+        int g_bits = EDGE_TILE_BITS - tb;
         const size_t units = ncos << (d - tb);
         while (g_bits > 0 && ((size_t)1 << g_bits) > units) --g_bits;
         const size_t lds = ((size_t)24) << (tb + g_bits);
         const size_t blocks = (units + ((size_t)1 << g_bits) - 1) >> g_bits;
         const int elems = 1 << (tb + g_bits);
-        const int threads = elems >= 2 * BLOCK_THREADS ? BLOCK_THREADS : (elems >= 128 ? elems / 2 : 64);
+        const int maxt = env_int("IOPX_EDGE_THREADS", 256, 64, 1024);
+        const int threads = elems >= 4 * maxt ? maxt : (elems >= 256 ? elems / 4 : 64);
         p.src = s; p.dst = dd; p.src_shared = shared;
         p.g_bits = g_bits; p.total_units = units; p.coset_base = cbase;
-        int rc = set_lds(k_bfly_edge<INV>, lds);
-        if (rc != IOPX_OK) return rc;
-        { ProfScope ps_("k_bfly_edge"); hipLaunchKernelGGL(k_bfly_edge<INV>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        p.rs_comb = comb_count ? rs_comb.u64() + 3 * (cbase - comb_base) * d : nullptr;
+        int rc;
+        if ((rc = set_lds(k_bfly_edge<INV, false>, lds)) != IOPX_OK) return rc;
+        { ProfScope ps_("k_bfly_edge"); hipLaunchKernelGGL((k_bfly_edge<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         return IOPX_OK;
     };
     auto launch_upper = [&](const Up &u, const uint64_t *s, uint64_t *dd, int shared, size_t ncos, size_t cbase) -> int {
@@ -674,10 +717,17 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         const size_t lds = ((size_t)24) << tbits;
         const size_t blocks = ncos << (d - tbits);
         p.total_units = blocks; p.coset_base = cbase;
-        const int threads = (1 << tbits) >= 2 * BLOCK_THREADS ? BLOCK_THREADS : ((1 << tbits) >= 128 ? (1 << tbits) / 2 : 64);
-        int rc = set_lds(k_bfly_upper<INV>, lds);
-        if (rc != IOPX_OK) return rc;
-        { ProfScope ps_("k_bfly_upper"); hipLaunchKernelGGL(k_bfly_upper<INV>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        p.rs_comb = comb_count ? rs_comb.u64() + 3 * (cbase - comb_base) * d : nullptr;
+        const int maxt = tuning().p2_threads;
+        const int threads = (1 << tbits) >= 2 * maxt ? maxt : ((1 << tbits) >= 128 ? (1 << tbits) / 2 : 64);
+        int rc;
+        if (tuning().comb) {
+            if ((rc = set_lds(k_bfly_upper<INV, true>, lds)) != IOPX_OK) return rc;
+            { ProfScope ps_("k_bfly_upper"); hipLaunchKernelGGL((k_bfly_upper<INV, true>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        } else {
+            if ((rc = set_lds(k_bfly_upper<INV, false>, lds)) != IOPX_OK) return rc;
+            { ProfScope ps_("k_bfly_upper"); hipLaunchKernelGGL((k_bfly_upper<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        }
         return IOPX_OK;
     };
 
@@ -719,6 +769,7 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         IOPX_HIP(hipStreamSynchronize(stream()));       // scratch is freed on return
     }
     IOPX_HIP(hipGetLastError());
+    if (comb_count) IOPX_HIP(hipStreamSynchronize(stream()));      // rs_comb is freed on return
     return IOPX_OK;
 }
 

@@ -14,6 +14,7 @@
 #include "../../oracle/algebra.hpp"
 #include "../../oracle/fri.hpp"
 #include "../../oracle/merkle.hpp"
+#include "../../oracle/mult.hpp"
 
 typedef oracle::gf192 FieldT;
 
@@ -76,6 +77,21 @@ static int run_gpu()
         bool threw = false;
         try { tree.construct_with_leaves_serialized_by_cosets(cols, cs); } catch (const std::logic_error &) { threw = true; }
         CHECK(threw);
+    }
+    {   // test_fft.cpp:88-121: multiplicative coset FFT == naive, IFFT inverts (edwards_Fr, shift = generator)
+        typedef oracle::edwards_Fr Fr;
+        for (size_t dim = 1; dim <= 10; ++dim) {
+            const size_t n = (size_t)1 << dim;
+            const oracle::mult_coset<Fr> od(n, Fr::multiplicative_generator());
+            const libiop_amd::multiplicative_coset<Fr> dom(n, od.g, od.shift);
+            std::vector<Fr> coeffs;
+            for (size_t i = 0; i < n - (dim > 2 ? 3 : 0); ++i) { uint64_t c[3] = { rng(), rng(), rng() & 0xfffffffffull }; coeffs.push_back(Fr::from_canonical(c)); }
+            const std::vector<Fr> got = libiop_amd::multiplicative_FFT<Fr>(coeffs, dom);
+            CHECK(got == oracle::naive_FFT<Fr>(coeffs, od.all_elements()));
+            std::vector<Fr> back = libiop_amd::multiplicative_IFFT<Fr>(got, dom);
+            back.resize(coeffs.size());
+            CHECK(back == coeffs);
+        }
     }
     printf("gpu ok\n");
     return 0;
