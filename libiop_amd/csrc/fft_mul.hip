@@ -207,20 +207,20 @@ static int fp_build_pow(uint64_t *out, const hfp3 &base, const hfp3 &init, int n
     hfp3 x = base;
     for (int k = 0; k < nb; ++k) { sq.insert(sq.end(), x.w, x.w + 3); x = x.squared(); }
     const hfp3 one = hfp3::one();
-    DevBuf dsq, dinit, done;
+    TmpBuf dsq, dinit, done;
     int rc;
     if ((rc = dsq.alloc(sq.size() * 8 + 8)) != IOPX_OK) return rc;
     if ((rc = dinit.alloc(24)) != IOPX_OK) return rc;
     if ((rc = done.alloc(24)) != IOPX_OK) return rc;
-    if (!sq.empty()) IOPX_HIP(hipMemcpyAsync(dsq.p, sq.data(), sq.size() * 8, hipMemcpyHostToDevice, stream()));
-    IOPX_HIP(hipMemcpyAsync(dinit.p, init.w, 24, hipMemcpyHostToDevice, stream()));
-    IOPX_HIP(hipMemcpyAsync(done.p, one.w, 24, hipMemcpyHostToDevice, stream()));
+    if (!sq.empty()) { int urc_ = upload(dsq.p, sq.data(), sq.size() * 8); if (urc_ != IOPX_OK) return urc_; }
+    { int urc_ = upload(dinit.p, init.w, 24); if (urc_ != IOPX_OK) return urc_; }
+    { int urc_ = upload(done.p, one.w, 24); if (urc_ != IOPX_OK) return urc_; }
     const size_t count = (size_t)1 << nb;
     if (nb <= 8) {
         { ProfScope ps_("k_fp_pow_direct"); hipLaunchKernelGGL(k_fp_pow_direct, dim3(mgrid(count, 256)), dim3(256), 0, stream(), out, (const uint64_t *)dsq.u64(), (const uint64_t *)dinit.u64(), nb, count); }
     } else {
         // out[0..256) = init * base^q ; hi[r] = (base^256)^r ; out[q] = out[q & 255] * hi[q >> 8]
-        DevBuf hi;
+        TmpBuf hi;
         if ((rc = hi.alloc((((size_t)1) << (nb - 8)) * 24)) != IOPX_OK) return rc;
         hfp3 b256 = base;
         for (int k = 0; k < 8; ++k) b256 = b256.squared();
@@ -228,10 +228,8 @@ static int fp_build_pow(uint64_t *out, const hfp3 &base, const hfp3 &init, int n
         if (rc != IOPX_OK) return rc;
         { ProfScope ps_("k_fp_pow_direct"); hipLaunchKernelGGL(k_fp_pow_direct, dim3(1), dim3(256), 0, stream(), out, (const uint64_t *)dsq.u64(), (const uint64_t *)dinit.u64(), 8, (size_t)256); }
         { ProfScope ps_("k_fp_pow_expand"); hipLaunchKernelGGL(k_fp_pow_expand, dim3(mgrid(count - 256, 256)), dim3(256), 0, stream(), out, (const uint64_t *)hi.u64(), count); }
-        IOPX_HIP(hipStreamSynchronize(stream()));
     }
-    IOPX_HIP(hipStreamSynchronize(stream()));
-    return IOPX_OK;
+    return IOPX_OK;         // temporaries are released in stream order
 }
 
 static int build_cache(MulPlan &pl, bool inverse)
@@ -275,7 +273,7 @@ static int get_mplan(int logn, const uint64_t *gen, MulPlan **out)
 }
 
 // two-level power tables: hi[q] = init * base^(4096 q) (q < 2^max(logc-12,0)), lo[r] = base^r (r < 4096)
-static int build_two_level(const hfp3 &base, const hfp3 &init, int logc, DevBuf &hi, DevBuf &lo)
+static int build_two_level(const hfp3 &base, const hfp3 &init, int logc, TmpBuf &hi, TmpBuf &lo)
 {
     const int lo_bits = logc < 12 ? logc : 12, hi_bits = logc > 12 ? logc - 12 : 0;
     int rc;
@@ -360,7 +358,7 @@ int iopx_mul_fft_fp3_dev(const uint64_t *d_coeffs, size_t n_coeffs, size_t log_n
     const int logd = (int)ceil_log2(n_coeffs);
     const hfp3 sh = hfp3::from_words(shift);
     if (sh.is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "multiplicative FFT: zero coset shift");
-    DevBuf scaled, hi, lo;
+    TmpBuf scaled, hi, lo;
     const uint64_t *src = d_coeffs;
     if (d_coeffs == d_out) {    // the first pass permutes: it cannot run in place
         if ((rc = scaled.alloc(n_coeffs * 24)) != IOPX_OK) return rc;
@@ -375,8 +373,7 @@ int iopx_mul_fft_fp3_dev(const uint64_t *d_coeffs, size_t n_coeffs, size_t log_n
     }
     rc = run_mfft(pl->cache_fwd.u64(), src, n_coeffs, d_out, (int)log_n, (int)log_n - logd, 0, nullptr, nullptr);
     if (rc != IOPX_OK) return rc;
-    IOPX_HIP(hipStreamSynchronize(stream()));           // per-call tables are freed on return
-    return IOPX_OK;
+    return IOPX_OK;                                     // per-call tables are released in stream order
 }
 
 int iopx_mul_ifft_fp3_dev(const uint64_t *d_evals, size_t log_n, const uint64_t *gen, const uint64_t *shift, uint64_t *d_out)
@@ -397,11 +394,11 @@ int iopx_mul_ifft_fp3_dev(const uint64_t *d_evals, size_t log_n, const uint64_t 
     const hfp3 sh = hfp3::from_words(shift);
     if (sh.is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "multiplicative IFFT: zero coset shift");
     const hfp3 ninv = hfp3::from_uint((uint64_t)n).inverse();
-    DevBuf hi, lo, tmp;
+    TmpBuf hi, lo, tmp;
     int scale = 1;
     if (sh == hfp3::one()) {
         if ((rc = hi.alloc(24)) != IOPX_OK) return rc;
-        IOPX_HIP(hipMemcpyAsync(hi.p, ninv.w, 24, hipMemcpyHostToDevice, stream()));
+        { int urc_ = upload(hi.p, ninv.w, 24); if (urc_ != IOPX_OK) return urc_; }
     } else {
         scale = 2;
         if ((rc = build_two_level(sh.inverse(), ninv, (int)log_n, hi, lo)) != IOPX_OK) return rc;
@@ -414,7 +411,6 @@ int iopx_mul_ifft_fp3_dev(const uint64_t *d_evals, size_t log_n, const uint64_t 
     }
     rc = run_mfft(pl->cache_inv.u64(), src, n, d_out, (int)log_n, 0, scale, hi.u64(), lo.p ? lo.u64() : nullptr);
     if (rc != IOPX_OK) return rc;
-    IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }
 
@@ -426,7 +422,7 @@ int iopx_mul_ifft_known_degree_fp3_dev(const uint64_t *d_evals, size_t degree, s
     if (log_n > 31 || degree == 0 || degree > ((size_t)1 << log_n)) return fail(IOPX_ERR_INVALID_ARGUMENT, "bad degree / domain size");
     const int k = (int)ceil_log2(degree);
     const size_t pow2 = (size_t)1 << k, stride = ((size_t)1 << log_n) >> k;
-    DevBuf sub;
+    TmpBuf sub;
     if ((rc = sub.alloc(pow2 * 24)) != IOPX_OK) return rc;
     { ProfScope ps_("k_fp_gather_stride"); hipLaunchKernelGGL(k_fp_gather_stride, dim3(mgrid(3 * pow2, 256)), dim3(256), 0, stream(), sub.u64(), d_evals, stride, pow2); }
     // generator of the sub-coset: g^(n / pow2)
@@ -434,7 +430,6 @@ int iopx_mul_ifft_known_degree_fp3_dev(const uint64_t *d_evals, size_t degree, s
     for (size_t s = stride; s > 1; s >>= 1) gs = gs.squared();
     rc = iopx_mul_ifft_fp3_dev(sub.u64(), (size_t)k, gs.w, shift, d_out);
     if (rc != IOPX_OK) return rc;
-    IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }
 
@@ -468,11 +463,11 @@ int iopx_fri_fold_mul_fp3_dev(const uint64_t *d_f_i, size_t log_n, const uint64_
         sh = sh.squared();
         x = x.squared();
     }
-    DevBuf dc;
+    TmpBuf dc;
     if ((rc = dc.alloc(hc.size() * 8)) != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(dc.p, hc.data(), hc.size() * 8, hipMemcpyHostToDevice, stream()));
+    { int urc_ = upload(dc.p, hc.data(), hc.size() * 8); if (urc_ != IOPX_OK) return urc_; }
     const uint64_t *ginv_top = pl->cache_inv.u64() + 3 * ((n >> 1) - 1);
-    DevBuf tmp[2];
+    TmpBuf tmp[2];
     const uint64_t *src = d_f_i;
     size_t cur = n;
     for (int e = 0; e < eta; ++e) {
@@ -489,7 +484,6 @@ int iopx_fri_fold_mul_fp3_dev(const uint64_t *d_f_i, size_t log_n, const uint64_
         cur = half;
     }
     IOPX_HIP(hipGetLastError());
-    IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }
 

@@ -86,11 +86,11 @@ int iopx_fri_fold_add_gf192_dev(const uint64_t *d_f_i, const uint64_t *basis, si
         x = x.squared() + b0 * x;
         b.swap(nb);
     }
-    DevBuf dc;
+    TmpBuf dc;
     if ((rc = dc.alloc(hc.size() * 8)) != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(dc.p, hc.data(), hc.size() * 8, hipMemcpyHostToDevice, stream()));
+    { int urc_ = upload(dc.p, hc.data(), hc.size() * 8); if (urc_ != IOPX_OK) return urc_; }
 
-    DevBuf tmp[2];
+    TmpBuf tmp[2];
     const uint64_t *src = d_f_i;
     size_t cur = n;
     for (int e = 0; e < eta; ++e) {
@@ -111,8 +111,7 @@ int iopx_fri_fold_add_gf192_dev(const uint64_t *d_f_i, const uint64_t *basis, si
         cur = n_out;
     }
     IOPX_HIP(hipGetLastError());
-    IOPX_HIP(hipStreamSynchronize(stream()));       // constants / temporaries are freed on return
-    return IOPX_OK;
+    return IOPX_OK;                                 // constants / temporaries are released in stream order
 }
 
 int iopx_fri_fold_add_gf192(const uint64_t *f_i, const uint64_t *basis, size_t m, const uint64_t *shift,

@@ -56,14 +56,42 @@ struct hgf192 {
     }
     hgf192 &operator*=(const hgf192 &o) { *this = *this * o; return *this; }
 
-    hgf192 squared() const { return *this * *this; }
+    // squaring is GF(2)-linear: spread the bits (bit i -> bit 2i) and reduce
+    hgf192 squared() const
+    {
+        uint64_t c[6];
+        for (int i = 0; i < 3; ++i) {
+            uint64_t lo = w[i] & 0xffffffffull, hi = w[i] >> 32;
+            lo = (lo | (lo << 16)) & 0x0000ffff0000ffffull; hi = (hi | (hi << 16)) & 0x0000ffff0000ffffull;
+            lo = (lo | (lo << 8)) & 0x00ff00ff00ff00ffull;  hi = (hi | (hi << 8)) & 0x00ff00ff00ff00ffull;
+            lo = (lo | (lo << 4)) & 0x0f0f0f0f0f0f0f0full;  hi = (hi | (hi << 4)) & 0x0f0f0f0f0f0f0f0full;
+            lo = (lo | (lo << 2)) & 0x3333333333333333ull;  hi = (hi | (hi << 2)) & 0x3333333333333333ull;
+            lo = (lo | (lo << 1)) & 0x5555555555555555ull;  hi = (hi | (hi << 1)) & 0x5555555555555555ull;
+            c[2 * i] = lo; c[2 * i + 1] = hi;
+        }
+        for (int i = 5; i >= 3; --i) {
+            const uint64_t t = c[i];
+            c[i - 3] ^= t ^ (t << 1) ^ (t << 2) ^ (t << 7);
+            c[i - 2] ^= (t >> 63) ^ (t >> 62) ^ (t >> 57);
+        }
+        hgf192 r; r.w[0] = c[0]; r.w[1] = c[1]; r.w[2] = c[2];
+        return r;
+    }
 
-    // a^(2^192 - 2)
+    // a^(2^192 - 2) = (a^(2^191 - 1))^2 by an Itoh–Tsujii addition chain on the exponent 191:
+    // beta_k = a^(2^k - 1), beta_{2k} = beta_k^(2^k) * beta_k, beta_{k+1} = beta_k^2 * a
     hgf192 inverse() const
     {
-        hgf192 r = *this;
-        for (int i = 0; i < 190; ++i) { r = r.squared(); r *= *this; }
-        return r.squared();
+        hgf192 beta = *this;
+        int k = 1;
+        for (int bit = 6; bit >= 0; --bit) {        // 191 = 0b10111111
+            hgf192 t = beta;
+            for (int i = 0; i < k; ++i) t = t.squared();
+            beta = t * beta;
+            k *= 2;
+            if ((191 >> bit) & 1) { beta = beta.squared() * *this; k += 1; }
+        }
+        return beta.squared();
     }
 };
 

@@ -178,9 +178,9 @@ int iopx_merkle_blake2b_dev(const void *const *d_oracles, size_t num_oracles, si
     if (L < 2 || (L & (L - 1))) return fail(IOPX_ERR_INVALID_ARGUMENT, "Merkle tree size must be a power of two, and at least 2.");
     if (d_salts && salt_bytes > 96) return fail(IOPX_ERR_INVALID_ARGUMENT, "zk salt of %zu bytes does not fit one BLAKE2b block", salt_bytes);
 
-    DevBuf dptrs;
+    TmpBuf dptrs;
     if ((rc = dptrs.alloc(num_oracles * sizeof(void *))) != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(dptrs.p, d_oracles, num_oracles * sizeof(void *), hipMemcpyHostToDevice, stream()));
+    { int urc_ = upload(dptrs.p, d_oracles, num_oracles * sizeof(void *)); if (urc_ != IOPX_OK) return urc_; }
 
     LeafParams p;
     p.oracles = (const uint64_t *const *)dptrs.p;
@@ -203,8 +203,7 @@ int iopx_merkle_blake2b_dev(const void *const *d_oracles, size_t num_oracles, si
     }
     { ProfScope ps_("k_merkle_top"); hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(count >= 256 ? 256 : 64), 0, stream(), (uint64_t *)d_nodes, count); }
     IOPX_HIP(hipGetLastError());
-    IOPX_HIP(hipStreamSynchronize(stream()));       // pointer table is freed on return
-    return IOPX_OK;
+    return IOPX_OK;                                 // the pointer table is released in stream order
 }
 
 int iopx_merkle_blake2b(const void *const *oracles, size_t num_oracles, size_t elem_bytes, size_t n,

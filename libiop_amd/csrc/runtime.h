@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include "../../include/libiop_amd.h"
 
@@ -45,6 +46,43 @@ struct DevBuf {
     void release()
     {
         if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    }
+    uint64_t *u64() const { return (uint64_t *)p; }
+};
+
+// Stream-ordered upload of a small host array (per-call constants): the bytes are copied into a pinned staging
+// chunk owned by the library, so the caller's buffer may be freed on return and the copy needs no synchronisation.
+int upload(void *dst_dev, const void *src_host, size_t bytes);
+
+// Per-call temporary in device memory.  All work of the library is enqueued on ONE stream in program order, so a
+// temporary released by one call may be handed to a later call without any synchronisation: the later call's
+// kernels run after the earlier call's kernels on that stream.  Blocks are cached in a free list (runtime.hip)
+// and returned to HIP by iopx_clear_plans(); iopx_set_stream() synchronises before switching streams.
+void *tmp_alloc(size_t bytes, size_t *cap);
+void tmp_free(void *p, size_t cap);
+void tmp_trim();
+
+struct TmpBuf {
+    void *p = nullptr;
+    size_t bytes = 0, cap = 0;
+    TmpBuf() {}
+    TmpBuf(const TmpBuf &) = delete;
+    TmpBuf &operator=(const TmpBuf &) = delete;
+    ~TmpBuf() { release(); }
+    int alloc(size_t n)
+    {
+        release();
+        if (n == 0) n = 8;
+        p = tmp_alloc(n, &cap);
+        if (!p) return fail(IOPX_ERR_RUNTIME, "device allocation of %zu bytes failed", n);
+        bytes = n;
+        return IOPX_OK;
+    }
+    void release()
+    {
+        if (!p) return;
+        tmp_free(p, cap);
+        p = nullptr; bytes = 0; cap = 0;
     }
     uint64_t *u64() const { return (uint64_t *)p; }
 };

@@ -59,8 +59,92 @@ int set_stream(void *s)
 {
     int rc = ensure_device();
     if (rc != IOPX_OK) return rc;
+    // temporaries are recycled in stream order: drain the old stream before work moves to another one
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
     std::lock_guard<std::mutex> lk(g_mu);
     g_stream = s ? (hipStream_t)s : g_own_stream;
+    return IOPX_OK;
+}
+
+// ---- cached device temporaries (single-stream reuse, see runtime.h) --------------------------------
+struct TmpBlock { void *p; size_t cap; };
+static std::vector<TmpBlock> g_tmp_free;
+static std::mutex g_tmp_mu;
+
+void *tmp_alloc(size_t bytes, size_t *cap)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_tmp_mu);
+        int best = -1;
+        for (size_t i = 0; i < g_tmp_free.size(); ++i) {
+            const size_t c = g_tmp_free[i].cap;
+            if (c >= bytes && c <= 2 * bytes + (1u << 20) && (best < 0 || c < g_tmp_free[best].cap)) best = (int)i;
+        }
+        if (best >= 0) {
+            TmpBlock b = g_tmp_free[best];
+            g_tmp_free.erase(g_tmp_free.begin() + best);
+            *cap = b.cap;
+            return b.p;
+        }
+    }
+    void *p = nullptr;
+    const size_t c = (bytes + 255) & ~(size_t)255;
+    if (hipMalloc(&p, c) != hipSuccess) {
+        // out of memory: drop the cache (after draining the stream) and retry once
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(g_stream);
+        std::lock_guard<std::mutex> lk(g_tmp_mu);
+        for (auto &b : g_tmp_free) (void)hipFree(b.p);
+        g_tmp_free.clear();
+        if (hipMalloc(&p, c) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    *cap = c;
+    return p;
+}
+
+void tmp_free(void *p, size_t cap)
+{
+    std::lock_guard<std::mutex> lk(g_tmp_mu);
+    g_tmp_free.push_back({p, cap});
+}
+
+void tmp_trim()
+{
+    (void)hipStreamSynchronize(g_stream);
+    std::lock_guard<std::mutex> lk(g_tmp_mu);
+    for (auto &b : g_tmp_free) (void)hipFree(b.p);
+    g_tmp_free.clear();
+}
+
+// ---- pinned staging for small uploads -------------------------------------------------------------
+struct StageChunk { void *p; size_t cap; hipEvent_t done; bool busy; };
+static std::vector<StageChunk> g_stage;
+static std::mutex g_stage_mu;
+
+int upload(void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (bytes == 0) return IOPX_OK;
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    StageChunk *c = nullptr;
+    for (auto &ch : g_stage) {
+        if (ch.busy && hipEventQuery(ch.done) == hipSuccess) ch.busy = false;
+        if (!ch.busy && ch.cap >= bytes && (!c || ch.cap < c->cap)) c = &ch;
+    }
+    if (!c) {
+        StageChunk ch;
+        ch.cap = bytes < 4096 ? 4096 : bytes;
+        ch.busy = false;
+        hipError_t e = hipHostMalloc(&ch.p, ch.cap, 0);
+        if (e != hipSuccess) return fail(IOPX_ERR_RUNTIME, "hipHostMalloc(%zu) failed: %s", ch.cap, hipGetErrorString(e));
+        e = hipEventCreateWithFlags(&ch.done, hipEventDisableTiming);
+        if (e != hipSuccess) return fail(IOPX_ERR_RUNTIME, "hipEventCreate failed: %s", hipGetErrorString(e));
+        g_stage.push_back(ch);
+        c = &g_stage.back();
+    }
+    memcpy(c->p, src_host, bytes);
+    IOPX_HIP(hipMemcpyAsync(dst_dev, c->p, bytes, hipMemcpyHostToDevice, g_stream));
+    IOPX_HIP(hipEventRecord(c->done, g_stream));
+    c->busy = true;
     return IOPX_OK;
 }
 

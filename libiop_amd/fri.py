@@ -20,11 +20,13 @@ class FRICommitResult:
 
 
 def fri_commit(lib, torch, d_codeword, basis, shift, localization_parameters, final_degree_bound, hashchain=None,
-               keep_codewords=False):
+               keep_codewords=False, domains=None):
     """Runs the FRI reductions on `d_codeword` ((2^m, 3) int64 torch tensor on the device `lib` is bound to).
-    Returns FRICommitResult.  `hashchain` defaults to a fresh Blake2bHashchain."""
+    Returns FRICommitResult.  `hashchain` defaults to a fresh Blake2bHashchain; `domains` is the chain
+    host.fri_additive_domains(...) — the reference computes it once in the protocol constructor
+    (FRI_protocol::compute_domains, fri_ldt.tcc:279-340), so callers that prove repeatedly pass it in."""
     hc = hashchain or host.Blake2bHashchain()
-    doms = host.fri_additive_domains(basis, shift, localization_parameters)
+    doms = domains or host.fri_additive_domains(basis, shift, localization_parameters)
     res = FRICommitResult()
     f = d_codeword
     for i, eta in enumerate(localization_parameters):
