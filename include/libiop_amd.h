@@ -78,6 +78,18 @@ int iopx_add_ifft_gf192_dev(const uint64_t *d_evals, const uint64_t *basis, size
 int iopx_add_ifft_gf192(const uint64_t *evals, const uint64_t *basis, size_t m, const uint64_t *shift,
                         uint64_t *out);
 
+/* Building blocks of ONE transform sharded across GPUs (libiop_amd/dist.py).  The top log2(N) levels of
+ * additive_FFT touch index bits that live on different GPUs; dist.py runs them with these calls plus peer exchanges.
+ *   iopx_add_taylor_gf192_dev   in place: S[i] *= d_twist[i] (optional), then the Taylor-expansion network of one
+ *                               level over all index bits of the shard (fft.tcc:62-83 with j = 0)
+ *   iopx_gf192_pow_table_dev    d_out[l] = init * base^l (the shard's slice of a twist-power table)
+ *   iopx_add_combine_gf192_dev  one butterfly level across shards (fft.tcc:116-117): tw_i = shift_term + sum_k
+ *                               bit_k(index_base + i) * basis[k]; out = a + tw*b (upper = 0) or a + tw*b + b (upper = 1) */
+int iopx_add_taylor_gf192_dev(uint64_t *d_S, size_t log_n, const uint64_t *d_twist);
+int iopx_gf192_pow_table_dev(uint64_t *d_out, size_t count, const uint64_t *base, const uint64_t *init);
+int iopx_add_combine_gf192_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count, size_t index_base,
+                               const uint64_t *basis, size_t nb, const uint64_t *shift_term, int upper);
+
 /* ---- multiplicative-coset FFT / IFFT / FRI fold over the 181-bit prime field (libff edwards_Fr) --- */
 /* Elements are libff Fp_model Montgomery words (3 x uint64, R = 2^192), exactly the bytes libiop hashes.
  * `gen` is the generator of the order-2^log_n subgroup (multiplicative_coset::generator(), subgroup.tcc:55-59),

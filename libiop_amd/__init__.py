@@ -34,7 +34,7 @@ DOMAIN_MULTIPLICATIVE = 1
 EXPORTED_SYMBOLS = [
     "iopx_version", "iopx_last_error", "iopx_device_count", "iopx_init", "iopx_set_stream", "iopx_synchronize",
     "iopx_malloc", "iopx_free", "iopx_memcpy_h2d", "iopx_memcpy_d2h", "iopx_clear_plans",
-    "iopx_add_fft_gf192_dev", "iopx_add_fft_gf192", "iopx_add_lde_gf192_dev", "iopx_add_ifft_gf192_dev", "iopx_add_ifft_gf192",
+    "iopx_add_fft_gf192_dev", "iopx_add_fft_gf192", "iopx_add_lde_gf192_dev", "iopx_add_taylor_gf192_dev", "iopx_gf192_pow_table_dev", "iopx_add_combine_gf192_dev", "iopx_add_ifft_gf192_dev", "iopx_add_ifft_gf192",
     "iopx_fri_fold_add_gf192_dev", "iopx_fri_fold_add_gf192",
     "iopx_mul_fft_fp3_dev", "iopx_mul_fft_fp3", "iopx_mul_ifft_fp3_dev", "iopx_mul_ifft_fp3",
     "iopx_mul_ifft_known_degree_fp3_dev", "iopx_fri_fold_mul_fp3_dev", "iopx_fri_fold_mul_fp3",
@@ -83,6 +83,9 @@ class Library:
         c.iopx_add_fft_gf192_dev.argtypes = [_vp, _sz, _u64p, _sz, _u64p, _vp]
         c.iopx_add_fft_gf192.argtypes = [_u64p, _sz, _u64p, _sz, _u64p, _u64p]
         c.iopx_add_lde_gf192_dev.argtypes = [_vp, _sz, _u64p, _sz, _u64p, _sz, _sz, _vp]
+        c.iopx_add_taylor_gf192_dev.argtypes = [_vp, _sz, _vp]
+        c.iopx_gf192_pow_table_dev.argtypes = [_vp, _sz, _u64p, _u64p]
+        c.iopx_add_combine_gf192_dev.argtypes = [_vp, _vp, _vp, _sz, _sz, _u64p, _sz, _u64p, ctypes.c_int]
         c.iopx_add_ifft_gf192_dev.argtypes = [_vp, _u64p, _sz, _u64p, _vp]
         c.iopx_add_ifft_gf192.argtypes = [_u64p, _u64p, _sz, _u64p, _u64p]
         c.iopx_fri_fold_add_gf192_dev.argtypes = [_vp, _u64p, _sz, _u64p, _sz, _u64p, _vp]
@@ -270,6 +273,18 @@ class Library:
         basis, shift = _as_u64(basis), _as_u64(shift)
         self._check(self.c.iopx_add_lde_gf192_dev(_vp(d_coeffs), n_coeffs, basis.ctypes.data_as(_u64p), basis.shape[0],
                                                   shift.ctypes.data_as(_u64p), coset_begin, coset_count, _vp(d_out)))
+
+    def taylor_dev(self, d_S, log_n, d_twist=0):
+        self._check(self.c.iopx_add_taylor_gf192_dev(_vp(d_S), log_n, _vp(d_twist)))
+
+    def pow_table_dev(self, d_out, count, base, init):
+        base, init = _as_u64(base), _as_u64(init)
+        self._check(self.c.iopx_gf192_pow_table_dev(_vp(d_out), count, base.ctypes.data_as(_u64p), init.ctypes.data_as(_u64p)))
+
+    def combine_dev(self, d_a, d_b, d_out, count, index_base, basis, shift_term, upper):
+        basis, shift_term = _as_u64(basis), _as_u64(shift_term)
+        self._check(self.c.iopx_add_combine_gf192_dev(_vp(d_a), _vp(d_b), _vp(d_out), count, index_base, basis.ctypes.data_as(_u64p),
+                                                      basis.shape[0], shift_term.ctypes.data_as(_u64p), int(upper)))
 
     def additive_IFFT_dev(self, d_evals, basis, shift, d_out):
         basis, shift = _as_u64(basis), _as_u64(shift)

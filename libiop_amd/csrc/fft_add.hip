@@ -189,12 +189,12 @@ __global__ void __launch_bounds__(512) k_phase1(P1Params p)
         const int ks = (j == p.j0) ? p.k_start : p.d - 2;
         const int ke = (j == p.j1) ? p.k_end : j;
         const bool twist = (ks == p.d - 2);
-        const uint64_t *powj = p.pow + 3 * ((((size_t)2) << p.d) - (((size_t)2) << (p.d - j)));
-        if (!INV && twist) {
+        const uint64_t *powj = p.pow ? p.pow + 3 * ((((size_t)2) << p.d) - (((size_t)2) << (p.d - j))) : nullptr;
+        if (!INV && twist && p.pow) {
             for (int li = tid; li < E; li += nt) {
                 const size_t gi = base | ((size_t)(li >> p.c) << p.h) | (size_t)(li & cmask);
                 const size_t q = gi >> j;
-                if (q) lds_put(s, E, li, gf_mul(lds_get(s, E, li), gf_load(powj, q)));
+                lds_put(s, E, li, gf_mul(lds_get(s, E, li), gf_load(powj, q)));
             }
             __syncthreads();
         }
@@ -221,11 +221,11 @@ __global__ void __launch_bounds__(512) k_phase1(P1Params p)
             }
             __syncthreads();
         }
-        if (INV && twist) {
+        if (INV && twist && p.pow) {
             for (int li = tid; li < E; li += nt) {
                 const size_t gi = base | ((size_t)(li >> p.c) << p.h) | (size_t)(li & cmask);
                 const size_t q = gi >> j;
-                if (q) lds_put(s, E, li, gf_mul(lds_get(s, E, li), gf_load(powj, q)));
+                lds_put(s, E, li, gf_mul(lds_get(s, E, li), gf_load(powj, q)));
             }
             __syncthreads();
         }
@@ -926,6 +926,80 @@ __global__ void k_gf192_mul(const uint64_t *a, const uint64_t *b, uint64_t *out,
     }
 }
 
+// ---- building blocks of a transform sharded across GPUs (libiop_amd/dist.py) ---------------------------------
+// One cross-block butterfly level (fft.tcc:116-117 with stride >= the shard size): tw_i = shift_term + sum_k
+// bit_k(index_base + i) * B[k];  lower half: out = a + tw * b;  upper half: out = (a + tw * b) + b.
+struct CombineParams {
+    const uint64_t *a, *b, *consts;     // consts[0] = shift term, consts[1 + k] = B[k]
+    uint64_t *out;
+    size_t count, index_base;
+    int nb, upper;
+};
+
+__global__ void k_combine(CombineParams p)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.count; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t idx = p.index_base + i;
+        gf192 tw = gf_load(p.consts, 0);
+        for (int k = 0; k < p.nb; ++k) {
+            if ((idx >> k) & 1) gf_add_to(tw, gf_load(p.consts, 1 + k));
+        }
+        const gf192 a = gf_load(p.a, i), b = gf_load(p.b, i);
+        gf192 r = gf_add(a, gf_mul(b, tw));
+        if (p.upper) gf_add_to(r, b);
+        gf_store(p.out, i, r);
+    }
+}
+
+int iopx_add_combine_gf192_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count, size_t index_base,
+                               const uint64_t *basis, size_t nb, const uint64_t *shift_term, int upper)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_a || !d_b || !d_out || !shift_term || (nb && !basis) || nb > 62) return fail(IOPX_ERR_INVALID_ARGUMENT, "bad argument");
+    if (count == 0) return IOPX_OK;
+    std::vector<uint64_t> hc(shift_term, shift_term + 3);
+    hc.insert(hc.end(), basis, basis + 3 * nb);
+    TmpBuf dc;
+    if ((rc = dc.alloc(hc.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(dc.p, hc.data(), hc.size() * 8)) != IOPX_OK) return rc;
+    CombineParams p;
+    p.a = d_a; p.b = d_b; p.consts = dc.u64(); p.out = d_out; p.count = count; p.index_base = index_base; p.nb = (int)nb; p.upper = upper;
+    { ProfScope ps_("k_combine"); hipLaunchKernelGGL(k_combine, dim3(grid_for(count, 256)), dim3(256), 0, stream(), p); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+// In place on 2^log_n elements: S[i] *= d_twist[i] (skipped when d_twist is null), then the Taylor-expansion network of
+// one Gao–Mateer level over ALL index bits (ops k = log_n - 2 .. 0, fft.tcc:73-83 with j = 0).
+int iopx_add_taylor_gf192_dev(uint64_t *d_S, size_t log_n, const uint64_t *d_twist)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_S || log_n > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "bad argument");
+    const int d = (int)log_n;
+    std::vector<P1Pass> sched;
+    if (d <= P1_TILE_BITS) {
+        sched.push_back({0, 0, d, 0, 0, d - 2, 0});
+    } else {
+        for (const P1Pass &ps : phase1_schedule(d)) if (ps.j0 == 0 && ps.j1 == 0) sched.push_back(ps);
+    }
+    for (const P1Pass &ps : sched) {
+        P1Params p;
+        p.S = d_S; p.pow = d_twist;
+        p.d = d; p.c = ps.c; p.h = ps.h; p.A = ps.A;
+        p.j0 = 0; p.j1 = 0; p.k_start = ps.k_start; p.k_end = ps.k_end;
+        const int tbits = ps.c + ps.A;
+        const size_t lds = ((size_t)24) << tbits;
+        const size_t blocks = (size_t)1 << (d - tbits);
+        const int threads = (1 << tbits) >= 4 * BLOCK_THREADS ? BLOCK_THREADS : ((1 << tbits) >= 256 ? 64 * ((1 << tbits) / 256) : 64);
+        if ((rc = set_lds(k_phase1<false>, lds)) != IOPX_OK) return rc;
+        { ProfScope ps_("k_phase1"); hipLaunchKernelGGL(k_phase1<false>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+    }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
 // d_out[i] = d_a[i] * c, c the same for every element (exercises the wave-uniform comb multiplier)
 __global__ void __launch_bounds__(256) k_gf192_mul_uniform(const uint64_t *a, const uint64_t *c, uint64_t *out, size_t count)
 {
@@ -941,6 +1015,30 @@ int iopx_gf192_mul_uniform_dev(const uint64_t *d_a, const uint64_t *d_c, uint64_
     if (rc != IOPX_OK) return rc;
     if (count == 0) return IOPX_OK;
     { ProfScope ps_("k_gf192_mul_uniform"); hipLaunchKernelGGL(k_gf192_mul_uniform, dim3(grid_for(count, 256)), dim3(256), 0, stream(), d_a, d_c, d_out, count); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+// d_out[l] = init * base^l for l < count
+int iopx_gf192_pow_table_dev(uint64_t *d_out, size_t count, const uint64_t *base, const uint64_t *init)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_out || !base || !init) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (count == 0) return IOPX_OK;
+    const int nb = (int)ceil_log2(count);
+    std::vector<uint64_t> sq;
+    hgf192 x = hgf192::from_words(base);
+    for (int k = 0; k < (nb > 0 ? nb : 1); ++k) { sq.insert(sq.end(), x.w, x.w + 3); x = x.squared(); }
+    TmpBuf dsq, full, dinit;
+    if ((rc = dsq.alloc(sq.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(dsq.p, sq.data(), sq.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = full.alloc((((size_t)1) << nb) * 24)) != IOPX_OK) return rc;
+    if ((rc = dinit.alloc(24)) != IOPX_OK) return rc;
+    if ((rc = upload(dinit.p, init, 24)) != IOPX_OK) return rc;
+    rc = build_pow_table(full.u64(), dsq.u64(), nb);
+    if (rc != IOPX_OK) return rc;
+    { ProfScope ps_("k_gf192_mul_uniform"); hipLaunchKernelGGL(k_gf192_mul_uniform, dim3(grid_for(count, 256)), dim3(256), 0, stream(), (const uint64_t *)full.u64(), (const uint64_t *)dinit.u64(), d_out, count); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
 }

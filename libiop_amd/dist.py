@@ -69,3 +69,156 @@ def sharded_fri_fold(lib, torch, d_f_local, basis, shift, coset_size, x_i, rank,
     out = torch.empty((d_f_local.shape[0] // coset_size, 3), dtype=torch.int64, device=d_f_local.device)
     lib.fri_fold_dev(d_f_local.data_ptr(), b_loc, s_loc, coset_size, x_i, out.data_ptr())
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ONE additive FFT sharded across N = 2^r GPUs (the case that does need exchange steps: the polynomial is as long
+# as the domain, so the transform does not split into independent cosets).
+#
+# Gao–Mateer's recursion (fft.tcc:55-96) splits the polynomial r times into 2^r sub-polynomials that are
+# interleaved in the coefficient index (sub-polynomial s = index mod 2^r).  Rank rho works on s = rev_r(rho):
+#   1. transpose: block-distributed coefficients -> "s-cyclic" layout (ONE all-to-all: RCCL over xGMI on GPUs),
+#   2. the top r levels: twist by the rank's slice of the power table and run the Taylor network over the
+#      local index bits (iopx_add_taylor_gf192_dev); the r(r+1)/2 network operations that touch the index bits
+#      which now identify ranks are XORs of whole (or half) shards exchanged between peer ranks,
+#   3. a complete LOCAL FFT of the rank's sub-polynomial over the depth-r recursed domain (existing kernels),
+#   4. the last r butterfly levels (fft.tcc:102-120, stride >= shard size): peers exchange shards and apply
+#      iopx_add_combine_gf192_dev.
+# Rank rho ends with the natural-order block rho of the evaluations (same sharding as sharded_lde).
+# ---------------------------------------------------------------------------------------------------------------
+def _rev(x, bits):
+    r = 0
+    for _ in range(bits):
+        r = (r << 1) | (x & 1)
+        x >>= 1
+    return r
+
+
+class DistributedFFTPlan:
+    """Per-(domain, rank) constants of the sharded transform; build once, reuse for every polynomial."""
+
+    def __init__(self, lib, torch, basis, shift, rank, world, device):
+        basis = np.asarray(basis, dtype=np.uint64)
+        self.m = m = basis.shape[0]
+        self.r = r = world.bit_length() - 1
+        if (1 << r) != world or r > m - 1:
+            raise ValueError("world size must be a power of two smaller than the domain")
+        self.rank, self.world, self.s = rank, world, _rev(rank, r)
+        self.n_loc = 1 << (m - r)
+        b = [host.gf_from_words(w) for w in basis]
+        sh = host.gf_from_words(np.asarray(shift, dtype=np.uint64))
+        self.rec, self.rs, self.twist = [], [], []
+        for j in range(r):                      # fft.tcc:57-96 for the top r levels
+            beta = b[m - 1 - j]
+            binv = host.gf_inv(beta)
+            # this rank's slice of the level-j twist: beta^((l * 2^r + s) >> j) = beta^(s >> j) * (beta^(2^(r-j)))^l
+            base = beta
+            for _ in range(r - j):
+                base = host.gf_sq(base)
+            init = 1
+            e, acc = self.s >> j, beta
+            while e:
+                if e & 1:
+                    init = host.gf_mul(init, acc)
+                acc = host.gf_sq(acc)
+                e >>= 1
+            tab = torch.empty((self.n_loc, 3), dtype=torch.int64, device=device)
+            lib.pow_table_dev(tab.data_ptr(), self.n_loc, host.gf_to_words(base), host.gf_to_words(init))
+            self.twist.append(tab)
+            newb = []
+            for i in range(m - 1 - j):
+                nb = host.gf_mul(b[i], binv)
+                newb.append(nb)
+                b[i] = host.gf_sq(nb) ^ nb
+            self.rec.append(newb)
+            ns = host.gf_mul(sh, binv)
+            self.rs.append(ns)
+            sh = host.gf_sq(ns) ^ ns
+            b = b[: m - 1 - j]
+        self.local_basis = np.array([host.gf_to_words(v) for v in b], dtype=np.uint64).reshape(-1, 3)
+        self.local_shift = host.gf_to_words(sh)
+        lib.synchronize()
+
+
+def _exchange(torch, dist, send_t, peer, recv_like):
+    """Symmetric shard exchange with one peer (NCCL/RCCL send+recv pair or gloo)."""
+    recv = torch.empty_like(recv_like)
+    ops = [dist.P2POp(dist.isend, send_t, peer), dist.P2POp(dist.irecv, recv, peer)]
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    return recv
+
+
+def _send(torch, dist, t, peer):
+    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, peer)]):
+        w.wait()
+
+
+def _recv(torch, dist, like, peer):
+    buf = torch.empty_like(like)
+    for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, peer)]):
+        w.wait()
+    return buf
+
+
+def distributed_fft(lib, torch, dist, plan, d_block):
+    """d_block: this rank's contiguous block of the 2^m coefficients ((2^m / N, 3) int64).  Returns the rank's
+    contiguous block of additive_FFT(coeffs, domain) (natural order)."""
+    r, m, s, world, rank, n_loc = plan.r, plan.m, plan.s, plan.world, plan.rank, plan.n_loc
+    # 1. transpose to the s-cyclic layout: coefficient (rank * n_loc + t) goes to the rank of sub-polynomial
+    #    t mod 2^r, local slot rank * (n_loc / N) + t // N
+    x = d_block.reshape(n_loc // world, world, 3).permute(1, 0, 2).contiguous()     # [s', t // N, :]
+    x = x[[_rev(q, r) for q in range(world)]].contiguous()                           # chunk q -> sub-polynomial rev(q)
+    S = torch.empty_like(x)
+    if world > 1:
+        dist.all_to_all_single(S.view(-1), x.view(-1))
+    else:
+        S.copy_(x)
+    S = S.reshape(n_loc, 3)
+    lib.synchronize() if S.device.type != "cpu" else None
+    peer_of = lambda s2: _rev(s2, r)
+    # 2. top r levels
+    for j in range(r):
+        lib.taylor_dev(S.data_ptr(), m - r, plan.twist[j].data_ptr())
+        lib.synchronize()
+        # network operations on global index bits (k+1, k), k = r-1 .. j
+        for k in range(r - 1, j - 1, -1):
+            if k + 1 < r:       # both bits select ranks: whole-shard XORs
+                hi, lo = (s >> (k + 1)) & 1, (s >> k) & 1
+                if (hi, lo) == (1, 1):
+                    _send(torch, dist, S, peer_of(s ^ (1 << k)))
+                elif (hi, lo) == (1, 0):
+                    S ^= _recv(torch, dist, S, peer_of(s | (1 << k)))
+                if (hi, lo) == (1, 0):
+                    _send(torch, dist, S, peer_of(s ^ (3 << k)))
+                elif (hi, lo) == (0, 1):
+                    S ^= _recv(torch, dist, S, peer_of(s ^ (3 << k)))
+            else:               # bit k selects the rank, bit k+1 is local index bit 0
+                bit = (s >> k) & 1
+                peer = peer_of(s ^ (1 << k))
+                odd = S[1::2]
+                if bit == 1:    # (1,1) -> (1,0); then (0,1) += (1,0)
+                    _send(torch, dist, odd.contiguous(), peer)
+                    S[0::2] ^= _recv(torch, dist, odd.contiguous(), peer)
+                else:
+                    S[1::2] ^= _recv(torch, dist, odd.contiguous(), peer)
+                    _send(torch, dist, S[1::2].contiguous(), peer)
+    # 3. local transform of the sub-polynomial over the recursed domain
+    loc = torch.empty_like(S)
+    lib.additive_FFT_dev(S.data_ptr(), n_loc, plan.local_basis, plan.local_shift, loc.data_ptr())
+    lib.synchronize()
+    # 4. the last r butterfly levels across blocks
+    cur = loc
+    for t in range(r):
+        peer = rank ^ (1 << t)
+        other = _exchange(torch, dist, cur, peer, cur)
+        upper = (rank >> t) & 1
+        a, bb = (other, cur) if upper else (cur, other)
+        lvl = r - 1 - t                                   # recursion level that produced these twiddles
+        B = np.array([host.gf_to_words(v) for v in plan.rec[lvl]], dtype=np.uint64).reshape(-1, 3)
+        out = torch.empty_like(cur)
+        lib.combine_dev(a.data_ptr(), bb.data_ptr(), out.data_ptr(), n_loc, (rank & ((1 << t) - 1)) * n_loc, B,
+                        host.gf_to_words(plan.rs[lvl]), upper)
+        lib.synchronize()
+        cur = out
+    return cur

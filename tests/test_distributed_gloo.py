@@ -68,3 +68,42 @@ def test_two_rank_sharded_pipeline():
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     for r in range(world):
         assert ret[r] == (True, True, True), (r, ret[r])
+
+
+def _fft_worker(rank, world, port, ret):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from emu_lib import emu
+        from helpers import rand_elems
+        from libiop_amd import dist as idist
+        lib = emu()
+        ok = []
+        for m, kind in ((6, "std"), (8, "general")):
+            basis = oracle.standard_basis(m, W) if kind == "std" else rand_elems(70 + m, m, W)
+            shift = rand_elems(71 + m, 1, W)[0]
+            coeffs = rand_elems(72 + m, 1 << m, W)
+            full = oracle.additive_fft(coeffs, basis, shift)
+            lo, per = idist.shard_range(1 << m, rank, world)
+            plan = idist.DistributedFFTPlan(lib, torch, basis, shift, rank, world, torch.device("cpu"))
+            mine = idist.distributed_fft(lib, torch, dist, plan, torch.from_numpy(coeffs[lo:lo + per].view(np.int64).copy()))
+            ok.append(bool(np.array_equal(mine.numpy().view(np.uint64), full[lo:lo + per])))
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_distributed_full_size_fft(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_fft_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret[r] == [True, True], (r, ret[r])
