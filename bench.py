@@ -118,6 +118,15 @@ def main():
     alg_bytes = 2 * n * ELEM
     achieved = alg_bytes / dom_avg_s / 1e9
 
+    # HBM traffic of the dominant kernel from the committed PMC run (profiles/), when it is for this kernel and size
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if tj.get("log_n") == m and dom_name in tj.get("kernels", {}):
+            traffic = tj["kernels"][dom_name]["traffic_bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
+
     mults, adds = ref_field_ops(total_m)
     ms_per_step = dt / args.steps * 1e3
     units = 1 if (args.sharded and world > 1) else world       # one big transform, or one transform per rank
@@ -143,7 +152,7 @@ def main():
                    "multi_gpu": ("one 2^%d-point transform sharded over %d ranks (all-to-all transpose + peer exchanges)" % (total_m, world))
                    if (args.sharded and world > 1) else "one independent transform per rank, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": dom_name, "launches_per_step": dom_cnt / args.steps, "avg_launch_ms": dom_avg_s * 1e3,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "gfx950 has no carry-less multiply: the GF(2^192) butterflies are integer-ALU-bound, see DESIGN.md",

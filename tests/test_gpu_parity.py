@@ -244,3 +244,11 @@ def test_cfg5_shape_properties(gpu):
     shift4 = oracle.fp_mul(oracle.fp_mul(shift[None, :], shift[None, :]), oracle.fp_mul(shift[None, :], shift[None, :]))[0]
     co = gpu.multiplicative_IFFT(nxt, shift4)
     assert not co[1 << (d - 2):].any()
+
+
+def test_sharded_transform_building_blocks(gpu):
+    import dist_blocks_check as c
+    c.check_pow_table(gpu, 5000)
+    for log_n in (1, 2, 5, 10, 12, 15):
+        c.check_taylor(gpu, log_n)
+    c.check_combine(gpu, count=20000)

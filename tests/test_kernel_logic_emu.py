@@ -160,3 +160,11 @@ def test_mult_fri_fold(logn, cs):
     x = oracle.fp_rand(99, 1)[0]
     for shift in _shifts()[:2]:
         assert np.array_equal(emu().multiplicative_evaluate_next_f_i(f, shift, cs, x), oracle.fri_fold_multiplicative(f, shift, cs, x))
+
+
+def test_sharded_transform_building_blocks():
+    import dist_blocks_check as c
+    c.check_pow_table(emu())
+    for log_n in (1, 2, 5, 10, 12):
+        c.check_taylor(emu(), log_n)
+    c.check_combine(emu())
