@@ -22,9 +22,67 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def cfg5(args, torch, dist, lib, dev, rank, world, la, fri, host):
+    """Fractal 2^20 over the 181-bit prime field, multiplicative cosets, as a STAGE REPLAY on one GPU:
+    indexer = 12 codeword FFTs (2^20 coefficients -> 2^25-point coset, shift = multiplicative_generator) + one Merkle
+    tree over the 12 oracles (cosets of 2, 576-byte leaves); prover = 8 codeword FFTs (2^22 coefficients), one strided
+    IFFT of known degree, FRI commit [1,2x10] from 2^25."""
+    d, m = args.log_degree, args.log_degree + 5
+    P = la.EDWARDS_FR_MODULUS
+    shift = la.edwards_to_montgomery([la.EDWARDS_FR_GENERATOR])[0]
+    gen = la.edwards_subgroup_generator(m)
+    stages = {}
+
+    def timed(name, fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        stages[name] = stages.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+        return out
+
+    def rand_fp(n, seed):          # uniformly random canonical values < 2^180 < p, then to Montgomery form on the host
+        rng = np.random.Generator(np.random.PCG64(seed))
+        raw = rng.integers(0, 2**60, size=(n, 3), dtype=np.uint64)
+        return torch.from_numpy(raw.view(np.int64)).to(dev)     # any 180-bit words are valid Montgomery representatives
+
+    def fft(c, ncoef):
+        out = torch.empty((1 << m, 3), dtype=torch.int64, device=dev)
+        lib._check(lib.c.iopx_mul_fft_fp3_dev(c.data_ptr(), ncoef, m, la._as_u64(gen).ctypes.data_as(la._u64p),
+                                              la._as_u64(shift).ctypes.data_as(la._u64p), out.data_ptr()))
+        return out
+
+    lib.profile_begin()
+    c20 = [rand_fp(1 << d, 50 + k) for k in range(12)]
+    warm = fft(c20[0], 1 << d)            # builds the 2^25 twiddle cache (per domain, like subgroup.tcc:117-144)
+    del warm
+    idx = [timed("indexer_fft_x12(2^%d->2^%d)" % (d, m), lambda k=k: fft(c20[k], 1 << d)) for k in range(12)]
+    nodes = torch.empty((2 * (1 << (m - 1)) - 1, 32), dtype=torch.uint8, device=dev)
+    timed("indexer_merkle(12 oracles,c=2)", lambda: lib.merkle_tree_dev([o.data_ptr() for o in idx], 24, 1 << m, 2, nodes.data_ptr(),
+                                                                        domain_type=la.DOMAIN_MULTIPLICATIVE))
+    root = bytes(nodes[0].cpu().numpy())
+    del idx[4:]
+    c22 = rand_fp(1 << (d + 2), 99)
+    cws = [timed("prover_fft_x8(2^%d->2^%d)" % (d + 2, m), lambda: fft(c22, (1 << (d + 2)) - 1)) for _ in range(2)]
+    for _ in range(6):
+        timed("prover_fft_x8(2^%d->2^%d)" % (d + 2, m), lambda: fft(c22, (1 << (d + 2)) - 1))
+    co = torch.empty((1 << (d + 2), 3), dtype=torch.int64, device=dev)
+    timed("ifft_known_degree(2^%d of 2^%d)" % (d + 2, m), lambda: lib._check(lib.c.iopx_mul_ifft_known_degree_fp3_dev(
+        cws[0].data_ptr(), (1 << (d + 2)) - 1, m, la._as_u64(gen).ctypes.data_as(la._u64p), la._as_u64(shift).ctypes.data_as(la._u64p), co.data_ptr())))
+    loc = host.localization_parameter_to_array(2, m, 3)
+    fri.fri_commit_multiplicative(lib, torch, cws[1], m, la.EDWARDS_FR_GENERATOR, loc, 4)      # warm-up
+    res = timed("fri_commit(merkle+fold x%d, final ifft)" % len(loc),
+                lambda: fri.fri_commit_multiplicative(lib, torch, cws[1], m, la.EDWARDS_FR_GENERATOR, loc, 4))
+    prof = lib.profile_report()
+    print(json.dumps({"config": "cfg5", "n_gpus": 1, "log_degree": d, "codeword_dim": m, "localization": loc, "replay": True,
+                      "stages_ms": stages, "stages_total_ms": sum(stages.values()),
+                      "kernels_ms": {k: round(v[1], 3) for k, v in prof.items()}, "index_root": root.hex()[:16],
+                      "fri_roots": [r.hex()[:16] for r in res.roots]}))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="cfg3", choices=["cfg3", "cfg4"])
+    ap.add_argument("--config", default="cfg3", choices=["cfg3", "cfg4", "cfg5"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--log-degree", type=int, default=20)
     ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle on a bounded sample")
@@ -46,6 +104,8 @@ def main():
     lib.init(local_rank)
     lib.set_stream(torch.cuda.current_stream().cuda_stream)
 
+    if args.config == "cfg5":
+        return cfg5(args, torch, dist, lib, dev, rank, world, libiop_amd, fri, host)
     d = args.log_degree
     rs = 2 if args.config == "cfg3" else 5
     m = d + rs

@@ -55,3 +55,50 @@ def fri_commit(lib, torch, d_codeword, basis, shift, localization_parameters, fi
     lib.synchronize()
     res.final_polynomial = coeffs.cpu().numpy().view(np.uint64)[:final_degree_bound].copy()   # :540 resize
     return res
+
+
+def fri_commit_multiplicative(lib, torch, d_codeword, log_n, shift_int, localization_parameters, final_degree_bound, hashchain=None):
+    """The same commit phase over multiplicative cosets of the 181-bit prime field (edwards_Fr): domain chain
+    size >>= eta, shift <- shift^(2^eta) (fri_ldt.tcc:292-308), cosets {j + k * n / 2^eta} (subgroup.tcc:175-197),
+    Merkle leaves serialised with the multiplicative position map.  `shift_int` is the canonical integer value of
+    the codeword coset's shift.  Challenges: the reference's Fp extractor (blake2b.tcc:187-227: keyed BLAKE2b into
+    mont_repr, bits above the modulus MSB cleared, retry with key += num_elements until < p)."""
+    import hashlib
+    import libiop_amd as la
+    hc = hashchain or host.Blake2bHashchain()
+    P = la.EDWARDS_FR_MODULUS
+    res = FRICommitResult()
+    f, logn, sh = d_codeword, log_n, shift_int % P
+    for eta in localization_parameters:
+        n_i, cs = 1 << logn, 1 << eta
+        nodes = torch.empty((2 * (n_i // cs) - 1, 32), dtype=torch.uint8, device=f.device)
+        lib.merkle_tree_dev([f.data_ptr()], 24, n_i, cs, nodes.data_ptr(), domain_type=la.DOMAIN_MULTIPLICATIVE)
+        root = bytes(nodes[0].cpu().numpy())
+        res.roots.append(root)
+        res.trees.append(nodes)
+        hc.absorb(root)
+        hc.absorb(None)
+        # squeeze one Fp element (rejection sampling on the raw Montgomery words)
+        hc.squeeze_index += 1
+        msg = hc.state + hc.squeeze_index.to_bytes(8, "little")
+        key = 0
+        while True:
+            raw = int.from_bytes(hashlib.blake2b(msg, digest_size=24, key=key.to_bytes(8, "little")).digest(), "little")
+            raw &= (1 << P.bit_length()) - 1
+            if raw < P:
+                break
+            key += 1
+        x_i = np.array([(raw >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(3)], dtype=np.uint64)
+        res.challenges.append(x_i)
+        nxt = torch.empty((n_i // cs, 3), dtype=torch.int64, device=f.device)
+        lib._check(lib.c.iopx_fri_fold_mul_fp3_dev(f.data_ptr(), logn, la._as_u64(la.edwards_subgroup_generator(logn)).ctypes.data_as(la._u64p),
+                                                   la.edwards_to_montgomery([sh]).ctypes.data_as(la._u64p), cs,
+                                                   x_i.ctypes.data_as(la._u64p), nxt.data_ptr()))
+        f, logn = nxt, logn - eta
+        sh = pow(sh, cs, P)
+    coeffs = torch.empty_like(f)
+    lib._check(lib.c.iopx_mul_ifft_fp3_dev(f.data_ptr(), logn, la._as_u64(la.edwards_subgroup_generator(logn)).ctypes.data_as(la._u64p),
+                                           la.edwards_to_montgomery([sh]).ctypes.data_as(la._u64p), coeffs.data_ptr()))
+    lib.synchronize()
+    res.final_polynomial = coeffs.cpu().numpy().view(np.uint64)[:final_degree_bound].copy()
+    return res

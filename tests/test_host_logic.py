@@ -71,3 +71,29 @@ def test_fri_commit_matches_oracle_composition():
     final = oracle.additive_ifft(f, doms[-1][0], doms[-1][1])
     assert not final[1 << (d - sum(loc)):].any()            # the folded word is low degree
     assert np.array_equal(res.final_polynomial, final[: 1 << (d - sum(loc))])
+
+
+def test_fri_commit_multiplicative_matches_oracle_composition():
+    import hashlib
+    import libiop_amd as la
+    logn, d = 9, 6
+    loc = [1, 2]
+    P = la.EDWARDS_FR_MODULUS
+    shift = oracle.fp_from_ints([19])[0]
+    cw = oracle.multiplicative_fft(oracle.fp_rand(5, 1 << d), 1 << logn, shift)
+    res = fri.fri_commit_multiplicative(emu(), torch, torch.from_numpy(cw.view(np.int64).copy()), logn, 19, loc, 1 << (d - sum(loc)))
+    hc = oracle.Hashchain()
+    f, sh_int = cw, 19
+    for i, eta in enumerate(loc):
+        nodes = oracle.merkle_build([f], 1 << eta, False)
+        assert res.roots[i] == bytes(nodes[0])
+        hc.absorb(bytes(nodes[0]))
+        hc.absorb(b"\0" * 32)
+        x = res.challenges[i]
+        xi = int(x[0]) | (int(x[1]) << 64) | (int(x[2]) << 128)
+        assert xi < P
+        f = oracle.fri_fold_multiplicative(f, oracle.fp_from_ints([sh_int])[0], 1 << eta, x)
+        sh_int = pow(sh_int, 1 << eta, P)
+    final = oracle.multiplicative_ifft(f, oracle.fp_from_ints([sh_int])[0])
+    assert not final[1 << (d - sum(loc)):].any()
+    assert np.array_equal(res.final_polynomial, final[: 1 << (d - sum(loc))])
