@@ -338,3 +338,77 @@ def fri_fold_multiplicative(f_i, shift, coset_size, x_i):
     out = np.empty((f_i.shape[0] // coset_size, 3), dtype=np.uint64)
     lib().oracle_fp_fri_fold(_p(f_i), ctypes.c_size_t(f_i.shape[0]), _p(shift), ctypes.c_size_t(coset_size), _p(x_i), _p(out))
     return out
+
+
+# ---- Poseidon over alt_bn128 Fr ((count, 4) uint64 Montgomery words) -------------------------------------------------
+BN128_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def _ints_to_words4(values):
+    return np.array([[(int(v) >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in values], dtype=np.uint64).reshape(-1, 4)
+
+
+def bn_from_ints(values):
+    c = _ints_to_words4(values)
+    out = np.empty_like(c)
+    lib().oracle_bn_from_canonical(_p(c), _p(out), ctypes.c_size_t(c.shape[0]))
+    return out
+
+
+def bn_to_ints(m):
+    m = _c(m).reshape(-1, 4)
+    out = np.empty_like(m)
+    lib().oracle_bn_to_canonical(_p(m), _p(out), ctypes.c_size_t(m.shape[0]))
+    return [sum(int(r[i]) << (64 * i) for i in range(4)) for r in out]
+
+
+class PoseidonParams:
+    """One parameter set (dict with alpha, full_rounds, partial_rounds, rate, state_size, near_mds, mds, ark as ints)."""
+
+    def __init__(self, d):
+        self.d = d
+        self.mds = _ints_to_words4([v for row in d["mds"] for v in row])
+        self.ark = _ints_to_words4([v for row in d["ark"] for v in row])
+
+    def args(self):
+        d = self.d
+        return (ctypes.c_size_t(d["alpha"]), ctypes.c_size_t(d["full_rounds"]), ctypes.c_size_t(d["partial_rounds"]),
+                ctypes.c_size_t(d["rate"]), ctypes.c_size_t(d["state_size"]), int(bool(d["near_mds"])), _p(self.mds), _p(self.ark))
+
+
+def poseidon_permute(params, state):
+    state = _c(state).copy()
+    lib().oracle_poseidon_permute(*params.args(), _p(state))
+    return state
+
+
+def poseidon_leafhash(params, leaf):
+    leaf = _c(leaf)
+    out = np.empty(4, dtype=np.uint64)
+    lib().oracle_poseidon_leafhash(*params.args(), _p(leaf), ctypes.c_size_t(leaf.shape[0]), _p(out))
+    return out
+
+
+def poseidon_two_to_one(params, l, r):
+    l, r = _c(l), _c(r)
+    out = np.empty(4, dtype=np.uint64)
+    lib().oracle_poseidon_two_to_one(*params.args(), _p(l), _p(r), _p(out))
+    return out
+
+
+def poseidon_salt_to_field(salt):
+    out = np.empty(4, dtype=np.uint64)
+    buf = (ctypes.c_uint8 * 32).from_buffer_copy(bytes(salt))
+    lib().oracle_poseidon_salt_to_field(buf, _p(out))
+    return out
+
+
+def poseidon_merkle(params, oracles, coset_size, additive=False):
+    oracles = [_c(o) for o in oracles]
+    n = oracles[0].shape[0]
+    L = n // coset_size
+    nodes = np.zeros((2 * L - 1, 4), dtype=np.uint64)
+    ptrs = (ctypes.c_void_p * len(oracles))(*[o.ctypes.data for o in oracles])
+    lib().oracle_poseidon_merkle(*params.args(), ptrs, ctypes.c_size_t(len(oracles)), ctypes.c_size_t(n), ctypes.c_size_t(coset_size),
+                                 int(additive), _p(nodes))
+    return nodes

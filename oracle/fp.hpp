@@ -26,6 +26,16 @@ struct edwards_Fr_params {
     static constexpr int two_adicity = 31;
 };
 
+// alt_bn128 Fr: p = 21888242871839275222246405745257275088548364400416034343698204186575808495617 (254 bits, 4 limbs),
+// 2-adicity 28, multiplicative_generator 5 — the only field the reference wires Poseidon for.
+struct alt_bn128_Fr_params {
+    static constexpr int limbs = 4;
+    static constexpr uint64_t modulus[4] = { 0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull };
+    static constexpr uint64_t inv = 0xc2e1f593efffffffull;
+    static constexpr uint64_t generator = 5;
+    static constexpr int two_adicity = 28;
+};
+
 template<typename P>
 struct Fp {
     static constexpr int N = P::limbs;
@@ -178,5 +188,6 @@ struct Fp {
 };
 
 typedef Fp<edwards_Fr_params> edwards_Fr;
+typedef Fp<alt_bn128_Fr_params> alt_bn128_Fr;
 
 } // namespace oracle

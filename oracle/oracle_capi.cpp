@@ -8,6 +8,7 @@
 #include "fri.hpp"
 #include "merkle.hpp"
 #include "mult.hpp"
+#include "poseidon.hpp"
 
 using namespace oracle;
 
@@ -248,6 +249,90 @@ void oracle_fp_fri_fold(const uint64_t *f_i, size_t order, const uint64_t *shift
 {
     FP x; memcpy(x.mont, x_i, 24);
     store<FP>(out, multiplicative_evaluate_next_f_i_over_entire_domain<FP>(load<FP>(f_i, order), load_coset(order, shift), coset_size, x));
+}
+
+
+// ---- Poseidon over alt_bn128 Fr (4 limbs).  Parameters travel as canonical 4-word integers. -------------------
+typedef alt_bn128_Fr BN;
+
+static poseidon_params<BN> load_poseidon(size_t alpha, size_t full_rounds, size_t partial_rounds, size_t rate, size_t t,
+                                         int near_mds, const uint64_t *mds, const uint64_t *ark)
+{
+    poseidon_params<BN> p;
+    p.alpha = alpha; p.full_rounds = full_rounds; p.partial_rounds = partial_rounds; p.rate = rate; p.state_size = t; p.near_mds = near_mds != 0;
+    for (size_t r = 0; r < t; ++r) {
+        std::vector<BN> row;
+        for (size_t c = 0; c < t; ++c) row.push_back(BN::from_canonical(mds + 4 * (r * t + c)));
+        p.mds.push_back(row);
+    }
+    for (size_t r = 0; r < full_rounds + partial_rounds; ++r) {
+        std::vector<BN> row;
+        for (size_t c = 0; c < t; ++c) row.push_back(BN::from_canonical(ark + 4 * (r * t + c)));
+        p.ark.push_back(row);
+    }
+    return p;
+}
+
+void oracle_bn_from_canonical(const uint64_t *c, uint64_t *out, size_t count)
+{
+    for (size_t i = 0; i < count; ++i) { const BN x = BN::from_canonical(c + 4 * i); memcpy(out + 4 * i, x.mont, 32); }
+}
+void oracle_bn_to_canonical(const uint64_t *m, uint64_t *out, size_t count)
+{
+    for (size_t i = 0; i < count; ++i) { BN x; memcpy(x.mont, m + 4 * i, 32); x.to_canonical(out + 4 * i); }
+}
+
+// state (t Montgomery elements) <- permutation(state)
+void oracle_poseidon_permute(size_t alpha, size_t fr, size_t pr, size_t rate, size_t t, int near_mds, const uint64_t *mds,
+                             const uint64_t *ark, uint64_t *state)
+{
+    poseidon_sponge<BN> sp(load_poseidon(alpha, fr, pr, rate, t, near_mds, mds, ark));
+    memcpy((void *)sp.state.data(), state, t * 32);
+    sp.permute();
+    memcpy(state, (const void *)sp.state.data(), t * 32);
+}
+
+// out = algebraic_leafhash::hash(leaf[count]) ; Montgomery words in / out
+void oracle_poseidon_leafhash(size_t alpha, size_t fr, size_t pr, size_t rate, size_t t, int near_mds, const uint64_t *mds,
+                              const uint64_t *ark, const uint64_t *leaf, size_t count, uint64_t *out)
+{
+    const BN h = poseidon_leafhash<BN>(load_poseidon(alpha, fr, pr, rate, t, near_mds, mds, ark), load<BN>(leaf, count));
+    memcpy(out, h.mont, 32);
+}
+
+void oracle_poseidon_two_to_one(size_t alpha, size_t fr, size_t pr, size_t rate, size_t t, int near_mds, const uint64_t *mds,
+                                const uint64_t *ark, const uint64_t *l, const uint64_t *r, uint64_t *out)
+{
+    BN a, b; memcpy(a.mont, l, 32); memcpy(b.mont, r, 32);
+    const BN h = poseidon_two_to_one<BN>(load_poseidon(alpha, fr, pr, rate, t, near_mds, mds, ark), a, b);
+    memcpy(out, h.mont, 32);
+}
+
+void oracle_poseidon_salt_to_field(const uint8_t *salt, uint64_t *out)
+{
+    const BN x = poseidon_salt_to_field<BN>(salt);
+    memcpy(out, x.mont, 32);
+}
+
+// Merkle tree with algebraic hashes (merkle_tree.tcc:92-229 with algebraic_leafhash / algebraic_two_to_one_hash):
+// nodes = (2L - 1) field elements (Montgomery words), heap order.
+void oracle_poseidon_merkle(size_t alpha, size_t fr, size_t pr, size_t rate, size_t t, int near_mds, const uint64_t *mds,
+                            const uint64_t *ark, const uint64_t *const *oracles, size_t num_oracles, size_t n, size_t coset_size,
+                            int additive, uint64_t *nodes)
+{
+    const poseidon_params<BN> P = load_poseidon(alpha, fr, pr, rate, t, near_mds, mds, ark);
+    const size_t L = n / coset_size;
+    std::vector<BN> nd(2 * L - 1);
+    for (size_t i = 0; i < L; ++i) {
+        std::vector<BN> slice(num_oracles * coset_size);
+        for (size_t j = 0; j < coset_size; ++j) {
+            const size_t pos = position_by_coset_indices(additive != 0, n, i, j, coset_size);
+            for (size_t k = 0; k < num_oracles; ++k) memcpy(slice[j + k * coset_size].mont, oracles[k] + 4 * pos, 32);
+        }
+        nd[L - 1 + i] = poseidon_leafhash<BN>(P, slice);
+    }
+    for (size_t j = L - 1; j-- > 0; ) nd[j] = poseidon_two_to_one<BN>(P, nd[2 * j + 1], nd[2 * j + 2]);
+    memcpy(nodes, (const void *)nd.data(), nd.size() * 32);
 }
 
 } // extern "C"
