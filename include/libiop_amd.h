@@ -142,6 +142,35 @@ int iopx_merkle_blake2b(const void *const *oracles, size_t num_oracles, size_t e
                         size_t coset_size, int domain_type, const uint8_t *salts, size_t salt_bytes,
                         uint8_t *nodes);
 
+/* ---- BCS Merkle tree, Poseidon over alt_bn128 Fr ------------------------------------------------- */
+/* A poseidon_params<FieldT> instance (libiop/bcs/hashing/poseidon.hpp:20-60; the shipped sets are
+ * poseidon.tcc:311-520, selected by hash_enum.tcc:73-110).  ark / mds hold CANONICAL integers, 4 little-endian
+ * 64-bit words each: ark[(full_rounds + partial_rounds) * state_size] round-major, mds[state_size^2] row-major
+ * (ignored when near_mds != 0: the add-only mixing layers of poseidon.tcc:195-224).  capacity = state_size - rate = 1. */
+typedef struct iopx_poseidon_params {
+    size_t alpha;            /* 3, 5 or 17 */
+    size_t full_rounds, partial_rounds;
+    size_t rate, state_size; /* state_size <= 4 */
+    int near_mds;
+    const uint64_t *ark;
+    const uint64_t *mds;
+} iopx_poseidon_params;
+
+/* FieldT(bigint): canonical 4-word integers -> Montgomery words (libff Fp_model::mont_repr), on the device. */
+int iopx_bn128_to_montgomery_dev(const uint64_t *d_canonical, uint64_t *d_out, size_t count);
+/* poseidon::apply_permutation (poseidon.tcc:273-297) on `count` states of state_size Montgomery elements, in place. */
+int iopx_poseidon_permute_bn128_dev(const iopx_poseidon_params *params, uint64_t *d_states, size_t count);
+/* merkle_tree<FieldT, FieldT> with algebraic_leafhash / algebraic_two_to_one_hash over a Poseidon sponge
+ * (algebraic_sponge.tcc:18-100,220-265; merkle_tree.tcc:92-151,200-229).  Oracles hold Montgomery elements (32 bytes);
+ *   salts   NULL, or num_leaves * 32 bytes: the zk salt of leaf i is parsed as algebraic_sponge.tcc:110-125 does and
+ *           absorbed after the slice (zk_hash, :232-245)
+ *   nodes   (2 L - 1) Montgomery elements, heap order as for iopx_merkle_blake2b. */
+int iopx_merkle_poseidon_bn128_dev(const iopx_poseidon_params *params, const void *const *d_oracles, size_t num_oracles,
+                                   size_t n, size_t coset_size, int domain_type, const uint8_t *d_salts,
+                                   uint64_t *d_nodes);
+int iopx_merkle_poseidon_bn128(const iopx_poseidon_params *params, const void *const *oracles, size_t num_oracles,
+                               size_t n, size_t coset_size, int domain_type, const uint8_t *salts, uint64_t *nodes);
+
 /* ---- measurement hooks -------------------------------------------------------------------------- */
 /* Per-kernel timing with HIP events recorded on the library's stream around every kernel launch.
  * iopx_profile_begin() starts recording; iopx_profile_report() synchronises, stops recording and writes

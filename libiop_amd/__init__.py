@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = [
     "iopx_mul_fft_fp3_dev", "iopx_mul_fft_fp3", "iopx_mul_ifft_fp3_dev", "iopx_mul_ifft_fp3",
     "iopx_mul_ifft_known_degree_fp3_dev", "iopx_fri_fold_mul_fp3_dev", "iopx_fri_fold_mul_fp3",
     "iopx_merkle_blake2b_dev", "iopx_merkle_blake2b",
+    "iopx_bn128_to_montgomery_dev", "iopx_poseidon_permute_bn128_dev", "iopx_merkle_poseidon_bn128_dev", "iopx_merkle_poseidon_bn128",
     "iopx_gf192_mul_dev", "iopx_gf192_mul_uniform_dev", "iopx_profile_begin", "iopx_profile_report",
 ]
 
@@ -60,6 +61,40 @@ def _as_u64(a, cols=3):
     if a.shape[-1] != cols:
         raise ValueError("expected (count, %d) uint64 words" % cols)
     return a
+
+
+class _PoseidonParamsC(ctypes.Structure):
+    _fields_ = [("alpha", _sz), ("full_rounds", _sz), ("partial_rounds", _sz), ("rate", _sz), ("state_size", _sz),
+                ("near_mds", ctypes.c_int), ("ark", _u64p), ("mds", _u64p)]
+
+
+def _ints_to_words4(values):
+    return np.array([[(int(v) >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in values], dtype=np.uint64).reshape(-1, 4)
+
+
+class PoseidonParams:
+    """poseidon_params<FieldT> (libiop/bcs/hashing/poseidon.hpp:20-60) for alt_bn128 Fr, as the C ABI takes it.
+
+    ``PoseidonParams.shipped(name)`` loads one of the sets the reference ships (poseidon.tcc:311-520, chosen by
+    hash_enum.tcc:73-110): "starkware_alpha5_t3", "high_alpha17_t3", "high_alpha17_t4"."""
+
+    def __init__(self, alpha, full_rounds, partial_rounds, rate, state_size, near_mds, ark, mds):
+        self.alpha, self.full_rounds, self.partial_rounds = int(alpha), int(full_rounds), int(partial_rounds)
+        self.rate, self.state_size, self.near_mds = int(rate), int(state_size), bool(near_mds)
+        self.ark = _ints_to_words4([v for row in ark for v in row])
+        self.mds = _ints_to_words4([v for row in mds for v in row]) if mds else None
+        self.c = _PoseidonParamsC(self.alpha, self.full_rounds, self.partial_rounds, self.rate, self.state_size, int(self.near_mds),
+                                  self.ark.ctypes.data_as(_u64p), self.mds.ctypes.data_as(_u64p) if self.mds is not None else None)
+
+    @classmethod
+    def from_dict(cls, d):
+        return cls(d["alpha"], d["full_rounds"], d["partial_rounds"], d["rate"], d["state_size"], d["near_mds"], d["ark"], d.get("mds"))
+
+    @classmethod
+    def shipped(cls, name):
+        import json
+        with open(os.path.join(_HERE, "data", "poseidon_alt_bn128.json")) as f:
+            return cls.from_dict(json.load(f)["sets"][name])
 
 
 class Library:
@@ -99,6 +134,11 @@ class Library:
         c.iopx_fri_fold_mul_fp3.argtypes = [_u64p, _sz, _u64p, _u64p, _sz, _u64p, _u64p]
         c.iopx_merkle_blake2b_dev.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _sz, _sz, ctypes.c_int, _vp, _sz, _vp]
         c.iopx_merkle_blake2b.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _sz, _sz, ctypes.c_int, _vp, _sz, _vp]
+        pp = ctypes.POINTER(_PoseidonParamsC)
+        c.iopx_bn128_to_montgomery_dev.argtypes = [_vp, _vp, _sz]
+        c.iopx_poseidon_permute_bn128_dev.argtypes = [pp, _vp, _sz]
+        c.iopx_merkle_poseidon_bn128_dev.argtypes = [pp, ctypes.POINTER(_vp), _sz, _sz, _sz, ctypes.c_int, _vp, _vp]
+        c.iopx_merkle_poseidon_bn128.argtypes = [pp, ctypes.POINTER(_vp), _sz, _sz, _sz, ctypes.c_int, _vp, _vp]
         c.iopx_gf192_mul_dev.argtypes = [_vp, _vp, _vp, _sz]
         c.iopx_gf192_mul_uniform_dev.argtypes = [_vp, _vp, _vp, _sz]
 
@@ -261,6 +301,58 @@ class Library:
             sp, sb = _vp(0), 0
         self._check(self.c.iopx_merkle_blake2b(ptrs, len(oracles), 8 * w, n, cs, int(domain_type), sp, sb, _vp(nodes.ctypes.data)))
         return nodes
+
+    # ---- Poseidon over alt_bn128 Fr: elements are (count, 4) uint64 Montgomery words ----
+    def bn128_to_montgomery(self, values):
+        """FieldT(bigint) for a list of Python ints / a (count, 4) array of canonical words."""
+        a = _as_u64(values, 4) if isinstance(values, np.ndarray) else _ints_to_words4(values)
+        n = a.shape[0]
+        d = self.malloc(max(a.nbytes, 8))
+        try:
+            self.h2d(d, a)
+            self._check(self.c.iopx_bn128_to_montgomery_dev(_vp(d), _vp(d), n))
+            out = np.empty_like(a)
+            self.d2h(out, d)
+        finally:
+            self.free(d)
+        return out
+
+    def poseidon_permute(self, params, states):
+        """poseidon::apply_permutation on (count, state_size, 4) Montgomery states."""
+        st = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, params.state_size, 4).copy()
+        d = self.malloc(max(st.nbytes, 8))
+        try:
+            self.h2d(d, st)
+            self._check(self.c.iopx_poseidon_permute_bn128_dev(ctypes.byref(params.c), _vp(d), st.shape[0]))
+            self.d2h(st, d)
+        finally:
+            self.free(d)
+        return st
+
+    def merkle_tree_poseidon(self, params, oracles, coset_size, domain_type=DOMAIN_MULTIPLICATIVE, salts=None):
+        """merkle_tree<FieldT, FieldT> with the algebraic leaf / two-to-one hashes (algebraic_sponge.tcc:220-265).
+        Returns the (2L-1, 4) uint64 node array (Montgomery words), row 0 = get_root()."""
+        oracles = [_as_u64(o, 4) for o in oracles]
+        n = oracles[0].shape[0]
+        for o in oracles:
+            if o.shape[0] != n:
+                raise AssertionError("Attempting to construct a Merkle tree with a constituent vector of wrong size")
+        cs = int(coset_size)
+        L = n // cs if cs > 0 else 0
+        nodes = np.zeros((max(2 * L - 1, 1), 4), dtype=np.uint64)
+        ptrs = (_vp * len(oracles))(*[o.ctypes.data for o in oracles])
+        if salts is not None:
+            salts = np.ascontiguousarray(salts, dtype=np.uint8).reshape(-1, 32)
+            sp = _vp(salts.ctypes.data)
+        else:
+            sp = _vp(0)
+        self._check(self.c.iopx_merkle_poseidon_bn128(ctypes.byref(params.c), ptrs, len(oracles), n, cs, int(domain_type), sp, _vp(nodes.ctypes.data)))
+        return nodes
+
+    def merkle_tree_poseidon_dev(self, params, d_oracles, n, coset_size, d_nodes, domain_type=DOMAIN_MULTIPLICATIVE, d_salts=0):
+        ptrs = (_vp * len(d_oracles))(*d_oracles)
+        self._check(self.c.iopx_merkle_poseidon_bn128_dev(ctypes.byref(params.c), ptrs, len(d_oracles), n, int(coset_size), int(domain_type),
+                                                          _vp(d_salts), _vp(d_nodes)))
 
     # ---- device-pointer operators (integers are raw device addresses, e.g. torch.Tensor.data_ptr()) ----
     def additive_FFT_dev(self, d_coeffs, n_coeffs, basis, shift, d_out):

@@ -790,8 +790,10 @@ extern "C" {
 int iopx_clear_plans(void)
 {
     std::lock_guard<std::mutex> lk(g_plan_mu);
-    if (!g_plans.empty()) (void)hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();
     g_plans.clear();
+    clear_mul_plans();
+    clear_poseidon_sets();
     tmp_trim();
     return IOPX_OK;
 }

@@ -192,6 +192,12 @@ struct MulPlan {
 static std::mutex g_mplan_mu;
 static std::map<std::vector<uint64_t>, std::unique_ptr<MulPlan>> g_mplans;
 
+void clear_mul_plans()
+{
+    std::lock_guard<std::mutex> lk(g_mplan_mu);
+    g_mplans.clear();
+}
+
 static int mgrid(size_t work, int threads)
 {
     size_t g = (work + threads - 1) / threads;

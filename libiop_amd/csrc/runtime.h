@@ -95,6 +95,10 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// Per-module plan caches dropped by iopx_clear_plans() (the caller has synchronised the device).
+void clear_mul_plans();
+void clear_poseidon_sets();
+
 static inline size_t ceil_log2(size_t n)
 {
     size_t r = ((n & (n - 1)) == 0 ? 0 : 1);

@@ -403,12 +403,15 @@ def poseidon_salt_to_field(salt):
     return out
 
 
-def poseidon_merkle(params, oracles, coset_size, additive=False):
+def poseidon_merkle(params, oracles, coset_size, additive=False, salts=None):
     oracles = [_c(o) for o in oracles]
     n = oracles[0].shape[0]
     L = n // coset_size
     nodes = np.zeros((2 * L - 1, 4), dtype=np.uint64)
+    if salts is not None:
+        salts = np.ascontiguousarray(salts, dtype=np.uint8)
+        assert salts.shape == (L, 32)
     ptrs = (ctypes.c_void_p * len(oracles))(*[o.ctypes.data for o in oracles])
     lib().oracle_poseidon_merkle(*params.args(), ptrs, ctypes.c_size_t(len(oracles)), ctypes.c_size_t(n), ctypes.c_size_t(coset_size),
-                                 int(additive), _p(nodes))
+                                 int(additive), ctypes.c_void_p(salts.ctypes.data) if salts is not None else None, _p(nodes))
     return nodes

@@ -318,7 +318,7 @@ void oracle_poseidon_salt_to_field(const uint8_t *salt, uint64_t *out)
 // nodes = (2L - 1) field elements (Montgomery words), heap order.
 void oracle_poseidon_merkle(size_t alpha, size_t fr, size_t pr, size_t rate, size_t t, int near_mds, const uint64_t *mds,
                             const uint64_t *ark, const uint64_t *const *oracles, size_t num_oracles, size_t n, size_t coset_size,
-                            int additive, uint64_t *nodes)
+                            int additive, const uint8_t *salts, uint64_t *nodes)
 {
     const poseidon_params<BN> P = load_poseidon(alpha, fr, pr, rate, t, near_mds, mds, ark);
     const size_t L = n / coset_size;
@@ -329,6 +329,7 @@ void oracle_poseidon_merkle(size_t alpha, size_t fr, size_t pr, size_t rate, siz
             const size_t pos = position_by_coset_indices(additive != 0, n, i, j, coset_size);
             for (size_t k = 0; k < num_oracles; ++k) memcpy(slice[j + k * coset_size].mont, oracles[k] + 4 * pos, 32);
         }
+        if (salts) slice.push_back(poseidon_salt_to_field<BN>(salts + 32 * i));     // zk_hash, algebraic_sponge.tcc:232-245
         nd[L - 1 + i] = poseidon_leafhash<BN>(P, slice);
     }
     for (size_t j = L - 1; j-- > 0; ) nd[j] = poseidon_two_to_one<BN>(P, nd[2 * j + 1], nd[2 * j + 2]);

@@ -252,3 +252,37 @@ def test_sharded_transform_building_blocks(gpu):
     for log_n in (1, 2, 5, 10, 12, 15):
         c.check_taylor(gpu, log_n)
     c.check_combine(gpu, count=20000)
+
+
+# ---- Poseidon over alt_bn128 Fr (algebraic leaf / two-to-one hashes of the BCS Merkle tree) --------------
+import poseidon_cases as pc
+
+
+def test_poseidon_to_montgomery(gpu):
+    pc.check_to_montgomery(gpu)
+
+
+def test_poseidon_permutation_kats(gpu):
+    pc.check_permutation_kats(gpu)
+
+
+@pytest.mark.parametrize("name", pc.SET_NAMES)
+def test_poseidon_permutation(gpu, name):
+    pc.check_permutation(gpu, name, count=200)
+
+
+@pytest.mark.parametrize("name,r,cs,L,additive,zk", [
+    ("test_params", 1, 1, 2, False, False), ("test_params", 1, 2, 8, False, True), ("test_params", 3, 2, 4, True, False),
+    ("starkware_alpha5_t3", 2, 4, 64, False, False), ("high_alpha17_t3", 1, 2, 512, False, True), ("high_alpha17_t4", 2, 3, 128, False, True),
+    ("high_alpha17_t4", 1, 6, 2, True, False), ("high_alpha17_t3", 4, 2, 4096, False, False), ("starkware_alpha5_t3", 1, 2, 2048, True, True),
+])
+def test_poseidon_merkle(gpu, name, r, cs, L, additive, zk):
+    pc.check_merkle(gpu, name, r, cs, L, additive, zk)
+
+
+def test_poseidon_leaf_and_two_to_one_kats(gpu):
+    pc.check_leaf_and_two_to_one_kats(gpu)
+
+
+def test_poseidon_errors(gpu):
+    pc.check_errors(gpu)
