@@ -171,6 +171,18 @@ int iopx_merkle_poseidon_bn128_dev(const iopx_poseidon_params *params, const voi
 int iopx_merkle_poseidon_bn128(const iopx_poseidon_params *params, const void *const *oracles, size_t num_oracles,
                                size_t n, size_t coset_size, int domain_type, const uint8_t *salts, uint64_t *nodes);
 
+/* ---- proof of work ------------------------------------------------------------------------------ */
+/* pow<FieldT, binary_hash_digest>::solve_pow (libiop/bcs/pow.tcc:67-103) with the BLAKE2b two-to-one hash: returns the
+ * FIRST candidate in the reference's order (the challenge itself, then the challenge with its last 8-byte word set to
+ * 0, 1, 2, ...) for which the last word of H(challenge || candidate) has its low pow_bitlen bits zero
+ * (verify_pow_internal, :143-162; pow_bitlen = pow_parameters::pow_bitlen(), :21-32).  challenge, pow: 32 host bytes. */
+int iopx_pow_solve_blake2b(const uint8_t *challenge, size_t pow_bitlen, uint8_t *pow);
+/* pow<FieldT, FieldT>::solve_pow (pow.tcc:73-84,129-141) with the Poseidon two-to-one hash over alt_bn128 Fr: the
+ * smallest k >= 0 such that word 0 of two_to_one(challenge, FieldT(k)) (canonical integer) has its low pow_bitlen bits
+ * zero.  challenge, pow: 4 host words each, Montgomery form. */
+int iopx_pow_solve_poseidon_bn128(const iopx_poseidon_params *params, const uint64_t *challenge, size_t pow_bitlen,
+                                  uint64_t *pow);
+
 /* ---- measurement hooks -------------------------------------------------------------------------- */
 /* Per-kernel timing with HIP events recorded on the library's stream around every kernel launch.
  * iopx_profile_begin() starts recording; iopx_profile_report() synchronises, stops recording and writes

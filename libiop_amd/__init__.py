@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = [
     "iopx_mul_ifft_known_degree_fp3_dev", "iopx_fri_fold_mul_fp3_dev", "iopx_fri_fold_mul_fp3",
     "iopx_merkle_blake2b_dev", "iopx_merkle_blake2b",
     "iopx_bn128_to_montgomery_dev", "iopx_poseidon_permute_bn128_dev", "iopx_merkle_poseidon_bn128_dev", "iopx_merkle_poseidon_bn128",
+    "iopx_pow_solve_blake2b", "iopx_pow_solve_poseidon_bn128",
     "iopx_gf192_mul_dev", "iopx_gf192_mul_uniform_dev", "iopx_profile_begin", "iopx_profile_report",
 ]
 
@@ -139,6 +140,8 @@ class Library:
         c.iopx_poseidon_permute_bn128_dev.argtypes = [pp, _vp, _sz]
         c.iopx_merkle_poseidon_bn128_dev.argtypes = [pp, ctypes.POINTER(_vp), _sz, _sz, _sz, ctypes.c_int, _vp, _vp]
         c.iopx_merkle_poseidon_bn128.argtypes = [pp, ctypes.POINTER(_vp), _sz, _sz, _sz, ctypes.c_int, _vp, _vp]
+        c.iopx_pow_solve_blake2b.argtypes = [_vp, _sz, _vp]
+        c.iopx_pow_solve_poseidon_bn128.argtypes = [pp, _vp, _sz, _vp]
         c.iopx_gf192_mul_dev.argtypes = [_vp, _vp, _vp, _sz]
         c.iopx_gf192_mul_uniform_dev.argtypes = [_vp, _vp, _vp, _sz]
 
@@ -353,6 +356,20 @@ class Library:
         ptrs = (_vp * len(d_oracles))(*d_oracles)
         self._check(self.c.iopx_merkle_poseidon_bn128_dev(ctypes.byref(params.c), ptrs, len(d_oracles), n, int(coset_size), int(domain_type),
                                                           _vp(d_salts), _vp(d_nodes)))
+
+    # ---- proof of work (pow.tcc) ----
+    def solve_pow(self, challenge, pow_bitlen, poseidon_params=None):
+        """pow::solve_pow: 32-byte challenge -> 32-byte answer (BLAKE2b), or, with `poseidon_params`, a (4,) uint64
+        Montgomery challenge -> the Montgomery words of the smallest passing counter."""
+        if poseidon_params is None:
+            ch = (ctypes.c_uint8 * 32).from_buffer_copy(bytes(challenge))
+            out = (ctypes.c_uint8 * 32)()
+            self._check(self.c.iopx_pow_solve_blake2b(ctypes.addressof(ch), int(pow_bitlen), ctypes.addressof(out)))
+            return bytes(out)
+        ch = np.ascontiguousarray(challenge, dtype=np.uint64).reshape(4)
+        out = np.empty(4, dtype=np.uint64)
+        self._check(self.c.iopx_pow_solve_poseidon_bn128(ctypes.byref(poseidon_params.c), _vp(ch.ctypes.data), int(pow_bitlen), _vp(out.ctypes.data)))
+        return out
 
     # ---- device-pointer operators (integers are raw device addresses, e.g. torch.Tensor.data_ptr()) ----
     def additive_FFT_dev(self, d_coeffs, n_coeffs, basis, shift, d_out):

@@ -7,6 +7,7 @@
 // buffers in the reference's serialisation order: oracle-major, then position within the coset
 // (merkle_tree.tcc:127-134).
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <memory>
 #include <vector>
 #include "runtime.h"
@@ -157,6 +158,29 @@ __global__ void k_merkle_top(uint64_t *nodes, size_t count)
     }
 }
 
+// Proof-of-work grind, binary digests (libiop/bcs/pow.tcc:86-103,111-119,143-162).  Candidate 0 is the challenge itself,
+// candidate k >= 1 the challenge with its last 8-byte word replaced by k - 1; a candidate passes when the last word of
+// H(challenge || candidate) has its low `bitlen` bits zero.  One lane per candidate; the smallest passing index wins.
+struct PowChallenge {
+    uint64_t w[4];
+};
+
+__global__ void k_pow_blake2b(PowChallenge c, uint64_t first, uint64_t count, uint64_t mask, unsigned long long *best)
+{
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t idx = first + g;
+        uint64_t h[8], m[16];
+        b2b_init(h);
+        m[0] = c.w[0]; m[1] = c.w[1]; m[2] = c.w[2]; m[3] = c.w[3];
+        m[4] = c.w[0]; m[5] = c.w[1]; m[6] = c.w[2];
+        m[7] = idx == 0 ? c.w[3] : idx - 1;
+#pragma unroll
+        for (int w = 8; w < 16; ++w) m[w] = 0;
+        b2b_compress(h, m, 64, true);
+        if ((h[3] & mask) == 0) atomicMin(best, (unsigned long long)idx);
+    }
+}
+
 } // namespace iopx
 
 using namespace iopx;
@@ -235,6 +259,35 @@ int iopx_merkle_blake2b(const void *const *oracles, size_t num_oracles, size_t e
     if (rc != IOPX_OK) return rc;
     IOPX_HIP(hipMemcpyAsync(nodes, dnodes.p, (2 * L - 1) * 32, hipMemcpyDeviceToHost, stream()));
     IOPX_HIP(hipStreamSynchronize(stream()));
+    return IOPX_OK;
+}
+
+int iopx_pow_solve_blake2b(const uint8_t *challenge, size_t pow_bitlen, uint8_t *pow)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!challenge || !pow) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (pow_bitlen > 30) return fail(IOPX_ERR_INVALID_ARGUMENT, "pow_bitlen %zu: the reference's `1 << pow_bitlen` is an int shift", pow_bitlen);
+    PowChallenge c;
+    memcpy(c.w, challenge, 32);
+    const uint64_t mask = ((uint64_t)1 << pow_bitlen) - 1;
+    TmpBuf best;
+    if ((rc = best.alloc(8)) != IOPX_OK) return rc;
+    const unsigned long long none = ~0ull;
+    if ((rc = upload(best.p, &none, 8)) != IOPX_OK) return rc;
+    unsigned long long found = none;
+    uint64_t first = 0, batch = (uint64_t)1 << 16;      // the first batch is small: low difficulties finish in one launch
+    while (found == none) {
+        { ProfScope ps_("k_pow_blake2b");
+          hipLaunchKernelGGL(k_pow_blake2b, dim3((unsigned)((batch + 255) / 256 > 16384 ? 16384 : (batch + 255) / 256)), dim3(256), 0, stream(),
+                             c, first, batch, mask, (unsigned long long *)best.p); }
+        IOPX_HIP(hipMemcpyAsync(&found, best.p, 8, hipMemcpyDeviceToHost, stream()));
+        IOPX_HIP(hipStreamSynchronize(stream()));
+        first += batch;
+        if (batch < ((uint64_t)1 << 24)) batch <<= 2;
+    }
+    memcpy(pow, challenge, 32);
+    if (found != 0) { const uint64_t v = found - 1; memcpy(pow + 24, &v, 8); }
     return IOPX_OK;
 }
 

@@ -453,6 +453,32 @@ __global__ void k_poseidon_top(PoseidonDev P, uint64_t *nodes, size_t count)
     }
 }
 
+// Proof-of-work grind, algebraic digests (libiop/bcs/pow.tcc:73-84,129-141): candidate k is FieldT(k); it passes when word 0 of
+// the canonical integer of two_to_one(challenge, k) has its low `bitlen` bits zero.  One lane per candidate, smallest index wins.
+struct PowChallengeBn {
+    uint64_t w[4];
+};
+
+template<int T>
+__global__ void k_pow_poseidon(PoseidonDev P, PowChallengeBn c, uint64_t first, uint64_t count, uint64_t mask, unsigned long long *best)
+{
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t idx = first + g;
+        const uint64_t k[4] = { idx, 0, 0, 0 };
+        pstate<T> s;
+        s.e[0] = bn9_load_mont(c.w, 0);
+        s.e[1] = bn9_mul(bn9_unpack(k), bn9_const(BN9_C522));
+        s.e[2] = bn9_zero();
+        if constexpr (T == 4) s.e[3] = bn9_zero();
+        poseidon_permute<T>(s, P);
+        bn9 one = bn9_zero();
+        one.l[0] = 1;
+        uint64_t canon[4];
+        bn9_store_canonical(canon, bn9_mul(s.e[0], one));       // x * 2^261 / 2^261
+        if ((canon[0] & mask) == 0) atomicMin(best, (unsigned long long)idx);
+    }
+}
+
 // ---- host: parameter cache ---------------------------------------------------------------------------------------
 struct PoseidonSet {
     DevBuf consts;
@@ -599,6 +625,41 @@ int iopx_merkle_poseidon_bn128(const iopx_poseidon_params *params, const void *c
                                         salts ? (const uint8_t *)dsalt.p : nullptr, dnodes.u64());
     if (rc != IOPX_OK) return rc;
     IOPX_HIP(hipMemcpyAsync(nodes, dnodes.p, (2 * L - 1) * 32, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(hipStreamSynchronize(stream()));
+    return IOPX_OK;
+}
+
+int iopx_pow_solve_poseidon_bn128(const iopx_poseidon_params *params, const uint64_t *challenge, size_t pow_bitlen, uint64_t *pow)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!challenge || !pow) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (pow_bitlen > 30) return fail(IOPX_ERR_INVALID_ARGUMENT, "pow_bitlen %zu: the reference's `1 << pow_bitlen` is an int shift", pow_bitlen);
+    PoseidonDev P;
+    if ((rc = get_poseidon(params, &P)) != IOPX_OK) return rc;
+    PowChallengeBn c;
+    memcpy(c.w, challenge, 32);
+    const uint64_t mask = ((uint64_t)1 << pow_bitlen) - 1;
+    TmpBuf best;                                        // [0]: smallest passing index, [1..4]: scratch for its Montgomery words
+    if ((rc = best.alloc(40)) != IOPX_OK) return rc;
+    const unsigned long long none = ~0ull;
+    if ((rc = upload(best.p, &none, 8)) != IOPX_OK) return rc;
+    unsigned long long found = none;
+    uint64_t first = 0, batch = (uint64_t)1 << 14;
+    while (found == none) {
+        const unsigned grid = (unsigned)((batch + 63) / 64 > 65536 ? 65536 : (batch + 63) / 64);
+        { ProfScope ps_("k_pow_poseidon");
+          if (P.t == 3) hipLaunchKernelGGL(k_pow_poseidon<3>, dim3(grid), dim3(64), 0, stream(), P, c, first, batch, mask, (unsigned long long *)best.p);
+          else hipLaunchKernelGGL(k_pow_poseidon<4>, dim3(grid), dim3(64), 0, stream(), P, c, first, batch, mask, (unsigned long long *)best.p); }
+        IOPX_HIP(hipMemcpyAsync(&found, best.p, 8, hipMemcpyDeviceToHost, stream()));
+        IOPX_HIP(hipStreamSynchronize(stream()));
+        first += batch;
+        if (batch < ((uint64_t)1 << 22)) batch <<= 2;
+    }
+    const uint64_t k[4] = { found, 0, 0, 0 };
+    if ((rc = upload((uint64_t *)best.p + 1, k, 32)) != IOPX_OK) return rc;
+    hipLaunchKernelGGL(k_bn_to_mont, dim3(1), dim3(64), 0, stream(), (uint64_t *)best.p + 1, (const uint64_t *)best.p + 1, (size_t)1);
+    IOPX_HIP(hipMemcpyAsync(pow, (uint64_t *)best.p + 1, 32, hipMemcpyDeviceToHost, stream()));
     IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }

@@ -415,3 +415,41 @@ def poseidon_merkle(params, oracles, coset_size, additive=False, salts=None):
     lib().oracle_poseidon_merkle(*params.args(), ptrs, ctypes.c_size_t(len(oracles)), ctypes.c_size_t(n), ctypes.c_size_t(coset_size),
                                  int(additive), ctypes.c_void_p(salts.ctypes.data) if salts is not None else None, _p(nodes))
     return nodes
+
+
+# ---- proof of work (pow.tcc) ----------------------------------------------------------------------------------
+def pow_bitlen(work_parameter, cost_per_hash):
+    f = lib().oracle_pow_bitlen
+    f.restype = ctypes.c_size_t
+    return int(f(ctypes.c_size_t(work_parameter), ctypes.c_size_t(cost_per_hash)))
+
+
+def _b32(b):
+    b = bytes(b)
+    assert len(b) == 32
+    return (ctypes.c_uint8 * 32).from_buffer_copy(b)
+
+
+def pow_verify_blake2b(challenge, pow_, bitlen):
+    return bool(lib().oracle_pow_verify_blake2b(_b32(challenge), _b32(pow_), ctypes.c_size_t(bitlen)))
+
+
+def pow_solve_blake2b(challenge, bitlen):
+    """Returns (pow bytes, number of candidates tried)."""
+    out = (ctypes.c_uint8 * 32)()
+    f = lib().oracle_pow_solve_blake2b
+    f.restype = ctypes.c_uint64
+    calls = f(_b32(challenge), ctypes.c_size_t(bitlen), out)
+    return bytes(out), int(calls)
+
+
+def pow_verify_poseidon(params, challenge, pow_, bitlen):
+    return bool(lib().oracle_pow_verify_poseidon(*params.args(), _p(_c(challenge)), _p(_c(pow_)), ctypes.c_size_t(bitlen)))
+
+
+def pow_solve_poseidon(params, challenge, bitlen):
+    out = np.empty(4, dtype=np.uint64)
+    f = lib().oracle_pow_solve_poseidon
+    f.restype = ctypes.c_uint64
+    calls = f(*params.args(), _p(_c(challenge)), ctypes.c_size_t(bitlen), _p(out))
+    return out, int(calls)

@@ -9,6 +9,7 @@
 #include "merkle.hpp"
 #include "mult.hpp"
 #include "poseidon.hpp"
+#include "pow.hpp"
 
 using namespace oracle;
 
@@ -334,6 +335,27 @@ void oracle_poseidon_merkle(size_t alpha, size_t fr, size_t pr, size_t rate, siz
     }
     for (size_t j = L - 1; j-- > 0; ) nd[j] = poseidon_two_to_one<BN>(P, nd[2 * j + 1], nd[2 * j + 2]);
     memcpy(nodes, (const void *)nd.data(), nd.size() * 32);
+}
+
+// proof of work (pow.tcc:21-32,73-162)
+size_t oracle_pow_bitlen(size_t work_parameter, size_t cost_per_hash) { return pow_bitlen(work_parameter, cost_per_hash); }
+int oracle_pow_verify_blake2b(const uint8_t *challenge, const uint8_t *pow, size_t bitlen) { return pow_verify_blake2b(challenge, pow, bitlen) ? 1 : 0; }
+uint64_t oracle_pow_solve_blake2b(const uint8_t *challenge, size_t bitlen, uint8_t *pow) { return pow_solve_blake2b(challenge, bitlen, pow); }
+int oracle_pow_verify_poseidon(size_t alpha, size_t fr, size_t pr, size_t rate, size_t t, int near_mds, const uint64_t *mds,
+                               const uint64_t *ark, const uint64_t *challenge, const uint64_t *pow, size_t bitlen)
+{
+    const poseidon_params<BN> P = load_poseidon(alpha, fr, pr, rate, t, near_mds, mds, ark);
+    BN c, w; memcpy(c.mont, challenge, 32); memcpy(w.mont, pow, 32);
+    return pow_verify_poseidon<BN>(P, c, w, bitlen) ? 1 : 0;
+}
+uint64_t oracle_pow_solve_poseidon(size_t alpha, size_t fr, size_t pr, size_t rate, size_t t, int near_mds, const uint64_t *mds,
+                                   const uint64_t *ark, const uint64_t *challenge, size_t bitlen, uint64_t *pow)
+{
+    const poseidon_params<BN> P = load_poseidon(alpha, fr, pr, rate, t, near_mds, mds, ark);
+    BN c, w; memcpy(c.mont, challenge, 32);
+    const uint64_t calls = pow_solve_poseidon<BN>(P, c, bitlen, w);
+    memcpy(pow, w.mont, 32);
+    return calls;
 }
 
 } // extern "C"

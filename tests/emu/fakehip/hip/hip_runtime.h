@@ -29,6 +29,12 @@ extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 static inline void __syncthreads() {}
 static inline void __threadfence_block() {}
+static inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v)
+{
+    const unsigned long long old = *p;
+    if (v < old) *p = v;
+    return old;
+}
 static inline void __threadfence() {}
 static inline uint32_t __brev(uint32_t x)
 {

@@ -286,3 +286,25 @@ def test_poseidon_leaf_and_two_to_one_kats(gpu):
 
 def test_poseidon_errors(gpu):
     pc.check_errors(gpu)
+
+
+# ---- proof of work (pow.tcc) -------------------------------------------------------------------------------
+import pow_cases as pw
+
+
+def test_pow_blake2b(gpu):
+    pw.check_blake2b(gpu, [0, 1, 4, 9, 12, 17, 20], [1, 2, 3])
+
+
+def test_pow_blake2b_reference_test_inputs(gpu):
+    pw.check_blake2b_reference_test_inputs(gpu)
+    pw.check_challenge_itself_passes(gpu)
+
+
+@pytest.mark.parametrize("name", pc.SET_NAMES)
+def test_pow_poseidon(gpu, name):
+    pw.check_poseidon(gpu, name, [0, 3, 8, 13], [1, 2])
+
+
+def test_pow_errors(gpu):
+    pw.check_errors(gpu)
