@@ -171,6 +171,21 @@ int iopx_merkle_poseidon_bn128_dev(const iopx_poseidon_params *params, const voi
 int iopx_merkle_poseidon_bn128(const iopx_poseidon_params *params, const void *const *oracles, size_t num_oracles,
                                size_t n, size_t coset_size, int domain_type, const uint8_t *salts, uint64_t *nodes);
 
+/* ---- LDT reducer -------------------------------------------------------------------------------- */
+/* combined_LDT_virtual_oracle::evaluated_contents (libiop/protocols/ldt/ldt_reducer_aux.tcc:39-131, constructor and
+ * set_random_coefficients :3-37; subset_element_powers, libiop/algebra/exponentiation.tcc:3-91): the random linear
+ * combination of all oracles, each submaximal one also multiplied by x^(max_degree - degree), over the whole codeword domain.
+ *   d_oracles            host array of num_oracles device pointers, 2^m elements each
+ *   degrees              input_oracle_degrees (host)
+ *   random_coefficients  the 2 * num_oracles elements given to set_random_coefficients (host)
+ * Writes 2^m elements to d_out. */
+int iopx_ldt_combine_gf192_dev(const void *const *d_oracles, size_t num_oracles, const size_t *degrees,
+                               const uint64_t *random_coefficients, const uint64_t *basis, size_t m, const uint64_t *shift,
+                               uint64_t *d_out);
+int iopx_ldt_combine_fp3_dev(const void *const *d_oracles, size_t num_oracles, const size_t *degrees,
+                             const uint64_t *random_coefficients, size_t log_n, const uint64_t *gen, const uint64_t *shift,
+                             uint64_t *d_out);
+
 /* ---- proof of work ------------------------------------------------------------------------------ */
 /* pow<FieldT, binary_hash_digest>::solve_pow (libiop/bcs/pow.tcc:67-103) with the BLAKE2b two-to-one hash: returns the
  * FIRST candidate in the reference's order (the challenge itself, then the challenge with its last 8-byte word set to

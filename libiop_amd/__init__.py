@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "iopx_mul_ifft_known_degree_fp3_dev", "iopx_fri_fold_mul_fp3_dev", "iopx_fri_fold_mul_fp3",
     "iopx_merkle_blake2b_dev", "iopx_merkle_blake2b",
     "iopx_bn128_to_montgomery_dev", "iopx_poseidon_permute_bn128_dev", "iopx_merkle_poseidon_bn128_dev", "iopx_merkle_poseidon_bn128",
-    "iopx_pow_solve_blake2b", "iopx_pow_solve_poseidon_bn128",
+    "iopx_pow_solve_blake2b", "iopx_pow_solve_poseidon_bn128", "iopx_ldt_combine_gf192_dev", "iopx_ldt_combine_fp3_dev",
     "iopx_gf192_mul_dev", "iopx_gf192_mul_uniform_dev", "iopx_profile_begin", "iopx_profile_report",
 ]
 
@@ -141,6 +141,8 @@ class Library:
         c.iopx_merkle_poseidon_bn128_dev.argtypes = [pp, ctypes.POINTER(_vp), _sz, _sz, _sz, ctypes.c_int, _vp, _vp]
         c.iopx_merkle_poseidon_bn128.argtypes = [pp, ctypes.POINTER(_vp), _sz, _sz, _sz, ctypes.c_int, _vp, _vp]
         c.iopx_pow_solve_blake2b.argtypes = [_vp, _sz, _vp]
+        c.iopx_ldt_combine_gf192_dev.argtypes = [ctypes.POINTER(_vp), _sz, ctypes.POINTER(_sz), _u64p, _u64p, _sz, _u64p, _vp]
+        c.iopx_ldt_combine_fp3_dev.argtypes = [ctypes.POINTER(_vp), _sz, ctypes.POINTER(_sz), _u64p, _sz, _u64p, _u64p, _vp]
         c.iopx_pow_solve_poseidon_bn128.argtypes = [pp, _vp, _sz, _vp]
         c.iopx_gf192_mul_dev.argtypes = [_vp, _vp, _vp, _sz]
         c.iopx_gf192_mul_uniform_dev.argtypes = [_vp, _vp, _vp, _sz]
@@ -356,6 +358,51 @@ class Library:
         ptrs = (_vp * len(d_oracles))(*d_oracles)
         self._check(self.c.iopx_merkle_poseidon_bn128_dev(ctypes.byref(params.c), ptrs, len(d_oracles), n, int(coset_size), int(domain_type),
                                                           _vp(d_salts), _vp(d_nodes)))
+
+    # ---- LDT reducer (ldt_reducer_aux.tcc:39-131) ----
+    def ldt_combine_dev(self, d_oracles, degrees, random_coefficients, basis, shift, d_out):
+        """combined_LDT_virtual_oracle::evaluated_contents over the affine subspace (basis, shift); device pointers."""
+        basis, shift, rc = _as_u64(basis), _as_u64(shift), _as_u64(random_coefficients)
+        if rc.shape[0] != 2 * len(d_oracles):
+            raise ValueError("Expected the nunmber of random coefficients to be twice the number of oracles.")
+        ptrs = (_vp * len(d_oracles))(*d_oracles)
+        deg = (_sz * len(degrees))(*[int(d) for d in degrees])
+        self._check(self.c.iopx_ldt_combine_gf192_dev(ptrs, len(d_oracles), deg, rc.ctypes.data_as(_u64p), basis.ctypes.data_as(_u64p),
+                                                      basis.shape[0], shift.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def ldt_combine_multiplicative_dev(self, d_oracles, degrees, random_coefficients, log_n, gen, shift, d_out):
+        gen, shift, rc = _as_u64(gen), _as_u64(shift), _as_u64(random_coefficients)
+        if rc.shape[0] != 2 * len(d_oracles):
+            raise ValueError("Expected the nunmber of random coefficients to be twice the number of oracles.")
+        ptrs = (_vp * len(d_oracles))(*d_oracles)
+        deg = (_sz * len(degrees))(*[int(d) for d in degrees])
+        self._check(self.c.iopx_ldt_combine_fp3_dev(ptrs, len(d_oracles), deg, rc.ctypes.data_as(_u64p), int(log_n),
+                                                    gen.ctypes.data_as(_u64p), shift.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def _ldt_combine_host(self, evals, call):
+        evals = [_as_u64(e) for e in evals]
+        n = evals[0].shape[0]
+        for e in evals:
+            if e.shape[0] != n:
+                raise ValueError("Vectors of mismatched size.")
+        bufs = [self.malloc(e.nbytes) for e in evals] + [self.malloc(evals[0].nbytes)]
+        try:
+            for b, e in zip(bufs, evals):
+                self.h2d(b, e)
+            call(bufs[:-1], bufs[-1])
+            out = np.empty_like(evals[0])
+            self.d2h(out, bufs[-1])
+        finally:
+            for b in bufs:
+                self.free(b)
+        return out
+
+    def ldt_combine(self, evals, degrees, random_coefficients, basis, shift):
+        """Host-array form of ldt_combine_dev (copies in and out)."""
+        return self._ldt_combine_host(evals, lambda d, o: self.ldt_combine_dev(d, degrees, random_coefficients, basis, shift, o))
+
+    def ldt_combine_multiplicative(self, evals, degrees, random_coefficients, log_n, gen, shift):
+        return self._ldt_combine_host(evals, lambda d, o: self.ldt_combine_multiplicative_dev(d, degrees, random_coefficients, log_n, gen, shift, o))
 
     # ---- proof of work (pow.tcc) ----
     def solve_pow(self, challenge, pow_bitlen, poseidon_params=None):

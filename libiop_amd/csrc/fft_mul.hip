@@ -279,7 +279,7 @@ static int get_mplan(int logn, const uint64_t *gen, MulPlan **out)
 }
 
 // two-level power tables: hi[q] = init * base^(4096 q) (q < 2^max(logc-12,0)), lo[r] = base^r (r < 4096)
-static int build_two_level(const hfp3 &base, const hfp3 &init, int logc, TmpBuf &hi, TmpBuf &lo)
+int build_two_level(const hfp3 &base, const hfp3 &init, int logc, TmpBuf &hi, TmpBuf &lo)
 {
     const int lo_bits = logc < 12 ? logc : 12, hi_bits = logc > 12 ? logc - 12 : 0;
     int rc;

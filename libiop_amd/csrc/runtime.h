@@ -95,6 +95,11 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// fft_mul.hip: two-level power tables of the 181-bit prime field on the device,
+// hi[q] = init * base^(4096 q) (q < 2^max(logc-12,0)), lo[r] = base^r (r < 4096), so init * base^j = hi[j >> 12] * lo[j & 4095]
+struct hfp3;
+int build_two_level(const hfp3 &base, const hfp3 &init, int logc, TmpBuf &hi, TmpBuf &lo);
+
 // Per-module plan caches dropped by iopx_clear_plans() (the caller has synchronised the device).
 void clear_mul_plans();
 void clear_poseidon_sets();

@@ -453,3 +453,43 @@ def pow_solve_poseidon(params, challenge, bitlen):
     f.restype = ctypes.c_uint64
     calls = f(*params.args(), _p(_c(challenge)), ctypes.c_size_t(bitlen), _p(out))
     return out, int(calls)
+
+
+# ---- LDT reducer (ldt_reducer_aux.tcc, exponentiation.tcc) -------------------------------------------------------
+def subspace_element_powers(basis, shift, exponent):
+    basis, shift = _c(basis), _c(shift)
+    m, w = basis.shape
+    out = np.empty((1 << m, w), dtype=np.uint64)
+    lib().oracle_subspace_element_powers(w, _p(basis), ctypes.c_size_t(m), _p(shift), ctypes.c_uint64(exponent), _p(out))
+    return out
+
+
+def _size_array(v):
+    return (ctypes.c_size_t * len(v))(*[int(x) for x in v])
+
+
+def ldt_combine_additive(evals, degrees, coefficients, basis, shift):
+    """combined_LDT_virtual_oracle::evaluated_contents over an affine subspace; coefficients = set_random_coefficients' argument."""
+    evals = [_c(e) for e in evals]
+    coefficients, basis, shift = _c(coefficients), _c(basis), _c(shift)
+    m, w = basis.shape
+    out = np.empty((1 << m, w), dtype=np.uint64)
+    ptrs = (ctypes.c_void_p * len(evals))(*[e.ctypes.data for e in evals])
+    lib().oracle_ldt_combine_additive(w, ptrs, ctypes.c_size_t(len(evals)), _size_array(degrees), _p(coefficients), _p(basis),
+                                      ctypes.c_size_t(m), _p(shift), _p(out))
+    return out
+
+
+def ldt_combine_fp(evals, degrees, coefficients, order, shift):
+    evals = [_c(e) for e in evals]
+    coefficients, shift = _c(coefficients), _c(shift)
+    out = np.empty((order, 3), dtype=np.uint64)
+    ptrs = (ctypes.c_void_p * len(evals))(*[e.ctypes.data for e in evals])
+    lib().oracle_ldt_combine_fp(ptrs, ctypes.c_size_t(len(evals)), _size_array(degrees), _p(coefficients), ctypes.c_size_t(order), _p(shift), _p(out))
+    return out
+
+
+def fp_coset_element_powers(order, shift, exponent):
+    out = np.empty((order, 3), dtype=np.uint64)
+    lib().oracle_fp_coset_element_powers(ctypes.c_size_t(order), _p(_c(shift)), ctypes.c_uint64(exponent), _p(out))
+    return out

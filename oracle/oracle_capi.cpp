@@ -10,6 +10,7 @@
 #include "mult.hpp"
 #include "poseidon.hpp"
 #include "pow.hpp"
+#include "ldt.hpp"
 
 using namespace oracle;
 
@@ -356,6 +357,39 @@ uint64_t oracle_pow_solve_poseidon(size_t alpha, size_t fr, size_t pr, size_t ra
     const uint64_t calls = pow_solve_poseidon<BN>(P, c, bitlen, w);
     memcpy(pow, w.mont, 32);
     return calls;
+}
+
+// LDT reducer (ldt_reducer_aux.tcc:3-136, exponentiation.tcc:3-91)
+int oracle_subspace_element_powers(int words, const uint64_t *basis, size_t m, const uint64_t *shift, uint64_t exponent, uint64_t *out)
+{
+    DISPATCH(words, { store<F>(out, subspace_element_powers<F>(load_domain<F>(basis, m, shift), exponent)); });
+    return 0;
+}
+// coefficients: the 2 * num_oracles elements handed to set_random_coefficients
+int oracle_ldt_combine_additive(int words, const uint64_t *const *evals, size_t num_oracles, const size_t *degrees,
+                                const uint64_t *coefficients, const uint64_t *basis, size_t m, const uint64_t *shift, uint64_t *out)
+{
+    DISPATCH(words, {
+        combined_LDT_virtual_oracle<F> vo(std::vector<size_t>(degrees, degrees + num_oracles));
+        vo.set_random_coefficients(load<F>(coefficients, 2 * num_oracles));
+        std::vector<std::vector<F>> ev;
+        for (size_t k = 0; k < num_oracles; ++k) ev.push_back(load<F>(evals[k], (size_t)1 << m));
+        store<F>(out, vo.evaluated_contents(load_domain<F>(basis, m, shift), ev));
+    });
+    return 0;
+}
+void oracle_ldt_combine_fp(const uint64_t *const *evals, size_t num_oracles, const size_t *degrees, const uint64_t *coefficients,
+                           size_t order, const uint64_t *shift, uint64_t *out)
+{
+    combined_LDT_virtual_oracle<FP> vo(std::vector<size_t>(degrees, degrees + num_oracles));
+    vo.set_random_coefficients(load<FP>(coefficients, 2 * num_oracles));
+    std::vector<std::vector<FP>> ev;
+    for (size_t k = 0; k < num_oracles; ++k) ev.push_back(load<FP>(evals[k], order));
+    store<FP>(out, vo.evaluated_contents(load_coset(order, shift), ev));
+}
+void oracle_fp_coset_element_powers(size_t order, const uint64_t *shift, uint64_t exponent, uint64_t *out)
+{
+    store<FP>(out, coset_element_powers<FP>(load_coset(order, shift), exponent));
 }
 
 } // extern "C"

@@ -308,3 +308,26 @@ def test_pow_poseidon(gpu, name):
 
 def test_pow_errors(gpu):
     pw.check_errors(gpu)
+
+
+# ---- LDT reducer (ldt_reducer_aux.tcc:39-131) -----------------------------------------------------------------
+import ldt_cases as lc
+
+
+@pytest.mark.parametrize("m,degrees,seed,kind", lc.ADDITIVE + [(14, [1 << 12, 1 << 11, (1 << 12) - 5, 77], 6, "standard")])
+def test_ldt_combine_additive(gpu, m, degrees, seed, kind):
+    lc.check_additive(gpu, m, degrees, seed, kind)
+
+
+@pytest.mark.parametrize("log_n,degrees,seed,shifted", lc.MULTIPLICATIVE + [(16, [1 << 14, (1 << 14) - 1, 12345], 5, True)])
+def test_ldt_combine_multiplicative(gpu, log_n, degrees, seed, shifted):
+    lc.check_multiplicative(gpu, log_n, degrees, seed, shifted)
+
+
+def test_ldt_combine_full_size_sampled(gpu):
+    # cfg3-sized codeword domain (2^22), Aurora-like degree spread
+    lc.check_additive_sampled(gpu, 22, [(1 << 21) - 1, 1 << 20, (1 << 20) + 2 * 41 - 1, (1 << 21) - 1], 11)
+
+
+def test_ldt_combine_errors(gpu):
+    lc.check_errors(gpu)
