@@ -77,6 +77,64 @@ __global__ void __launch_bounds__(256) k_ldt_combine_add(LdtAddParams p)
     }
 }
 
+// Shared powers: many oracles have the same degree, and the exponents 2^k - 1 - small of an Aurora-style degree spread share
+// most of their bits.  The host turns the distinct exponents into "slots" (a bit set, optionally on top of a parent slot's
+// value); a lane computes every slot once into LDS and each oracle picks its slot.
+#define LDT_MAX_SLOTS 16
+struct LdtSlotParams {
+    LdtAddParams a;
+    const uint64_t *slot_bits;      // per slot: exponent bits multiplied onto the parent's value
+    const int *slot_parent;         // per slot: parent slot or -1
+    const int *oracle_slot;         // per oracle: slot or -1 (maximal)
+    int num_slots;
+};
+
+__global__ void __launch_bounds__(256) k_ldt_combine_add_slots(LdtSlotParams q)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
+    uint32_t *iopx_ldt_smem = (uint32_t *)iopx_smem;                            // [slot][word][lane]
+    const LdtAddParams &p = q.a;
+    for (size_t base = (size_t)blockIdx.x * 256; base < p.n; base += (size_t)gridDim.x * 256) {
+        const uint32_t jhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 8));
+        const size_t end = base + 256 < p.n ? base + 256 : p.n;
+        for (size_t j = base + threadIdx.x; j < end; j += blockDim.x) {
+            const uint32_t lane = (uint32_t)(j & 255);
+            for (int s = 0; s < q.num_slots; ++s) {
+                const int parent = q.slot_parent[s];
+                uint64_t e = q.slot_bits[s];
+                gf192 v;
+                bool have = parent >= 0;
+                if (have) {
+#pragma unroll
+                    for (int w = 0; w < 6; ++w) v.w[w] = iopx_ldt_smem[(parent * 6 + w) * 256 + lane];
+                }
+                for (int i = 0; e; ++i, e >>= 1) {
+                    if (!(e & 1)) continue;
+                    const gf192 t = ldt_subset_sum(p.tab + 3 * (size_t)i * (p.m + 1), p.m, lane, jhi);
+                    v = have ? gf_mul(v, t) : t;
+                    have = true;
+                }
+#pragma unroll
+                for (int w = 0; w < 6; ++w) iopx_ldt_smem[(s * 6 + w) * 256 + lane] = v.w[w];
+            }
+            gf192 acc = gf_zero();
+            for (int o = 0; o < p.num_oracles; ++o) {
+                const gf192 f = gf_load(p.oracles[o], j);
+                gf192 c = gf_load(p.coef, 2 * o);
+                const int s = q.oracle_slot[o];
+                if (s >= 0) {
+                    gf192 v;
+#pragma unroll
+                    for (int w = 0; w < 6; ++w) v.w[w] = iopx_ldt_smem[(s * 6 + w) * 256 + lane];
+                    gf_add_to(c, gf_mul(gf_load(p.coef, 2 * o + 1), v));
+                }
+                gf_add_to(acc, gf_mul(c, f));
+            }
+            gf_store(p.out, j, acc);
+        }
+    }
+}
+
 struct LdtFpParams {
     const uint64_t *const *oracles; // device array of num_oracles device pointers
     const uint64_t *const *hi;      // per oracle: hi table (nullptr = maximal)
@@ -184,7 +242,48 @@ int iopx_ldt_combine_gf192_dev(const void *const *d_oracles, size_t num_oracles,
     p.out = d_out;
     p.tab = dtab.u64(); p.coef = dcoef.u64(); p.expo = dexpo.u64();
     p.n = (size_t)1 << m; p.m = (int)m; p.num_oracles = (int)num_oracles;
-    { ProfScope ps_("k_ldt_combine_add"); hipLaunchKernelGGL(k_ldt_combine_add, dim3(ldt_grid(p.n)), dim3(256), 0, stream(), p); }
+    // slots: distinct exponents; those with >= 3 bits that all contain a common bit set hang off one slot holding that set
+    std::vector<uint64_t> distinct;
+    for (uint64_t e : pl.expo) if (e && std::find(distinct.begin(), distinct.end(), e) == distinct.end()) distinct.push_back(e);
+    uint64_t common = ~(uint64_t)0;
+    size_t multi = 0;
+    for (uint64_t e : distinct) if (__builtin_popcountll(e) >= 3) { common &= e; ++multi; }
+    if (multi < 2 || __builtin_popcountll(common) < 2) common = 0;
+    std::vector<uint64_t> slot_bits;
+    std::vector<int> slot_parent, oracle_slot(num_oracles, -1);
+    if (common) { slot_bits.push_back(common); slot_parent.push_back(-1); }
+    for (uint64_t e : distinct) {
+        int slot;
+        if (common && e == common) slot = 0;
+        else {
+            const bool on_common = common && __builtin_popcountll(e) >= 3;
+            slot_bits.push_back(on_common ? e & ~common : e);
+            slot_parent.push_back(on_common ? 0 : -1);
+            slot = (int)slot_bits.size() - 1;
+        }
+        for (size_t k = 0; k < num_oracles; ++k) if (pl.expo[k] == e) oracle_slot[k] = slot;
+    }
+    if (slot_bits.size() > LDT_MAX_SLOTS) {
+        ProfScope ps_("k_ldt_combine_add");
+        hipLaunchKernelGGL(k_ldt_combine_add, dim3(ldt_grid(p.n)), dim3(256), 0, stream(), p);
+    } else {
+        const size_t ns = slot_bits.size() ? slot_bits.size() : 1;
+        slot_bits.resize(ns, 0);
+        slot_parent.resize(ns, -1);
+        TmpBuf dbits, dparent, dslot;
+        if ((rc = dbits.alloc(ns * 8)) != IOPX_OK) return rc;
+        if ((rc = dparent.alloc(ns * 4)) != IOPX_OK) return rc;
+        if ((rc = dslot.alloc(num_oracles * 4)) != IOPX_OK) return rc;
+        if ((rc = upload(dbits.p, slot_bits.data(), ns * 8)) != IOPX_OK) return rc;
+        if ((rc = upload(dparent.p, slot_parent.data(), ns * 4)) != IOPX_OK) return rc;
+        if ((rc = upload(dslot.p, oracle_slot.data(), num_oracles * 4)) != IOPX_OK) return rc;
+        LdtSlotParams q;
+        q.a = p;
+        q.slot_bits = dbits.u64(); q.slot_parent = (const int *)dparent.p; q.oracle_slot = (const int *)dslot.p;
+        q.num_slots = (int)(distinct.empty() ? 0 : ns);
+        ProfScope ps_("k_ldt_combine_add_slots");
+        hipLaunchKernelGGL(k_ldt_combine_add_slots, dim3(ldt_grid(p.n)), dim3(256), ns * 6 * 256 * 4, stream(), q);
+    }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
 }

@@ -49,6 +49,12 @@ def check_errors(lib):
 ADDITIVE = [
     (1, [1], 0, "random"), (3, [5, 5, 5], 1, "random"), (6, [40, 17, 40, 33], 2, "random"), (9, [300, 44, 1, 299, 300], 3, "standard"),
     (10, [1 << 9, (1 << 9) - 1, 7], 4, "standard"), (4, [3, 9], 5, "random"),
+    # Aurora-like spread: exponents 2^k - 1 (shared by three oracles), 2^k - 82 (shares 17 bits with it), 1, 2^k
+    (8, [(1 << 7) - 1, 1 << 6, 1 << 6, 1 << 6, (1 << 6) + 21, (1 << 7) - 2, (1 << 6) - 1], 6, "standard"),
+    # more distinct exponents than shared-power slots: the direct kernel
+    (5, [200] + [200 - 3 * k - 1 for k in range(20)], 7, "random"),
+    # all multi-bit exponents identical to the common set
+    (6, [100, 100 - 7, 100 - 7, 100 - 15], 8, "random"),
 ]
 MULTIPLICATIVE = [(1, [1], 0, True), (5, [20, 20], 1, True), (8, [100, 37, 100, 1], 2, True), (13, [5000, 4097, 3], 3, False)]
 
