@@ -42,7 +42,7 @@ def main():
     mx = max(degrees)
     products = n * sum(1 + (bin(mx - dg).count("1") if dg < mx else 0) for dg in degrees)
     print(json.dumps({"workload": "ldt_combine gf192 2^%d x %d oracles" % (m, len(degrees)), "degrees": degrees, "ms": round(ms, 3),
-                      "field_products": products, "products_per_s": products / ms * 1e3,
+                      "reference_field_products": products,
                       "algorithmic_bytes": (len(degrees) + 1) * n * 24, "GBps": (len(degrees) + 1) * n * 24 / ms / 1e6}))
 
 
