@@ -171,6 +171,19 @@ int iopx_merkle_poseidon_bn128_dev(const iopx_poseidon_params *params, const voi
 int iopx_merkle_poseidon_bn128(const iopx_poseidon_params *params, const void *const *oracles, size_t num_oracles,
                                size_t n, size_t coset_size, int domain_type, const uint8_t *salts, uint64_t *nodes);
 
+/* ---- transcript extraction ------------------------------------------------------------------------ */
+/* merkle_tree::get_set_membership_proof (libiop/bcs/merkle_tree.tcc:242-336) from a device-resident node array (32-byte
+ * digests in heap order: BLAKE2b or Poseidon trees): writes the auxiliary hashes, in the reference's order, to host memory.
+ * positions: leaf indices in any order, duplicates allowed (:256-258).  *num_aux receives the count; fails with
+ * IOPX_ERR_INVALID_ARGUMENT when aux_capacity is smaller (then *num_aux says how many are needed).  The zk randomness
+ * hashes (:268-276) are the caller's own salts at the sorted positions. */
+int iopx_merkle_membership_proof_dev(const uint8_t *d_nodes, size_t num_leaves, const size_t *positions, size_t num_positions,
+                                     uint8_t *aux_hashes, size_t aux_capacity, size_t *num_aux);
+/* The query responses of bcs_prover::get_transcript (libiop/bcs/bcs_prover.tcc:187-197): values[p][k] = oracle_k[positions[p]]
+ * (position-major), copied to host memory; oracles are n elements of elem_bytes each. */
+int iopx_query_responses_dev(const void *const *d_oracles, size_t num_oracles, size_t elem_bytes, size_t n, const size_t *positions,
+                             size_t num_positions, void *values);
+
 /* ---- LDT reducer -------------------------------------------------------------------------------- */
 /* combined_LDT_virtual_oracle::evaluated_contents (libiop/protocols/ldt/ldt_reducer_aux.tcc:39-131, constructor and
  * set_random_coefficients :3-37; subset_element_powers, libiop/algebra/exponentiation.tcc:3-91): the random linear

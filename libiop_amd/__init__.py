@@ -41,6 +41,7 @@ EXPORTED_SYMBOLS = [
     "iopx_merkle_blake2b_dev", "iopx_merkle_blake2b",
     "iopx_bn128_to_montgomery_dev", "iopx_poseidon_permute_bn128_dev", "iopx_merkle_poseidon_bn128_dev", "iopx_merkle_poseidon_bn128",
     "iopx_pow_solve_blake2b", "iopx_pow_solve_poseidon_bn128", "iopx_ldt_combine_gf192_dev", "iopx_ldt_combine_fp3_dev",
+    "iopx_merkle_membership_proof_dev", "iopx_query_responses_dev",
     "iopx_gf192_mul_dev", "iopx_gf192_mul_uniform_dev", "iopx_profile_begin", "iopx_profile_report",
 ]
 
@@ -141,6 +142,8 @@ class Library:
         c.iopx_merkle_poseidon_bn128_dev.argtypes = [pp, ctypes.POINTER(_vp), _sz, _sz, _sz, ctypes.c_int, _vp, _vp]
         c.iopx_merkle_poseidon_bn128.argtypes = [pp, ctypes.POINTER(_vp), _sz, _sz, _sz, ctypes.c_int, _vp, _vp]
         c.iopx_pow_solve_blake2b.argtypes = [_vp, _sz, _vp]
+        c.iopx_merkle_membership_proof_dev.argtypes = [_vp, _sz, ctypes.POINTER(_sz), _sz, _vp, _sz, ctypes.POINTER(_sz)]
+        c.iopx_query_responses_dev.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _sz, ctypes.POINTER(_sz), _sz, _vp]
         c.iopx_ldt_combine_gf192_dev.argtypes = [ctypes.POINTER(_vp), _sz, ctypes.POINTER(_sz), _u64p, _u64p, _sz, _u64p, _vp]
         c.iopx_ldt_combine_fp3_dev.argtypes = [ctypes.POINTER(_vp), _sz, ctypes.POINTER(_sz), _u64p, _sz, _u64p, _u64p, _vp]
         c.iopx_pow_solve_poseidon_bn128.argtypes = [pp, _vp, _sz, _vp]
@@ -358,6 +361,24 @@ class Library:
         ptrs = (_vp * len(d_oracles))(*d_oracles)
         self._check(self.c.iopx_merkle_poseidon_bn128_dev(ctypes.byref(params.c), ptrs, len(d_oracles), n, int(coset_size), int(domain_type),
                                                           _vp(d_salts), _vp(d_nodes)))
+
+    # ---- transcript extraction (merkle_tree.tcc:242-336, bcs_prover.tcc:187-197) ----
+    def get_set_membership_proof_dev(self, d_nodes, num_leaves, positions):
+        """Auxiliary hashes of merkle_tree::get_set_membership_proof as a (count, 32) uint8 array; d_nodes on the device."""
+        pos = (_sz * max(len(positions), 1))(*[int(p) for p in positions])
+        cap = max(1, len(positions) * max(1, int(num_leaves).bit_length()))
+        out = np.zeros((cap, 32), dtype=np.uint8)
+        cnt = _sz(0)
+        self._check(self.c.iopx_merkle_membership_proof_dev(_vp(d_nodes), int(num_leaves), pos, len(positions), _vp(out.ctypes.data), cap, ctypes.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    def query_responses_dev(self, d_oracles, elem_bytes, n, positions):
+        """values[p][k] = oracle_k[positions[p]] as a (positions, oracles, elem_bytes / 8) uint64 array."""
+        pos = (_sz * max(len(positions), 1))(*[int(p) for p in positions])
+        ptrs = (_vp * len(d_oracles))(*d_oracles)
+        out = np.zeros((len(positions), len(d_oracles), elem_bytes // 8), dtype=np.uint64)
+        self._check(self.c.iopx_query_responses_dev(ptrs, len(d_oracles), int(elem_bytes), int(n), pos, len(positions), _vp(out.ctypes.data)))
+        return out
 
     # ---- LDT reducer (ldt_reducer_aux.tcc:39-131) ----
     def ldt_combine_dev(self, d_oracles, degrees, random_coefficients, basis, shift, d_out):

@@ -7,6 +7,7 @@
 // buffers in the reference's serialisation order: oracle-major, then position within the coset
 // (merkle_tree.tcc:127-134).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -158,6 +159,26 @@ __global__ void k_merkle_top(uint64_t *nodes, size_t count)
     }
 }
 
+// Transcript extraction: only the O(queries * log L) digests and the queried codeword entries leave the device.
+// out[i] = 32-byte node idx[i]
+__global__ void k_gather_nodes(uint64_t *out, const uint64_t *nodes, const uint64_t *idx, size_t count)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 4 * count; i += (size_t)gridDim.x * blockDim.x) {
+        out[i] = nodes[4 * idx[i >> 2] + (i & 3)];
+    }
+}
+
+// out[(p * num_oracles + k) * elem_words + w] = oracle_k[pos[p]] word w
+__global__ void k_gather_responses(uint64_t *out, const uint64_t *const *oracles, const uint64_t *pos, size_t num_oracles,
+                                   size_t elem_words, size_t count)
+{
+    const size_t total = count * num_oracles * elem_words;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t w = i % elem_words, k = (i / elem_words) % num_oracles, q = i / (elem_words * num_oracles);
+        out[i] = oracles[k][pos[q] * elem_words + w];
+    }
+}
+
 // Proof-of-work grind, binary digests (libiop/bcs/pow.tcc:86-103,111-119,143-162).  Candidate 0 is the challenge itself,
 // candidate k >= 1 the challenge with its last 8-byte word replaced by k - 1; a candidate passes when the last word of
 // H(challenge || candidate) has its low `bitlen` bits zero.  One lane per candidate; the smallest passing index wins.
@@ -288,6 +309,74 @@ int iopx_pow_solve_blake2b(const uint8_t *challenge, size_t pow_bitlen, uint8_t 
     }
     memcpy(pow, challenge, 32);
     if (found != 0) { const uint64_t v = found - 1; memcpy(pow + 24, &v, 8); }
+    return IOPX_OK;
+}
+
+// merkle_tree::get_set_membership_proof (libiop/bcs/merkle_tree.tcc:242-336) on a device-resident node array.
+int iopx_merkle_membership_proof_dev(const uint8_t *d_nodes, size_t num_leaves, const size_t *positions, size_t num_positions,
+                                     uint8_t *aux_hashes, size_t aux_capacity, size_t *num_aux)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_nodes || !num_aux || (num_positions && !positions)) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (num_leaves < 2 || (num_leaves & (num_leaves - 1))) return fail(IOPX_ERR_INVALID_ARGUMENT, "Merkle tree size must be a power of two, and at least 2.");
+    *num_aux = 0;
+    if (num_positions == 0) return IOPX_OK;
+    // the sorted set of queried nodes of one level; a node whose sibling is not in the set contributes the sibling
+    std::vector<uint64_t> level(positions, positions + num_positions), want;
+    std::sort(level.begin(), level.end());
+    level.erase(std::unique(level.begin(), level.end()), level.end());
+    if (level.back() >= num_leaves) return fail(IOPX_ERR_INVALID_ARGUMENT, "All positions must be between 0 and num_leaves-1.");
+    for (uint64_t &v : level) v += num_leaves - 1;
+    while (!(level.size() == 1 && level[0] == 0)) {
+        std::vector<uint64_t> parents;
+        for (size_t i = 0; i < level.size(); ++i) {
+            const uint64_t node = level[i];
+            parents.push_back((node - 1) / 2);
+            if ((node & 1) == 0) want.push_back(node - 1);
+            else if (i + 1 < level.size() && level[i + 1] == node + 1) ++i;
+            else want.push_back(node + 1);
+        }
+        level.swap(parents);
+    }
+    *num_aux = want.size();
+    if (want.empty()) return IOPX_OK;
+    if (!aux_hashes || aux_capacity < want.size()) return fail(IOPX_ERR_INVALID_ARGUMENT, "auxiliary hash buffer too small: %zu needed", want.size());
+    TmpBuf didx, dout;
+    if ((rc = didx.alloc(want.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = dout.alloc(want.size() * 32)) != IOPX_OK) return rc;
+    if ((rc = upload(didx.p, want.data(), want.size() * 8)) != IOPX_OK) return rc;
+    { ProfScope ps_("k_gather_nodes");
+      hipLaunchKernelGGL(k_gather_nodes, dim3((unsigned)((4 * want.size() + 255) / 256)), dim3(256), 0, stream(), dout.u64(), (const uint64_t *)d_nodes,
+                         (const uint64_t *)didx.u64(), want.size()); }
+    IOPX_HIP(hipMemcpyAsync(aux_hashes, dout.p, want.size() * 32, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(hipStreamSynchronize(stream()));
+    return IOPX_OK;
+}
+
+// The query responses of bcs_prover::get_transcript (libiop/bcs/bcs_prover.tcc:187-197): values[p][k] = oracle_k[positions[p]].
+int iopx_query_responses_dev(const void *const *d_oracles, size_t num_oracles, size_t elem_bytes, size_t n, const size_t *positions,
+                             size_t num_positions, void *values)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_oracles || num_oracles == 0 || (num_positions && (!positions || !values))) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (elem_bytes == 0 || (elem_bytes & 7)) return fail(IOPX_ERR_INVALID_ARGUMENT, "element size %zu is not a multiple of 8 bytes", elem_bytes);
+    if (num_positions == 0) return IOPX_OK;
+    std::vector<uint64_t> pos(positions, positions + num_positions);
+    for (uint64_t v : pos) if (v >= n) return fail(IOPX_ERR_INVALID_ARGUMENT, "query position %llu outside the domain", (unsigned long long)v);
+    const size_t words = elem_bytes / 8, total = num_positions * num_oracles * words;
+    TmpBuf dptrs, dpos, dout;
+    if ((rc = dptrs.alloc(num_oracles * sizeof(void *))) != IOPX_OK) return rc;
+    if ((rc = dpos.alloc(num_positions * 8)) != IOPX_OK) return rc;
+    if ((rc = dout.alloc(total * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(dptrs.p, d_oracles, num_oracles * sizeof(void *))) != IOPX_OK) return rc;
+    if ((rc = upload(dpos.p, pos.data(), num_positions * 8)) != IOPX_OK) return rc;
+    { ProfScope ps_("k_gather_responses");
+      hipLaunchKernelGGL(k_gather_responses, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, stream(), dout.u64(),
+                         (const uint64_t *const *)dptrs.p, (const uint64_t *)dpos.u64(), num_oracles, words, num_positions); }
+    IOPX_HIP(hipMemcpyAsync(values, dout.p, total * 8, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }
 

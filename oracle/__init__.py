@@ -493,3 +493,33 @@ def fp_coset_element_powers(order, shift, exponent):
     out = np.empty((order, 3), dtype=np.uint64)
     lib().oracle_fp_coset_element_powers(ctypes.c_size_t(order), _p(_c(shift)), ctypes.c_uint64(exponent), _p(out))
     return out
+
+
+# ---- Merkle set-membership proofs (merkle_tree.tcc:242-515) -----------------------------------------------------------
+def membership_proof_indices(num_leaves, positions):
+    """Heap indices of the auxiliary hashes of get_set_membership_proof, in emission order."""
+    f = lib().oracle_membership_proof_indices
+    f.restype = ctypes.c_size_t
+    cap = max(1, len(positions) * max(1, int(num_leaves).bit_length()))
+    out = (ctypes.c_size_t * cap)()
+    cnt = f(ctypes.c_size_t(num_leaves), _size_array(positions), ctypes.c_size_t(len(positions)), out, ctypes.c_size_t(cap))
+    if cnt == ctypes.c_size_t(-1).value:
+        raise ValueError("All positions must be between 0 and num_leaves-1.")
+    return [int(out[i]) for i in range(cnt)]
+
+
+def membership_proof_validate(root, num_leaves, positions, leaf_hashes, aux):
+    """validate_set_membership_proof for a non-zk BLAKE2b tree; positions sorted unique, leaf_hashes (count, 32) uint8."""
+    lh = np.ascontiguousarray(leaf_hashes, dtype=np.uint8).reshape(-1, 32)
+    ax = np.ascontiguousarray(aux, dtype=np.uint8).reshape(-1, 32)
+    rc = lib().oracle_membership_proof_validate(_b32(root), ctypes.c_size_t(num_leaves), _size_array(positions), ctypes.c_size_t(len(positions)),
+                                                ctypes.c_void_p(lh.ctypes.data), ctypes.c_void_p(ax.ctypes.data), ctypes.c_size_t(ax.shape[0]))
+    if rc < 0:
+        raise AssertionError("Validation did not consume the entire proof.")
+    return bool(rc)
+
+
+def count_hashes_to_verify(num_leaves, positions):
+    f = lib().oracle_count_hashes_to_verify
+    f.restype = ctypes.c_size_t
+    return int(f(ctypes.c_size_t(num_leaves), _size_array(positions), ctypes.c_size_t(len(positions))))

@@ -4,6 +4,7 @@
 // BLAKE2b hashchain.  Field elements are hashed as raw in-memory bytes (sizeof(FieldT) * count),
 // exactly as libiop/bcs/hashing/blake2b.tcc:140-160 does.  Citations relative to /root/reference.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -108,5 +109,83 @@ struct blake2b_hashchain {
         return out;
     }
 };
+
+// merkle_tree::get_set_membership_proof (merkle_tree.tcc:242-336): indices into the heap-ordered node array of the
+// auxiliary hashes, in the order the reference emits them; positions are leaf indices (any order, duplicates allowed)
+static inline std::vector<size_t> membership_proof_node_indices(size_t num_leaves, const std::vector<size_t> &positions)
+{
+    std::vector<size_t> out;
+    if (positions.empty()) return out;
+    std::vector<size_t> S = positions;
+    std::sort(S.begin(), S.end());
+    S.erase(std::unique(S.begin(), S.end()), S.end());
+    for (size_t pos : S) if (pos >= num_leaves) throw std::invalid_argument("All positions must be between 0 and num_leaves-1.");
+    for (size_t &pos : S) pos += num_leaves - 1;
+    while (true) {
+        if (S.size() == 1 && S[0] == 0) break;
+        std::vector<size_t> new_S;
+        size_t i = 0;
+        while (i < S.size()) {
+            const size_t it_pos = S[i];
+            size_t next = i + 1;
+            new_S.push_back((it_pos - 1) / 2);
+            if ((it_pos & 1) == 0) out.push_back(it_pos - 1);                   // right node: left sibling is auxiliary
+            else if (next == S.size() || S[next] != it_pos + 1) out.push_back(it_pos + 1);   // a) right sibling not in S
+            else ++next;                                                        // b) right sibling in S: skip it
+            i = next;
+        }
+        S.swap(new_S);
+    }
+    return out;
+}
+
+// merkle_tree::validate_set_membership_proof (merkle_tree.tcc:338-483) for non-zk BLAKE2b trees, given the leaf HASHES
+// of the queried positions (the caller hashes the leaf contents); positions sorted ascending, unique
+static inline bool membership_proof_validate(const uint8_t *root, size_t num_leaves, const std::vector<size_t> &positions,
+                                             const std::vector<std::vector<uint8_t>> &leaf_hashes, const std::vector<std::vector<uint8_t>> &aux)
+{
+    typedef std::pair<size_t, std::vector<uint8_t>> pd;
+    std::vector<pd> S;
+    for (size_t i = 0; i < positions.size(); ++i) S.push_back(pd(positions[i] + num_leaves - 1, leaf_hashes[i]));
+    size_t a = 0;
+    while (true) {
+        if (S.size() == 1 && S[0].first == 0) break;
+        std::vector<pd> new_S;
+        size_t i = 0;
+        while (i < S.size()) {
+            const size_t it_pos = S[i].first;
+            size_t next = i + 1;
+            std::vector<uint8_t> l, r;
+            if ((it_pos & 1) == 0) { if (a >= aux.size()) return false; l = aux[a++]; r = S[i].second; }
+            else {
+                l = S[i].second;
+                if (next == S.size() || S[next].first != it_pos + 1) { if (a >= aux.size()) return false; r = aux[a++]; }
+                else { r = S[next].second; ++next; }
+            }
+            std::vector<uint8_t> h(DIGEST_LEN);
+            two_to_one(l.data(), r.data(), h.data());
+            new_S.push_back(pd((it_pos - 1) / 2, h));
+            i = next;
+        }
+        S.swap(new_S);
+    }
+    if (a != aux.size()) throw std::logic_error("Validation did not consume the entire proof.");
+    return memcmp(S[0].second.data(), root, DIGEST_LEN) == 0;
+}
+
+// merkle_tree::count_hashes_to_verify_set_membership_proof (merkle_tree.tcc:485-515)
+static inline size_t count_hashes_to_verify_set_membership_proof(size_t num_leaves, std::vector<size_t> positions)
+{
+    size_t total = 0, depth = 0;
+    while (((size_t)1 << depth) < num_leaves) ++depth;
+    std::sort(positions.begin(), positions.end());
+    for (size_t d = depth; d > 0; --d) {
+        std::vector<size_t> next;
+        for (size_t p : positions) if (next.empty() || next.back() != p / 2) next.push_back(p / 2);
+        total += next.size();
+        positions = next;
+    }
+    return total;
+}
 
 } // namespace oracle

@@ -392,4 +392,29 @@ void oracle_fp_coset_element_powers(size_t order, const uint64_t *shift, uint64_
     store<FP>(out, coset_element_powers<FP>(load_coset(order, shift), exponent));
 }
 
+// membership proofs (merkle_tree.tcc:242-515)
+// returns the number of auxiliary node indices written to out (cap entries available), or (size_t)-1 for a bad position
+size_t oracle_membership_proof_indices(size_t num_leaves, const size_t *positions, size_t count, size_t *out, size_t cap)
+{
+    try {
+        const std::vector<size_t> v = membership_proof_node_indices(num_leaves, std::vector<size_t>(positions, positions + count));
+        for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
+        return v.size();
+    } catch (const std::invalid_argument &) { return (size_t)-1; }
+}
+int oracle_membership_proof_validate(const uint8_t *root, size_t num_leaves, const size_t *positions, size_t count,
+                                     const uint8_t *leaf_hashes, const uint8_t *aux, size_t num_aux)
+{
+    std::vector<std::vector<uint8_t>> lh, ax;
+    for (size_t i = 0; i < count; ++i) lh.emplace_back(leaf_hashes + 32 * i, leaf_hashes + 32 * i + 32);
+    for (size_t i = 0; i < num_aux; ++i) ax.emplace_back(aux + 32 * i, aux + 32 * i + 32);
+    try {
+        return membership_proof_validate(root, num_leaves, std::vector<size_t>(positions, positions + count), lh, ax) ? 1 : 0;
+    } catch (const std::logic_error &) { return -1; }
+}
+size_t oracle_count_hashes_to_verify(size_t num_leaves, const size_t *positions, size_t count)
+{
+    return count_hashes_to_verify_set_membership_proof(num_leaves, std::vector<size_t>(positions, positions + count));
+}
+
 } // extern "C"

@@ -331,3 +331,18 @@ def test_ldt_combine_full_size_sampled(gpu):
 
 def test_ldt_combine_errors(gpu):
     lc.check_errors(gpu)
+
+
+# ---- transcript extraction (merkle_tree.tcc:242-336, bcs_prover.tcc:187-197) ----------------------------------
+import transcript_cases as tc
+
+
+def test_membership_proofs(gpu):
+    tc.check_membership_proofs(gpu, 1 << 12, 1, [1, 2, 5, 17, 64, 200, 5000])
+    tc.check_membership_proofs(gpu, 2, 2, [1, 2, 3])
+    tc.check_all_subsets_of_small_tree(gpu)
+    tc.check_empty_and_errors(gpu)
+
+
+def test_query_responses(gpu):
+    tc.check_query_responses(gpu, 1 << 16, 4, 5)

@@ -1,0 +1,21 @@
+"""Transcript extraction on the CPU (product .hip sources compiled by tests/emu) against the oracle."""
+import transcript_cases as tc
+from emu_lib import emu
+from transcript_cases import test_hash_count_expectation  # noqa: F401
+
+
+def test_membership_proofs():
+    tc.check_membership_proofs(emu(), 64, 1, [1, 2, 5, 17, 64, 200])
+    tc.check_membership_proofs(emu(), 2, 2, [1, 2, 3])
+
+
+def test_all_subsets_of_small_tree():
+    tc.check_all_subsets_of_small_tree(emu())
+
+
+def test_empty_and_errors():
+    tc.check_empty_and_errors(emu())
+
+
+def test_query_responses():
+    tc.check_query_responses(emu(), 256, 3, 5)

@@ -1,0 +1,82 @@
+"""Transcript-extraction parity cases shared by the CPU-emulation and the GPU suites (merkle_tree.tcc:242-336,
+bcs_prover.tcc:187-197)."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import rand_elems
+
+
+def _device_tree(lib, oracles, cs, additive):
+    nodes = oracle.merkle_build(oracles, cs, additive)
+    d = lib.malloc(nodes.nbytes)
+    lib.h2d(d, nodes)
+    return nodes, d
+
+
+def check_membership_proofs(lib, L, seed, subsets):
+    cs = 2
+    oracles = [rand_elems(seed, L * cs, 3)]
+    nodes, d = _device_tree(lib, oracles, cs, True)
+    try:
+        rng = np.random.default_rng(seed)
+        for k in subsets:
+            positions = [int(v) for v in rng.integers(0, L, size=k)]        # unsorted, duplicates possible (:256-258)
+            got = lib.get_set_membership_proof_dev(d, L, positions)
+            idx = oracle.membership_proof_indices(L, positions)
+            assert np.array_equal(got, nodes[idx]), (L, positions)
+            S = sorted(set(positions))
+            assert oracle.membership_proof_validate(bytes(nodes[0]), L, S, nodes[[L - 1 + p for p in S]], got)     # test_merkle_tree.cpp:160-166
+            if len(got):
+                bad = got.copy()
+                bad[0, 0] ^= 1
+                assert not oracle.membership_proof_validate(bytes(nodes[0]), L, S, nodes[[L - 1 + p for p in S]], bad)
+    finally:
+        lib.free(d)
+
+
+def check_all_subsets_of_small_tree(lib):
+    # test_merkle_tree.cpp:127-167 (run_multi_test): every non-empty subset of the 8 leaves... of a 16-leaf tree here, sampled
+    L = 16
+    oracles = [rand_elems(3, L, 3)]
+    nodes, d = _device_tree(lib, oracles, 1, True)
+    try:
+        for subset in list(range(1, 64)) + [0xFFFF, 0x8001, 0x5555, 0xAAAA, 0x0FF0]:
+            positions = [k for k in range(L) if subset >> k & 1]
+            got = lib.get_set_membership_proof_dev(d, L, positions)
+            assert np.array_equal(got, nodes[oracle.membership_proof_indices(L, positions)])
+            assert oracle.membership_proof_validate(bytes(nodes[0]), L, positions, nodes[[L - 1 + p for p in positions]], got)
+    finally:
+        lib.free(d)
+
+
+def check_empty_and_errors(lib):
+    nodes, d = _device_tree(lib, [rand_elems(1, 8, 3)], 1, True)
+    try:
+        assert lib.get_set_membership_proof_dev(d, 8, []).shape == (0, 32)          # merkle_tree.tcc:251-254
+        with pytest.raises(ValueError):                                             # :260-264
+            lib.get_set_membership_proof_dev(d, 8, [1, 8])
+    finally:
+        lib.free(d)
+
+
+def check_query_responses(lib, n, r, seed):
+    cols = [rand_elems(seed + k, n, 3) for k in range(r)]
+    ds = [lib.malloc(c.nbytes) for c in cols]
+    try:
+        for dd, c in zip(ds, cols):
+            lib.h2d(dd, c)
+        pos = sorted(set(int(v) for v in np.random.default_rng(seed).integers(0, n, size=37)))
+        got = lib.query_responses_dev(ds, 24, n, pos)
+        want = np.stack([np.stack([c[p] for c in cols]) for p in pos])
+        assert np.array_equal(got, want)
+        with pytest.raises(ValueError):
+            lib.query_responses_dev(ds, 24, n, [n])
+    finally:
+        for dd in ds:
+            lib.free(dd)
+
+
+def test_hash_count_expectation():
+    # test_merkle_tree.cpp:178-199
+    assert oracle.count_hashes_to_verify(8, [1, 3, 6, 7]) == 6
