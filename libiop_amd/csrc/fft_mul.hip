@@ -211,16 +211,14 @@ static int fp_build_pow(uint64_t *out, const hfp3 &base, const hfp3 &init, int n
 {
     std::vector<uint64_t> sq;
     hfp3 x = base;
-    for (int k = 0; k < nb; ++k) { sq.insert(sq.end(), x.w, x.w + 3); x = x.squared(); }
-    const hfp3 one = hfp3::one();
-    TmpBuf dsq, dinit, done;
+    for (int k = 0; k < nb; ++k) { const hfp3 t = x.table_form(); sq.insert(sq.end(), t.w, t.w + 3); x = x.squared(); }
+    const hfp3 init_t = init.table_form();
+    TmpBuf dsq, dinit;
     int rc;
     if ((rc = dsq.alloc(sq.size() * 8 + 8)) != IOPX_OK) return rc;
     if ((rc = dinit.alloc(24)) != IOPX_OK) return rc;
-    if ((rc = done.alloc(24)) != IOPX_OK) return rc;
     if (!sq.empty()) { int urc_ = upload(dsq.p, sq.data(), sq.size() * 8); if (urc_ != IOPX_OK) return urc_; }
-    { int urc_ = upload(dinit.p, init.w, 24); if (urc_ != IOPX_OK) return urc_; }
-    { int urc_ = upload(done.p, one.w, 24); if (urc_ != IOPX_OK) return urc_; }
+    { int urc_ = upload(dinit.p, init_t.w, 24); if (urc_ != IOPX_OK) return urc_; }
     const size_t count = (size_t)1 << nb;
     if (nb <= 8) {
         { ProfScope ps_("k_fp_pow_direct"); hipLaunchKernelGGL(k_fp_pow_direct, dim3(mgrid(count, 256)), dim3(256), 0, stream(), out, (const uint64_t *)dsq.u64(), (const uint64_t *)dinit.u64(), nb, count); }
@@ -230,7 +228,7 @@ static int fp_build_pow(uint64_t *out, const hfp3 &base, const hfp3 &init, int n
         if ((rc = hi.alloc((((size_t)1) << (nb - 8)) * 24)) != IOPX_OK) return rc;
         hfp3 b256 = base;
         for (int k = 0; k < 8; ++k) b256 = b256.squared();
-        rc = fp_build_pow(hi.u64(), b256, one, nb - 8);
+        rc = fp_build_pow(hi.u64(), b256, hfp3::one(), nb - 8);
         if (rc != IOPX_OK) return rc;
         { ProfScope ps_("k_fp_pow_direct"); hipLaunchKernelGGL(k_fp_pow_direct, dim3(1), dim3(256), 0, stream(), out, (const uint64_t *)dsq.u64(), (const uint64_t *)dinit.u64(), 8, (size_t)256); }
         { ProfScope ps_("k_fp_pow_expand"); hipLaunchKernelGGL(k_fp_pow_expand, dim3(mgrid(count - 256, 256)), dim3(256), 0, stream(), out, (const uint64_t *)hi.u64(), count); }
@@ -404,7 +402,8 @@ int iopx_mul_ifft_fp3_dev(const uint64_t *d_evals, size_t log_n, const uint64_t 
     int scale = 1;
     if (sh == hfp3::one()) {
         if ((rc = hi.alloc(24)) != IOPX_OK) return rc;
-        { int urc_ = upload(hi.p, ninv.w, 24); if (urc_ != IOPX_OK) return urc_; }
+        const hfp3 ninv_t = ninv.table_form();
+        { int urc_ = upload(hi.p, ninv_t.w, 24); if (urc_ != IOPX_OK) return urc_; }
     } else {
         scale = 2;
         if ((rc = build_two_level(sh.inverse(), ninv, (int)log_n, hi, lo)) != IOPX_OK) return rc;
@@ -460,10 +459,10 @@ int iopx_fri_fold_mul_fp3_dev(const uint64_t *d_f_i, size_t log_n, const uint64_
     if (!pl->have_inv && (rc = build_cache(*pl, true)) != IOPX_OK) return rc;
     hfp3 sh = hfp3::from_words(shift), x = hfp3::from_words(x_i);
     if (sh.is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "FRI fold: zero coset shift");
-    const hfp3 inv2 = hfp3::from_uint(2).inverse();
+    const hfp3 inv2 = hfp3::from_uint(2).inverse().table_form();
     std::vector<uint64_t> hc;
     for (int e = 0; e < eta; ++e) {
-        const hfp3 xs = x * sh.inverse();
+        const hfp3 xs = (x * sh.inverse()).table_form();
         hc.insert(hc.end(), xs.w, xs.w + 3);
         hc.insert(hc.end(), inv2.w, inv2.w + 3);
         sh = sh.squared();

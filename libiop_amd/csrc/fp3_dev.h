@@ -3,9 +3,8 @@
 //
 // Elements are Montgomery representatives a * 2^192 mod p stored as three little-endian uint64 words — libff
 // Fp_model's `mont_repr`, which libiop hashes and samples raw (libiop/bcs/hashing/blake2b.tcc:148-152,197-227) —
-// so HBM buffers are byte-compatible with the reference's std::vector<FieldT>.  On the device an element is six
-// 32-bit limbs; products are CIOS Montgomery multiplications on v_mad_u64_u32 (measured 32 T lane-ops/s on
-// MI355X, tools/ubench/valu_rates.hip): 72 multiply-adds per field product.
+// so HBM buffers are byte-compatible with the reference's std::vector<FieldT>.  On the device a stored element is six
+// 32-bit words (additions, subtractions); products run on seven 29-bit limbs (see "products: radix 2^29" below).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -97,40 +96,85 @@ __device__ __forceinline__ fp3 fp_sub(const fp3 &a, const fp3 &b)
     return r;
 }
 
-// Montgomery product a * b * 2^-192 mod p (CIOS, 32-bit limbs)
+// ---- products: radix 2^29 -------------------------------------------------------------------------------------------
+// gfx950's integer multiplier is v_mad_u64_u32 (32 x 32 + 64 -> 64, no carry-in).  With seven 29-bit limbs a whole column of
+// a Montgomery product (7 a_i * b_j + 7 m_i * p_j terms, each < 2^60) fits the 64-bit accumulator, so a product is 49 + 42
+// multiply-adds and no carry chains (the 6 x 32-bit CIOS form compiled to 77 multiply-adds plus ~320 carry / move ops).
+// The Montgomery radix of this form is 2^203, not libff's 2^192.  Every product in this library is DATA x TABLE (twiddle,
+// scale factor, fold or combination coefficient) or TABLE x TABLE, never data x data, so: data stays in libff's form
+// (x * 2^192), tables are kept as t * 2^203 ("table form", hfp3::table_form()), and
+//     fp_mul(data, table) = (x 2^192)(t 2^203) / 2^203 = (x t) 2^192      data again,
+//     fp_mul(table, table) = (s 2^203)(t 2^203) / 2^203 = (s t) 2^203     table again.
+struct fp7 {
+    uint32_t l[7];
+};
+
+#define FP7_MASK 0x1fffffffu
+__device__ static const uint32_t FP7_P[7] = { 0x00000001u, 0x0f2a993cu, 0x0b84b307u, 0x05c92772u, 0x08e56c4eu, 0x1abf93a5u, 0x00000040u };
+#define FP7_INV 0x1fffffffu             /* -p^{-1} mod 2^29 (p = 1 mod 2^29) */
+
+// 192-bit value -> seven 29-bit limbs (the top limb takes bits 174..191)
+__device__ __forceinline__ fp7 fp7_unpack(const fp3 &a)
+{
+    fp7 r;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int bit = 29 * i, wi = bit >> 5, sh = bit & 31;
+        const uint64_t two = (uint64_t)a.w[wi] | ((uint64_t)(wi + 1 < 6 ? a.w[wi + 1] : 0u) << 32);
+        r.l[i] = (uint32_t)(two >> sh) & FP7_MASK;
+    }
+    return r;
+}
+
+// normalised limbs (value < 2^192) -> six 32-bit words
+__device__ __forceinline__ fp3 fp7_pack(const fp7 &y)
+{
+    fp3 r;
+    uint64_t acc = 0;
+    int bits = 0, wi = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        acc |= (uint64_t)y.l[i] << bits;
+        bits += 29;
+        if (bits >= 32 && wi < 6) { r.w[wi++] = (uint32_t)acc; acc >>= 32; bits -= 32; }
+    }
+    return r;                   // 7 * 29 = 203 bits: six words emitted, the 11 bits above them are zero for values < 2^192
+}
+
+// a * b * 2^-203 mod p, result < 2p with normalised limbs.  Column sums stay below 2^64 for operand limbs up to 2^30 (both)
+// or 2^31 against a normalised operand; values up to 2^192 on both sides keep the result below 2p.
+__device__ __forceinline__ fp7 fp7_mul(const fp7 &a, const fp7 &b)
+{
+    uint32_t m[7];
+    fp7 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * FP7_P[k - i];
+        m[k] = ((uint32_t)acc * FP7_INV) & FP7_MASK;
+        acc += (uint64_t)m[k] * FP7_P[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 7; k < 13; ++k) {
+#pragma unroll
+        for (int i = k - 6; i < 7; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+        for (int i = k - 6; i < 7; ++i) acc += (uint64_t)m[i] * FP7_P[k - i];
+        r.l[k - 7] = (uint32_t)acc & FP7_MASK;
+        acc >>= 29;
+    }
+    r.l[6] = (uint32_t)acc;
+    return r;
+}
+
+// data x table (or table x table) product on the stored form: canonical in, canonical out
 __device__ __forceinline__ fp3 fp_mul(const fp3 &a, const fp3 &b)
 {
-    uint32_t t[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        uint64_t carry = 0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const uint64_t cur = (uint64_t)a.w[j] * b.w[i] + t[j] + carry;
-            t[j] = (uint32_t)cur;
-            carry = cur >> 32;
-        }
-        uint64_t cur = (uint64_t)t[6] + carry;
-        t[6] = (uint32_t)cur;
-        t[7] = (uint32_t)(cur >> 32);
-        const uint32_t m = t[0] * FP3_INV32;
-        cur = (uint64_t)m * FP3_P[0] + t[0];
-        carry = cur >> 32;
-#pragma unroll
-        for (int j = 1; j < 6; ++j) {
-            cur = (uint64_t)m * FP3_P[j] + t[j] + carry;
-            t[j - 1] = (uint32_t)cur;
-            carry = cur >> 32;
-        }
-        cur = (uint64_t)t[6] + carry;
-        t[5] = (uint32_t)cur;
-        t[6] = t[7] + (uint32_t)(cur >> 32);
-    }
-    fp3 r;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) r.w[i] = t[i];
-    fp_cond_sub_p(r.w);         // the CIOS result is < 2p and p < 2^181, so t[6] is always zero
+    fp3 r = fp7_pack(fp7_mul(fp7_unpack(a), fp7_unpack(b)));
+    fp_cond_sub_p(r.w);
     return r;
 }

@@ -77,6 +77,9 @@ struct hfp3 {
         }
         return raw * r2;
     }
+    // The device multiplies in Montgomery radix 2^203 (fp3_dev.h): a multiplier t is uploaded as t * 2^203 mod p, i.e. the
+    // stored words of t * 2^11.
+    hfp3 table_form() const { return *this * from_uint(2048); }
 };
 
 } // namespace iopx

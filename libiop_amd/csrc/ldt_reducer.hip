@@ -306,7 +306,7 @@ int iopx_ldt_combine_fp3_dev(const void *const *d_oracles, size_t num_oracles, c
     std::vector<std::unique_ptr<TmpBuf>> tabs;
     std::vector<const uint64_t *> hhi(num_oracles, nullptr), hlo(num_oracles, nullptr);
     for (size_t k = 0; k < num_oracles; ++k) {
-        const hfp3 a = coef(pl.own[k]);
+        const hfp3 a = coef(pl.own[k]).table_form();       // multipliers are uploaded in the device's table form (fp3_dev.h)
         hcoef.insert(hcoef.end(), a.w, a.w + 3);
         if (!pl.shifted[k]) continue;
         // cur_bump_factor = c[num + i] * shift^e, multiplied by g^e per position (ldt_reducer_aux.tcc:112-126)
