@@ -9,7 +9,10 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libiop_amd.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-               "-fno-gpu-rdc", "-I" + os.path.join(CSRC, "include")]
+               "-fno-gpu-rdc", "-I" + os.path.join(CSRC, "include"),
+               # `#pragma unroll` is a directive here, not a hint: the prime-field kernels keep whole radix-8 butterfly groups
+               # and Poseidon states in registers, which needs every limb loop flattened (else the arrays land in scratch)
+               "-mllvm", "-pragma-unroll-threshold=1000000"]
 
 
 def sources():

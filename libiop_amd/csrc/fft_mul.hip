@@ -104,7 +104,39 @@ struct MfParams {
     int c, h, A;            // tile: columns on bits [0,c), rows on bits [h, h+A)
     int b_lo, b_hi;         // butterfly bits of this pass (ascending)
     int scale;              // 0 none, 1 sc_hi[0] only (n^-1), 2 two-level table
+    int final;              // last pass of a transform: store canonical values (earlier passes store lazily reduced ones)
 };
+
+// R levels starting at global index bit b on 2^R elements per lane (local indices i0 | k << bl).  Level b + lev pairs k with
+// k | 1 << lev; its twiddle index is the element's index below bit b + lev: lowidx plus the already-processed bits of k.
+template<int R>
+__device__ __forceinline__ void mfft_step(uint64_t *s, int E, const MfParams &p, size_t base, int cmask, int b, int tid, int nt)
+{
+    const int bl = b - p.h + p.c;                           // tile-local bit of level b
+    for (int grp = tid; grp < (E >> R); grp += nt) {
+        const int low = grp & ((1 << bl) - 1), high = grp >> bl;
+        const int i0 = (high << (bl + R)) | low;
+        const size_t gi0 = base | ((size_t)(i0 >> p.c) << p.h) | (size_t)(i0 & cmask);
+        const size_t lowidx = gi0 & ((((size_t)1) << b) - 1);
+        fp7 v[1 << R];
+#pragma unroll
+        for (int k = 0; k < (1 << R); ++k) v[k] = fp7_unpack(mlds_get(s, E, i0 | (k << bl)));
+#pragma unroll
+        for (int lev = 0; lev < R; ++lev) {
+            const uint64_t *lvl = p.cache + 3 * ((((size_t)1) << (b + lev)) - 1);
+#pragma unroll
+            for (int q = 0; q < (1 << lev); ++q) {
+                const fp7 w = fp7_unpack(fp_load(lvl, lowidx + ((size_t)q << b)));
+#pragma unroll
+                for (int k = 0; k < (1 << R); ++k) {
+                    if ((k & ((1 << lev) - 1)) == q && !((k >> lev) & 1)) fp7_bfly(v[k], v[k | (1 << lev)], w);   // t = w * a[k+j+m] (fft.tcc:303-309)
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < (1 << R); ++k) mlds_put(s, E, i0 | (k << bl), fp7_pack(v[k]));
+    }
+}
 
 __global__ void __launch_bounds__(512) k_mfft_pass(MfParams p)
 {
@@ -133,27 +165,19 @@ __global__ void __launch_bounds__(512) k_mfft_pass(MfParams p)
     }
     __syncthreads();
 
-    for (int b = p.b_lo; b <= p.b_hi; ++b) {
-        const int bl = b - p.h + p.c;                       // tile-local bit
-        const uint64_t *lvl = p.cache + 3 * ((((size_t)1) << b) - 1);
-        for (int bf = tid; bf < (E >> 1); bf += nt) {
-            const int low = bf & ((1 << bl) - 1), high = bf >> bl;
-            const int ia = (high << (bl + 1)) | low, ib = ia | (1 << bl);
-            const size_t gi = base | ((size_t)(ia >> p.c) << p.h) | (size_t)(ia & cmask);
-            const fp3 w = fp_load(lvl, gi & ((((size_t)1) << b) - 1));
-            const fp3 x = mlds_get(s, E, ia);
-            const fp3 t = fp_mul(w, mlds_get(s, E, ib));       // t = w * a[k+j+m]; a[k+j+m] = a[k+j] - t; a[k+j] += t
-            mlds_put(s, E, ib, fp_sub(x, t));
-            mlds_put(s, E, ia, fp_add(x, t));
-        }
-        __syncthreads();
-    }
+    // radix-8 / 4 / 2 steps: a lane keeps 2^R elements in registers across R levels, so the tile makes one LDS round trip
+    // and one barrier per three levels
+    int b = p.b_lo;
+    for (; b + 2 <= p.b_hi; b += 3) { mfft_step<3>(s, E, p, base, cmask, b, tid, nt); __syncthreads(); }
+    if (b + 1 <= p.b_hi) { mfft_step<2>(s, E, p, base, cmask, b, tid, nt); __syncthreads(); b += 2; }
+    if (b <= p.b_hi) { mfft_step<1>(s, E, p, base, cmask, b, tid, nt); __syncthreads(); }
 
     for (int li = tid; li < E; li += nt) {
         const size_t gi = base | ((size_t)(li >> p.c) << p.h) | (size_t)(li & cmask);
-        fp3 v = mlds_get(s, E, li);
+        fp3 v = mlds_get(s, E, li);                     // below 2^192, not necessarily canonical
         if (p.scale == 1) v = fp_mul(v, fp_load(p.sc_hi, 0));
-        if (p.scale == 2) v = fp_mul(fp_mul(v, fp_load(p.sc_hi, gi >> 12)), fp_load(p.sc_lo, gi & 4095));
+        else if (p.scale == 2) v = fp_mul(fp_mul(v, fp_load(p.sc_hi, gi >> 12)), fp_load(p.sc_lo, gi & 4095));
+        else if (p.final) v = fp7_canonical(fp7_unpack(v));
         fp_store(p.dst, gi, v);
     }
 }
@@ -324,7 +348,7 @@ static int run_mfft(const uint64_t *cache, const uint64_t *src, size_t n_src, ui
         p.logn = logn; p.logrho = logrho;
         p.gather = (i == 0);
         p.c = ps.c; p.h = ps.h; p.A = ps.A; p.b_lo = ps.b_lo; p.b_hi = ps.b_hi;
-        if (i + 1 == passes.size()) { p.scale = scale; p.sc_hi = sc_hi; p.sc_lo = sc_lo; }
+        if (i + 1 == passes.size()) { p.scale = scale; p.sc_hi = sc_hi; p.sc_lo = sc_lo; p.final = 1; }
         const int tbits = ps.c + ps.A;
         const size_t lds = ((size_t)24) << tbits;
         const size_t blocks = (size_t)1 << (logn - tbits);

@@ -171,6 +171,43 @@ __device__ __forceinline__ fp7 fp7_mul(const fp7 &a, const fp7 &b)
     return r;
 }
 
+// ---- lazily reduced butterflies ---------------------------------------------------------------------------------------
+// A radix-2 butterfly (x, y) -> (x + w y, x - w y) on limb vectors: the product is below 2p, so x + t and x + (2p - t) grow by
+// at most 2p per level and stay far below 2^192 for any transform length of this field (2-adicity 31): no modular reduction,
+// only carry propagation (signed for the difference).  Values are made canonical once, when a transform's last pass stores.
+__device__ static const uint32_t FP7_2P[7] = { 0x00000002u, 0x1e553278u, 0x1709660eu, 0x0b924ee4u, 0x11cad89cu, 0x157f274au, 0x00000081u };
+__device__ static const uint32_t FP7_ONE_T[7] = { 0x1f81a675u, 0x0910f06bu, 0x1f077a07u, 0x02c7785du, 0x1a4c3b6au, 0x144d5829u, 0x00000011u };  // 2^203 mod p
+
+__device__ __forceinline__ void fp7_bfly(fp7 &x, fp7 &y, const fp7 &w)
+{
+    const fp7 t = fp7_mul(w, y);
+    uint32_t cu = 0;
+    int32_t cs = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const uint32_t u = x.l[i] + t.l[i] + cu;
+        const int32_t d = (int32_t)(x.l[i] + FP7_2P[i] - t.l[i]) + cs;
+        if (i < 6) {
+            x.l[i] = u & FP7_MASK; cu = u >> 29;
+            y.l[i] = (uint32_t)d & FP7_MASK; cs = d >> 29;
+        } else {
+            x.l[i] = u;
+            y.l[i] = (uint32_t)d;
+        }
+    }
+}
+
+// any value below 2^192 -> canonical stored form (one product with the table form of 1)
+__device__ __forceinline__ fp3 fp7_canonical(const fp7 &v)
+{
+    fp7 one;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) one.l[i] = FP7_ONE_T[i];
+    fp3 r = fp7_pack(fp7_mul(v, one));
+    fp_cond_sub_p(r.w);
+    return r;
+}
+
 // data x table (or table x table) product on the stored form: canonical in, canonical out
 __device__ __forceinline__ fp3 fp_mul(const fp3 &a, const fp3 &b)
 {
