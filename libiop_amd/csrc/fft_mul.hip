@@ -27,9 +27,16 @@
 
 namespace iopx {
 
-static const int MF_TILE_BITS = 12;
-static const int MF_COLS = 4;
-static const int MF_THREADS = 512;
+// tile geometry of k_mfft_pass (overridable for tuning runs: IOPX_MF_TILE_BITS, IOPX_MF_COLS)
+static int mf_env(const char *name, int dflt, int lo, int hi)
+{
+    const char *v = getenv(name);
+    if (!v) return dflt;
+    const int x = atoi(v);
+    return x < lo || x > hi ? dflt : x;
+}
+static const int MF_TILE_BITS = mf_env("IOPX_MF_TILE_BITS", 11, 6, 12);
+static const int MF_COLS = mf_env("IOPX_MF_COLS", 4, 0, 6);
 
 __device__ __forceinline__ fp3 mlds_get(const uint64_t *s, int E, int li)
 {
@@ -352,7 +359,7 @@ static int run_mfft(const uint64_t *cache, const uint64_t *src, size_t n_src, ui
         const int tbits = ps.c + ps.A;
         const size_t lds = ((size_t)24) << tbits;
         const size_t blocks = (size_t)1 << (logn - tbits);
-        const int threads = (1 << tbits) >= 2 * MF_THREADS ? MF_THREADS : ((1 << tbits) >= 128 ? (1 << tbits) / 2 : 64);
+        const int threads = (1 << tbits) >= 512 ? (1 << tbits) / 8 : 64;          // one radix-8 group per lane and step
         if (lds > 64 * 1024) IOPX_HIP(hipFuncSetAttribute((const void *)k_mfft_pass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         { ProfScope ps_("k_mfft_pass"); hipLaunchKernelGGL(k_mfft_pass, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
     }
