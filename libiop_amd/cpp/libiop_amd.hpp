@@ -11,12 +11,16 @@
 //   IFFT_of_known_degree_over_field_subset                 libiop/algebra/fft.hpp:62-88   (fft.tcc:407-475)
 //   evaluate_next_f_i_over_entire_domain                   libiop/protocols/ldt/fri/fri_aux.hpp:23-28
 //   merkle_tree<FieldT, binary_hash_digest>                libiop/bcs/merkle_tree.hpp:67-104 (construct*, get_root)
+//   merkle_tree::get_set_membership_proof                  libiop/bcs/merkle_tree.tcc:242-336 (from the device-resident tree)
+//   combined_LDT_virtual_oracle<FieldT>                    libiop/protocols/ldt/ldt_reducer_aux.hpp (evaluated_contents)
+//   pow_parameters, pow<FieldT, binary_hash_digest>        libiop/bcs/pow.hpp (solve_pow)
 //   multiplicative_coset<FieldT>, multiplicative_FFT / _IFFT,
 //   multiplicative_evaluate_next_f_i_over_entire_domain    field_subset/subgroup.hpp, fft.hpp:40-52, fri_aux.tcc:106-249
 //                                                          (FieldT with libff::edwards_Fr's layout)
 //
 // INTEGRATION.md shows how libiop's own headers bind to this instead of their CPU bodies.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -253,6 +257,12 @@ std::shared_ptr<std::vector<FieldT>> evaluate_next_f_i_over_entire_domain(
 // ---- Merkle tree (libiop/bcs/merkle_tree.hpp) -----------------------------------------------------
 typedef std::string binary_hash_digest;       // libiop/bcs/hashing/hashing.hpp:21
 
+// libiop/bcs/merkle_tree.hpp:18-36
+struct merkle_tree_set_membership_proof {
+    std::vector<binary_hash_digest> auxiliary_hashes;
+    std::vector<std::string> randomness_hashes;    // zk salts of the queried leaves, in sorted position order
+};
+
 template<typename FieldT>
 class merkle_tree {
     std::size_t num_leaves_;
@@ -308,6 +318,105 @@ public:
         return binary_hash_digest(reinterpret_cast<const char *>(nodes_.data()) + 32 * heap_index, 32);
     }
     std::size_t num_leaves() const { return num_leaves_; }
+
+    // merkle_tree.tcc:242-336.  The node array is staged on the device for the call; a prover that keeps its trees in HBM
+    // calls iopx_merkle_membership_proof_dev on them directly and only these digests cross PCIe.
+    merkle_tree_set_membership_proof get_set_membership_proof(const std::vector<std::size_t> &positions) const
+    {
+        if (!constructed_) throw std::logic_error("Attempting to obtain a Merkle tree authentication path without constructing the tree first.");
+        merkle_tree_set_membership_proof result;
+        if (positions.empty()) return result;
+        std::vector<std::size_t> S = positions;
+        std::sort(S.begin(), S.end());
+        S.erase(std::unique(S.begin(), S.end()), S.end());
+        void *d_nodes = nullptr;
+        check(iopx_malloc(&d_nodes, nodes_.size()));
+        std::vector<uint8_t> aux(32 * S.size() * 64);
+        std::size_t count = 0;
+        int rc = iopx_memcpy_h2d(d_nodes, nodes_.data(), nodes_.size());
+        if (rc == IOPX_OK) rc = iopx_merkle_membership_proof_dev((const uint8_t *)d_nodes, num_leaves_, positions.data(), positions.size(), aux.data(), aux.size() / 32, &count);
+        iopx_free(d_nodes);
+        check(rc);
+        for (std::size_t i = 0; i < count; ++i) result.auxiliary_hashes.emplace_back(reinterpret_cast<const char *>(aux.data()) + 32 * i, 32);
+        if (make_zk_) for (std::size_t pos : S) result.randomness_hashes.emplace_back(reinterpret_cast<const char *>(zk_salts_.data()) + pos * salt_bytes_, salt_bytes_);
+        return result;
+    }
+};
+
+// ---- LDT reducer (libiop/protocols/ldt/ldt_reducer_aux.hpp) ------------------------------------------------------------
+template<typename FieldT>
+class combined_LDT_virtual_oracle {
+    field_subset<FieldT> codeword_domain_;
+    std::vector<std::size_t> input_oracle_degrees_;
+    std::vector<FieldT> random_coefficients_;
+public:
+    combined_LDT_virtual_oracle(const field_subset<FieldT> &codeword_domain, const std::vector<std::size_t> &input_oracle_degrees)
+        : codeword_domain_(codeword_domain), input_oracle_degrees_(input_oracle_degrees) {}
+
+    void set_random_coefficients(const std::vector<FieldT> &random_coefficients)        // ldt_reducer_aux.tcc:26-37
+    {
+        if (random_coefficients.size() != 2 * input_oracle_degrees_.size())
+            throw std::invalid_argument("Expected the nunmber of random coefficients to be twice the number of oracles.");
+        random_coefficients_ = random_coefficients;
+    }
+
+    std::shared_ptr<std::vector<FieldT>> evaluated_contents(                              // ldt_reducer_aux.tcc:39-131
+        const std::vector<std::shared_ptr<std::vector<FieldT>>> &constituent_oracle_evaluations) const
+    {
+        static_assert(is_gf192_layout<FieldT>::value, "FieldT must have libff::gf192's 24-byte layout");
+        if (constituent_oracle_evaluations.size() != input_oracle_degrees_.size())
+            throw std::invalid_argument("Expected same number of evaluations as in registration.");
+        const std::size_t n = constituent_oracle_evaluations[0]->size();
+        for (auto &v : constituent_oracle_evaluations) if (v->size() != n) throw std::invalid_argument("Vectors of mismatched size.");
+        if (n != codeword_domain_.num_elements()) throw std::invalid_argument("Vectors of mismatched size.");
+        std::vector<void *> bufs(constituent_oracle_evaluations.size() + 1, nullptr);
+        auto result = std::make_shared<std::vector<FieldT>>(n);
+        int rc = IOPX_OK;
+        for (std::size_t k = 0; k < bufs.size() && rc == IOPX_OK; ++k) rc = iopx_malloc(&bufs[k], n * sizeof(FieldT));
+        for (std::size_t k = 0; k + 1 < bufs.size() && rc == IOPX_OK; ++k)
+            rc = iopx_memcpy_h2d(bufs[k], constituent_oracle_evaluations[k]->data(), n * sizeof(FieldT));
+        if (rc == IOPX_OK)
+            rc = iopx_ldt_combine_gf192_dev(bufs.data(), bufs.size() - 1, input_oracle_degrees_.data(), detail::words(random_coefficients_.data()),
+                                            detail::words(codeword_domain_.basis().data()), codeword_domain_.dimension(),
+                                            detail::words(&codeword_domain_.shift()), (uint64_t *)bufs.back());
+        if (rc == IOPX_OK) rc = iopx_memcpy_d2h(result->data(), bufs.back(), n * sizeof(FieldT));
+        for (void *b : bufs) if (b) iopx_free(b);
+        check(rc);
+        return result;
+    }
+};
+
+// ---- proof of work (libiop/bcs/pow.hpp) ------------------------------------------------------------------------------
+class pow_parameters {
+    std::size_t work_parameter_, cost_per_hash_;
+public:
+    pow_parameters(std::size_t work_parameter = 0, std::size_t cost_per_hash = 1) : work_parameter_(work_parameter), cost_per_hash_(cost_per_hash) {}
+    std::size_t pow_bitlen() const                                                        // pow.tcc:21-32
+    {
+        std::size_t log_cost = 0;
+        while (((std::size_t)1 << log_cost) < cost_per_hash_) ++log_cost;
+        if (((std::size_t)1 << log_cost) > cost_per_hash_) log_cost -= 1;
+        return work_parameter_ - log_cost;
+    }
+    std::size_t pow_upperbound() const { return 0; }
+    std::size_t work_parameter() const { return work_parameter_; }
+};
+
+// pow<FieldT, binary_hash_digest> with the BLAKE2b two-to-one hash (pow.tcc:67-103)
+class binary_pow {
+    pow_parameters parameters_;
+public:
+    explicit binary_pow(const pow_parameters &params, std::size_t digest_len_bytes = 32) : parameters_(params)
+    {
+        if (digest_len_bytes != 32) throw std::invalid_argument("libiop_amd: only 32-byte BLAKE2b digests are supported");
+    }
+    binary_hash_digest solve_pow(const binary_hash_digest &challenge) const
+    {
+        if (challenge.size() != 32) throw std::invalid_argument("libiop_amd: the proof-of-work challenge is a 32-byte digest");
+        uint8_t out[32];
+        check(iopx_pow_solve_blake2b(reinterpret_cast<const uint8_t *>(challenge.data()), parameters_.pow_bitlen(), out));
+        return binary_hash_digest(reinterpret_cast<const char *>(out), 32);
+    }
 };
 
 } // namespace libiop_amd

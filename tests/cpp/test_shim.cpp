@@ -15,6 +15,8 @@
 #include "../../oracle/fri.hpp"
 #include "../../oracle/merkle.hpp"
 #include "../../oracle/mult.hpp"
+#include "../../oracle/ldt.hpp"
+#include "../../oracle/pow.hpp"
 
 typedef oracle::gf192 FieldT;
 
@@ -92,6 +94,57 @@ static int run_gpu()
             back.resize(coeffs.size());
             CHECK(back == coeffs);
         }
+    }
+    {   // tests/bcs/test_merkle_tree.cpp:127-167: every queried subset verifies against the root (zk and non-zk)
+        const size_t n = 64;
+        std::vector<std::shared_ptr<std::vector<FieldT>>> cols = { std::make_shared<std::vector<FieldT>>(rnd_vec(n)) };
+        libiop_amd::merkle_tree<FieldT> tree(n);
+        tree.construct(cols);
+        const uint8_t *raw[1] = { (const uint8_t *)cols[0]->data() };
+        std::vector<uint8_t> nodes((2 * n - 1) * 32);
+        oracle::merkle_build(raw, 1, sizeof(FieldT), n, 1, true, nullptr, 0, nodes.data());
+        for (uint64_t subset : { 0x1ull, 0x8000000000000000ull, 0xF0F0ull, 0x123456789ABCDEFull, ~0ull }) {
+            std::vector<size_t> pos;
+            for (size_t k = 0; k < n; ++k) if (subset >> k & 1) pos.push_back(k);
+            const libiop_amd::merkle_tree_set_membership_proof mp = tree.get_set_membership_proof(pos);
+            const std::vector<size_t> idx = oracle::membership_proof_node_indices(n, pos);
+            CHECK(mp.auxiliary_hashes.size() == idx.size());
+            std::vector<std::vector<uint8_t>> leaf_hashes, aux;
+            for (size_t i = 0; i < idx.size(); ++i) {
+                CHECK(mp.auxiliary_hashes[i] == std::string((const char *)&nodes[32 * idx[i]], 32));
+                aux.emplace_back(mp.auxiliary_hashes[i].begin(), mp.auxiliary_hashes[i].end());
+            }
+            for (size_t q : pos) leaf_hashes.emplace_back(nodes.begin() + 32 * (n - 1 + q), nodes.begin() + 32 * (n + q));
+            CHECK(oracle::membership_proof_validate(nodes.data(), n, pos, leaf_hashes, aux));
+        }
+    }
+    {   // tests/protocols/test_ldt_reducer.cpp: the combined oracle equals the oracle's literal combination
+        const size_t m = 9;
+        const FieldT shift = rnd();
+        const libiop_amd::field_subset<FieldT> domain(libiop_amd::affine_subspace<FieldT>::shifted_standard_basis(m, shift));
+        const std::vector<size_t> degrees = { 200, 77, 200, 199, 1 };
+        std::vector<std::shared_ptr<std::vector<FieldT>>> evals;
+        std::vector<std::vector<FieldT>> oevals;
+        for (size_t k = 0; k < degrees.size(); ++k) { oevals.push_back(rnd_vec((size_t)1 << m)); evals.push_back(std::make_shared<std::vector<FieldT>>(oevals.back())); }
+        const std::vector<FieldT> r = rnd_vec(2 * degrees.size());
+        libiop_amd::combined_LDT_virtual_oracle<FieldT> vo(domain, degrees);
+        vo.set_random_coefficients(r);
+        oracle::combined_LDT_virtual_oracle<FieldT> ovo(degrees);
+        ovo.set_random_coefficients(r);
+        CHECK(*vo.evaluated_contents(evals) == ovo.evaluated_contents(oracle::affine_subspace<FieldT>::standard(m, shift), oevals));
+        bool threw = false;
+        try { vo.set_random_coefficients(rnd_vec(3)); } catch (const std::invalid_argument &) { threw = true; }     // ldt_reducer_aux.tcc:29-32
+        CHECK(threw);
+    }
+    {   // tests/snark/test_pow.cpp:13-33
+        const libiop_amd::pow_parameters params(20, 1);
+        const libiop_amd::binary_pow prover(params, 32);
+        const std::string challenge = "abcdefghijklmnopqrstuvwxyzabcdef";
+        const std::string proof = prover.solve_pow(challenge);
+        CHECK(oracle::pow_verify_blake2b((const uint8_t *)challenge.data(), (const uint8_t *)proof.data(), params.pow_bitlen()));
+        uint8_t want[32];
+        oracle::pow_solve_blake2b((const uint8_t *)challenge.data(), params.pow_bitlen(), want);
+        CHECK(proof == std::string((const char *)want, 32));
     }
     printf("gpu ok\n");
     return 0;

@@ -30,6 +30,19 @@ def test_cpp_shim_without_device():
     assert r.returncode == 0 and "nodevice ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_cpp_shim_parity_on_cpu_emulation():
+    """The same parity half, linked against the CPU build of the kernel sources (tests/emu): host-side logic of the shim."""
+    from emu_lib import emu
+    emu()
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    exe = os.path.join(ROOT, "tests", "cpp", "test_shim_emu")
+    src = os.path.join(ROOT, "tests", "cpp", "test_shim.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-mpclmul", "-msse4.1", src, "-o", exe, os.path.join(emu_dir, "libiopx_emu.so"),
+                           "-Wl,-rpath," + emu_dir])
+    r = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "gpu ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_cpp_shim_parity_on_gpu():
     exe = _build()
