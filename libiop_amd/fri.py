@@ -57,6 +57,58 @@ def fri_commit(lib, torch, d_codeword, basis, shift, localization_parameters, fi
     return res
 
 
+class FRIProof:
+    """What the BCS transformation of the FRI protocol sends (bcs_common.hpp:36-106), for one oracle / one interaction:
+    per round the Merkle root, the queried leaf positions, the codeword values of the queried cosets and a pruned
+    set-membership proof; the final polynomial; the proof-of-work answer."""
+
+    def __init__(self):
+        self.roots = []
+        self.final_polynomial = None
+        self.proof_of_work = None
+        self.leaf_positions = []        # per round: sorted unique leaf (coset) indices
+        self.query_responses = []       # per round: (len(leaf_positions), coset_size, 3) uint64
+        self.membership_proofs = []     # per round: (count, 32) uint8 auxiliary hashes
+
+
+def fri_query_positions(hashchain, num_queries, domain_size):
+    """One squeezed position per query repetition in the codeword domain (bcs_common.tcc:536-548)."""
+    return [hashchain.squeeze_query_positions(1, domain_size)[0] for _ in range(num_queries)]
+
+
+def fri_prove(lib, torch, d_codeword, basis, shift, localization_parameters, final_degree_bound, num_queries, pow_bitlen,
+              domains=None):
+    """Non-interactive FRI prover for one device-resident codeword over an affine subspace of GF(2^192): commit phase
+    (fri_commit), proof of work on the hashchain's root-type squeeze (bcs_prover.tcc:52-59), query positions from the
+    hashchain, then transcript extraction straight from the device-resident trees and codewords (bcs_prover.tcc:136-233).
+    Round i's leaves are the cosets of size 2^eta_i of L^(i); a query at position s of L^(0) touches leaf s >> (eta_0 + .. +
+    eta_i) of round i (fri_aux.tcc:355-387 for affine subspaces)."""
+    hc = host.Blake2bHashchain()
+    com = fri_commit(lib, torch, d_codeword, basis, shift, localization_parameters, final_degree_bound, hashchain=hc,
+                     keep_codewords=True, domains=domains)
+    proof = FRIProof()
+    proof.roots = com.roots
+    proof.final_polynomial = com.final_polynomial
+    hc.absorb(None)                                       # the last round's prover message: the final polynomial (F8: state only)
+    challenge = hc.squeeze_root_type()
+    proof.proof_of_work = lib.solve_pow(challenge, pow_bitlen)
+    hc.absorb(proof.proof_of_work)
+    n0 = d_codeword.shape[0]
+    positions = fri_query_positions(hc, num_queries, n0)
+    shift_bits = 0
+    for i, eta in enumerate(localization_parameters):
+        shift_bits += eta
+        f_i, nodes = com.codewords[i], com.trees[i]
+        cs = 1 << eta
+        leaves = sorted(set(p >> shift_bits for p in positions))
+        elems = [leaf * cs + k for leaf in leaves for k in range(cs)]
+        vals = lib.query_responses_dev([f_i.data_ptr()], 24, f_i.shape[0], elems)
+        proof.leaf_positions.append(leaves)
+        proof.query_responses.append(vals.reshape(len(leaves), cs, 3))
+        proof.membership_proofs.append(lib.get_set_membership_proof_dev(nodes.data_ptr(), f_i.shape[0] // cs, leaves))
+    return proof
+
+
 def fri_commit_multiplicative(lib, torch, d_codeword, log_n, shift_int, localization_parameters, final_degree_bound, hashchain=None):
     """The same commit phase over multiplicative cosets of the 181-bit prime field (edwards_Fr): domain chain
     size >>= eta, shift <- shift^(2^eta) (fri_ldt.tcc:292-308), cosets {j + k * n / 2^eta} (subgroup.tcc:175-197),

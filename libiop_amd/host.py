@@ -112,6 +112,11 @@ class Blake2bHashchain:
             out[i] = np.frombuffer(d, dtype=np.uint64)
         return out
 
+    def squeeze_root_type(self):
+        """:105-110 — one squeezed element hashed to a digest (blake2b_field_element_hash, :140-160)."""
+        x = self.squeeze_gf192(1)
+        return hashlib.blake2b(x.tobytes(), digest_size=self.DIGEST_LEN).digest()
+
     def squeeze_query_positions(self, num_positions, range_of_positions):
         """:88-105 + blake2b.cpp:50-74."""
         if range_of_positions & (range_of_positions - 1):

@@ -523,3 +523,21 @@ def count_hashes_to_verify(num_leaves, positions):
     f = lib().oracle_count_hashes_to_verify
     f.restype = ctypes.c_size_t
     return int(f(ctypes.c_size_t(num_leaves), _size_array(positions), ctypes.c_size_t(len(positions))))
+
+
+# ---- FRI verifier pieces (fri_aux.tcc:270-303) ------------------------------------------------------------------------
+def fri_fold_at_coset(coset_evals, coset_basis, shift, x_i):
+    coset_evals, coset_basis, shift, x_i = _c(coset_evals), _c(coset_basis), _c(shift), _c(x_i)
+    w = coset_evals.shape[1]
+    out = np.empty(w, dtype=np.uint64)
+    lib().oracle_fri_fold_at_coset(w, _p(coset_evals), ctypes.c_size_t(coset_evals.shape[0]), _p(coset_basis), ctypes.c_size_t(coset_basis.shape[0]),
+                                   _p(shift), _p(x_i), _p(out))
+    return out
+
+
+def poly_eval(coeffs, x):
+    coeffs, x = _c(coeffs), _c(x)
+    w = coeffs.shape[1]
+    out = np.empty(w, dtype=np.uint64)
+    lib().oracle_poly_eval(w, _p(coeffs), ctypes.c_size_t(coeffs.shape[0]), _p(x), _p(out))
+    return out

@@ -58,6 +58,28 @@ std::vector<F> additive_evaluate_next_f_i_over_entire_domain(const std::vector<F
     return next;
 }
 
+// libiop/protocols/ldt/fri/fri_aux.tcc:270-303 — additive_evaluate_next_f_i_at_coset: the verifier's single-coset fold.
+//   coset_basis : the first eta basis vectors of L^(i) (the unshifted coset / localizer domain)
+//   shift       : the queried coset's first element
+template<typename F>
+F additive_evaluate_next_f_i_at_coset(const std::vector<F> &f_i_evals_over_coset, const std::vector<F> &coset_basis,
+                                      const F &shift, const F &x_i)
+{
+    const std::vector<F> unshifted_vp = vanishing_polynomial_from_subspace<F>(affine_subspace<F>(coset_basis, F::zero()));
+    const F vp_x = linearized_eval<F>(unshifted_vp, x_i) - linearized_eval<F>(unshifted_vp, shift);   // :281-282
+    const F c = unshifted_vp[1].inverse();                                                            // :283
+    const bool x_in_domain = (vp_x == F::zero());
+    const std::vector<F> coset_elems = all_subset_sums<F>(coset_basis, x_i + shift);                  // :286-287
+    if (x_in_domain) {
+        for (size_t k = 0; k < f_i_evals_over_coset.size(); ++k)
+            if (coset_elems[k] == F::zero()) return f_i_evals_over_coset[k];                          // :288-296
+    }
+    const std::vector<F> lagrange = batch_inverse_and_mul<F>(coset_elems, vp_x * c);                 // :297
+    F interpolation = F::zero();
+    for (size_t k = 0; k < coset_elems.size(); ++k) interpolation += lagrange[k] * f_i_evals_over_coset[k];
+    return interpolation;
+}
+
 // libiop/protocols/ldt/fri/fri_ldt.tcc:310-338 — additive domain chain: L^(i+1) has
 // basis q(basis[eta..]) and shift q(shift), q = vanishing polynomial of span(basis[0..eta)).
 template<typename F>

@@ -417,4 +417,28 @@ size_t oracle_count_hashes_to_verify(size_t num_leaves, const size_t *positions,
     return count_hashes_to_verify_set_membership_proof(num_leaves, std::vector<size_t>(positions, positions + count));
 }
 
+// verifier-side single-coset fold (fri_aux.tcc:270-303) and Horner evaluation of the final polynomial
+int oracle_fri_fold_at_coset(int words, const uint64_t *coset_evals, size_t coset_size, const uint64_t *coset_basis, size_t eta,
+                             const uint64_t *shift, const uint64_t *x_i, uint64_t *out)
+{
+    DISPATCH(words, {
+        F s; memcpy((void *)&s, shift, sizeof(F));
+        F x; memcpy((void *)&x, x_i, sizeof(F));
+        const F r = additive_evaluate_next_f_i_at_coset<F>(load<F>(coset_evals, coset_size), load<F>(coset_basis, eta), s, x);
+        memcpy(out, (const void *)&r, sizeof(F));
+    });
+    return 0;
+}
+int oracle_poly_eval(int words, const uint64_t *coeffs, size_t n, const uint64_t *x, uint64_t *out)
+{
+    DISPATCH(words, {
+        F xx; memcpy((void *)&xx, x, sizeof(F));
+        const std::vector<F> c = load<F>(coeffs, n);
+        F r = F::zero();
+        for (size_t i = n; i-- > 0; ) { r *= xx; r += c[i]; }
+        memcpy(out, (const void *)&r, sizeof(F));
+    });
+    return 0;
+}
+
 } // extern "C"

@@ -1,0 +1,79 @@
+"""TEST INFRASTRUCTURE ONLY: an independent FRI verifier built on the oracle (no product code): replays the hashchain,
+checks the proof of work, re-derives the query positions, authenticates every queried coset against its round's Merkle
+root (validate_set_membership_proof, merkle_tree.tcc:338-483), checks each fold with the verifier-side single-coset
+interpolation (additive_evaluate_next_f_i_at_coset, fri_aux.tcc:270-303) and the last one against the final polynomial
+(FRI_protocol::verifier_predicate, fri_ldt.tcc:551-690)."""
+import numpy as np
+
+import oracle
+
+
+def _domains(basis, shift, loc):
+    """fri_ldt.tcc:310-338 through the oracle: [(basis_i, shift_i)]"""
+    return [(np.asarray(basis, dtype=np.uint64), np.asarray(shift, dtype=np.uint64))] + oracle.fri_domains_additive(basis, shift, loc)
+
+
+def _element(basis, shift, idx):
+    """utils.tcc:8-30 ordering: shift + sum of the basis vectors selected by the bits of idx"""
+    r = np.array(shift, dtype=np.uint64).copy()
+    for k in range(basis.shape[0]):
+        if idx >> k & 1:
+            r ^= basis[k]
+    return r
+
+
+def verify(proof, basis, shift, loc, final_degree_bound, num_queries, pow_bitlen):
+    m = basis.shape[0]
+    doms = _domains(basis, shift, loc)
+    hc = oracle.Hashchain()
+    xs = []
+    if len(proof.roots) != len(loc):
+        return False, "round count"
+    for root in proof.roots:
+        hc.absorb(root)
+        hc.absorb(bytes(32))
+        xs.append(hc.squeeze(1, 3)[0])
+    hc.absorb(bytes(32))
+    challenge = oracle.blake2b(hc.squeeze(1, 3).tobytes(), 32)
+    if not oracle.pow_verify_blake2b(challenge, proof.proof_of_work, pow_bitlen):
+        return False, "proof of work"
+    hc.absorb(proof.proof_of_work)
+    positions = [hc.squeeze_query_positions(1, 1 << m)[0] for _ in range(num_queries)]
+    if proof.final_polynomial.shape[0] > final_degree_bound:
+        return False, "final polynomial degree"
+    shift_bits = 0
+    # value each query carries into the next round: position -> folded value
+    carried = {}
+    for i, eta in enumerate(loc):
+        b_i, s_i = doms[i]
+        n_i, cs = 1 << b_i.shape[0], 1 << eta
+        prev_bits, shift_bits = shift_bits, shift_bits + eta
+        leaves = sorted(set(p >> shift_bits for p in positions))
+        if list(proof.leaf_positions[i]) != leaves:
+            return False, "leaf positions of round %d" % i
+        vals = proof.query_responses[i]
+        # leaf hash = BLAKE2b of the coset's values in position order (one oracle: merkle_tree.tcc:127-134)
+        leaf_hashes = np.stack([np.frombuffer(oracle.blake2b(vals[k].tobytes(), 32), dtype=np.uint8) for k in range(len(leaves))])
+        try:
+            ok = oracle.membership_proof_validate(proof.roots[i], n_i // cs, leaves, leaf_hashes, proof.membership_proofs[i])
+        except AssertionError:
+            return False, "membership proof of round %d not consumed" % i
+        if not ok:
+            return False, "membership proof of round %d" % i
+        nxt = {}
+        for k, leaf in enumerate(leaves):
+            # consistency with the previous round's fold at the positions the queries came from
+            for p in positions:
+                if p >> shift_bits == leaf and i > 0:
+                    pos_i = p >> prev_bits
+                    if not np.array_equal(vals[k][pos_i - leaf * cs], carried[pos_i]):
+                        return False, "fold consistency entering round %d" % i
+            coset_shift = _element(b_i, s_i, leaf * cs)
+            nxt[leaf] = oracle.fri_fold_at_coset(vals[k], b_i[:eta], coset_shift, xs[i])
+        carried = nxt
+    b_l, s_l = doms[len(loc)]
+    for leaf, v in carried.items():
+        point = _element(b_l, s_l, leaf)
+        if not np.array_equal(oracle.poly_eval(proof.final_polynomial, point), v):
+            return False, "final polynomial"
+    return True, "accept"

@@ -346,3 +346,17 @@ def test_membership_proofs(gpu):
 
 def test_query_responses(gpu):
     tc.check_query_responses(gpu, 1 << 16, 4, 5)
+
+
+# ---- end-to-end FRI: device prover, independent oracle verifier ---------------------------------------------------
+import fri_cases as fc
+
+
+@pytest.mark.parametrize("m,rs_extra,loc_param,queries,pow_bits,kind", [(10, 3, 2, 10, 9, "random"), (16, 2, 2, 24, 16, "standard"),
+                                                                       (22, 2, 2, 32, 20, "standard")])
+def test_fri_prove_and_verify(gpu, m, rs_extra, loc_param, queries, pow_bits, kind):
+    import torch
+    dev = torch.device("cuda:0")
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    to_device = lambda arr: torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).to(dev)
+    assert fc.prove_and_verify(gpu, torch, to_device, m, rs_extra, loc_param, queries, pow_bits, 5, kind)
