@@ -60,7 +60,7 @@ def cfg5(args, torch, dist, lib, dev, rank, world, la, fri, host):
     nodes = torch.empty((2 * (1 << (m - 1)) - 1, 32), dtype=torch.uint8, device=dev)
     timed("indexer_merkle(12 oracles,c=2)", lambda: lib.merkle_tree_dev([o.data_ptr() for o in idx], 24, 1 << m, 2, nodes.data_ptr(),
                                                                         domain_type=la.DOMAIN_MULTIPLICATIVE))
-    root = bytes(nodes[0].cpu().numpy())
+    root = lib.read_digest(nodes.data_ptr())
     del idx[4:]
     c22 = rand_fp(1 << (d + 2), 99)
     cws = [timed("prover_fft_x8(2^%d->2^%d)" % (d + 2, m), lambda: fft(c22, (1 << (d + 2)) - 1)) for _ in range(2)]

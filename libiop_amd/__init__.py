@@ -198,6 +198,13 @@ class Library:
         assert arr.flags["C_CONTIGUOUS"]
         self._check(self.c.iopx_memcpy_d2h(_vp(arr.ctypes.data), _vp(dptr), arr.nbytes))
 
+    def read_digest(self, d_nodes, index=0):
+        """32-byte node `index` of a device-resident tree, copied on the library's stream (ordered after the kernels that
+        produce it — a torch `.cpu()` on another stream is not)."""
+        out = np.empty(32, dtype=np.uint8)
+        self.d2h(out, int(d_nodes) + 32 * index)
+        return bytes(out)
+
     # ---- host-pointer operators (std::vector in / out, like the reference templates) ----
     def additive_FFT(self, poly_coeffs, basis, shift):
         """additive_FFT(poly_coeffs, affine_subspace(basis, shift)) — fft.tcc:39-124."""

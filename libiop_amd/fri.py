@@ -37,7 +37,7 @@ def fri_commit(lib, torch, d_codeword, basis, shift, localization_parameters, fi
         nodes = torch.empty((2 * leaves - 1, 32), dtype=torch.uint8, device=f.device)
         # signal_prover_round_done: Merkle tree over f_i with cosets of size 2^eta_i (bcs_prover.tcc:36-46)
         lib.merkle_tree_dev([f.data_ptr()], 24, n_i, cs, nodes.data_ptr())
-        root = bytes(nodes[0].cpu().numpy())
+        root = lib.read_digest(nodes.data_ptr())        # merkle_tree::get_root, on the library's stream
         res.roots.append(root)
         res.trees.append(nodes)
         if keep_codewords:
@@ -125,7 +125,7 @@ def fri_commit_multiplicative(lib, torch, d_codeword, log_n, shift_int, localiza
         n_i, cs = 1 << logn, 1 << eta
         nodes = torch.empty((2 * (n_i // cs) - 1, 32), dtype=torch.uint8, device=f.device)
         lib.merkle_tree_dev([f.data_ptr()], 24, n_i, cs, nodes.data_ptr(), domain_type=la.DOMAIN_MULTIPLICATIVE)
-        root = bytes(nodes[0].cpu().numpy())
+        root = lib.read_digest(nodes.data_ptr())        # merkle_tree::get_root, on the library's stream
         res.roots.append(root)
         res.trees.append(nodes)
         hc.absorb(root)

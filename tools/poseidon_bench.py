@@ -51,7 +51,7 @@ def main():
         perms = L * chunks + (L - 1)
         out = {"set": name, "log_n": args.log_n, "oracles": r, "coset": cs, "ms_per_tree": round(ms, 3), "permutations": perms,
                "perm_per_s": perms / ms * 1e3, "kernels_ms": {k: round(v[1] / args.reps, 3) for k, v in prof.items()},
-               "root": nodes[0].cpu().numpy().view(np.uint64).tolist()}
+               "root": np.frombuffer(lib.read_digest(nodes.data_ptr()), dtype=np.uint64).tolist()}
         if args.cpu:
             import oracle
             with open(os.path.join(ROOT, "libiop_amd", "data", "poseidon_alt_bn128.json")) as f:
