@@ -131,6 +131,14 @@ def test_merkle_zk_and_errors(gpu):
         gpu.additive_FFT(rand_elems(1, 9, W), oracle.standard_basis(3, W), np.zeros(W, dtype=np.uint64))
 
 
+def test_merkle_zk_2p18_leaves(gpu):
+    # test_merkle_tree.cpp:106-115: zk tree with 2^18 leaves (the reference's salt batching case)
+    L = 1 << 18
+    oracles = [rand_elems(21, L, W), rand_elems(22, L, W)]
+    salts = np.random.default_rng(4).integers(0, 256, size=(L, 32), dtype=np.uint8)
+    assert np.array_equal(gpu.merkle_tree(oracles, 1, 0, salts), oracle.merkle_build(oracles, 1, True, salts))
+
+
 # ---- full-size properties (BASELINE.json configs 2 / 3: sizes the oracle cannot sweep in seconds) --------
 def _horner_at(coeffs, x):
     acc = np.zeros((1, W), dtype=np.uint64)

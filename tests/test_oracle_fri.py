@@ -75,3 +75,19 @@ def test_domain_chain_is_consistent_with_fold():
         deg >>= eta
         coeffs = oracle.additive_ifft(cw, cur_b, cur_s)
         assert not coeffs[deg:].any()
+
+
+@pytest.mark.parametrize("words", [1, 3])
+def test_single_coset_verifier_formula_equals_the_whole_domain_fold(words):
+    # test_fri_aux.cpp:47-86: evaluate_next_f_i_at_coset on one coset == the entry of evaluate_next_f_i_over_entire_domain,
+    # including a point inside the coset (fri_aux.tcc:288-296)
+    m, eta = 8, 3
+    cs = 1 << eta
+    f = rand_elems(5 + words, 1 << m, words)
+    basis, shift = rand_elems(6, m, words), rand_elems(7, 1, words)[0]
+    pts = oracle.all_subset_sums(basis, shift)
+    for x in [rand_elems(8, 1, words)[0], pts[5 * cs + 3]]:
+        whole = oracle.fri_fold_additive(f, basis, shift, cs, x)
+        for j in [0, 5, (1 << m) // cs - 1]:
+            got = oracle.fri_fold_at_coset(f[j * cs:(j + 1) * cs], basis[:eta], pts[j * cs], x)
+            assert np.array_equal(got, whole[j]), (j,)
