@@ -2,7 +2,12 @@
 the CPU tests).  SURVEY.md §8(e): a codeword over a 2^m-point affine subspace of a polynomial with 2^d
 coefficients is 2^(m-d) independent transforms on contiguous blocks, so rank g of N owns the contiguous block
 [g * 2^m / N, (g+1) * 2^m / N) of every oracle.  FRI cosets (contiguous, subspace.tcc:73-91) and Merkle leaves
-are local to a rank; the only cross-rank data are N sub-tree roots (32 bytes each) per Merkle tree."""
+are local to a rank; the only cross-rank data are N sub-tree roots (32 bytes each) per Merkle tree.
+
+Streams: the library enqueues on its own non-blocking HIP stream (or the one given to Library.set_stream).  sharded_lde and
+sharded_fri_fold only enqueue — chain further library calls freely, and call lib.synchronize() before torch (or a
+collective) touches their results; sharded_merkle_root and distributed_fft, which mix library kernels with collectives,
+synchronise both directions themselves."""
 import hashlib
 
 import numpy as np
@@ -140,6 +145,13 @@ class DistributedFFTPlan:
         lib.synchronize()
 
 
+def _torch_sync(torch, t):
+    """The library enqueues on its own (non-blocking) stream: before it consumes a buffer that torch ops or collectives
+    produced on torch's streams, those must have completed.  (After library calls the callers use lib.synchronize().)"""
+    if t.device.type != "cpu":
+        torch.cuda.current_stream(t.device).synchronize()
+
+
 def _exchange(torch, dist, send_t, peer, recv_like):
     """Symmetric shard exchange with one peer (NCCL/RCCL send+recv pair or gloo)."""
     recv = torch.empty_like(recv_like)
@@ -175,10 +187,10 @@ def distributed_fft(lib, torch, dist, plan, d_block):
     else:
         S.copy_(x)
     S = S.reshape(n_loc, 3)
-    lib.synchronize() if S.device.type != "cpu" else None
     peer_of = lambda s2: _rev(s2, r)
     # 2. top r levels
     for j in range(r):
+        _torch_sync(torch, S)
         lib.taylor_dev(S.data_ptr(), m - r, plan.twist[j].data_ptr())
         lib.synchronize()
         # network operations on global index bits (k+1, k), k = r-1 .. j
@@ -205,6 +217,7 @@ def distributed_fft(lib, torch, dist, plan, d_block):
                     _send(torch, dist, S[1::2].contiguous(), peer)
     # 3. local transform of the sub-polynomial over the recursed domain
     loc = torch.empty_like(S)
+    _torch_sync(torch, S)
     lib.additive_FFT_dev(S.data_ptr(), n_loc, plan.local_basis, plan.local_shift, loc.data_ptr())
     lib.synchronize()
     # 4. the last r butterfly levels across blocks
@@ -217,6 +230,7 @@ def distributed_fft(lib, torch, dist, plan, d_block):
         lvl = r - 1 - t                                   # recursion level that produced these twiddles
         B = np.array([host.gf_to_words(v) for v in plan.rec[lvl]], dtype=np.uint64).reshape(-1, 3)
         out = torch.empty_like(cur)
+        _torch_sync(torch, other)
         lib.combine_dev(a.data_ptr(), bb.data_ptr(), out.data_ptr(), n_loc, (rank & ((1 << t) - 1)) * n_loc, B,
                         host.gf_to_words(plan.rs[lvl]), upper)
         lib.synchronize()
