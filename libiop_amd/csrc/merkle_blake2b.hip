@@ -19,14 +19,23 @@ __device__ static const uint64_t B2B_IV[8] = {
     0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull,
     0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull };
 
-__device__ __forceinline__ uint64_t rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+// 64-bit rotations on the 32-bit halves: by 32 a swap, otherwise two v_alignbit_b32 (the generic shift form compiles to
+// five instructions)
+template<int N>
+__device__ __forceinline__ uint64_t rotr64(uint64_t x)
+{
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    if (N == 32) return ((uint64_t)lo << 32) | hi;
+    if (N < 32) return ((uint64_t)__builtin_amdgcn_alignbit(lo, hi, N) << 32) | __builtin_amdgcn_alignbit(hi, lo, N);
+    return ((uint64_t)__builtin_amdgcn_alignbit(hi, lo, N - 32) << 32) | __builtin_amdgcn_alignbit(lo, hi, N - 32);
+}
 
 #define B2B_G(a, b, c, d, x, y)                                   \
     do {                                                          \
-        v[a] = v[a] + v[b] + (x); v[d] = rotr64(v[d] ^ v[a], 32); \
-        v[c] = v[c] + v[d];       v[b] = rotr64(v[b] ^ v[c], 24); \
-        v[a] = v[a] + v[b] + (y); v[d] = rotr64(v[d] ^ v[a], 16); \
-        v[c] = v[c] + v[d];       v[b] = rotr64(v[b] ^ v[c], 63); \
+        v[a] = v[a] + v[b] + (x); v[d] = rotr64<32>(v[d] ^ v[a]); \
+        v[c] = v[c] + v[d];       v[b] = rotr64<24>(v[b] ^ v[c]); \
+        v[a] = v[a] + v[b] + (y); v[d] = rotr64<16>(v[d] ^ v[a]); \
+        v[c] = v[c] + v[d];       v[b] = rotr64<63>(v[b] ^ v[c]); \
     } while (0)
 
 #define B2B_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \

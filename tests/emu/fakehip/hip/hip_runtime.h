@@ -64,6 +64,11 @@ static inline int __builtin_amdgcn_sbfe(int v, unsigned off, unsigned width)
 }
 
 static inline uint32_t __builtin_amdgcn_readfirstlane(uint32_t x) { return x; }
+// v_alignbit_b32: the low 32 bits of ((hi:lo) >> (s & 31))
+static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t s)
+{
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31));
+}
 
 static inline unsigned long long __brevll(unsigned long long x)
 {

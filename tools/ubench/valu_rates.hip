@@ -28,6 +28,11 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed)
             if (OP == 10) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
             if (OP == 11) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b));
             if (OP == 12) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if (OP == 13) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(*(uint64_t *)&a[i & 6]) : "v"(*(uint64_t *)&a[(i + 2) & 6]));
+            if (OP == 14) asm volatile("v_add_co_u32 %0, vcc, %0, %1\n\tv_addc_co_u32 %2, vcc, %2, %3, vcc" : "+v"(a[i & 6]), "+v"(b), "+v"(a[(i & 6) + 1]), "+v"(c) : : "vcc");
+            if (OP == 15) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 16) asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(*(uint64_t *)&a[i & 6]));
+            if (OP == 17) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
         }
     }
     uint32_t s = 0;
@@ -65,5 +70,10 @@ int main()
     run<11>("v_mul_u32_u24", d);
     run<7>("v_mul_lo_u32", d);
     run<8>("v_mad_u64_u32", d);
+    run<13>("v_lshl_add_u64 (64-bit add)", d);
+    run<14>("v_add_co + v_addc_co pair", d);
+    run<15>("v_add_u32", d);
+    run<17>("v_add3_u32", d);
+    run<16>("v_lshrrev_b64", d);
     return 0;
 }
