@@ -34,7 +34,7 @@ namespace iopx {
 // Tile geometry.  Defaults: 4096-element tiles (96 KiB of LDS per workgroup).  The IOPX_TILE_BITS /
 // IOPX_P1_COLS / IOPX_P2_COLS / IOPX_P2_TOP environment variables override them (read once): used for
 // tuning, and by the tests to exercise the multi-pass schedules at small transform sizes.
-struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads; };
+struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols; };
 static int env_int(const char *name, int dflt, int lo, int hi)
 {
     const char *v = getenv(name);
@@ -49,6 +49,9 @@ static const Tuning &tuning()
         u.tile_bits = env_int("IOPX_TILE_BITS", 12, 4, 12);
         u.p1_tile_bits = env_int("IOPX_P1_TILE_BITS", u.tile_bits < 10 ? u.tile_bits : 10, 4, 12);   // phase 1 is latency-bound: smaller tiles, more workgroups per CU
         u.p1_cols = env_int("IOPX_P1_COLS", 3, 0, u.p1_tile_bits - 3);  // strided phase-1 tiles: 2^c contiguous columns
+        // the last phase-1 pass runs every remaining level inside its tile (multiplier-bound): it may use a larger, narrower tile
+        u.p1_fin_tile_bits = env_int("IOPX_P1_FIN_TILE_BITS", u.p1_tile_bits, u.p1_tile_bits, u.tile_bits > u.p1_tile_bits ? u.tile_bits : u.p1_tile_bits);
+        u.p1_fin_cols = env_int("IOPX_P1_FIN_COLS", 0, 0, u.p1_fin_tile_bits - 3);   // measured: 4.74 -> 4.59 ms at 2^22 with single-element columns
         u.p2_cols = env_int("IOPX_P2_COLS", 4, 0, u.tile_bits - 2);     // phase-2 upper passes: 2^c contiguous columns
         // the edge pass holds the levels whose twiddles are not wave-uniform (pair bits < 6): general multiplier,
         // small tiles for occupancy; 2^p2_top natural-order runs
@@ -592,7 +595,9 @@ static std::vector<P1Pass> phase1_schedule(int d)
         return sched;
     }
     const int A = P1_TILE_BITS - P1_COLS;
-    const int hfin = d - A;                 // levels >= hfin live entirely in the top A bits
+    const int fin_cols = d <= tuning().p1_fin_tile_bits ? 0 : tuning().p1_fin_cols;
+    const int Afin = (d <= tuning().p1_fin_tile_bits ? d : tuning().p1_fin_tile_bits) - fin_cols;
+    const int hfin = d - Afin;              // levels >= hfin live entirely in the top Afin bits
     for (int j = 0; j < hfin; ++j) {
         int k = d - 2;
         while (k >= j) {
@@ -606,7 +611,7 @@ static std::vector<P1Pass> phase1_schedule(int d)
             k = ke - 1;
         }
     }
-    sched.push_back({P1_COLS, hfin, A, hfin, d - 1, d - 2, d - 1});
+    sched.push_back({fin_cols, hfin, Afin, hfin, d - 1, d - 2, d - 1});
     return sched;
 }
 
