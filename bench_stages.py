@@ -162,11 +162,20 @@ def main():
                 timed("ifft_6x2^20+1x2^21", lambda: lib.additive_IFFT_dev(cws[6].data_ptr(), b21, shift, tmp.data_ptr()))
         r0 = timed("merkle_round0(4 oracles,c=2)", lambda: idist.sharded_merkle_root(lib, torch, dist, cws[:4], n_loc, 2, rank, world))[0]
         r1 = timed("merkle_round1(1 oracle,c=2)", lambda: idist.sharded_merkle_root(lib, torch, dist, cws[7:8], n_loc, 2, rank, world))[0]
+        # LDT reducer: the random combination of the round's oracles that FRI is run on (ldt_reducer_aux.tcc:39-131); pointwise, so
+        # a rank combines its own block over its local sub-domain.  Aurora-like degree spread (one maximal oracle).
+        degrees = [(1 << (d + 1)) - 1, 1 << d, 1 << d, 1 << d, (1 << d) + 2 * 41 - 1, (1 << (d + 1)) - 2, (1 << d) - 1]
+        rcoef = np.random.default_rng(7).integers(0, 2**63, size=(2 * len(degrees), 3), dtype=np.uint64)
+        b_loc, s_loc = idist.local_subdomain(basis, shift, rank, world)
+        comb = torch.empty_like(cws[0])
+        ldt = lambda: lib.ldt_combine_dev([c.data_ptr() for c in cws[:7]], degrees, rcoef, b_loc, s_loc, comb.data_ptr())
+        ldt()
+        timed("ldt_combine(7 oracles)", ldt)
         # FRI commit on the sharded codeword: per round Merkle (sub-roots gathered) + local fold; when a round's
         # codeword has fewer cosets than ranks the remainder is finished on rank 0 after an all-gather
         hc = host.Blake2bHashchain()
         doms = host.fri_additive_domains(basis, shift, loc)
-        f, roots = cws[4], []
+        f, roots, kept = comb, [], []
 
         def fri_rounds():
             nonlocal f
@@ -180,16 +189,37 @@ def main():
                     f = torch.cat(parts, 0)
                     gathered, cur_world = True, 1
                 if gathered:
-                    root, _ = idist.sharded_merkle_root(lib, torch, dist, [f], f.shape[0], cs, 0, 1)
-                    x = None
+                    root, nodes = idist.sharded_merkle_root(lib, torch, dist, [f], f.shape[0], cs, 0, 1)
                 else:
-                    root, _ = idist.sharded_merkle_root(lib, torch, dist, [f], f.shape[0], cs, rank, world)
+                    root, nodes = idist.sharded_merkle_root(lib, torch, dist, [f], f.shape[0], cs, rank, world)
                 roots.append(root)
+                kept.append((f, nodes, cs))
                 hc.absorb(root); hc.absorb(None)
                 x = hc.squeeze_gf192(1)[0]
                 f = idist.sharded_fri_fold(lib, torch, f, b_i, s_i, cs, x, 0 if gathered else rank, cur_world)
         timed("fri_commit(merkle+fold x%d)" % len(loc), fri_rounds)
+        # proof of work at the config's difficulty (dim_h + 3 bits, common_bcs_parameters.tcc:23-25), then — single GPU — the
+        # transcript: query positions, pruned membership proofs and the queried cosets of every FRI round
+        hc.absorb(None)
+        challenge = hc.squeeze_root_type()
+        answer = timed("pow(%d bits)" % (d + 3), lambda: lib.solve_pow(challenge, d + 3) if rank == 0 else None)
         extra = {"root0": r0.hex()[:16], "root1": r1.hex()[:16], "fri_roots": [r.hex()[:16] for r in roots]}
+        if world == 1:
+            hc.absorb(answer)
+            num_queries = 32
+            positions = fri.fri_query_positions(hc, num_queries, 1 << m)
+
+            def transcript():
+                sizes, sb = [], 0
+                for (f_i, nodes, cs), eta in zip(kept, loc):
+                    sb += eta
+                    leaves = sorted(set(p >> sb for p in positions))
+                    vals = lib.query_responses_dev([f_i.data_ptr()], 24, f_i.shape[0], [l * cs + k for l in leaves for k in range(cs)])
+                    aux = lib.get_set_membership_proof_dev(nodes.data_ptr(), f_i.shape[0] // cs, leaves)
+                    sizes.append(vals.nbytes + aux.nbytes)
+                return sizes
+            sizes = timed("transcript(%d queries: responses + membership proofs)" % num_queries, transcript)
+            extra["fri_transcript_bytes"] = int(sum(sizes))
     total_ms = (time.perf_counter() - t_all) * 1e3
     prof = lib.profile_report()
 
