@@ -31,7 +31,7 @@
 
 namespace iopx {
 
-// Tile geometry.  Defaults: 4096-element tiles (96 KiB of LDS per workgroup).  The IOPX_TILE_BITS /
+// Tile geometry.  Defaults: 2048-element phase-2 tiles (48 KiB of LDS per workgroup), 1024-element phase-1 and edge tiles.  The IOPX_TILE_BITS /
 // IOPX_P1_COLS / IOPX_P2_COLS / IOPX_P2_TOP environment variables override them (read once): used for
 // tuning, and by the tests to exercise the multi-pass schedules at small transform sizes.
 struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols; };
@@ -46,7 +46,7 @@ static const Tuning &tuning()
 {
     static const Tuning t = [] {
         Tuning u;
-        u.tile_bits = env_int("IOPX_TILE_BITS", 12, 4, 12);
+        u.tile_bits = env_int("IOPX_TILE_BITS", 11, 4, 12);   // 2048-element tiles: two comb workgroups per CU overlap their load / compute phases
         u.p1_tile_bits = env_int("IOPX_P1_TILE_BITS", u.tile_bits < 10 ? u.tile_bits : 10, 4, 12);   // phase 1 is latency-bound: smaller tiles, more workgroups per CU
         u.p1_cols = env_int("IOPX_P1_COLS", 3, 0, u.p1_tile_bits - 3);  // strided phase-1 tiles: 2^c contiguous columns
         // the last phase-1 pass runs every remaining level inside its tile (multiplier-bound): it may use a larger, narrower tile
@@ -58,7 +58,7 @@ static const Tuning &tuning()
         u.edge_tile_bits = env_int("IOPX_EDGE_TILE_BITS", u.tile_bits < 10 ? u.tile_bits : 10, 4, u.tile_bits);
         u.p2_top = env_int("IOPX_P2_TOP", 4, 0, u.edge_tile_bits - 2);
         u.comb = env_int("IOPX_COMB", 1, 0, 1);                         // 1: asm comb multiplier where the twiddle is wave-uniform
-        u.p2_threads = env_int("IOPX_P2_THREADS", u.comb ? 512 : 1024, 64, u.comb ? 512 : 1024);
+        u.p2_threads = env_int("IOPX_P2_THREADS", u.comb ? (u.tile_bits >= 12 ? 512 : 256) : 1024, 64, u.comb ? 512 : 1024);
         return u;
     }();
     return t;
