@@ -141,7 +141,7 @@ __device__ __forceinline__ void mfft_step(uint64_t *s, int E, const MfParams &p,
             }
         }
 #pragma unroll
-        for (int k = 0; k < (1 << R); ++k) mlds_put(s, E, i0 | (k << bl), fp7_pack(v[k]));
+        for (int k = 0; k < (1 << R); ++k) mlds_put(s, E, i0 | (k << bl), fp7_pack(fp7_norm(v[k])));
     }
 }
 

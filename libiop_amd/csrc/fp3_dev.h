@@ -172,29 +172,38 @@ __device__ __forceinline__ fp7 fp7_mul(const fp7 &a, const fp7 &b)
 }
 
 // ---- lazily reduced butterflies ---------------------------------------------------------------------------------------
-// A radix-2 butterfly (x, y) -> (x + w y, x - w y) on limb vectors: the product is below 2p, so x + t and x + (2p - t) grow by
-// at most 2p per level and stay far below 2^192 for any transform length of this field (2-adicity 31): no modular reduction,
-// only carry propagation (signed for the difference).  Values are made canonical once, when a transform's last pass stores.
-__device__ static const uint32_t FP7_2P[7] = { 0x00000002u, 0x1e553278u, 0x1709660eu, 0x0b924ee4u, 0x11cad89cu, 0x157f274au, 0x00000081u };
+// A radix-2 butterfly (x, y) -> (x + w y, x - w y) on limb vectors with NO carry handling: t = w y is below 2p with 29-bit
+// limbs; the difference is formed as x + (8p - t) with 8p written so that each of its lower six limbs is at least 2^29 - 1
+// (and the top one above t's), so every limb stays non-negative.  Limbs grow by at most 1.5 * 2^29 per level — below 2^32 after
+// the three levels a lane runs on its registers — and fp7_mul takes one operand with any 32-bit limbs against a normalised
+// twiddle (7 * 2^32 * 2^29 + 7 * 2^58 < 2^64).  Values grow by at most 8p per level: below 2^189 for any transform length
+// of this field (2-adicity 31), so they fit the 192-bit stored form; a transform's last pass makes them canonical.
+__device__ static const uint32_t FP7_8P_SPREAD[7] = { 0x20000008u, 0x3954c9dfu, 0x3c25983au, 0x2e493b91u, 0x272b6270u, 0x35fc9d29u, 0x00000205u };
 __device__ static const uint32_t FP7_ONE_T[7] = { 0x1f81a675u, 0x0910f06bu, 0x1f077a07u, 0x02c7785du, 0x1a4c3b6au, 0x144d5829u, 0x00000011u };  // 2^203 mod p
 
 __device__ __forceinline__ void fp7_bfly(fp7 &x, fp7 &y, const fp7 &w)
 {
     const fp7 t = fp7_mul(w, y);
-    uint32_t cu = 0;
-    int32_t cs = 0;
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-        const uint32_t u = x.l[i] + t.l[i] + cu;
-        const int32_t d = (int32_t)(x.l[i] + FP7_2P[i] - t.l[i]) + cs;
-        if (i < 6) {
-            x.l[i] = u & FP7_MASK; cu = u >> 29;
-            y.l[i] = (uint32_t)d & FP7_MASK; cs = d >> 29;
-        } else {
-            x.l[i] = u;
-            y.l[i] = (uint32_t)d;
-        }
+        y.l[i] = x.l[i] + (FP7_8P_SPREAD[i] - t.l[i]);
+        x.l[i] = x.l[i] + t.l[i];
     }
+}
+
+// carry propagation: same value, limbs 0..5 back below 2^29
+__device__ __forceinline__ fp7 fp7_norm(const fp7 &a)
+{
+    fp7 r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const uint32_t v = a.l[i] + c;
+        r.l[i] = v & FP7_MASK;
+        c = v >> 29;
+    }
+    r.l[6] = a.l[6] + c;
+    return r;
 }
 
 // any value below 2^192 -> canonical stored form (one product with the table form of 1)
