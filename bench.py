@@ -156,7 +156,13 @@ def main():
                      "kernel": dom_name, "launches_per_step": dom_cnt / args.steps, "avg_launch_ms": dom_avg_s * 1e3,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "gfx950 has no carry-less multiply: the GF(2^192) butterflies are integer-ALU-bound, see DESIGN.md",
-                     "kernels_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()}},
+                     "kernels_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
+                     # the bound that actually binds: GF(2^192) products per second of the dominant kernel (each launch that
+                     # twists multiplies every element once) against the measured rate of the in-register multiplier
+                     # (tools/ubench/mul_rates.hip: 4.4e10/s general operands)
+                     "valu": {"products_per_s": (n * (m if dom_name.startswith("k_phase1") else m / 2)) / (dom_ms / args.steps / 1e3),
+                              "multiplier_peak_per_s": 4.4e10,
+                              "frac": (n * (m if dom_name.startswith("k_phase1") else m / 2)) / (dom_ms / args.steps / 1e3) / 4.4e10}},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
