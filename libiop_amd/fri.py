@@ -109,7 +109,26 @@ def fri_prove(lib, torch, d_codeword, basis, shift, localization_parameters, fin
     return proof
 
 
-def fri_commit_multiplicative(lib, torch, d_codeword, log_n, shift_int, localization_parameters, final_degree_bound, hashchain=None):
+def squeeze_edwards_fr(hc):
+    """One element of the 181-bit prime field from the hashchain: the reference's Fp extractor (blake2b.tcc:187-227: keyed
+    BLAKE2b into mont_repr, bits above the modulus MSB cleared, retry with the next key until below p)."""
+    import hashlib
+    import libiop_amd as la
+    P = la.EDWARDS_FR_MODULUS
+    hc.squeeze_index += 1
+    msg = hc.state + hc.squeeze_index.to_bytes(8, "little")
+    key = 0
+    while True:
+        raw = int.from_bytes(hashlib.blake2b(msg, digest_size=24, key=key.to_bytes(8, "little")).digest(), "little")
+        raw &= (1 << P.bit_length()) - 1
+        if raw < P:
+            break
+        key += 1
+    return np.array([(raw >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(3)], dtype=np.uint64)
+
+
+def fri_commit_multiplicative(lib, torch, d_codeword, log_n, shift_int, localization_parameters, final_degree_bound, hashchain=None,
+                              keep_codewords=False):
     """The same commit phase over multiplicative cosets of the 181-bit prime field (edwards_Fr): domain chain
     size >>= eta, shift <- shift^(2^eta) (fri_ldt.tcc:292-308), cosets {j + k * n / 2^eta} (subgroup.tcc:175-197),
     Merkle leaves serialised with the multiplicative position map.  `shift_int` is the canonical integer value of
@@ -128,19 +147,11 @@ def fri_commit_multiplicative(lib, torch, d_codeword, log_n, shift_int, localiza
         root = lib.read_digest(nodes.data_ptr())        # merkle_tree::get_root, on the library's stream
         res.roots.append(root)
         res.trees.append(nodes)
+        if keep_codewords:
+            res.codewords.append(f)
         hc.absorb(root)
         hc.absorb(None)
-        # squeeze one Fp element (rejection sampling on the raw Montgomery words)
-        hc.squeeze_index += 1
-        msg = hc.state + hc.squeeze_index.to_bytes(8, "little")
-        key = 0
-        while True:
-            raw = int.from_bytes(hashlib.blake2b(msg, digest_size=24, key=key.to_bytes(8, "little")).digest(), "little")
-            raw &= (1 << P.bit_length()) - 1
-            if raw < P:
-                break
-            key += 1
-        x_i = np.array([(raw >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(3)], dtype=np.uint64)
+        x_i = squeeze_edwards_fr(hc)
         res.challenges.append(x_i)
         nxt = torch.empty((n_i // cs, 3), dtype=torch.int64, device=f.device)
         lib._check(lib.c.iopx_fri_fold_mul_fp3_dev(f.data_ptr(), logn, la._as_u64(la.edwards_subgroup_generator(logn)).ctypes.data_as(la._u64p),
@@ -154,3 +165,32 @@ def fri_commit_multiplicative(lib, torch, d_codeword, log_n, shift_int, localiza
     lib.synchronize()
     res.final_polynomial = coeffs.cpu().numpy().view(np.uint64)[:final_degree_bound].copy()
     return res
+
+
+def fri_prove_multiplicative(lib, torch, d_codeword, log_n, shift_int, localization_parameters, final_degree_bound, num_queries, pow_bitlen):
+    """fri_prove over multiplicative cosets of the 181-bit prime field.  Round i's leaf j is the coset {j + k * n_i / 2^eta_i} of
+    L^(i) (subgroup.tcc:175-197); a query at position p of L^(i) lands in leaf p mod (n_i / 2^eta_i), which is also its position
+    in L^(i+1) (fri_aux.tcc:355-387 for multiplicative cosets)."""
+    hc = host.Blake2bHashchain()
+    com = fri_commit_multiplicative(lib, torch, d_codeword, log_n, shift_int, localization_parameters, final_degree_bound, hashchain=hc,
+                                    keep_codewords=True)
+    proof = FRIProof()
+    proof.roots = com.roots
+    proof.final_polynomial = com.final_polynomial
+    hc.absorb(None)
+    import hashlib
+    challenge = hashlib.blake2b(squeeze_edwards_fr(hc).tobytes(), digest_size=32).digest()     # squeeze_root_type (blake2b.tcc:105-110)
+    proof.proof_of_work = lib.solve_pow(challenge, pow_bitlen)
+    hc.absorb(proof.proof_of_work)
+    positions = fri_query_positions(hc, num_queries, 1 << log_n)
+    for i, eta in enumerate(localization_parameters):
+        f_i, nodes = com.codewords[i], com.trees[i]
+        cs = 1 << eta
+        num_leaves = f_i.shape[0] // cs
+        positions = [p % num_leaves for p in positions]
+        leaves = sorted(set(positions))
+        vals = lib.query_responses_dev([f_i.data_ptr()], 24, f_i.shape[0], [leaf + k * num_leaves for leaf in leaves for k in range(cs)])
+        proof.leaf_positions.append(leaves)
+        proof.query_responses.append(vals.reshape(len(leaves), cs, 3))
+        proof.membership_proofs.append(lib.get_set_membership_proof_dev(nodes.data_ptr(), num_leaves, leaves))
+    return proof

@@ -541,3 +541,23 @@ def poly_eval(coeffs, x):
     out = np.empty(w, dtype=np.uint64)
     lib().oracle_poly_eval(w, _p(coeffs), ctypes.c_size_t(coeffs.shape[0]), _p(x), _p(out))
     return out
+
+
+def fp_fri_fold_at_coset(coset_evals, g, h, x_i):
+    coset_evals = _c(coset_evals)
+    out = np.empty(3, dtype=np.uint64)
+    lib().oracle_fp_fri_fold_at_coset(_p(coset_evals), ctypes.c_size_t(coset_evals.shape[0]), _p(_c(g)), _p(_c(h)), _p(_c(x_i)), _p(out))
+    return out
+
+
+def fp_poly_eval(coeffs, x):
+    coeffs = _c(coeffs)
+    out = np.empty(3, dtype=np.uint64)
+    lib().oracle_fp_poly_eval(_p(coeffs), ctypes.c_size_t(coeffs.shape[0]), _p(_c(x)), _p(out))
+    return out
+
+
+def fp_pow(a, e):
+    out = np.empty(3, dtype=np.uint64)
+    lib().oracle_fp_pow(_p(_c(a)), ctypes.c_uint64(e), _p(out))
+    return out

@@ -199,4 +199,29 @@ std::vector<F> multiplicative_evaluate_next_f_i_over_entire_domain(const std::ve
     return next;
 }
 
+// libiop/protocols/ldt/fri/fri_aux.tcc:305-349 — multiplicative_evaluate_next_f_i_at_coset: the verifier's single-coset fold.
+//   g : generator of the order-|coset| subgroup, h : the coset's first element (shift of the queried coset)
+template<typename F>
+F multiplicative_evaluate_next_f_i_at_coset(const std::vector<F> &f_i_evals_over_coset, const F &g, const F &h, const F &x_i)
+{
+    const size_t coset_size = f_i_evals_over_coset.size();
+    const F vp_x = x_i.pow(coset_size) - h.pow(coset_size);                                           // :317-318
+    const bool x_in_domain = (vp_x == F::zero());
+    const F c = vp_x * (F((uint64_t)coset_size) * h.pow(coset_size - 1)).inverse();                   // :320
+    std::vector<F> shifted;
+    F cur = h;
+    for (size_t k = 0; k < coset_size; ++k) {
+        if (x_in_domain && cur == x_i) return f_i_evals_over_coset[k];                                // :332-334
+        shifted.push_back(x_i - cur);
+        cur *= g;
+    }
+    const std::vector<F> inverted = batch_inverse_and_mul<F>(shifted, c);                             // :339
+    F interpolation = F::zero(), unshifted = F::one();
+    for (size_t k = 0; k < coset_size; ++k) {
+        interpolation += inverted[k] * unshifted * f_i_evals_over_coset[k];                           // :342-347
+        unshifted *= g;
+    }
+    return interpolation;
+}
+
 } // namespace oracle

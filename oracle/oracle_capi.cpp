@@ -441,4 +441,26 @@ int oracle_poly_eval(int words, const uint64_t *coeffs, size_t n, const uint64_t
     return 0;
 }
 
+// multiplicative verifier-side fold (fri_aux.tcc:305-349) and Horner evaluation over the prime field
+void oracle_fp_fri_fold_at_coset(const uint64_t *coset_evals, size_t coset_size, const uint64_t *g, const uint64_t *h, const uint64_t *x_i, uint64_t *out)
+{
+    FP gg, hh, x; memcpy(gg.mont, g, 24); memcpy(hh.mont, h, 24); memcpy(x.mont, x_i, 24);
+    const FP r = multiplicative_evaluate_next_f_i_at_coset<FP>(load<FP>(coset_evals, coset_size), gg, hh, x);
+    memcpy(out, r.mont, 24);
+}
+void oracle_fp_poly_eval(const uint64_t *coeffs, size_t n, const uint64_t *x, uint64_t *out)
+{
+    FP xx; memcpy(xx.mont, x, 24);
+    const std::vector<FP> c = load<FP>(coeffs, n);
+    FP r = FP::zero();
+    for (size_t i = n; i-- > 0; ) { r *= xx; r += c[i]; }
+    memcpy(out, r.mont, 24);
+}
+void oracle_fp_pow(const uint64_t *a, uint64_t e, uint64_t *out)
+{
+    FP x; memcpy(x.mont, a, 24);
+    const FP r = x.pow(e);
+    memcpy(out, r.mont, 24);
+}
+
 } // extern "C"

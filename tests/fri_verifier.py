@@ -77,3 +77,77 @@ def verify(proof, basis, shift, loc, final_degree_bound, num_queries, pow_bitlen
         if not np.array_equal(oracle.poly_eval(proof.final_polynomial, point), v):
             return False, "final polynomial"
     return True, "accept"
+
+
+# ---- multiplicative cosets of the 181-bit prime field -------------------------------------------------------------------
+def _squeeze_fp(hc):
+    """blake2b.tcc:187-227 on the oracle's own BLAKE2b: keyed hash of state || index into mont_repr, bits above the modulus MSB
+    cleared, next key until the value is below p."""
+    P = oracle.EDWARDS_R
+    hc.idx.value += 1
+    msg = bytes(hc.state) + int(hc.idx.value).to_bytes(8, "little")
+    key = 0
+    while True:
+        raw = int.from_bytes(oracle.blake2b(msg, 24, key.to_bytes(8, "little")), "little") & ((1 << P.bit_length()) - 1)
+        if raw < P:
+            return np.array([(raw >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(3)], dtype=np.uint64)
+        key += 1
+
+
+def verify_multiplicative(proof, log_n, shift_int, loc, final_degree_bound, num_queries, pow_bitlen):
+    P = oracle.EDWARDS_R
+    hc = oracle.Hashchain()
+    xs = []
+    if len(proof.roots) != len(loc):
+        return False, "round count"
+    for root in proof.roots:
+        hc.absorb(root)
+        hc.absorb(bytes(32))
+        xs.append(_squeeze_fp(hc))
+    hc.absorb(bytes(32))
+    challenge = oracle.blake2b(_squeeze_fp(hc).tobytes(), 32)
+    if not oracle.pow_verify_blake2b(challenge, proof.proof_of_work, pow_bitlen):
+        return False, "proof of work"
+    hc.absorb(proof.proof_of_work)
+    positions = [hc.squeeze_query_positions(1, 1 << log_n)[0] for _ in range(num_queries)]
+    if proof.final_polynomial.shape[0] > final_degree_bound:
+        return False, "final polynomial degree"
+    logn, sh = log_n, shift_int % P
+    carried = {}
+    for i, eta in enumerate(loc):
+        n_i, cs = 1 << logn, 1 << eta
+        num_leaves = n_i // cs
+        prev = positions
+        positions = [p % num_leaves for p in prev]
+        leaves = sorted(set(positions))
+        if list(proof.leaf_positions[i]) != leaves:
+            return False, "leaf positions of round %d" % i
+        vals = proof.query_responses[i]
+        leaf_hashes = np.stack([np.frombuffer(oracle.blake2b(vals[k].tobytes(), 32), dtype=np.uint8) for k in range(len(leaves))])
+        try:
+            ok = oracle.membership_proof_validate(proof.roots[i], num_leaves, leaves, leaf_hashes, proof.membership_proofs[i])
+        except AssertionError:
+            return False, "membership proof of round %d not consumed" % i
+        if not ok:
+            return False, "membership proof of round %d" % i
+        g_i = oracle.fp_subgroup_generator(n_i)                   # generator of L^(i)'s subgroup
+        g_coset = oracle.fp_subgroup_generator(cs)                # order-2^eta subgroup the cosets are shifts of
+        shift_w = oracle.fp_from_ints([sh])[0]
+        nxt = {}
+        for k, leaf in enumerate(leaves):
+            if i > 0:
+                for p in prev:                                    # positions in L^(i): element p sits at slot p // num_leaves of leaf p % num_leaves
+                    if p % num_leaves == leaf and not np.array_equal(vals[k][p // num_leaves], carried[p]):
+                        return False, "fold consistency entering round %d" % i
+            h = oracle.fp_mul(shift_w[None, :], oracle.fp_pow(g_i, leaf)[None, :])[0]
+            nxt[leaf] = oracle.fp_fri_fold_at_coset(vals[k], g_coset, h, xs[i])
+        carried = nxt
+        logn -= eta
+        sh = pow(sh, cs, P)
+    g_l = oracle.fp_subgroup_generator(1 << logn)
+    shift_w = oracle.fp_from_ints([sh])[0]
+    for leaf, v in carried.items():
+        point = oracle.fp_mul(shift_w[None, :], oracle.fp_pow(g_l, leaf)[None, :])[0]
+        if not np.array_equal(oracle.fp_poly_eval(proof.final_polynomial, point), v):
+            return False, "final polynomial"
+    return True, "accept"

@@ -10,3 +10,9 @@ from emu_lib import emu
 def test_prove_and_verify(m, rs_extra, loc_param, queries, pow_bits, kind):
     torch, to_device = fc.host_env()
     assert fc.prove_and_verify(emu(), torch, to_device, m, rs_extra, loc_param, queries, pow_bits, 5, kind)
+
+
+@pytest.mark.parametrize("log_n,rs_extra,loc_param,queries,pow_bits", [(8, 2, 2, 6, 5), (9, 3, 1, 8, 7), (10, 2, 3, 10, 0)])
+def test_prove_and_verify_multiplicative(log_n, rs_extra, loc_param, queries, pow_bits):
+    torch, to_device = fc.host_env()
+    assert fc.prove_and_verify_multiplicative(emu(), torch, to_device, log_n, rs_extra, loc_param, queries, pow_bits, 7)

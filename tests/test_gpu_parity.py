@@ -368,3 +368,12 @@ def test_fri_prove_and_verify(gpu, m, rs_extra, loc_param, queries, pow_bits, ki
     gpu.set_stream(torch.cuda.current_stream().cuda_stream)
     to_device = lambda arr: torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).to(dev)
     assert fc.prove_and_verify(gpu, torch, to_device, m, rs_extra, loc_param, queries, pow_bits, 5, kind)
+
+
+@pytest.mark.parametrize("log_n,rs_extra,loc_param,queries,pow_bits", [(10, 3, 2, 10, 8), (16, 2, 2, 24, 14), (20, 3, 2, 32, 18)])
+def test_fri_prove_and_verify_multiplicative(gpu, log_n, rs_extra, loc_param, queries, pow_bits):
+    import torch
+    dev = torch.device("cuda:0")
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    to_device = lambda arr: torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).to(dev)
+    assert fc.prove_and_verify_multiplicative(gpu, torch, to_device, log_n, rs_extra, loc_param, queries, pow_bits, 7)
