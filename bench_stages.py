@@ -33,21 +33,29 @@ def prewarm(torch, dev, count, nbytes):
 
 
 def cfg5(args, torch, dist, lib, dev, rank, world, la, fri, host):
-    """Fractal 2^20 over the 181-bit prime field, multiplicative cosets, as a STAGE REPLAY on one GPU:
+    """Fractal 2^20 over the 181-bit prime field, multiplicative cosets, as a STAGE REPLAY:
     indexer = 12 codeword FFTs (2^20 coefficients -> 2^25-point coset, shift = multiplicative_generator) + one Merkle
     tree over the 12 oracles (cosets of 2, 576-byte leaves); prover = 8 codeword FFTs (2^22 coefficients), one strided
-    IFFT of known degree, FRI commit [1,2x10] from 2^25."""
+    IFFT of known degree, FRI commit [1,2x10] from 2^25.  With --gpus N (torchrun) every codeword is sharded by residue
+    class mod N (libiop_amd/dist.py): LDE and folds are local, a tree needs one all-to-all of leaf digests and an all-gather of
+    N sub-roots; when a FRI round has too few cosets to stay sharded the rest is gathered and finished on every rank."""
+    from libiop_amd import dist as idist
     d, m = args.log_degree, args.log_degree + 5
     P = la.EDWARDS_FR_MODULUS
-    shift = la.edwards_to_montgomery([la.EDWARDS_FR_GENERATOR])[0]
-    gen = la.edwards_subgroup_generator(m)
+    shift_int = la.EDWARDS_FR_GENERATOR
+    gen_int = pow(la.EDWARDS_FR_GENERATOR, (P - 1) >> m, P)
+    n_loc = (1 << m) // world
     stages = {}
 
     def timed(name, fn):
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         t0 = time.perf_counter()
         out = fn()
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         stages[name] = stages.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
         return out
 
@@ -57,38 +65,67 @@ def cfg5(args, torch, dist, lib, dev, rank, world, la, fri, host):
         return torch.from_numpy(raw.view(np.int64)).to(dev)     # any 180-bit words are valid Montgomery representatives
 
     def fft(c, ncoef):
-        out = torch.empty((1 << m, 3), dtype=torch.int64, device=dev)
-        lib._check(lib.c.iopx_mul_fft_fp3_dev(c.data_ptr(), ncoef, m, la._as_u64(gen).ctypes.data_as(la._u64p),
-                                              la._as_u64(shift).ctypes.data_as(la._u64p), out.data_ptr()))
-        return out
+        return idist.sharded_mul_lde(lib, torch, la, c, ncoef, m, gen_int, shift_int, rank, world)
 
-    prewarm(torch, dev, 14, (1 << m) * 24)
+    prewarm(torch, dev, 14, n_loc * 24)
     lib.profile_begin()
     c20 = [rand_fp(1 << d, 50 + k) for k in range(12)]
-    warm = fft(c20[0], 1 << d)            # builds the 2^25 twiddle cache (per domain, like subgroup.tcc:117-144)
+    warm = fft(c20[0], 1 << d)            # builds the twiddle cache of the rank's coset (per domain, like subgroup.tcc:117-144)
     del warm
     idx = [timed("indexer_fft_x12(2^%d->2^%d)" % (d, m), lambda k=k: fft(c20[k], 1 << d)) for k in range(12)]
-    nodes = torch.empty((2 * (1 << (m - 1)) - 1, 32), dtype=torch.uint8, device=dev)
-    timed("indexer_merkle(12 oracles,c=2)", lambda: lib.merkle_tree_dev([o.data_ptr() for o in idx], 24, 1 << m, 2, nodes.data_ptr(),
-                                                                        domain_type=la.DOMAIN_MULTIPLICATIVE))
-    root = lib.read_digest(nodes.data_ptr())
+    root, _ = timed("indexer_merkle(12 oracles,c=2)", lambda: idist.sharded_mul_merkle_root(lib, torch, dist, la, idx, n_loc, 2, rank, world))
     del idx[4:]
     c22 = rand_fp(1 << (d + 2), 99)
     cws = [timed("prover_fft_x8(2^%d->2^%d)" % (d + 2, m), lambda: fft(c22, (1 << (d + 2)) - 1)) for _ in range(2)]
     for _ in range(6):
         timed("prover_fft_x8(2^%d->2^%d)" % (d + 2, m), lambda: fft(c22, (1 << (d + 2)) - 1))
-    co = torch.empty((1 << (d + 2), 3), dtype=torch.int64, device=dev)
-    timed("ifft_known_degree(2^%d of 2^%d)" % (d + 2, m), lambda: lib._check(lib.c.iopx_mul_ifft_known_degree_fp3_dev(
-        cws[0].data_ptr(), (1 << (d + 2)) - 1, m, la._as_u64(gen).ctypes.data_as(la._u64p), la._as_u64(shift).ctypes.data_as(la._u64p), co.data_ptr())))
+    # IFFT_of_known_degree reads every (n / 2^ceil(log degree))-th evaluation (fft.tcc:450-454): a multiple of N apart for N <= 8,
+    # i.e. all inside residue class 0
+    lg_loc, g_loc, s_loc = idist.local_coset(m, gen_int, shift_int, 0, world, P)
+    if rank == 0:
+        co = torch.empty((1 << (d + 2), 3), dtype=torch.int64, device=dev)
+        kd = lambda: lib._check(lib.c.iopx_mul_ifft_known_degree_fp3_dev(
+            cws[0].data_ptr(), (1 << (d + 2)) - 1, lg_loc, la._as_u64(la.edwards_to_montgomery([g_loc])[0]).ctypes.data_as(la._u64p),
+            la._as_u64(la.edwards_to_montgomery([s_loc])[0]).ctypes.data_as(la._u64p), co.data_ptr()))
+        kd()
+    timed("ifft_known_degree(2^%d of 2^%d)" % (d + 2, m), lambda: kd() if rank == 0 else None)
     loc = host.localization_parameter_to_array(2, m, 3)
-    fri.fri_commit_multiplicative(lib, torch, cws[1], m, la.EDWARDS_FR_GENERATOR, loc, 4)      # warm-up
-    res = timed("fri_commit(merkle+fold x%d, final ifft)" % len(loc),
-                lambda: fri.fri_commit_multiplicative(lib, torch, cws[1], m, la.EDWARDS_FR_GENERATOR, loc, 4))
+
+    def fri_commit():
+        hc = host.Blake2bHashchain()
+        f, logn, sh, gi, w, rk, roots = cws[1], m, shift_int, gen_int, world, rank, []
+        for eta in loc:
+            cs = 1 << eta
+            if w > 1 and (((1 << logn) // cs) % (w * w) or (1 << logn) // cs < w * w):
+                f = idist.gather_residues(torch, dist, f, w)        # too few cosets to stay sharded: every rank finishes the tail
+                idist._torch_sync(torch, f)
+                w, rk = 1, 0
+            r, _ = idist.sharded_mul_merkle_root(lib, torch, dist, la, [f], f.shape[0], cs, rk, w)
+            roots.append(r)
+            hc.absorb(r)
+            hc.absorb(None)
+            x = fri.squeeze_edwards_fr(hc)
+            f = idist.sharded_mul_fri_fold(lib, torch, la, f, logn, gi, sh, cs, x, rk, w)
+            logn, sh, gi = logn - eta, pow(sh, cs, P), pow(gi, cs, P)
+        if w > 1:
+            f = idist.gather_residues(torch, dist, f, w)
+            idist._torch_sync(torch, f)
+        coeffs = torch.empty_like(f)
+        lib._check(lib.c.iopx_mul_ifft_fp3_dev(f.data_ptr(), logn, la._as_u64(la.edwards_to_montgomery([gi])[0]).ctypes.data_as(la._u64p),
+                                               la._as_u64(la.edwards_to_montgomery([sh])[0]).ctypes.data_as(la._u64p), coeffs.data_ptr()))
+        lib.synchronize()
+        return roots
+
+    fri_commit()        # warm-up: twiddle caches of the round domains
+    roots = timed("fri_commit(merkle+fold x%d, final ifft)" % len(loc), fri_commit)
     prof = lib.profile_report()
-    print(json.dumps({"config": "cfg5", "n_gpus": 1, "log_degree": d, "codeword_dim": m, "localization": loc, "replay": True,
-                      "stages_ms": stages, "stages_total_ms": sum(stages.values()),
-                      "kernels_ms": {k: round(v[1], 3) for k, v in prof.items()}, "index_root": root.hex()[:16],
-                      "fri_roots": [r.hex()[:16] for r in res.roots]}))
+    if rank == 0:
+        print(json.dumps({"config": "cfg5", "n_gpus": world, "log_degree": d, "codeword_dim": m, "localization": loc, "replay": True,
+                          "stages_ms": stages, "stages_total_ms": sum(stages.values()),
+                          "kernels_ms": {k: round(v[1], 3) for k, v in prof.items()}, "index_root": root.hex()[:16],
+                          "fri_roots": [r.hex()[:16] for r in roots]}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():

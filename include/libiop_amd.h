@@ -141,6 +141,13 @@ int iopx_merkle_blake2b_dev(const void *const *d_oracles, size_t num_oracles, si
 int iopx_merkle_blake2b(const void *const *oracles, size_t num_oracles, size_t elem_bytes, size_t n,
                         size_t coset_size, int domain_type, const uint8_t *salts, size_t salt_bytes,
                         uint8_t *nodes);
+/* The two halves of the construction, for trees whose leaves are hashed on several GPUs (libiop_amd/dist.py):
+ *   iopx_merkle_leaves_blake2b_dev   merkle_tree.tcc:116-149 only: the leaf digests, written to nodes[L-1 .. 2L-2]
+ *   iopx_merkle_inner_blake2b_dev    compute_inner_nodes (merkle_tree.tcc:200-229) over leaf digests already in place */
+int iopx_merkle_leaves_blake2b_dev(const void *const *d_oracles, size_t num_oracles, size_t elem_bytes, size_t n,
+                                   size_t coset_size, int domain_type, const uint8_t *d_salts, size_t salt_bytes,
+                                   uint8_t *d_nodes);
+int iopx_merkle_inner_blake2b_dev(uint8_t *d_nodes, size_t num_leaves);
 
 /* ---- BCS Merkle tree, Poseidon over alt_bn128 Fr ------------------------------------------------- */
 /* A poseidon_params<FieldT> instance (libiop/bcs/hashing/poseidon.hpp:20-60; the shipped sets are

@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "iopx_fri_fold_add_gf192_dev", "iopx_fri_fold_add_gf192",
     "iopx_mul_fft_fp3_dev", "iopx_mul_fft_fp3", "iopx_mul_ifft_fp3_dev", "iopx_mul_ifft_fp3",
     "iopx_mul_ifft_known_degree_fp3_dev", "iopx_fri_fold_mul_fp3_dev", "iopx_fri_fold_mul_fp3",
-    "iopx_merkle_blake2b_dev", "iopx_merkle_blake2b",
+    "iopx_merkle_blake2b_dev", "iopx_merkle_blake2b", "iopx_merkle_leaves_blake2b_dev", "iopx_merkle_inner_blake2b_dev",
     "iopx_bn128_to_montgomery_dev", "iopx_poseidon_permute_bn128_dev", "iopx_merkle_poseidon_bn128_dev", "iopx_merkle_poseidon_bn128",
     "iopx_pow_solve_blake2b", "iopx_pow_solve_poseidon_bn128", "iopx_ldt_combine_gf192_dev", "iopx_ldt_combine_fp3_dev",
     "iopx_merkle_membership_proof_dev", "iopx_query_responses_dev",
@@ -136,6 +136,8 @@ class Library:
         c.iopx_fri_fold_mul_fp3.argtypes = [_u64p, _sz, _u64p, _u64p, _sz, _u64p, _u64p]
         c.iopx_merkle_blake2b_dev.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _sz, _sz, ctypes.c_int, _vp, _sz, _vp]
         c.iopx_merkle_blake2b.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _sz, _sz, ctypes.c_int, _vp, _sz, _vp]
+        c.iopx_merkle_leaves_blake2b_dev.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _sz, _sz, ctypes.c_int, _vp, _sz, _vp]
+        c.iopx_merkle_inner_blake2b_dev.argtypes = [_vp, _sz]
         pp = ctypes.POINTER(_PoseidonParamsC)
         c.iopx_bn128_to_montgomery_dev.argtypes = [_vp, _vp, _sz]
         c.iopx_poseidon_permute_bn128_dev.argtypes = [pp, _vp, _sz]
@@ -484,6 +486,16 @@ class Library:
         ptrs = (_vp * len(d_oracles))(*d_oracles)
         self._check(self.c.iopx_merkle_blake2b_dev(ptrs, len(d_oracles), elem_bytes, n, int(coset_size), int(domain_type),
                                                    _vp(d_salts), salt_bytes, _vp(d_nodes)))
+
+    def merkle_leaves_dev(self, d_oracles, elem_bytes, n, coset_size, d_nodes, domain_type=DOMAIN_ADDITIVE, d_salts=0, salt_bytes=0):
+        """Leaf digests only, into nodes[L-1 .. 2L-2] (merkle_tree.tcc:116-149)."""
+        ptrs = (_vp * len(d_oracles))(*d_oracles)
+        self._check(self.c.iopx_merkle_leaves_blake2b_dev(ptrs, len(d_oracles), elem_bytes, n, int(coset_size), int(domain_type),
+                                                          _vp(d_salts), salt_bytes, _vp(d_nodes)))
+
+    def merkle_inner_dev(self, d_nodes, num_leaves):
+        """compute_inner_nodes (merkle_tree.tcc:200-229) over leaf digests already stored in the node array."""
+        self._check(self.c.iopx_merkle_inner_blake2b_dev(_vp(d_nodes), int(num_leaves)))
 
     def profile_begin(self):
         self._check(self.c.iopx_profile_begin())

@@ -217,9 +217,9 @@ using namespace iopx;
 
 extern "C" {
 
-int iopx_merkle_blake2b_dev(const void *const *d_oracles, size_t num_oracles, size_t elem_bytes, size_t n,
-                            size_t coset_size, int domain_type, const uint8_t *d_salts, size_t salt_bytes,
-                            uint8_t *d_nodes)
+static int merkle_blake2b_impl(const void *const *d_oracles, size_t num_oracles, size_t elem_bytes, size_t n,
+                               size_t coset_size, int domain_type, const uint8_t *d_salts, size_t salt_bytes,
+                               uint8_t *d_nodes, bool leaves_only)
 {
     int rc = ensure_device();
     if (rc != IOPX_OK) return rc;
@@ -247,6 +247,33 @@ int iopx_merkle_blake2b_dev(const void *const *d_oracles, size_t num_oracles, si
     if (grid > 65536) grid = 65536;
     { ProfScope ps_("k_merkle_leaves"); hipLaunchKernelGGL(k_merkle_leaves, dim3((unsigned)grid), dim3(256), 0, stream(), p); }
 
+    if (leaves_only) return IOPX_OK;
+    return iopx_merkle_inner_blake2b_dev(d_nodes, L);   // the pointer table is released in stream order
+}
+
+int iopx_merkle_blake2b_dev(const void *const *d_oracles, size_t num_oracles, size_t elem_bytes, size_t n,
+                            size_t coset_size, int domain_type, const uint8_t *d_salts, size_t salt_bytes,
+                            uint8_t *d_nodes)
+{
+    return merkle_blake2b_impl(d_oracles, num_oracles, elem_bytes, n, coset_size, domain_type, d_salts, salt_bytes, d_nodes, false);
+}
+
+// the leaf digests only (nodes[L-1 .. 2L-2]); the inner nodes are left untouched
+int iopx_merkle_leaves_blake2b_dev(const void *const *d_oracles, size_t num_oracles, size_t elem_bytes, size_t n,
+                                   size_t coset_size, int domain_type, const uint8_t *d_salts, size_t salt_bytes,
+                                   uint8_t *d_nodes)
+{
+    return merkle_blake2b_impl(d_oracles, num_oracles, elem_bytes, n, coset_size, domain_type, d_salts, salt_bytes, d_nodes, true);
+}
+
+// merkle_tree::compute_inner_nodes (merkle_tree.tcc:200-229) on a node array whose leaf digests are already in place
+int iopx_merkle_inner_blake2b_dev(uint8_t *d_nodes, size_t num_leaves)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_nodes) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    const size_t L = num_leaves;
+    if (L < 2 || (L & (L - 1))) return fail(IOPX_ERR_INVALID_ARGUMENT, "Merkle tree size must be a power of two, and at least 2.");
     // inner levels: L/2, L/4, ... nodes; the last levels (<= 1024 nodes) in one workgroup
     size_t count = L / 2;
     while (count > 1024) {
@@ -257,7 +284,7 @@ int iopx_merkle_blake2b_dev(const void *const *d_oracles, size_t num_oracles, si
     }
     { ProfScope ps_("k_merkle_top"); hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(count >= 256 ? 256 : 64), 0, stream(), (uint64_t *)d_nodes, count); }
     IOPX_HIP(hipGetLastError());
-    return IOPX_OK;                                 // the pointer table is released in stream order
+    return IOPX_OK;
 }
 
 int iopx_merkle_blake2b(const void *const *oracles, size_t num_oracles, size_t elem_bytes, size_t n,

@@ -236,3 +236,97 @@ def distributed_fft(lib, torch, dist, plan, d_block):
         lib.synchronize()
         cur = out
     return cur
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Multiplicative cosets of the 181-bit prime field (BASELINE config 5), sharded by RESIDUE: rank g of N owns
+# the evaluations at positions i = g (mod N) of every codeword, stored as the local array a_g[i'] = codeword[g + N i'].  That
+# array is the codeword over the coset (shift * gen^g) * <gen^N> of order n / N in natural order, so
+#   * the LDE is one ordinary transform per rank over that coset (no exchange),
+#   * FRI / Merkle cosets {j + k n/c} (subgroup.tcc:175-197) stay inside one residue class as long as n/c is a multiple of N:
+#     the fold is the ordinary fold of the local coset and produces the rank's residue class of f_{i+1},
+#   * leaf l of a tree belongs to rank l mod N, so the rank's leaf digests are an interleaved subset of the heap's leaf level:
+#     ONE all-to-all of 32-byte digests (1/18 of the bytes of a 12-oracle leaf) hands every rank a contiguous run of leaves,
+#     whose sub-tree it builds; N sub-roots are all-gathered as in the additive case.
+# ---------------------------------------------------------------------------------------------------------------
+def _fp_pow_int(base, e, p):
+    return pow(int(base), int(e), int(p))
+
+
+def local_coset(log_n, gen_int, shift_int, rank, world, modulus):
+    """(log2 of the local order, generator, shift) of rank's residue class, as canonical integers."""
+    lg = world.bit_length() - 1
+    assert (1 << lg) == world and lg <= log_n
+    return log_n - lg, _fp_pow_int(gen_int, world, modulus), int(shift_int) * _fp_pow_int(gen_int, rank, modulus) % modulus
+
+
+def _mont(la, v):
+    return la.edwards_to_montgomery([v])[0]
+
+
+def sharded_mul_lde(lib, torch, la, d_coeffs, n_coeffs, log_n, gen_int, shift_int, rank, world):
+    """The rank's residue class of multiplicative_FFT(coeffs, coset(2^log_n, shift)): n_coeffs <= 2^log_n / world."""
+    lg_loc, g_loc, s_loc = local_coset(log_n, gen_int, shift_int, rank, world, la.EDWARDS_FR_MODULUS)
+    if n_coeffs > (1 << lg_loc):
+        raise ValueError("more coefficients than a residue class holds: this transform needs the exchange steps")
+    out = torch.empty((1 << lg_loc, 3), dtype=torch.int64, device=d_coeffs.device)
+    lib._check(lib.c.iopx_mul_fft_fp3_dev(d_coeffs.data_ptr(), n_coeffs, lg_loc, la._as_u64(_mont(la, g_loc)).ctypes.data_as(la._u64p),
+                                          la._as_u64(_mont(la, s_loc)).ctypes.data_as(la._u64p), out.data_ptr()))
+    return out
+
+
+def sharded_mul_fri_fold(lib, torch, la, d_f_local, log_n, gen_int, shift_int, coset_size, x_i, rank, world):
+    """multiplicative_evaluate_next_f_i_over_entire_domain on the rank's residue class of f_i (domain of order 2^log_n): returns
+    its residue class of f_{i+1}.  Needs 2^log_n / coset_size to be a multiple of world."""
+    if ((1 << log_n) // coset_size) % world:
+        raise ValueError("domain too small to stay residue-sharded: gather it first (gather_residues)")
+    lg_loc, g_loc, s_loc = local_coset(log_n, gen_int, shift_int, rank, world, la.EDWARDS_FR_MODULUS)
+    out = torch.empty((d_f_local.shape[0] // coset_size, 3), dtype=torch.int64, device=d_f_local.device)
+    x = np.ascontiguousarray(x_i, dtype=np.uint64)
+    lib._check(lib.c.iopx_fri_fold_mul_fp3_dev(d_f_local.data_ptr(), lg_loc, la._as_u64(_mont(la, g_loc)).ctypes.data_as(la._u64p),
+                                               la._as_u64(_mont(la, s_loc)).ctypes.data_as(la._u64p), coset_size,
+                                               x.ctypes.data_as(la._u64p), out.data_ptr()))
+    return out
+
+
+def sharded_mul_merkle_root(lib, torch, dist, la, d_oracles_local, n_local, coset_size, rank, world):
+    """Merkle root over residue-sharded multiplicative oracles (every rank passes its local arrays, n_local = n / world).
+    Returns (global root, node buffer of the rank's contiguous sub-tree: leaves [rank * L / N, (rank + 1) * L / N))."""
+    leaves_loc = n_local // coset_size                  # = L / N
+    dev = d_oracles_local[0].device
+    nodes = torch.empty((2 * leaves_loc - 1, 32), dtype=torch.uint8, device=dev)
+    # local leaf l' is global leaf rank + N l'
+    lib.merkle_leaves_dev([o.data_ptr() for o in d_oracles_local], 24, n_local, coset_size, nodes.data_ptr(),
+                          domain_type=la.DOMAIN_MULTIPLICATIVE)
+    lib.synchronize()
+    if world > 1:
+        if leaves_loc % world:
+            raise ValueError("fewer leaves per rank than ranks: gather the oracle first (gather_residues)")
+        mine = nodes[leaves_loc - 1:].contiguous()      # (L/N, 32): chunk q holds the leaves that fall into rank q's run
+        got = torch.empty_like(mine)
+        dist.all_to_all_single(got.view(-1), mine.view(-1))
+        # chunk s, entry u is global leaf rank * L/N + s + N u  ->  position s + N u of the run
+        run = got.reshape(world, leaves_loc // world, 32).permute(1, 0, 2).contiguous().reshape(leaves_loc, 32)
+        nodes[leaves_loc - 1:] = run
+        _torch_sync(torch, nodes)
+    lib.merkle_inner_dev(nodes.data_ptr(), leaves_loc)
+    lib.synchronize()
+    sub_root = nodes[0].clone()
+    if world == 1:
+        return bytes(sub_root.cpu().numpy()), nodes
+    gathered = [torch.empty_like(sub_root) for _ in range(world)]
+    dist.all_gather(gathered, sub_root)
+    level = [bytes(g.cpu().numpy()) for g in gathered]
+    while len(level) > 1:
+        level = [hashlib.blake2b(level[2 * i] + level[2 * i + 1], digest_size=32).digest() for i in range(len(level) // 2)]
+    return level[0], nodes
+
+
+def gather_residues(torch, dist, d_local, world):
+    """All residue classes -> the natural-order array on every rank (the tail of FRI, where a round has fewer cosets than
+    ranks, and the host boundary)."""
+    if world == 1:
+        return d_local
+    parts = [torch.empty_like(d_local) for _ in range(world)]
+    dist.all_gather(parts, d_local.contiguous())
+    return torch.stack(parts, dim=1).reshape(d_local.shape[0] * world, *d_local.shape[1:]).contiguous()

@@ -107,3 +107,62 @@ def test_distributed_full_size_fft(world):
     mp.spawn(_fft_worker, args=(world, port, ret), nprocs=world, join=True)
     for r in range(world):
         assert ret[r] == [True, True], (r, ret[r])
+
+
+def _mul_worker(rank, world, port, ret):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import libiop_amd as la
+        import oracle
+        from emu_lib import emu
+        from libiop_amd import dist as idist
+        lib = emu()
+        P = la.EDWARDS_FR_MODULUS
+        log_n, ncoef, cs = 9, 60, 2
+        n = 1 << log_n
+        shift_int = la.EDWARDS_FR_GENERATOR
+        gen_int = pow(la.EDWARDS_FR_GENERATOR, (P - 1) >> log_n, P)
+        shift_w = la.edwards_to_montgomery([shift_int])[0]
+        rng = np.random.default_rng(5)
+        cols = [la.edwards_to_montgomery([int.from_bytes(rng.bytes(32), "little") % P for _ in range(ncoef)]) for _ in range(2)]
+        full = [oracle.multiplicative_fft(c, n, shift_w) for c in cols]
+        # residue-sharded low-degree extension: the rank's positions are rank, rank + world, ...
+        mine = [idist.sharded_mul_lde(lib, torch, la, torch.from_numpy(c.view(np.int64).copy()), ncoef, log_n, gen_int, shift_int, rank, world) for c in cols]
+        ok_lde = all(np.array_equal(mine[k].numpy().view(np.uint64), full[k][rank::world]) for k in range(2))
+        # Merkle root over both oracles, cosets of 2 and of 4
+        ok_root = []
+        for c in (2, 4):
+            root, nodes = idist.sharded_mul_merkle_root(lib, torch, dist, la, mine, n // world, c, rank, world)
+            want = oracle.merkle_build(full, c, False)
+            L, per = n // c, n // c // world
+            ok_root.append(root == bytes(want[0]) and np.array_equal(nodes[per - 1:].numpy(), want[L - 1 + rank * per:L - 1 + (rank + 1) * per]))
+        # fold, then one more fold of the result (the residue sharding carries over to the next domain)
+        x = la.edwards_to_montgomery([int.from_bytes(rng.bytes(32), "little") % P])[0]
+        nxt = idist.sharded_mul_fri_fold(lib, torch, la, mine[0], log_n, gen_int, shift_int, 4, x, rank, world)
+        exp = oracle.fri_fold_multiplicative(full[0], shift_w, 4, x)
+        ok_fold = np.array_equal(nxt.numpy().view(np.uint64), exp[rank::world])
+        sh2, g2 = pow(shift_int, 4, P), pow(gen_int, 4, P)
+        nxt2 = idist.sharded_mul_fri_fold(lib, torch, la, nxt, log_n - 2, g2, sh2, 2, x, rank, world)
+        exp2 = oracle.fri_fold_multiplicative(exp, la.edwards_to_montgomery([sh2])[0], 2, x)
+        ok_fold2 = np.array_equal(nxt2.numpy().view(np.uint64), exp2[rank::world])
+        allv = idist.gather_residues(torch, dist, nxt2, world)
+        ok_gather = np.array_equal(allv.numpy().view(np.uint64), exp2)
+        ret[rank] = (ok_lde, ok_root, ok_fold, ok_fold2, ok_gather)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_residue_sharded_multiplicative_pipeline(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_mul_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret[r] == (True, [True, True], True, True, True), (r, ret[r])
