@@ -92,29 +92,7 @@ def cfg5(args, torch, dist, lib, dev, rank, world, la, fri, host):
     loc = host.localization_parameter_to_array(2, m, 3)
 
     def fri_commit():
-        hc = host.Blake2bHashchain()
-        f, logn, sh, gi, w, rk, roots = cws[1], m, shift_int, gen_int, world, rank, []
-        for eta in loc:
-            cs = 1 << eta
-            if w > 1 and (((1 << logn) // cs) % (w * w) or (1 << logn) // cs < w * w):
-                f = idist.gather_residues(torch, dist, f, w)        # too few cosets to stay sharded: every rank finishes the tail
-                idist._torch_sync(torch, f)
-                w, rk = 1, 0
-            r, _ = idist.sharded_mul_merkle_root(lib, torch, dist, la, [f], f.shape[0], cs, rk, w)
-            roots.append(r)
-            hc.absorb(r)
-            hc.absorb(None)
-            x = fri.squeeze_edwards_fr(hc)
-            f = idist.sharded_mul_fri_fold(lib, torch, la, f, logn, gi, sh, cs, x, rk, w)
-            logn, sh, gi = logn - eta, pow(sh, cs, P), pow(gi, cs, P)
-        if w > 1:
-            f = idist.gather_residues(torch, dist, f, w)
-            idist._torch_sync(torch, f)
-        coeffs = torch.empty_like(f)
-        lib._check(lib.c.iopx_mul_ifft_fp3_dev(f.data_ptr(), logn, la._as_u64(la.edwards_to_montgomery([gi])[0]).ctypes.data_as(la._u64p),
-                                               la._as_u64(la.edwards_to_montgomery([sh])[0]).ctypes.data_as(la._u64p), coeffs.data_ptr()))
-        lib.synchronize()
-        return roots
+        return idist.sharded_mul_fri_commit(lib, torch, dist, la, fri, cws[1], m, gen_int, shift_int, loc, 4, rank, world)[0]
 
     fri_commit()        # warm-up: twiddle caches of the round domains
     roots = timed("fri_commit(merkle+fold x%d, final ifft)" % len(loc), fri_commit)

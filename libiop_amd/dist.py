@@ -330,3 +330,76 @@ def gather_residues(torch, dist, d_local, world):
     parts = [torch.empty_like(d_local) for _ in range(world)]
     dist.all_gather(parts, d_local.contiguous())
     return torch.stack(parts, dim=1).reshape(d_local.shape[0] * world, *d_local.shape[1:]).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# FRI commit phase on sharded codewords (the round loop of libiop_amd/fri.py with the sharded primitives above).  Both return
+# (roots, final polynomial coefficients as a (k, 3) uint64 array) and are bit-identical to the single-process commit.
+# ---------------------------------------------------------------------------------------------------------------
+def sharded_fri_commit(lib, torch, dist, d_f_local, basis, shift, localization_parameters, final_degree_bound, rank, world,
+                       hashchain=None, domains=None):
+    """Additive domains: every rank holds its contiguous block of the codeword.  While a round has at least one coset per
+    rank the tree is built from N sub-trees and the fold is local; then the remainder is all-gathered and every rank finishes
+    it (identically)."""
+    hc = hashchain or host.Blake2bHashchain()
+    doms = domains or host.fri_additive_domains(basis, shift, localization_parameters)
+    f, w, rk, roots = d_f_local, world, rank, []
+    for i, eta in enumerate(localization_parameters):
+        b_i, s_i = doms[i]
+        cs = 1 << eta
+        if w > 1 and f.shape[0] // cs < 2:
+            lib.synchronize()
+            parts = [torch.empty_like(f) for _ in range(w)]
+            dist.all_gather(parts, f.contiguous())
+            f = torch.cat(parts, 0)
+            _torch_sync(torch, f)
+            w, rk = 1, 0
+        root, _ = sharded_merkle_root(lib, torch, dist, [f], f.shape[0], cs, rk, w)
+        roots.append(root)
+        hc.absorb(root)
+        hc.absorb(None)
+        x = hc.squeeze_gf192(1)[0]
+        f = sharded_fri_fold(lib, torch, f, b_i, s_i, cs, x, rk, w)
+    if w > 1:
+        lib.synchronize()
+        parts = [torch.empty_like(f) for _ in range(w)]
+        dist.all_gather(parts, f.contiguous())
+        f = torch.cat(parts, 0)
+        _torch_sync(torch, f)
+    b_l, s_l = doms[len(localization_parameters)]
+    coeffs = torch.empty_like(f)
+    lib.additive_IFFT_dev(f.data_ptr(), b_l, s_l, coeffs.data_ptr())
+    lib.synchronize()
+    return roots, coeffs.cpu().numpy().view(np.uint64)[:final_degree_bound].copy()
+
+
+def sharded_mul_fri_commit(lib, torch, dist, la, fri, d_f_local, log_n, gen_int, shift_int, localization_parameters,
+                           final_degree_bound, rank, world, hashchain=None):
+    """Multiplicative cosets: every rank holds its residue class.  A round stays sharded while it has at least N^2 cosets (fold
+    locality needs a multiple of N, the digest all-to-all a multiple of N per rank)."""
+    P = la.EDWARDS_FR_MODULUS
+    hc = hashchain or host.Blake2bHashchain()
+    f, logn, sh, gi, w, rk, roots = d_f_local, log_n, int(shift_int), int(gen_int), world, rank, []
+    for eta in localization_parameters:
+        cs = 1 << eta
+        if w > 1 and ((1 << logn) // cs) % (w * w):
+            lib.synchronize()
+            f = gather_residues(torch, dist, f, w)
+            _torch_sync(torch, f)
+            w, rk = 1, 0
+        root, _ = sharded_mul_merkle_root(lib, torch, dist, la, [f], f.shape[0], cs, rk, w)
+        roots.append(root)
+        hc.absorb(root)
+        hc.absorb(None)
+        x = fri.squeeze_edwards_fr(hc)
+        f = sharded_mul_fri_fold(lib, torch, la, f, logn, gi, sh, cs, x, rk, w)
+        logn, sh, gi = logn - eta, pow(sh, cs, P), pow(gi, cs, P)
+    if w > 1:
+        lib.synchronize()
+        f = gather_residues(torch, dist, f, w)
+        _torch_sync(torch, f)
+    coeffs = torch.empty_like(f)
+    lib._check(lib.c.iopx_mul_ifft_fp3_dev(f.data_ptr(), logn, la._as_u64(_mont(la, gi)).ctypes.data_as(la._u64p),
+                                           la._as_u64(_mont(la, sh)).ctypes.data_as(la._u64p), coeffs.data_ptr()))
+    lib.synchronize()
+    return roots, coeffs.cpu().numpy().view(np.uint64)[:final_degree_bound].copy()

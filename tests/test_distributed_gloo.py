@@ -166,3 +166,56 @@ def test_residue_sharded_multiplicative_pipeline(world):
     mp.spawn(_mul_worker, args=(world, port, ret), nprocs=world, join=True)
     for r in range(world):
         assert ret[r] == (True, [True, True], True, True, True), (r, ret[r])
+
+
+def _commit_worker(rank, world, port, ret):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fri_cases as fc
+        import libiop_amd as la
+        import oracle
+        from emu_lib import emu
+        from helpers import rand_elems
+        from libiop_amd import dist as idist, fri, host
+        lib = emu()
+        htorch, to_dev = fc.host_env()
+        # additive: contiguous blocks
+        m, rs = 10, 2
+        basis, shift = oracle.standard_basis(m, W), np.array([1 << m, 0, 0], dtype=np.uint64)
+        cw = oracle.additive_fft(rand_elems(3, 1 << (m - rs), W), basis, shift)
+        loc = host.localization_parameter_to_array(2, m, rs)
+        single = fri.fri_commit(lib, htorch, to_dev(cw), basis, shift, loc, 4)
+        lo, per = idist.shard_range(1 << m, rank, world)
+        roots, final = idist.sharded_fri_commit(lib, torch, dist, torch.from_numpy(cw[lo:lo + per].view(np.int64).copy()), basis, shift, loc, 4, rank, world)
+        ok_add = roots == single.roots and np.array_equal(final, single.final_polynomial)
+        # multiplicative: residue classes
+        P = la.EDWARDS_FR_MODULUS
+        log_n = 10
+        shift_int, gen_int = la.EDWARDS_FR_GENERATOR, pow(la.EDWARDS_FR_GENERATOR, (P - 1) >> log_n, P)
+        rng = np.random.default_rng(9)
+        coeffs = la.edwards_to_montgomery([int.from_bytes(rng.bytes(32), "little") % P for _ in range(1 << (log_n - rs))])
+        cwm = oracle.multiplicative_fft(coeffs, 1 << log_n, la.edwards_to_montgomery([shift_int])[0])
+        locm = host.localization_parameter_to_array(2, log_n, rs)
+        singlem = fri.fri_commit_multiplicative(lib, htorch, to_dev(cwm), log_n, shift_int, locm, 4)
+        rootsm, finalm = idist.sharded_mul_fri_commit(lib, torch, dist, la, fri, torch.from_numpy(cwm[rank::world].view(np.int64).copy()),
+                                                      log_n, gen_int, shift_int, locm, 4, rank, world)
+        ok_mul = rootsm == singlem.roots and np.array_equal(finalm, singlem.final_polynomial)
+        ret[rank] = (ok_add, ok_mul)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_fri_commit_equals_single_process(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_commit_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret[r] == (True, True), (r, ret[r])
