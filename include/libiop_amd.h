@@ -206,6 +206,18 @@ int iopx_ldt_combine_fp3_dev(const void *const *d_oracles, size_t num_oracles, c
                              const uint64_t *random_coefficients, size_t log_n, const uint64_t *gen, const uint64_t *shift,
                              uint64_t *d_out);
 
+/* ---- R1CS row check -------------------------------------------------------------------------------- */
+/* rowcheck_ABC_virtual_oracle::evaluated_contents (libiop/protocols/encoded/common/rowcheck.tcc:16-88):
+ * out[x] = Z_H(x)^-1 * (Az(x) * Bz(x) - Cz(x)) over the whole codeword domain, all buffers on the device.
+ *   gf192: the constraint domain H is span(basis[0 .. constraint_dim)) + constraint_shift (a prefix of the codeword basis, as
+ *          the reference assumes, :31-33)
+ *   fp3:   H is the coset constraint_shift * <gen^(2^log_n / 2^constraint_log_order)> of order 2^constraint_log_order
+ * Fails with IOPX_ERR_INVALID_ARGUMENT when the two domains intersect (Z_H vanishes on the codeword domain). */
+int iopx_rowcheck_gf192_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const uint64_t *d_Cz, const uint64_t *basis, size_t m,
+                            const uint64_t *shift, size_t constraint_dim, const uint64_t *constraint_shift, uint64_t *d_out);
+int iopx_rowcheck_fp3_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const uint64_t *d_Cz, size_t log_n, const uint64_t *gen,
+                          const uint64_t *shift, size_t constraint_log_order, const uint64_t *constraint_shift, uint64_t *d_out);
+
 /* ---- proof of work ------------------------------------------------------------------------------ */
 /* pow<FieldT, binary_hash_digest>::solve_pow (libiop/bcs/pow.tcc:67-103) with the BLAKE2b two-to-one hash: returns the
  * FIRST candidate in the reference's order (the challenge itself, then the challenge with its last 8-byte word set to

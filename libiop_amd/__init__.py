@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "iopx_merkle_blake2b_dev", "iopx_merkle_blake2b", "iopx_merkle_leaves_blake2b_dev", "iopx_merkle_inner_blake2b_dev",
     "iopx_bn128_to_montgomery_dev", "iopx_poseidon_permute_bn128_dev", "iopx_merkle_poseidon_bn128_dev", "iopx_merkle_poseidon_bn128",
     "iopx_pow_solve_blake2b", "iopx_pow_solve_poseidon_bn128", "iopx_ldt_combine_gf192_dev", "iopx_ldt_combine_fp3_dev",
-    "iopx_merkle_membership_proof_dev", "iopx_query_responses_dev",
+    "iopx_merkle_membership_proof_dev", "iopx_query_responses_dev", "iopx_rowcheck_gf192_dev", "iopx_rowcheck_fp3_dev",
     "iopx_gf192_mul_dev", "iopx_gf192_mul_uniform_dev", "iopx_profile_begin", "iopx_profile_report",
 ]
 
@@ -144,6 +144,8 @@ class Library:
         c.iopx_merkle_poseidon_bn128_dev.argtypes = [pp, ctypes.POINTER(_vp), _sz, _sz, _sz, ctypes.c_int, _vp, _vp]
         c.iopx_merkle_poseidon_bn128.argtypes = [pp, ctypes.POINTER(_vp), _sz, _sz, _sz, ctypes.c_int, _vp, _vp]
         c.iopx_pow_solve_blake2b.argtypes = [_vp, _sz, _vp]
+        c.iopx_rowcheck_gf192_dev.argtypes = [_vp, _vp, _vp, _u64p, _sz, _u64p, _sz, _u64p, _vp]
+        c.iopx_rowcheck_fp3_dev.argtypes = [_vp, _vp, _vp, _sz, _u64p, _u64p, _sz, _u64p, _vp]
         c.iopx_merkle_membership_proof_dev.argtypes = [_vp, _sz, ctypes.POINTER(_sz), _sz, _vp, _sz, ctypes.POINTER(_sz)]
         c.iopx_query_responses_dev.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _sz, ctypes.POINTER(_sz), _sz, _vp]
         c.iopx_ldt_combine_gf192_dev.argtypes = [ctypes.POINTER(_vp), _sz, ctypes.POINTER(_sz), _u64p, _u64p, _sz, _u64p, _vp]
@@ -388,6 +390,25 @@ class Library:
         out = np.zeros((len(positions), len(d_oracles), elem_bytes // 8), dtype=np.uint64)
         self._check(self.c.iopx_query_responses_dev(ptrs, len(d_oracles), int(elem_bytes), int(n), pos, len(positions), _vp(out.ctypes.data)))
         return out
+
+    # ---- R1CS row check (rowcheck.tcc:16-88) ----
+    def rowcheck_dev(self, d_az, d_bz, d_cz, basis, shift, constraint_dim, constraint_shift, d_out):
+        basis, shift, cs = _as_u64(basis), _as_u64(shift), _as_u64(constraint_shift)
+        self._check(self.c.iopx_rowcheck_gf192_dev(_vp(d_az), _vp(d_bz), _vp(d_cz), basis.ctypes.data_as(_u64p), basis.shape[0],
+                                                   shift.ctypes.data_as(_u64p), int(constraint_dim), cs.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def rowcheck_multiplicative_dev(self, d_az, d_bz, d_cz, log_n, gen, shift, constraint_log_order, constraint_shift, d_out):
+        gen, shift, cs = _as_u64(gen), _as_u64(shift), _as_u64(constraint_shift)
+        self._check(self.c.iopx_rowcheck_fp3_dev(_vp(d_az), _vp(d_bz), _vp(d_cz), int(log_n), gen.ctypes.data_as(_u64p),
+                                                 shift.ctypes.data_as(_u64p), int(constraint_log_order), cs.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def rowcheck(self, az, bz, cz, basis, shift, constraint_dim, constraint_shift):
+        """Host-array form of rowcheck_dev."""
+        return self._ldt_combine_host([az, bz, cz], lambda d, o: self.rowcheck_dev(d[0], d[1], d[2], basis, shift, constraint_dim, constraint_shift, o))
+
+    def rowcheck_multiplicative(self, az, bz, cz, log_n, gen, shift, constraint_log_order, constraint_shift):
+        return self._ldt_combine_host([az, bz, cz], lambda d, o: self.rowcheck_multiplicative_dev(d[0], d[1], d[2], log_n, gen, shift,
+                                                                                                 constraint_log_order, constraint_shift, o))
 
     # ---- LDT reducer (ldt_reducer_aux.tcc:39-131) ----
     def ldt_combine_dev(self, d_oracles, degrees, random_coefficients, basis, shift, d_out):

@@ -47,6 +47,14 @@ struct hfp3 {
         if (t[3] || geq_p(r.w)) sub_p(r.w);
         return r;
     }
+    hfp3 operator-(const hfp3 &b) const
+    {
+        hfp3 r;
+        u128 borrow = 0;
+        for (int i = 0; i < 3; ++i) { const u128 d = (u128)w[i] - b.w[i] - borrow; r.w[i] = (uint64_t)d; borrow = (d >> 64) & 1; }
+        if (borrow) { u128 carry = 0; for (int i = 0; i < 3; ++i) { const u128 t = (u128)r.w[i] + P[i] + carry; r.w[i] = (uint64_t)t; carry = t >> 64; } }
+        return r;
+    }
     hfp3 squared() const { return *this * *this; }
     static hfp3 one()           // R mod p, by doubling 1 192 times
     {

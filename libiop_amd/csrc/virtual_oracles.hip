@@ -1,0 +1,130 @@
+// Virtual-oracle evaluation over the whole codeword domain on gfx950: the R1CS row check.
+//
+// Replaces rowcheck_ABC_virtual_oracle::evaluated_contents (libiop/protocols/encoded/common/rowcheck.tcc:16-88):
+//     result[x] = Z_H(x)^-1 * (Az(x) * Bz(x) - Cz(x)),     H = the constraint domain.
+// Z_H is |H|-to-1 on the codeword domain L, so it takes |L| / |H| values (vanishing_polynomial::unique_evaluations_over_field_subset,
+// libiop/algebra/polynomials/vanishing_polynomial.tcc:77-95): the host evaluates and inverts those (32 of them at rate 1/32) and
+// the kernel looks the inverse up by coset —
+//   affine subspaces: H = span(basis[0..h)) + shift_H is a prefix of L's basis, cosets are contiguous blocks (position >> h);
+//   multiplicative cosets: Z_H(x) = x^|H| - shift_H^|H|, the coset of position p is p mod (|L| / |H|) (rowcheck.tcc:50-65).
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <vector>
+#include "gf192_dev.h"
+#include "gf192_host.h"
+#include "fp3_dev.h"
+#include "fp3_host.h"
+#include "runtime.h"
+
+namespace iopx {
+
+__global__ void __launch_bounds__(256) k_rowcheck_add(uint64_t *out, const uint64_t *az, const uint64_t *bz, const uint64_t *cz,
+                                                      const uint64_t *zinv, int h, size_t n)
+{
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        gf192 t = gf_mul(gf_load(az, j), gf_load(bz, j));
+        gf_add_to(t, gf_load(cz, j));                       // characteristic 2: a b - c = a b + c
+        gf_store(out, j, gf_mul(t, gf_load(zinv, j >> h)));
+    }
+}
+
+// The field products of this library are data x table (fp3_dev.h): the product of two DATA values comes out as a b 2^181, so
+// Cz is brought to the same scale (times the stored 1 = 2^192) and the inverse table carries the missing 2^11 twice.
+__global__ void __launch_bounds__(256) k_rowcheck_fp(uint64_t *out, const uint64_t *az, const uint64_t *bz, const uint64_t *cz,
+                                                     const uint64_t *zinv_scaled, const uint64_t *one_stored, size_t num_cosets, size_t n)
+{
+    const fp3 one = fp_load(one_stored, 0);
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        const fp3 ab = fp_mul(fp_load(az, j), fp_load(bz, j));
+        const fp3 c = fp_mul(fp_load(cz, j), one);
+        fp_store(out, j, fp_mul(fp_sub(ab, c), fp_load(zinv_scaled, j % num_cosets)));
+    }
+}
+
+static int vo_grid(size_t n)
+{
+    size_t g = (n + 255) / 256;
+    if (g > 16384) g = 16384;
+    return (int)(g ? g : 1);
+}
+
+} // namespace iopx
+
+using namespace iopx;
+
+extern "C" {
+
+int iopx_rowcheck_gf192_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const uint64_t *d_Cz, const uint64_t *basis, size_t m,
+                            const uint64_t *shift, size_t constraint_dim, const uint64_t *constraint_shift, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_Az || !d_Bz || !d_Cz || !d_out || (m > 0 && !basis) || !shift || !constraint_shift) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (constraint_dim > m || m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "the constraint domain must be a sub-domain of the codeword domain");
+    const size_t h = constraint_dim, cosets = (size_t)1 << (m - h);
+    // Z_H = prod_{v in H} (X - v): the subspace polynomial of span(basis[0..h)) built factor by factor, Z <- Z(X) (Z(X) + Z(b)),
+    // shifted by its value at shift_H (vanishing_polynomial.tcc:373-395)
+    std::vector<hgf192> lin(1, hgf192::one());             // lin[i] multiplies X^(2^i)
+    for (size_t k = 0; k < h; ++k) {
+        const hgf192 b = hgf192::from_words(basis + 3 * k);
+        hgf192 zb = hgf192::zero(), bp = b;
+        for (size_t i = 0; i < lin.size(); ++i) { zb += lin[i] * bp; bp = bp.squared(); }
+        std::vector<hgf192> nxt(lin.size() + 1, hgf192::zero());
+        for (size_t i = 0; i < lin.size(); ++i) { nxt[i + 1] += lin[i].squared(); nxt[i] += lin[i] * zb; }
+        lin.swap(nxt);
+    }
+    auto eval = [&](const hgf192 &x) { hgf192 r = hgf192::zero(), xp = x; for (size_t i = 0; i < lin.size(); ++i) { r += lin[i] * xp; xp = xp.squared(); } return r; };
+    const hgf192 z_shift = eval(hgf192::from_words(constraint_shift));
+    std::vector<uint64_t> zinv(3 * cosets);
+    for (size_t c = 0; c < cosets; ++c) {
+        hgf192 x = hgf192::from_words(shift);               // first element of the coset: index c << h (utils.tcc:8-30)
+        for (size_t k = h; k < m; ++k) if ((c >> (k - h)) & 1) x += hgf192::from_words(basis + 3 * k);
+        const hgf192 z = eval(x) + z_shift;
+        if (z.is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the codeword domain intersects the constraint domain");
+        const hgf192 zi = z.inverse();
+        memcpy(&zinv[3 * c], zi.w, 24);
+    }
+    TmpBuf dz;
+    if ((rc = dz.alloc(zinv.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(dz.p, zinv.data(), zinv.size() * 8)) != IOPX_OK) return rc;
+    const size_t n = (size_t)1 << m;
+    { ProfScope ps_("k_rowcheck_add"); hipLaunchKernelGGL(k_rowcheck_add, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_Az, d_Bz, d_Cz, (const uint64_t *)dz.u64(), (int)h, n); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+int iopx_rowcheck_fp3_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const uint64_t *d_Cz, size_t log_n, const uint64_t *gen,
+                          const uint64_t *shift, size_t constraint_log_order, const uint64_t *constraint_shift, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_Az || !d_Bz || !d_Cz || !d_out || !gen || !shift || !constraint_shift) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (constraint_log_order > log_n || log_n > 31) return fail(IOPX_ERR_INVALID_ARGUMENT, "the constraint domain must be a sub-domain of the codeword domain");
+    const size_t order_h = (size_t)1 << constraint_log_order, cosets = (size_t)1 << (log_n - constraint_log_order);
+    hfp3 g, s, hs;
+    memcpy(g.w, gen, 24); memcpy(s.w, shift, 24); memcpy(hs.w, constraint_shift, 24);
+    // Z_H(shift g^j) = (shift g^j)^|H| - shift_H^|H| for j < |L| / |H|
+    const hfp3 vp_shift = hs.pow(order_h), g_h = g.pow(order_h);
+    hfp3 cur = s.pow(order_h);
+    std::vector<uint64_t> zinv(3 * cosets);
+    for (size_t j = 0; j < cosets; ++j) {
+        const hfp3 z = cur - vp_shift;
+        if (z.is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the codeword domain intersects the constraint domain");
+        const hfp3 zi = z.inverse().table_form().table_form();
+        memcpy(&zinv[3 * j], zi.w, 24);
+        cur = cur * g_h;
+    }
+    const hfp3 one = hfp3::one();
+    TmpBuf dz, done;
+    if ((rc = dz.alloc(zinv.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = done.alloc(24)) != IOPX_OK) return rc;
+    if ((rc = upload(dz.p, zinv.data(), zinv.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(done.p, one.w, 24)) != IOPX_OK) return rc;
+    const size_t n = (size_t)1 << log_n;
+    { ProfScope ps_("k_rowcheck_fp"); hipLaunchKernelGGL(k_rowcheck_fp, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_Az, d_Bz, d_Cz, (const uint64_t *)dz.u64(),
+                                                        (const uint64_t *)done.u64(), cosets, n); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+} // extern "C"

@@ -561,3 +561,19 @@ def fp_pow(a, e):
     out = np.empty(3, dtype=np.uint64)
     lib().oracle_fp_pow(_p(_c(a)), ctypes.c_uint64(e), _p(out))
     return out
+
+
+# ---- R1CS row check (rowcheck.tcc:16-88) -------------------------------------------------------------------------------
+def rowcheck_additive(az, bz, cz, basis, shift, h, constraint_shift):
+    az, bz, cz, basis, shift, constraint_shift = _c(az), _c(bz), _c(cz), _c(basis), _c(shift), _c(constraint_shift)
+    m, w = basis.shape
+    out = np.empty_like(az)
+    lib().oracle_rowcheck_additive(w, _p(az), _p(bz), _p(cz), _p(basis), ctypes.c_size_t(m), _p(shift), ctypes.c_size_t(h), _p(constraint_shift), _p(out))
+    return out
+
+
+def rowcheck_fp(az, bz, cz, shift, order_h, constraint_shift):
+    az, bz, cz = _c(az), _c(bz), _c(cz)
+    out = np.empty_like(az)
+    lib().oracle_rowcheck_fp(_p(az), _p(bz), _p(cz), ctypes.c_size_t(az.shape[0]), _p(_c(shift)), ctypes.c_size_t(order_h), _p(_c(constraint_shift)), _p(out))
+    return out

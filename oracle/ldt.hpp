@@ -113,4 +113,40 @@ struct combined_LDT_virtual_oracle {
     }
 };
 
+// libiop/protocols/encoded/common/rowcheck.tcc:16-88 — rowcheck_ABC_virtual_oracle::evaluated_contents over an affine
+// subspace: Z_H^-1 (Az Bz - Cz), Z_H taken at its |L| / |H| unique evaluations (vanishing_polynomial.tcc:77-95), one per
+// contiguous coset of H = span(first h basis vectors) + constraint_shift
+template<typename F>
+std::vector<F> rowcheck_additive(const std::vector<F> &Az, const std::vector<F> &Bz, const std::vector<F> &Cz,
+                                 const affine_subspace<F> &codeword_domain, size_t h, const F &constraint_shift)
+{
+    const affine_subspace<F> H(std::vector<F>(codeword_domain.basis.begin(), codeword_domain.basis.begin() + h), constraint_shift);
+    const std::vector<F> Z = vanishing_polynomial_from_subspace<F>(H);
+    const size_t order_H = (size_t)1 << h, n = codeword_domain.num_elements(), num_cosets = n / order_H;
+    std::vector<F> z_unique;
+    for (size_t i = 0; i < num_cosets; ++i) z_unique.push_back(linearized_eval<F>(Z, codeword_domain.element_by_index(i * order_H)));
+    const std::vector<F> Z_inv = batch_inverse_and_mul<F>(z_unique, F::one());
+    std::vector<F> result;
+    for (size_t i = 0; i < num_cosets; ++i)                                             // :67-82
+        for (size_t pos = i * order_H; pos < (i + 1) * order_H; ++pos) result.push_back(Z_inv[i] * (Az[pos] * Bz[pos] - Cz[pos]));
+    return result;
+}
+
+// the multiplicative arm (:50-65): Z_H(x) = x^|H| - shift_H^|H|, position i * num_cosets + j lies in coset j
+template<typename F>
+std::vector<F> rowcheck_multiplicative(const std::vector<F> &Az, const std::vector<F> &Bz, const std::vector<F> &Cz,
+                                       const mult_coset<F> &codeword_domain, size_t order_H, const F &constraint_shift)
+{
+    const size_t n = codeword_domain.order, num_cosets = n / order_H;
+    const F vp_shift = constraint_shift.pow(order_H);
+    std::vector<F> z_unique;
+    F cur = codeword_domain.shift;
+    for (size_t j = 0; j < num_cosets; ++j) { z_unique.push_back(cur.pow(order_H) - vp_shift); cur *= codeword_domain.g; }
+    const std::vector<F> Z_inv = batch_inverse_and_mul<F>(z_unique, F::one());
+    std::vector<F> result;
+    for (size_t i = 0; i < order_H; ++i)
+        for (size_t j = 0; j < num_cosets; ++j) { const size_t pos = i * num_cosets + j; result.push_back(Z_inv[j] * (Az[pos] * Bz[pos] - Cz[pos])); }
+    return result;
+}
+
 } // namespace oracle

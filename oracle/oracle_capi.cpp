@@ -463,4 +463,22 @@ void oracle_fp_pow(const uint64_t *a, uint64_t e, uint64_t *out)
     memcpy(out, r.mont, 24);
 }
 
+// row check (rowcheck.tcc:16-88)
+int oracle_rowcheck_additive(int words, const uint64_t *az, const uint64_t *bz, const uint64_t *cz, const uint64_t *basis, size_t m,
+                             const uint64_t *shift, size_t h, const uint64_t *constraint_shift, uint64_t *out)
+{
+    DISPATCH(words, {
+        F cs; memcpy((void *)&cs, constraint_shift, sizeof(F));
+        const size_t n = (size_t)1 << m;
+        store<F>(out, rowcheck_additive<F>(load<F>(az, n), load<F>(bz, n), load<F>(cz, n), load_domain<F>(basis, m, shift), h, cs));
+    });
+    return 0;
+}
+void oracle_rowcheck_fp(const uint64_t *az, const uint64_t *bz, const uint64_t *cz, size_t order, const uint64_t *shift, size_t order_h,
+                        const uint64_t *constraint_shift, uint64_t *out)
+{
+    FP cs; memcpy(cs.mont, constraint_shift, 24);
+    store<FP>(out, rowcheck_multiplicative<FP>(load<FP>(az, order), load<FP>(bz, order), load<FP>(cz, order), load_coset(order, shift), order_h, cs));
+}
+
 } // extern "C"

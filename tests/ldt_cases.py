@@ -95,3 +95,47 @@ def check_additive_sampled(lib, m, degrees, seed, samples=256):
             sub += 1
         want ^= oracle.gf_mul(coef, evals[k][pos])
     assert np.array_equal(got[pos], want)
+
+
+# ---- R1CS row check (rowcheck.tcc:16-88) -------------------------------------------------------------------------------
+def check_rowcheck_additive(lib, m, h, seed, kind="aurora"):
+    n = 1 << m
+    if kind == "aurora":        # standard basis, codeword domain shifted off the constraint domain (aurora_iop.tcc:37-43)
+        basis, shift, cshift = oracle.standard_basis(m, W), np.array([1 << m, 0, 0], dtype=np.uint64), np.zeros(W, dtype=np.uint64)
+    else:
+        basis, shift, cshift = rand_elems(seed + 1, m, W), rand_elems(seed + 2, 1, W)[0], rand_elems(seed + 3, 1, W)[0]
+    az, bz, cz = rand_elems(seed + 4, n, W), rand_elems(seed + 5, n, W), rand_elems(seed + 6, n, W)
+    got = lib.rowcheck(az, bz, cz, basis, shift, h, cshift)
+    assert np.array_equal(got, oracle.rowcheck_additive(az, bz, cz, basis, shift, h, cshift))
+
+
+def check_rowcheck_is_a_polynomial_division(lib, m, h, seed):
+    """When Az Bz - Cz vanishes on H the result is the codeword of the quotient polynomial: interpolating it gives degree
+    < 2 deg - |H| (the identity the protocol rests on, r1cs_rs_iop.tcc:372-377)."""
+    n, dH = 1 << m, 1 << h
+    basis, shift, cshift = oracle.standard_basis(m, W), np.array([1 << m, 0, 0], dtype=np.uint64), np.zeros(W, dtype=np.uint64)
+    a_c, b_c = rand_elems(seed, dH, W), rand_elems(seed + 1, dH, W)
+    hb = basis[:h]
+    a_on_h, b_on_h = oracle.additive_fft(a_c, hb, cshift), oracle.additive_fft(b_c, hb, cshift)
+    c_c = oracle.additive_ifft(oracle.gf_mul(a_on_h, b_on_h), hb, cshift)       # C = A B on H, degree < |H|
+    az, bz, cz = (oracle.additive_fft(v, basis, shift) for v in (a_c, b_c, c_c))
+    q = lib.rowcheck(az, bz, cz, basis, shift, h, cshift)
+    coeffs = oracle.additive_ifft(q, basis, shift)
+    assert not coeffs[dH - 1:].any()            # deg(A B - C) <= 2 |H| - 2, so the quotient has degree <= |H| - 2
+
+
+def check_rowcheck_multiplicative(lib, log_n, log_h, seed):
+    n = 1 << log_n
+    gen = libiop_amd.edwards_subgroup_generator(log_n)
+    shift = libiop_amd.edwards_to_montgomery([libiop_amd.EDWARDS_FR_GENERATOR])[0]
+    cshift = libiop_amd.edwards_to_montgomery([1])[0]
+    az, bz, cz = _rand_fp(seed, n), _rand_fp(seed + 1, n), _rand_fp(seed + 2, n)
+    got = lib.rowcheck_multiplicative(az, bz, cz, log_n, gen, shift, log_h, cshift)
+    assert np.array_equal(got, oracle.rowcheck_fp(az, bz, cz, shift, 1 << log_h, cshift))
+
+
+def check_rowcheck_errors(lib):
+    basis, zero = oracle.standard_basis(4, W), np.zeros(W, dtype=np.uint64)
+    v = rand_elems(1, 16, W)
+    with pytest.raises(ValueError):         # L = H-aligned and unshifted: Z_H vanishes on the codeword domain
+        lib.rowcheck(v, v, v, basis, zero, 2, zero)

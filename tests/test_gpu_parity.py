@@ -377,3 +377,22 @@ def test_fri_prove_and_verify_multiplicative(gpu, log_n, rs_extra, loc_param, qu
     gpu.set_stream(torch.cuda.current_stream().cuda_stream)
     to_device = lambda arr: torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).to(dev)
     assert fc.prove_and_verify_multiplicative(gpu, torch, to_device, log_n, rs_extra, loc_param, queries, pow_bits, 7)
+
+
+# ---- R1CS row check (rowcheck.tcc:16-88) -------------------------------------------------------------------------
+@pytest.mark.parametrize("m,h,seed,kind", [(5, 2, 1, "aurora"), (8, 3, 2, "general"), (7, 7, 3, "aurora"), (6, 0, 4, "general"), (16, 11, 5, "aurora")])
+def test_rowcheck_additive(gpu, m, h, seed, kind):
+    lc.check_rowcheck_additive(gpu, m, h, seed, kind)
+
+
+def test_rowcheck_is_a_polynomial_division(gpu):
+    lc.check_rowcheck_is_a_polynomial_division(gpu, 14, 9, 3)
+
+
+@pytest.mark.parametrize("log_n,log_h,seed", [(5, 2, 1), (8, 4, 2), (6, 6, 3), (7, 0, 4), (15, 10, 5)])
+def test_rowcheck_multiplicative(gpu, log_n, log_h, seed):
+    lc.check_rowcheck_multiplicative(gpu, log_n, log_h, seed)
+
+
+def test_rowcheck_errors(gpu):
+    lc.check_rowcheck_errors(gpu)

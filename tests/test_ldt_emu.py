@@ -67,3 +67,21 @@ def test_oracle_combination_is_the_stated_polynomial_identity():
         xp = oracle.subspace_element_powers(basis, shift, 9 - degrees[k])
         want ^= oracle.gf_mul(oracle.gf_mul(np.repeat(c[4 + i:5 + i], 1 << m, axis=0), xp), evals[k])
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("m,h,seed,kind", [(5, 2, 1, "aurora"), (8, 3, 2, "general"), (7, 7, 3, "aurora"), (6, 0, 4, "general")])
+def test_rowcheck_additive(m, h, seed, kind):
+    lc.check_rowcheck_additive(emu(), m, h, seed, kind)
+
+
+def test_rowcheck_is_a_polynomial_division():
+    lc.check_rowcheck_is_a_polynomial_division(emu(), 8, 5, 3)
+
+
+@pytest.mark.parametrize("log_n,log_h,seed", [(5, 2, 1), (8, 4, 2), (6, 6, 3), (7, 0, 4)])
+def test_rowcheck_multiplicative(log_n, log_h, seed):
+    lc.check_rowcheck_multiplicative(emu(), log_n, log_h, seed)
+
+
+def test_rowcheck_errors():
+    lc.check_rowcheck_errors(emu())
