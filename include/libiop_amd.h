@@ -218,6 +218,15 @@ int iopx_rowcheck_gf192_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const ui
 int iopx_rowcheck_fp3_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const uint64_t *d_Cz, size_t log_n, const uint64_t *gen,
                           const uint64_t *shift, size_t constraint_log_order, const uint64_t *constraint_shift, uint64_t *d_out);
 
+/* fz_virtual_oracle::evaluated_contents (libiop/protocols/encoded/r1cs_rs_iop/r1cs_rs_iop.tcc:181-222):
+ * out[x] = fw(x) * Z_I(x) + f_1v(x), I = the input variable domain (gf192: span(input_basis) + input_shift; fp3: the coset
+ * input_shift * <order 2^input_log_order subgroup>), f_1v already extended to the codeword domain (:207-212 are two ordinary
+ * transforms: iopx_add_ifft_gf192 on |I| points, iopx_add_fft_gf192_dev onto the codeword domain). */
+int iopx_fz_gf192_dev(const uint64_t *d_fw, const uint64_t *d_f1v, const uint64_t *basis, size_t m, const uint64_t *shift,
+                      const uint64_t *input_basis, size_t input_dim, const uint64_t *input_shift, uint64_t *d_out);
+int iopx_fz_fp3_dev(const uint64_t *d_fw, const uint64_t *d_f1v, size_t log_n, const uint64_t *gen, const uint64_t *shift,
+                    size_t input_log_order, const uint64_t *input_shift, uint64_t *d_out);
+
 /* ---- proof of work ------------------------------------------------------------------------------ */
 /* pow<FieldT, binary_hash_digest>::solve_pow (libiop/bcs/pow.tcc:67-103) with the BLAKE2b two-to-one hash: returns the
  * FIRST candidate in the reference's order (the challenge itself, then the challenge with its last 8-byte word set to

@@ -42,6 +42,7 @@ EXPORTED_SYMBOLS = [
     "iopx_bn128_to_montgomery_dev", "iopx_poseidon_permute_bn128_dev", "iopx_merkle_poseidon_bn128_dev", "iopx_merkle_poseidon_bn128",
     "iopx_pow_solve_blake2b", "iopx_pow_solve_poseidon_bn128", "iopx_ldt_combine_gf192_dev", "iopx_ldt_combine_fp3_dev",
     "iopx_merkle_membership_proof_dev", "iopx_query_responses_dev", "iopx_rowcheck_gf192_dev", "iopx_rowcheck_fp3_dev",
+    "iopx_fz_gf192_dev", "iopx_fz_fp3_dev",
     "iopx_gf192_mul_dev", "iopx_gf192_mul_uniform_dev", "iopx_profile_begin", "iopx_profile_report",
 ]
 
@@ -146,6 +147,8 @@ class Library:
         c.iopx_pow_solve_blake2b.argtypes = [_vp, _sz, _vp]
         c.iopx_rowcheck_gf192_dev.argtypes = [_vp, _vp, _vp, _u64p, _sz, _u64p, _sz, _u64p, _vp]
         c.iopx_rowcheck_fp3_dev.argtypes = [_vp, _vp, _vp, _sz, _u64p, _u64p, _sz, _u64p, _vp]
+        c.iopx_fz_gf192_dev.argtypes = [_vp, _vp, _u64p, _sz, _u64p, _u64p, _sz, _u64p, _vp]
+        c.iopx_fz_fp3_dev.argtypes = [_vp, _vp, _sz, _u64p, _u64p, _sz, _u64p, _vp]
         c.iopx_merkle_membership_proof_dev.argtypes = [_vp, _sz, ctypes.POINTER(_sz), _sz, _vp, _sz, ctypes.POINTER(_sz)]
         c.iopx_query_responses_dev.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _sz, ctypes.POINTER(_sz), _sz, _vp]
         c.iopx_ldt_combine_gf192_dev.argtypes = [ctypes.POINTER(_vp), _sz, ctypes.POINTER(_sz), _u64p, _u64p, _sz, _u64p, _vp]
@@ -409,6 +412,24 @@ class Library:
     def rowcheck_multiplicative(self, az, bz, cz, log_n, gen, shift, constraint_log_order, constraint_shift):
         return self._ldt_combine_host([az, bz, cz], lambda d, o: self.rowcheck_multiplicative_dev(d[0], d[1], d[2], log_n, gen, shift,
                                                                                                  constraint_log_order, constraint_shift, o))
+
+    # ---- fz virtual oracle (r1cs_rs_iop.tcc:181-222) ----
+    def fz_dev(self, d_fw, d_f1v, basis, shift, input_basis, input_shift, d_out):
+        basis, shift, ish = _as_u64(basis), _as_u64(shift), _as_u64(input_shift)
+        ib = np.ascontiguousarray(input_basis, dtype=np.uint64).reshape(-1, 3)
+        self._check(self.c.iopx_fz_gf192_dev(_vp(d_fw), _vp(d_f1v), basis.ctypes.data_as(_u64p), basis.shape[0], shift.ctypes.data_as(_u64p),
+                                             ib.ctypes.data_as(_u64p), ib.shape[0], ish.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def fz_multiplicative_dev(self, d_fw, d_f1v, log_n, gen, shift, input_log_order, input_shift, d_out):
+        gen, shift, ish = _as_u64(gen), _as_u64(shift), _as_u64(input_shift)
+        self._check(self.c.iopx_fz_fp3_dev(_vp(d_fw), _vp(d_f1v), int(log_n), gen.ctypes.data_as(_u64p), shift.ctypes.data_as(_u64p),
+                                           int(input_log_order), ish.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def fz(self, fw, f1v, basis, shift, input_basis, input_shift):
+        return self._ldt_combine_host([fw, f1v], lambda d, o: self.fz_dev(d[0], d[1], basis, shift, input_basis, input_shift, o))
+
+    def fz_multiplicative(self, fw, f1v, log_n, gen, shift, input_log_order, input_shift):
+        return self._ldt_combine_host([fw, f1v], lambda d, o: self.fz_multiplicative_dev(d[0], d[1], log_n, gen, shift, input_log_order, input_shift, o))
 
     # ---- LDT reducer (ldt_reducer_aux.tcc:39-131) ----
     def ldt_combine_dev(self, d_oracles, degrees, random_coefficients, basis, shift, d_out):

@@ -1,4 +1,4 @@
-// Virtual-oracle evaluation over the whole codeword domain on gfx950: the R1CS row check.
+// Virtual-oracle evaluation over the whole codeword domain on gfx950: the R1CS row check and the fz oracle.
 //
 // Replaces rowcheck_ABC_virtual_oracle::evaluated_contents (libiop/protocols/encoded/common/rowcheck.tcc:16-88):
 //     result[x] = Z_H(x)^-1 * (Az(x) * Bz(x) - Cz(x)),     H = the constraint domain.
@@ -38,6 +38,45 @@ __global__ void __launch_bounds__(256) k_rowcheck_fp(uint64_t *out, const uint64
         const fp3 ab = fp_mul(fp_load(az, j), fp_load(bz, j));
         const fp3 c = fp_mul(fp_load(cz, j), one);
         fp_store(out, j, fp_mul(fp_sub(ab, c), fp_load(zinv_scaled, j % num_cosets)));
+    }
+}
+
+// fz_virtual_oracle::evaluated_contents (libiop/protocols/encoded/r1cs_rs_iop/r1cs_rs_iop.tcc:181-222):
+//     result[x] = fw(x) * Z_I(x) + f_1v(x),      I = the input variable domain, f_1v already extended to the codeword domain.
+// Z_I is an affine linearized polynomial, so Z_I(x_j) = Z_I(shift) + sum_{bit k of j} Z_lin(basis[k])
+// (vanishing_polynomial::evaluations_over_subspace -> linearized_polynomial.tcc:83-108): an (m + 1)-entry table; index bits
+// 0-7 differ across a workgroup's lanes, the rest are uniform.
+__global__ void __launch_bounds__(256) k_fz_add(uint64_t *out, const uint64_t *fw, const uint64_t *f1v, const uint64_t *tab, int m, size_t n)
+{
+    for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+        const uint32_t jhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 8));
+        const size_t end = base + 256 < n ? base + 256 : n;
+        for (size_t j = base + threadIdx.x; j < end; j += blockDim.x) {
+            gf192 z = gf_load(tab, 0);
+            const uint32_t jlo = (uint32_t)(j & 255);
+            const int lo_bits = m < 8 ? m : 8;
+            for (int k = 0; k < lo_bits; ++k) {
+                const uint32_t mask = 0u - ((jlo >> k) & 1u);
+                const gf192 b = gf_load(tab, 1 + k);
+#pragma unroll
+                for (int w = 0; w < 6; ++w) z.w[w] = xor_and(z.w[w], mask, b.w[w]);
+            }
+            for (int k = 8; k < m; ++k) if ((jhi >> (k - 8)) & 1u) gf_add_to(z, gf_load(tab, 1 + k));
+            gf192 r = gf_mul(gf_load(fw, j), z);
+            gf_add_to(r, gf_load(f1v, j));
+            gf_store(out, j, r);
+        }
+    }
+}
+
+// multiplicative arm: Z_I(shift g^j) = (shift g^j)^|I| - shift_I^|I|, the power from a two-level table (table form)
+__global__ void __launch_bounds__(256) k_fz_fp(uint64_t *out, const uint64_t *fw, const uint64_t *f1v, const uint64_t *hi, const uint64_t *lo,
+                                               const uint64_t *vp_shift_t, size_t n)
+{
+    const fp3 c = fp_load(vp_shift_t, 0);
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        const fp3 z = fp_sub(fp_mul(fp_load(hi, j >> 12), fp_load(lo, j & 4095)), c);       // table form of Z_I(x_j)
+        fp_store(out, j, fp_add(fp_mul(fp_load(fw, j), z), fp_load(f1v, j)));
     }
 }
 
@@ -123,6 +162,59 @@ int iopx_rowcheck_fp3_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const uint
     const size_t n = (size_t)1 << log_n;
     { ProfScope ps_("k_rowcheck_fp"); hipLaunchKernelGGL(k_rowcheck_fp, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_Az, d_Bz, d_Cz, (const uint64_t *)dz.u64(),
                                                         (const uint64_t *)done.u64(), cosets, n); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+int iopx_fz_gf192_dev(const uint64_t *d_fw, const uint64_t *d_f1v, const uint64_t *basis, size_t m, const uint64_t *shift,
+                      const uint64_t *input_basis, size_t input_dim, const uint64_t *input_shift, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_fw || !d_f1v || !d_out || (m > 0 && !basis) || !shift || (input_dim > 0 && !input_basis) || !input_shift)
+        return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (input_dim > m || m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "Codeword domain must be bigger than the input variable domain.");
+    std::vector<hgf192> lin(1, hgf192::one());             // Z_I's linear part: lin[i] multiplies X^(2^i)
+    for (size_t k = 0; k < input_dim; ++k) {
+        const hgf192 b = hgf192::from_words(input_basis + 3 * k);
+        hgf192 zb = hgf192::zero(), bp = b;
+        for (size_t i = 0; i < lin.size(); ++i) { zb += lin[i] * bp; bp = bp.squared(); }
+        std::vector<hgf192> nxt(lin.size() + 1, hgf192::zero());
+        for (size_t i = 0; i < lin.size(); ++i) { nxt[i + 1] += lin[i].squared(); nxt[i] += lin[i] * zb; }
+        lin.swap(nxt);
+    }
+    auto eval = [&](const hgf192 &x) { hgf192 r = hgf192::zero(), xp = x; for (size_t i = 0; i < lin.size(); ++i) { r += lin[i] * xp; xp = xp.squared(); } return r; };
+    std::vector<uint64_t> tab(3 * (m + 1));
+    const hgf192 t0 = eval(hgf192::from_words(shift)) + eval(hgf192::from_words(input_shift));      // Z_I(shift) = lin(shift) + lin(shift_I)
+    memcpy(&tab[0], t0.w, 24);
+    for (size_t k = 0; k < m; ++k) { const hgf192 t = eval(hgf192::from_words(basis + 3 * k)); memcpy(&tab[3 * (k + 1)], t.w, 24); }
+    TmpBuf dt;
+    if ((rc = dt.alloc(tab.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(dt.p, tab.data(), tab.size() * 8)) != IOPX_OK) return rc;
+    const size_t n = (size_t)1 << m;
+    { ProfScope ps_("k_fz_add"); hipLaunchKernelGGL(k_fz_add, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_fw, d_f1v, (const uint64_t *)dt.u64(), (int)m, n); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+int iopx_fz_fp3_dev(const uint64_t *d_fw, const uint64_t *d_f1v, size_t log_n, const uint64_t *gen, const uint64_t *shift,
+                    size_t input_log_order, const uint64_t *input_shift, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_fw || !d_f1v || !d_out || !gen || !shift || !input_shift) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (input_log_order > log_n || log_n > 31) return fail(IOPX_ERR_INVALID_ARGUMENT, "Codeword domain must be bigger than the input variable domain.");
+    hfp3 g, s, is;
+    memcpy(g.w, gen, 24); memcpy(s.w, shift, 24); memcpy(is.w, input_shift, 24);
+    const uint64_t order_i = (uint64_t)1 << input_log_order;
+    TmpBuf hi, lo, dc;
+    if ((rc = build_two_level(g.pow(order_i), s.pow(order_i), (int)log_n, hi, lo)) != IOPX_OK) return rc;
+    const hfp3 c = is.pow(order_i).table_form();
+    if ((rc = dc.alloc(24)) != IOPX_OK) return rc;
+    if ((rc = upload(dc.p, c.w, 24)) != IOPX_OK) return rc;
+    const size_t n = (size_t)1 << log_n;
+    { ProfScope ps_("k_fz_fp"); hipLaunchKernelGGL(k_fz_fp, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_fw, d_f1v, (const uint64_t *)hi.u64(),
+                                                  (const uint64_t *)lo.u64(), (const uint64_t *)dc.u64(), n); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
 }

@@ -577,3 +577,18 @@ def rowcheck_fp(az, bz, cz, shift, order_h, constraint_shift):
     out = np.empty_like(az)
     lib().oracle_rowcheck_fp(_p(az), _p(bz), _p(cz), ctypes.c_size_t(az.shape[0]), _p(_c(shift)), ctypes.c_size_t(order_h), _p(_c(constraint_shift)), _p(out))
     return out
+
+
+def fz_additive(fw, f1v, basis, shift, input_basis, input_shift):
+    fw, f1v, basis, shift, ib, ish = _c(fw), _c(f1v), _c(basis), _c(shift), _c(input_basis).reshape(-1, _c(basis).shape[1]), _c(input_shift)
+    m, w = basis.shape
+    out = np.empty_like(fw)
+    lib().oracle_fz_additive(w, _p(fw), _p(f1v), _p(basis), ctypes.c_size_t(m), _p(shift), _p(ib), ctypes.c_size_t(ib.shape[0]), _p(ish), _p(out))
+    return out
+
+
+def fz_fp(fw, f1v, shift, input_order, input_shift):
+    fw, f1v = _c(fw), _c(f1v)
+    out = np.empty_like(fw)
+    lib().oracle_fz_fp(_p(fw), _p(f1v), ctypes.c_size_t(fw.shape[0]), _p(_c(shift)), ctypes.c_size_t(input_order), _p(_c(input_shift)), _p(out))
+    return out

@@ -149,4 +149,28 @@ std::vector<F> rowcheck_multiplicative(const std::vector<F> &Az, const std::vect
     return result;
 }
 
+// libiop/protocols/encoded/r1cs_rs_iop/r1cs_rs_iop.tcc:181-222 — fz_virtual_oracle::evaluated_contents given f_1v already
+// evaluated over the codeword domain (the reference gets it with IFFT_over_field_subset / FFT_over_field_subset, :207-212)
+template<typename F>
+std::vector<F> fz_additive(const std::vector<F> &fw, const std::vector<F> &f1v, const affine_subspace<F> &codeword_domain,
+                           const affine_subspace<F> &input_domain)
+{
+    const std::vector<F> Z = vanishing_polynomial_from_subspace<F>(input_domain);
+    const std::vector<F> pts = codeword_domain.all_elements();
+    std::vector<F> result;
+    for (size_t i = 0; i < pts.size(); ++i) result.push_back(fw[i] * linearized_eval<F>(Z, pts[i]) + f1v[i]);     // :216-220
+    return result;
+}
+
+template<typename F>
+std::vector<F> fz_multiplicative(const std::vector<F> &fw, const std::vector<F> &f1v, const mult_coset<F> &codeword_domain,
+                                 size_t input_order, const F &input_shift)
+{
+    const F vp_shift = input_shift.pow(input_order);
+    const std::vector<F> pts = codeword_domain.all_elements();
+    std::vector<F> result;
+    for (size_t i = 0; i < pts.size(); ++i) result.push_back(fw[i] * (pts[i].pow(input_order) - vp_shift) + f1v[i]);
+    return result;
+}
+
 } // namespace oracle

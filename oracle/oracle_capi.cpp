@@ -481,4 +481,20 @@ void oracle_rowcheck_fp(const uint64_t *az, const uint64_t *bz, const uint64_t *
     store<FP>(out, rowcheck_multiplicative<FP>(load<FP>(az, order), load<FP>(bz, order), load<FP>(cz, order), load_coset(order, shift), order_h, cs));
 }
 
+// fz virtual oracle (r1cs_rs_iop.tcc:181-222)
+int oracle_fz_additive(int words, const uint64_t *fw, const uint64_t *f1v, const uint64_t *basis, size_t m, const uint64_t *shift,
+                       const uint64_t *ibasis, size_t idim, const uint64_t *ishift, uint64_t *out)
+{
+    DISPATCH(words, {
+        const size_t n = (size_t)1 << m;
+        store<F>(out, fz_additive<F>(load<F>(fw, n), load<F>(f1v, n), load_domain<F>(basis, m, shift), load_domain<F>(ibasis, idim, ishift)));
+    });
+    return 0;
+}
+void oracle_fz_fp(const uint64_t *fw, const uint64_t *f1v, size_t order, const uint64_t *shift, size_t input_order, const uint64_t *input_shift, uint64_t *out)
+{
+    FP is; memcpy(is.mont, input_shift, 24);
+    store<FP>(out, fz_multiplicative<FP>(load<FP>(fw, order), load<FP>(f1v, order), load_coset(order, shift), input_order, is));
+}
+
 } // extern "C"

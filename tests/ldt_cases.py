@@ -139,3 +139,27 @@ def check_rowcheck_errors(lib):
     v = rand_elems(1, 16, W)
     with pytest.raises(ValueError):         # L = H-aligned and unshifted: Z_H vanishes on the codeword domain
         lib.rowcheck(v, v, v, basis, zero, 2, zero)
+
+
+# ---- fz virtual oracle (r1cs_rs_iop.tcc:181-222) -----------------------------------------------------------------------
+def check_fz_additive(lib, m, idim, seed, kind="aurora"):
+    n = 1 << m
+    if kind == "aurora":
+        basis, shift = oracle.standard_basis(m, W), np.array([1 << m, 0, 0], dtype=np.uint64)
+        ib, ish = oracle.standard_basis(idim, W) if idim else np.zeros((0, W), dtype=np.uint64), np.zeros(W, dtype=np.uint64)
+    else:
+        basis, shift = rand_elems(seed + 1, m, W), rand_elems(seed + 2, 1, W)[0]
+        ib, ish = rand_elems(seed + 3, max(idim, 1), W)[:idim], rand_elems(seed + 4, 1, W)[0]
+    fw, f1v = rand_elems(seed + 5, n, W), rand_elems(seed + 6, n, W)
+    got = lib.fz(fw, f1v, basis, shift, ib, ish)
+    assert np.array_equal(got, oracle.fz_additive(fw, f1v, basis, shift, ib, ish))
+
+
+def check_fz_multiplicative(lib, log_n, ilog, seed):
+    n = 1 << log_n
+    gen = libiop_amd.edwards_subgroup_generator(log_n)
+    shift = libiop_amd.edwards_to_montgomery([libiop_amd.EDWARDS_FR_GENERATOR])[0]
+    ish = libiop_amd.edwards_to_montgomery([1])[0]
+    fw, f1v = _rand_fp(seed, n), _rand_fp(seed + 1, n)
+    got = lib.fz_multiplicative(fw, f1v, log_n, gen, shift, ilog, ish)
+    assert np.array_equal(got, oracle.fz_fp(fw, f1v, shift, 1 << ilog, ish))

@@ -396,3 +396,14 @@ def test_rowcheck_multiplicative(gpu, log_n, log_h, seed):
 
 def test_rowcheck_errors(gpu):
     lc.check_rowcheck_errors(gpu)
+
+
+# ---- fz virtual oracle (r1cs_rs_iop.tcc:181-222) ---------------------------------------------------------------------
+@pytest.mark.parametrize("m,idim,seed,kind", [(5, 2, 1, "aurora"), (9, 4, 2, "general"), (7, 0, 3, "general"), (16, 5, 4, "aurora")])
+def test_fz_additive(gpu, m, idim, seed, kind):
+    lc.check_fz_additive(gpu, m, idim, seed, kind)
+
+
+@pytest.mark.parametrize("log_n,ilog,seed", [(5, 2, 1), (9, 4, 2), (14, 3, 3), (6, 0, 4)])
+def test_fz_multiplicative(gpu, log_n, ilog, seed):
+    lc.check_fz_multiplicative(gpu, log_n, ilog, seed)

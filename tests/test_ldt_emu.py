@@ -85,3 +85,13 @@ def test_rowcheck_multiplicative(log_n, log_h, seed):
 
 def test_rowcheck_errors():
     lc.check_rowcheck_errors(emu())
+
+
+@pytest.mark.parametrize("m,idim,seed,kind", [(5, 2, 1, "aurora"), (9, 4, 2, "general"), (7, 0, 3, "general"), (10, 5, 4, "aurora")])
+def test_fz_additive(m, idim, seed, kind):
+    lc.check_fz_additive(emu(), m, idim, seed, kind)
+
+
+@pytest.mark.parametrize("log_n,ilog,seed", [(5, 2, 1), (9, 4, 2), (13, 3, 3), (6, 0, 4)])
+def test_fz_multiplicative(log_n, ilog, seed):
+    lc.check_fz_multiplicative(emu(), log_n, ilog, seed)
