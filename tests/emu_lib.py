@@ -13,6 +13,10 @@ _emu = None
 def emu():
     global _emu
     if _emu is None:
-        subprocess.check_call(["make", "-s", "-C", _EMU_DIR])
-        _emu = libiop_amd.Library(os.path.join(_EMU_DIR, "libiopx_emu.so"))
+        override = os.environ.get("IOPX_EMU_LIB")       # e.g. an AddressSanitizer build of the same sources (CPU only)
+        if override:
+            _emu = libiop_amd.Library(override)
+        else:
+            subprocess.check_call(["make", "-s", "-C", _EMU_DIR])
+            _emu = libiop_amd.Library(os.path.join(_EMU_DIR, "libiopx_emu.so"))
     return _emu
