@@ -227,6 +227,17 @@ int iopx_fz_gf192_dev(const uint64_t *d_fw, const uint64_t *d_f1v, const uint64_
 int iopx_fz_fp3_dev(const uint64_t *d_fw, const uint64_t *d_f1v, size_t log_n, const uint64_t *gen, const uint64_t *shift,
                     size_t input_log_order, const uint64_t *input_shift, uint64_t *d_out);
 
+/* sumcheck_g_oracle::evaluated_contents (libiop/protocols/encoded/sumcheck/sumcheck.tcc:58-119; sumcheck_aux.tcc:3-32), H = the
+ * summation domain, mu = claimed_sum:
+ *   gf192: out[x] = f(x) - eps^-1 mu x^(|H| - 1) - Z_H(x) h(x), eps = the linear coefficient of Z_H (a zero domain element
+ *          contributes 0 to the middle term, as the reference's batch inversion does)
+ *   fp3:   out[x] = (f(x) - |H|^-1 mu - Z_H(x) h(x)) / x */
+int iopx_sumcheck_g_gf192_dev(const uint64_t *d_f, const uint64_t *d_h, const uint64_t *basis, size_t m, const uint64_t *shift,
+                              const uint64_t *summation_basis, size_t summation_dim, const uint64_t *summation_shift,
+                              const uint64_t *claimed_sum, uint64_t *d_out);
+int iopx_sumcheck_g_fp3_dev(const uint64_t *d_f, const uint64_t *d_h, size_t log_n, const uint64_t *gen, const uint64_t *shift,
+                            size_t summation_log_order, const uint64_t *summation_shift, const uint64_t *claimed_sum, uint64_t *d_out);
+
 /* ---- proof of work ------------------------------------------------------------------------------ */
 /* pow<FieldT, binary_hash_digest>::solve_pow (libiop/bcs/pow.tcc:67-103) with the BLAKE2b two-to-one hash: returns the
  * FIRST candidate in the reference's order (the challenge itself, then the challenge with its last 8-byte word set to

@@ -42,7 +42,7 @@ EXPORTED_SYMBOLS = [
     "iopx_bn128_to_montgomery_dev", "iopx_poseidon_permute_bn128_dev", "iopx_merkle_poseidon_bn128_dev", "iopx_merkle_poseidon_bn128",
     "iopx_pow_solve_blake2b", "iopx_pow_solve_poseidon_bn128", "iopx_ldt_combine_gf192_dev", "iopx_ldt_combine_fp3_dev",
     "iopx_merkle_membership_proof_dev", "iopx_query_responses_dev", "iopx_rowcheck_gf192_dev", "iopx_rowcheck_fp3_dev",
-    "iopx_fz_gf192_dev", "iopx_fz_fp3_dev",
+    "iopx_fz_gf192_dev", "iopx_fz_fp3_dev", "iopx_sumcheck_g_gf192_dev", "iopx_sumcheck_g_fp3_dev",
     "iopx_gf192_mul_dev", "iopx_gf192_mul_uniform_dev", "iopx_profile_begin", "iopx_profile_report",
 ]
 
@@ -149,6 +149,8 @@ class Library:
         c.iopx_rowcheck_fp3_dev.argtypes = [_vp, _vp, _vp, _sz, _u64p, _u64p, _sz, _u64p, _vp]
         c.iopx_fz_gf192_dev.argtypes = [_vp, _vp, _u64p, _sz, _u64p, _u64p, _sz, _u64p, _vp]
         c.iopx_fz_fp3_dev.argtypes = [_vp, _vp, _sz, _u64p, _u64p, _sz, _u64p, _vp]
+        c.iopx_sumcheck_g_gf192_dev.argtypes = [_vp, _vp, _u64p, _sz, _u64p, _u64p, _sz, _u64p, _u64p, _vp]
+        c.iopx_sumcheck_g_fp3_dev.argtypes = [_vp, _vp, _sz, _u64p, _u64p, _sz, _u64p, _u64p, _vp]
         c.iopx_merkle_membership_proof_dev.argtypes = [_vp, _sz, ctypes.POINTER(_sz), _sz, _vp, _sz, ctypes.POINTER(_sz)]
         c.iopx_query_responses_dev.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _sz, ctypes.POINTER(_sz), _sz, _vp]
         c.iopx_ldt_combine_gf192_dev.argtypes = [ctypes.POINTER(_vp), _sz, ctypes.POINTER(_sz), _u64p, _u64p, _sz, _u64p, _vp]
@@ -430,6 +432,25 @@ class Library:
 
     def fz_multiplicative(self, fw, f1v, log_n, gen, shift, input_log_order, input_shift):
         return self._ldt_combine_host([fw, f1v], lambda d, o: self.fz_multiplicative_dev(d[0], d[1], log_n, gen, shift, input_log_order, input_shift, o))
+
+    # ---- sumcheck g oracle (sumcheck.tcc:58-119) ----
+    def sumcheck_g_dev(self, d_f, d_h, basis, shift, summation_basis, summation_shift, claimed_sum, d_out):
+        basis, shift, ssh, mu = _as_u64(basis), _as_u64(shift), _as_u64(summation_shift), _as_u64(claimed_sum)
+        sb = np.ascontiguousarray(summation_basis, dtype=np.uint64).reshape(-1, 3)
+        self._check(self.c.iopx_sumcheck_g_gf192_dev(_vp(d_f), _vp(d_h), basis.ctypes.data_as(_u64p), basis.shape[0], shift.ctypes.data_as(_u64p),
+                                                     sb.ctypes.data_as(_u64p), sb.shape[0], ssh.ctypes.data_as(_u64p), mu.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def sumcheck_g_multiplicative_dev(self, d_f, d_h, log_n, gen, shift, summation_log_order, summation_shift, claimed_sum, d_out):
+        gen, shift, ssh, mu = _as_u64(gen), _as_u64(shift), _as_u64(summation_shift), _as_u64(claimed_sum)
+        self._check(self.c.iopx_sumcheck_g_fp3_dev(_vp(d_f), _vp(d_h), int(log_n), gen.ctypes.data_as(_u64p), shift.ctypes.data_as(_u64p),
+                                                   int(summation_log_order), ssh.ctypes.data_as(_u64p), mu.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def sumcheck_g(self, f, h, basis, shift, summation_basis, summation_shift, claimed_sum):
+        return self._ldt_combine_host([f, h], lambda d, o: self.sumcheck_g_dev(d[0], d[1], basis, shift, summation_basis, summation_shift, claimed_sum, o))
+
+    def sumcheck_g_multiplicative(self, f, h, log_n, gen, shift, summation_log_order, summation_shift, claimed_sum):
+        return self._ldt_combine_host([f, h], lambda d, o: self.sumcheck_g_multiplicative_dev(d[0], d[1], log_n, gen, shift, summation_log_order,
+                                                                                              summation_shift, claimed_sum, o))
 
     # ---- LDT reducer (ldt_reducer_aux.tcc:39-131) ----
     def ldt_combine_dev(self, d_oracles, degrees, random_coefficients, basis, shift, d_out):

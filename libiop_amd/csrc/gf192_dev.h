@@ -198,3 +198,41 @@ __device__ __forceinline__ gf192 gf_mul_uniform(const gf192 &a, const gf192 &c_u
     comb_clmul_192_uniform(r, a.w, c);
     return gf_reduce(r);
 }
+
+// ---- squaring and inversion -------------------------------------------------------------------------------------------
+// Squaring is GF(2)-linear: bit i moves to bit 2i (four shift-and-mask steps per 16 bits), then the usual reduction: about a
+// sixth of a product.  Inversion is a^(2^192 - 2) by the Itoh-Tsujii chain on 191 = 0b10111111: 191 squarings + 10 products.
+__device__ __forceinline__ uint32_t gf_spread16(uint32_t x)
+{
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+__device__ __forceinline__ gf192 gf_sqr(const gf192 &a)
+{
+    uint32_t c[12];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        c[2 * i] = gf_spread16(a.w[i] & 0xFFFFu);
+        c[2 * i + 1] = gf_spread16(a.w[i] >> 16);
+    }
+    return gf_reduce(c);
+}
+
+__device__ inline gf192 gf_inv(const gf192 &a)
+{
+    gf192 beta = a;                         // beta_k = a^(2^k - 1)
+    int k = 1;
+    for (int bit = 6; bit >= 0; --bit) {
+        gf192 t = beta;
+        for (int i = 0; i < k; ++i) t = gf_sqr(t);
+        beta = gf_mul(t, beta);             // beta_2k
+        k *= 2;
+        if ((191 >> bit) & 1) { beta = gf_mul(gf_sqr(beta), a); k += 1; }
+    }
+    return gf_sqr(beta);
+}
+

@@ -80,6 +80,94 @@ __global__ void __launch_bounds__(256) k_fz_fp(uint64_t *out, const uint64_t *fw
     }
 }
 
+// sumcheck_g_oracle::evaluated_contents (libiop/protocols/encoded/sumcheck/sumcheck.tcc:58-119), affine subspaces:
+//     p'(x) = f(x) - eps^-1 mu x^(|H| - 1) - Z_H(x) h(x),      eps = the linear coefficient of Z_H.
+// x^(|H| - 1) = x^|H| / x as the reference does (sumcheck_aux.tcc:3-32): x^|H| is a subset sum, the inverses come from
+// Montgomery's trick over the 8 positions a lane owns (one field inversion per 8 elements, gf_inv), the constant rides on the
+// inverted product for free; a zero element (unshifted domain) inverts to zero (utils.tcc:79-97).
+struct SumcheckAddParams {
+    const uint64_t *f, *h;
+    uint64_t *out;
+    const uint64_t *xtab, *htab, *ztab;     // (m + 1)-entry subset-sum tables of x, x^|H|, Z_H(x)
+    const uint64_t *c;                      // eps^-1 * mu
+    int m;
+    size_t n;
+};
+
+__device__ __forceinline__ gf192 vo_subset_sum(const uint64_t *t, int m, uint32_t jlo, uint32_t jhi_uniform)
+{
+    gf192 v = gf_load(t, 0);
+    const int lo_bits = m < 8 ? m : 8;
+    for (int k = 0; k < lo_bits; ++k) {
+        const uint32_t mask = 0u - ((jlo >> k) & 1u);
+        const gf192 b = gf_load(t, 1 + k);
+#pragma unroll
+        for (int w = 0; w < 6; ++w) v.w[w] = xor_and(v.w[w], mask, b.w[w]);
+    }
+    for (int k = 8; k < m; ++k) if ((jhi_uniform >> (k - 8)) & 1u) gf_add_to(v, gf_load(t, 1 + k));
+    return v;
+}
+
+#define SUMCHECK_BATCH 8
+__global__ void __launch_bounds__(256, 2) k_sumcheck_g_add(SumcheckAddParams p)
+{
+    // running products of the lane's batch: [r][word][lane] (dynamic r: LDS, not registers)
+    __shared__ uint32_t prefix[SUMCHECK_BATCH * 6 * 256];
+    const gf192 cst = gf_load(p.c, 0);
+    gf192 one = gf_zero();
+    one.w[0] = 1;
+    // a workgroup owns 256 * SUMCHECK_BATCH consecutive positions; lane t takes t, t + 256, ...: its low 8 index bits are fixed
+    for (size_t base = (size_t)blockIdx.x * (256 * SUMCHECK_BATCH); base < p.n; base += (size_t)gridDim.x * (256 * SUMCHECK_BATCH)) {
+        for (uint32_t t = threadIdx.x; t < 256; t += blockDim.x) {
+            gf192 run = one;
+#pragma unroll 1
+            for (int r = 0; r < SUMCHECK_BATCH; ++r) {
+                const size_t j = base + t + 256 * (size_t)r;
+                const uint32_t jhi = __builtin_amdgcn_readfirstlane((uint32_t)((base >> 8) + r));
+                gf192 x = j < p.n ? vo_subset_sum(p.xtab, p.m, t, jhi) : one;
+                if (gf_is_zero(x)) x = one;
+                run = gf_mul(run, x);
+#pragma unroll
+                for (int w = 0; w < 6; ++w) prefix[(r * 6 + w) * 256 + t] = run.w[w];
+            }
+            gf192 inv = gf_mul(gf_inv(run), cst);
+#pragma unroll 1
+            for (int r = SUMCHECK_BATCH - 1; r >= 0; --r) {
+                const size_t j = base + t + 256 * (size_t)r;
+                const uint32_t jhi = __builtin_amdgcn_readfirstlane((uint32_t)((base >> 8) + r));
+                gf192 x = j < p.n ? vo_subset_sum(p.xtab, p.m, t, jhi) : one;
+                const bool zero = gf_is_zero(x);
+                if (zero) x = one;
+                gf192 before = one;                                 // product of the batch's earlier elements
+                if (r > 0) {
+#pragma unroll
+                    for (int w = 0; w < 6; ++w) before.w[w] = prefix[((r - 1) * 6 + w) * 256 + t];
+                }
+                gf192 xinv_c = gf_mul(before, inv);                 // c / x
+                inv = gf_mul(inv, x);
+                if (j >= p.n) continue;
+                if (zero) xinv_c = gf_zero();
+                gf192 acc = gf_load(p.f, j);
+                gf_add_to(acc, gf_mul(vo_subset_sum(p.htab, p.m, t, jhi), xinv_c));
+                gf_add_to(acc, gf_mul(vo_subset_sum(p.ztab, p.m, t, jhi), gf_load(p.h, j)));
+                gf_store(p.out, j, acc);
+            }
+        }
+    }
+}
+
+// multiplicative arm (sumcheck.tcc:96-117): p'(x) = (f(x) - |H|^-1 mu - Z_H(x) h(x)) / x
+__global__ void __launch_bounds__(256) k_sumcheck_g_fp(uint64_t *out, const uint64_t *f, const uint64_t *h, const uint64_t *zhi, const uint64_t *zlo,
+                                                       const uint64_t *ihi, const uint64_t *ilo, const uint64_t *consts, size_t n)
+{
+    const fp3 vp_shift_t = fp_load(consts, 0), mu_scaled = fp_load(consts, 1);
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        const fp3 z = fp_sub(fp_mul(fp_load(zhi, j >> 12), fp_load(zlo, j & 4095)), vp_shift_t);
+        const fp3 t = fp_sub(fp_sub(fp_load(f, j), mu_scaled), fp_mul(fp_load(h, j), z));
+        fp_store(out, j, fp_mul(t, fp_mul(fp_load(ihi, j >> 12), fp_load(ilo, j & 4095))));
+    }
+}
+
 static int vo_grid(size_t n)
 {
     size_t g = (n + 255) / 256;
@@ -215,6 +303,83 @@ int iopx_fz_fp3_dev(const uint64_t *d_fw, const uint64_t *d_f1v, size_t log_n, c
     const size_t n = (size_t)1 << log_n;
     { ProfScope ps_("k_fz_fp"); hipLaunchKernelGGL(k_fz_fp, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_fw, d_f1v, (const uint64_t *)hi.u64(),
                                                   (const uint64_t *)lo.u64(), (const uint64_t *)dc.u64(), n); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+int iopx_sumcheck_g_gf192_dev(const uint64_t *d_f, const uint64_t *d_h, const uint64_t *basis, size_t m, const uint64_t *shift,
+                              const uint64_t *summation_basis, size_t summation_dim, const uint64_t *summation_shift,
+                              const uint64_t *claimed_sum, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_f || !d_h || !d_out || (m > 0 && !basis) || !shift || (summation_dim > 0 && !summation_basis) || !summation_shift || !claimed_sum)
+        return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (m > 40 || summation_dim > 63) return fail(IOPX_ERR_INVALID_ARGUMENT, "domain dimension too large");
+    std::vector<hgf192> lin(1, hgf192::one());             // Z_H's linear part: lin[i] multiplies X^(2^i)
+    for (size_t k = 0; k < summation_dim; ++k) {
+        const hgf192 b = hgf192::from_words(summation_basis + 3 * k);
+        hgf192 zb = hgf192::zero(), bp = b;
+        for (size_t i = 0; i < lin.size(); ++i) { zb += lin[i] * bp; bp = bp.squared(); }
+        std::vector<hgf192> nxt(lin.size() + 1, hgf192::zero());
+        for (size_t i = 0; i < lin.size(); ++i) { nxt[i + 1] += lin[i].squared(); nxt[i] += lin[i] * zb; }
+        lin.swap(nxt);
+    }
+    auto eval = [&](const hgf192 &x) { hgf192 r = hgf192::zero(), xp = x; for (size_t i = 0; i < lin.size(); ++i) { r += lin[i] * xp; xp = xp.squared(); } return r; };
+    if (lin[0].is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the summation domain's basis is linearly dependent");
+    const hgf192 c = lin[0].inverse() * hgf192::from_words(claimed_sum);         // eps^-1 mu (sumcheck.tcc:52-54)
+    std::vector<uint64_t> xtab(3 * (m + 1)), htab(3 * (m + 1)), ztab(3 * (m + 1));
+    for (size_t k = 0; k <= m; ++k) {
+        const hgf192 v = hgf192::from_words(k == 0 ? shift : basis + 3 * (k - 1));
+        hgf192 vh = v;
+        for (size_t i = 0; i < summation_dim; ++i) vh = vh.squared();             // v^|H|
+        hgf192 vz = eval(v);
+        if (k == 0) vz += eval(hgf192::from_words(summation_shift));             // Z_H(shift) = lin(shift) + lin(shift_H)
+        memcpy(&xtab[3 * k], v.w, 24); memcpy(&htab[3 * k], vh.w, 24); memcpy(&ztab[3 * k], vz.w, 24);
+    }
+    TmpBuf dx, dh, dz, dc;
+    if ((rc = dx.alloc(xtab.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = dh.alloc(htab.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = dz.alloc(ztab.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = dc.alloc(24)) != IOPX_OK) return rc;
+    if ((rc = upload(dx.p, xtab.data(), xtab.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(dh.p, htab.data(), htab.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(dz.p, ztab.data(), ztab.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(dc.p, c.w, 24)) != IOPX_OK) return rc;
+    SumcheckAddParams p;
+    p.f = d_f; p.h = d_h; p.out = d_out;
+    p.xtab = dx.u64(); p.htab = dh.u64(); p.ztab = dz.u64(); p.c = dc.u64();
+    p.m = (int)m; p.n = (size_t)1 << m;
+    size_t g = (p.n + 256 * SUMCHECK_BATCH - 1) / (256 * SUMCHECK_BATCH);
+    if (g > 16384) g = 16384;
+    { ProfScope ps_("k_sumcheck_g_add"); hipLaunchKernelGGL(k_sumcheck_g_add, dim3((unsigned)(g ? g : 1)), dim3(256), 0, stream(), p); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+int iopx_sumcheck_g_fp3_dev(const uint64_t *d_f, const uint64_t *d_h, size_t log_n, const uint64_t *gen, const uint64_t *shift,
+                            size_t summation_log_order, const uint64_t *summation_shift, const uint64_t *claimed_sum, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_f || !d_h || !d_out || !gen || !shift || !summation_shift || !claimed_sum) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (summation_log_order > 62 || log_n > 31) return fail(IOPX_ERR_INVALID_ARGUMENT, "domain dimension too large");
+    hfp3 g, s, hs, mu;
+    memcpy(g.w, gen, 24); memcpy(s.w, shift, 24); memcpy(hs.w, summation_shift, 24); memcpy(mu.w, claimed_sum, 24);
+    if (s.is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "zero coset shift");
+    const uint64_t order_h = (uint64_t)1 << summation_log_order;
+    TmpBuf zhi, zlo, ihi, ilo, dc;
+    if ((rc = build_two_level(g.pow(order_h), s.pow(order_h), (int)log_n, zhi, zlo)) != IOPX_OK) return rc;
+    if ((rc = build_two_level(g.inverse(), s.inverse(), (int)log_n, ihi, ilo)) != IOPX_OK) return rc;
+    const hfp3 vp_shift_t = hs.pow(order_h).table_form();
+    const hfp3 mu_scaled = hfp3::from_uint(order_h).inverse() * mu;              // |H|^-1 mu, a data value (sumcheck.tcc:46-49)
+    uint64_t consts[6];
+    memcpy(consts, vp_shift_t.w, 24); memcpy(consts + 3, mu_scaled.w, 24);
+    if ((rc = dc.alloc(48)) != IOPX_OK) return rc;
+    if ((rc = upload(dc.p, consts, 48)) != IOPX_OK) return rc;
+    const size_t n = (size_t)1 << log_n;
+    { ProfScope ps_("k_sumcheck_g_fp"); hipLaunchKernelGGL(k_sumcheck_g_fp, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_f, d_h, (const uint64_t *)zhi.u64(),
+                                                          (const uint64_t *)zlo.u64(), (const uint64_t *)ihi.u64(), (const uint64_t *)ilo.u64(), (const uint64_t *)dc.u64(), n); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
 }

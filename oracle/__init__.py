@@ -592,3 +592,19 @@ def fz_fp(fw, f1v, shift, input_order, input_shift):
     out = np.empty_like(fw)
     lib().oracle_fz_fp(_p(fw), _p(f1v), ctypes.c_size_t(fw.shape[0]), _p(_c(shift)), ctypes.c_size_t(input_order), _p(_c(input_shift)), _p(out))
     return out
+
+
+def sumcheck_g_additive(f, h, basis, shift, sbasis, sshift, mu):
+    f, h, basis, shift, sshift, mu = _c(f), _c(h), _c(basis), _c(shift), _c(sshift), _c(mu)
+    sb = _c(sbasis).reshape(-1, basis.shape[1])
+    m, w = basis.shape
+    out = np.empty_like(f)
+    lib().oracle_sumcheck_g_additive(w, _p(f), _p(h), _p(basis), ctypes.c_size_t(m), _p(shift), _p(sb), ctypes.c_size_t(sb.shape[0]), _p(sshift), _p(mu), _p(out))
+    return out
+
+
+def sumcheck_g_fp(f, h, shift, order_h, sshift, mu):
+    f, h = _c(f), _c(h)
+    out = np.empty_like(f)
+    lib().oracle_sumcheck_g_fp(_p(f), _p(h), ctypes.c_size_t(f.shape[0]), _p(_c(shift)), ctypes.c_size_t(order_h), _p(_c(sshift)), _p(_c(mu)), _p(out))
+    return out

@@ -173,4 +173,43 @@ std::vector<F> fz_multiplicative(const std::vector<F> &fw, const std::vector<F> 
     return result;
 }
 
+// libiop/protocols/encoded/sumcheck/sumcheck.tcc:58-119 with sumcheck_aux.tcc:3-32 — sumcheck_g_oracle::evaluated_contents
+template<typename F>
+std::vector<F> sumcheck_g_additive(const std::vector<F> &f, const std::vector<F> &h, const affine_subspace<F> &codeword_domain,
+                                   const affine_subspace<F> &summation_domain, const F &claimed_sum)
+{
+    const std::vector<F> Z = vanishing_polynomial_from_subspace<F>(summation_domain);
+    const F eps_inv_times_claimed_sum = Z[1].inverse() * claimed_sum;                      // :36-38, :52-54
+    const size_t order_H = summation_domain.num_elements();
+    // constant_times_subspace_to_order_H_minus_1 (sumcheck_aux.tcc:3-32)
+    const std::vector<F> x_to_H = subspace_element_powers<F>(codeword_domain, order_H);
+    std::vector<F> elems = codeword_domain.all_elements();
+    std::vector<size_t> zeros;                                                              // utils.tcc:79-97
+    for (size_t i = 0; i < elems.size(); ++i) if (elems[i] == F::zero()) { zeros.push_back(i); elems[i] = F::one(); }
+    std::vector<F> x_inv_c = batch_inverse_and_mul<F>(elems, eps_inv_times_claimed_sum);
+    for (size_t i : zeros) x_inv_c[i] = F::zero();
+    const std::vector<F> pts = codeword_domain.all_elements();
+    std::vector<F> result(f);
+    for (size_t i = 0; i < result.size(); ++i) result[i] -= (x_to_H[i] * x_inv_c[i] + linearized_eval<F>(Z, pts[i]) * h[i]);   // :88-92
+    return result;
+}
+
+template<typename F>
+std::vector<F> sumcheck_g_multiplicative(const std::vector<F> &f, const std::vector<F> &h, const mult_coset<F> &codeword_domain,
+                                         size_t order_H, const F &summation_shift, const F &claimed_sum)
+{
+    const F c = F((uint64_t)order_H).inverse() * claimed_sum;                               // :46-49
+    const F vp_shift = summation_shift.pow(order_H);
+    F cur_x_inv = codeword_domain.shift.inverse();
+    const F g_inv = codeword_domain.g.inverse();
+    const std::vector<F> pts = codeword_domain.all_elements();
+    std::vector<F> result(f);
+    for (size_t i = 0; i < result.size(); ++i) {                                            // :107-115
+        result[i] -= (c + (pts[i].pow(order_H) - vp_shift) * h[i]);
+        result[i] *= cur_x_inv;
+        cur_x_inv *= g_inv;
+    }
+    return result;
+}
+
 } // namespace oracle

@@ -497,4 +497,22 @@ void oracle_fz_fp(const uint64_t *fw, const uint64_t *f1v, size_t order, const u
     store<FP>(out, fz_multiplicative<FP>(load<FP>(fw, order), load<FP>(f1v, order), load_coset(order, shift), input_order, is));
 }
 
+// sumcheck g oracle (sumcheck.tcc:58-119)
+int oracle_sumcheck_g_additive(int words, const uint64_t *f, const uint64_t *h, const uint64_t *basis, size_t m, const uint64_t *shift,
+                               const uint64_t *sbasis, size_t sdim, const uint64_t *sshift, const uint64_t *mu, uint64_t *out)
+{
+    DISPATCH(words, {
+        F cs; memcpy((void *)&cs, mu, sizeof(F));
+        const size_t n = (size_t)1 << m;
+        store<F>(out, sumcheck_g_additive<F>(load<F>(f, n), load<F>(h, n), load_domain<F>(basis, m, shift), load_domain<F>(sbasis, sdim, sshift), cs));
+    });
+    return 0;
+}
+void oracle_sumcheck_g_fp(const uint64_t *f, const uint64_t *h, size_t order, const uint64_t *shift, size_t order_h, const uint64_t *sshift,
+                          const uint64_t *mu, uint64_t *out)
+{
+    FP ss, m; memcpy(ss.mont, sshift, 24); memcpy(m.mont, mu, 24);
+    store<FP>(out, sumcheck_g_multiplicative<FP>(load<FP>(f, order), load<FP>(h, order), load_coset(order, shift), order_h, ss, m));
+}
+
 } // extern "C"

@@ -163,3 +163,30 @@ def check_fz_multiplicative(lib, log_n, ilog, seed):
     fw, f1v = _rand_fp(seed, n), _rand_fp(seed + 1, n)
     got = lib.fz_multiplicative(fw, f1v, log_n, gen, shift, ilog, ish)
     assert np.array_equal(got, oracle.fz_fp(fw, f1v, shift, 1 << ilog, ish))
+
+
+# ---- sumcheck g oracle (sumcheck.tcc:58-119) ---------------------------------------------------------------------------
+def check_sumcheck_g_additive(lib, m, sdim, seed, kind="aurora"):
+    n = 1 << m
+    if kind == "aurora":
+        basis, shift = oracle.standard_basis(m, W), np.array([1 << m, 0, 0], dtype=np.uint64)
+        sb, ssh = oracle.standard_basis(sdim, W) if sdim else np.zeros((0, W), dtype=np.uint64), np.zeros(W, dtype=np.uint64)
+    elif kind == "unshifted":       # the codeword domain contains zero: its inverse is taken as zero (utils.tcc:79-97)
+        basis, shift = rand_elems(seed + 1, m, W), np.zeros(W, dtype=np.uint64)
+        sb, ssh = rand_elems(seed + 3, max(sdim, 1), W)[:sdim], rand_elems(seed + 4, 1, W)[0]
+    else:
+        basis, shift = rand_elems(seed + 1, m, W), rand_elems(seed + 2, 1, W)[0]
+        sb, ssh = rand_elems(seed + 3, max(sdim, 1), W)[:sdim], rand_elems(seed + 4, 1, W)[0]
+    f, h, mu = rand_elems(seed + 5, n, W), rand_elems(seed + 6, n, W), rand_elems(seed + 7, 1, W)[0]
+    got = lib.sumcheck_g(f, h, basis, shift, sb, ssh, mu)
+    assert np.array_equal(got, oracle.sumcheck_g_additive(f, h, basis, shift, sb, ssh, mu))
+
+
+def check_sumcheck_g_multiplicative(lib, log_n, slog, seed):
+    n = 1 << log_n
+    gen = libiop_amd.edwards_subgroup_generator(log_n)
+    shift = libiop_amd.edwards_to_montgomery([libiop_amd.EDWARDS_FR_GENERATOR])[0]
+    ssh = libiop_amd.edwards_to_montgomery([1])[0]
+    f, h, mu = _rand_fp(seed, n), _rand_fp(seed + 1, n), _rand_fp(seed + 2, 1)[0]
+    got = lib.sumcheck_g_multiplicative(f, h, log_n, gen, shift, slog, ssh, mu)
+    assert np.array_equal(got, oracle.sumcheck_g_fp(f, h, shift, 1 << slog, ssh, mu))

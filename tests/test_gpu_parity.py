@@ -407,3 +407,14 @@ def test_fz_additive(gpu, m, idim, seed, kind):
 @pytest.mark.parametrize("log_n,ilog,seed", [(5, 2, 1), (9, 4, 2), (14, 3, 3), (6, 0, 4)])
 def test_fz_multiplicative(gpu, log_n, ilog, seed):
     lc.check_fz_multiplicative(gpu, log_n, ilog, seed)
+
+
+# ---- sumcheck g oracle (sumcheck.tcc:58-119) -------------------------------------------------------------------------
+@pytest.mark.parametrize("m,sdim,seed,kind", [(5, 2, 1, "aurora"), (9, 4, 2, "general"), (7, 3, 3, "unshifted"), (16, 11, 4, "aurora"), (3, 1, 5, "general")])
+def test_sumcheck_g_additive(gpu, m, sdim, seed, kind):
+    lc.check_sumcheck_g_additive(gpu, m, sdim, seed, kind)
+
+
+@pytest.mark.parametrize("log_n,slog,seed", [(5, 2, 1), (9, 4, 2), (15, 10, 3), (6, 0, 4)])
+def test_sumcheck_g_multiplicative(gpu, log_n, slog, seed):
+    lc.check_sumcheck_g_multiplicative(gpu, log_n, slog, seed)

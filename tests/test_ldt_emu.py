@@ -95,3 +95,13 @@ def test_fz_additive(m, idim, seed, kind):
 @pytest.mark.parametrize("log_n,ilog,seed", [(5, 2, 1), (9, 4, 2), (13, 3, 3), (6, 0, 4)])
 def test_fz_multiplicative(log_n, ilog, seed):
     lc.check_fz_multiplicative(emu(), log_n, ilog, seed)
+
+
+@pytest.mark.parametrize("m,sdim,seed,kind", [(5, 2, 1, "aurora"), (9, 4, 2, "general"), (7, 3, 3, "unshifted"), (12, 6, 4, "aurora"), (3, 1, 5, "general")])
+def test_sumcheck_g_additive(m, sdim, seed, kind):
+    lc.check_sumcheck_g_additive(emu(), m, sdim, seed, kind)
+
+
+@pytest.mark.parametrize("log_n,slog,seed", [(5, 2, 1), (9, 4, 2), (13, 3, 3), (6, 0, 4)])
+def test_sumcheck_g_multiplicative(log_n, slog, seed):
+    lc.check_sumcheck_g_multiplicative(emu(), log_n, slog, seed)
