@@ -238,6 +238,15 @@ int iopx_sumcheck_g_gf192_dev(const uint64_t *d_f, const uint64_t *d_h, const ui
 int iopx_sumcheck_g_fp3_dev(const uint64_t *d_f, const uint64_t *d_h, size_t log_n, const uint64_t *gen, const uint64_t *shift,
                             size_t summation_log_order, const uint64_t *summation_shift, const uint64_t *claimed_sum, uint64_t *d_out);
 
+/* multi_lincheck_virtual_oracle::evaluated_contents (libiop/protocols/encoded/lincheck/basic_lincheck_aux.tcc:102-144):
+ * out[x] = (sum_m r_Mz[m] * Mz_m(x)) * p_alpha_prime(x) - fz(x) * p_alpha_ABC(x) over n positions; the two p_alpha codewords are the
+ * ordinary transforms of :112-118 (iopx_add_fft_gf192_dev / iopx_mul_fft_fp3_dev of the polynomials set_challenge computed).
+ * d_Mz: host array of num_matrices (<= 8) device pointers; r_Mz: host coefficients. */
+int iopx_lincheck_gf192_dev(const uint64_t *d_fz, const void *const *d_Mz, size_t num_matrices, const uint64_t *r_Mz,
+                            const uint64_t *d_p_alpha_prime, const uint64_t *d_p_alpha_ABC, size_t n, uint64_t *d_out);
+int iopx_lincheck_fp3_dev(const uint64_t *d_fz, const void *const *d_Mz, size_t num_matrices, const uint64_t *r_Mz,
+                          const uint64_t *d_p_alpha_prime, const uint64_t *d_p_alpha_ABC, size_t n, uint64_t *d_out);
+
 /* ---- proof of work ------------------------------------------------------------------------------ */
 /* pow<FieldT, binary_hash_digest>::solve_pow (libiop/bcs/pow.tcc:67-103) with the BLAKE2b two-to-one hash: returns the
  * FIRST candidate in the reference's order (the challenge itself, then the challenge with its last 8-byte word set to

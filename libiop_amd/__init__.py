@@ -43,6 +43,7 @@ EXPORTED_SYMBOLS = [
     "iopx_pow_solve_blake2b", "iopx_pow_solve_poseidon_bn128", "iopx_ldt_combine_gf192_dev", "iopx_ldt_combine_fp3_dev",
     "iopx_merkle_membership_proof_dev", "iopx_query_responses_dev", "iopx_rowcheck_gf192_dev", "iopx_rowcheck_fp3_dev",
     "iopx_fz_gf192_dev", "iopx_fz_fp3_dev", "iopx_sumcheck_g_gf192_dev", "iopx_sumcheck_g_fp3_dev",
+    "iopx_lincheck_gf192_dev", "iopx_lincheck_fp3_dev",
     "iopx_gf192_mul_dev", "iopx_gf192_mul_uniform_dev", "iopx_profile_begin", "iopx_profile_report",
 ]
 
@@ -151,6 +152,8 @@ class Library:
         c.iopx_fz_fp3_dev.argtypes = [_vp, _vp, _sz, _u64p, _u64p, _sz, _u64p, _vp]
         c.iopx_sumcheck_g_gf192_dev.argtypes = [_vp, _vp, _u64p, _sz, _u64p, _u64p, _sz, _u64p, _u64p, _vp]
         c.iopx_sumcheck_g_fp3_dev.argtypes = [_vp, _vp, _sz, _u64p, _u64p, _sz, _u64p, _u64p, _vp]
+        c.iopx_lincheck_gf192_dev.argtypes = [_vp, ctypes.POINTER(_vp), _sz, _u64p, _vp, _vp, _sz, _vp]
+        c.iopx_lincheck_fp3_dev.argtypes = [_vp, ctypes.POINTER(_vp), _sz, _u64p, _vp, _vp, _sz, _vp]
         c.iopx_merkle_membership_proof_dev.argtypes = [_vp, _sz, ctypes.POINTER(_sz), _sz, _vp, _sz, ctypes.POINTER(_sz)]
         c.iopx_query_responses_dev.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _sz, ctypes.POINTER(_sz), _sz, _vp]
         c.iopx_ldt_combine_gf192_dev.argtypes = [ctypes.POINTER(_vp), _sz, ctypes.POINTER(_sz), _u64p, _u64p, _sz, _u64p, _vp]
@@ -451,6 +454,19 @@ class Library:
     def sumcheck_g_multiplicative(self, f, h, log_n, gen, shift, summation_log_order, summation_shift, claimed_sum):
         return self._ldt_combine_host([f, h], lambda d, o: self.sumcheck_g_multiplicative_dev(d[0], d[1], log_n, gen, shift, summation_log_order,
                                                                                               summation_shift, claimed_sum, o))
+
+    # ---- lincheck virtual oracle (basic_lincheck_aux.tcc:102-144) ----
+    def lincheck_dev(self, d_fz, d_mz, r_mz, d_p1, d_p2, n, d_out, prime_field=False):
+        r = _as_u64(r_mz)
+        if r.shape[0] != len(d_mz):
+            raise ValueError("Not enough random linear combination coefficients were provided")
+        ptrs = (_vp * len(d_mz))(*d_mz)
+        fn = self.c.iopx_lincheck_fp3_dev if prime_field else self.c.iopx_lincheck_gf192_dev
+        self._check(fn(_vp(d_fz), ptrs, len(d_mz), r.ctypes.data_as(_u64p), _vp(d_p1), _vp(d_p2), int(n), _vp(d_out)))
+
+    def lincheck(self, fz, mz, r_mz, p1, p2, prime_field=False):
+        n = _as_u64(fz).shape[0]
+        return self._ldt_combine_host([fz, p1, p2] + list(mz), lambda d, o: self.lincheck_dev(d[0], d[3:], r_mz, d[1], d[2], n, o, prime_field))
 
     # ---- LDT reducer (ldt_reducer_aux.tcc:39-131) ----
     def ldt_combine_dev(self, d_oracles, degrees, random_coefficients, basis, shift, d_out):

@@ -168,6 +168,42 @@ __global__ void __launch_bounds__(256) k_sumcheck_g_fp(uint64_t *out, const uint
     }
 }
 
+// multi_lincheck_virtual_oracle::evaluated_contents (libiop/protocols/encoded/lincheck/basic_lincheck_aux.tcc:102-144), given
+// p_alpha^1 and p_alpha^2 already extended to the codeword domain (two ordinary transforms, :112-118):
+//     result[x] = (sum_m r_m Mz_m(x)) * p_alpha^1(x) - fz(x) * p_alpha^2(x)
+#define LINCHECK_MAX_MATRICES 8
+struct LincheckParams {
+    const uint64_t *fz, *p1, *p2;
+    const uint64_t *mz[LINCHECK_MAX_MATRICES];
+    const uint64_t *r;              // num_matrices coefficients (fp3: table form), then (fp3 only) the rescaling constant
+    uint64_t *out;
+    int num_matrices;
+    size_t n;
+};
+
+__global__ void __launch_bounds__(256) k_lincheck_add(LincheckParams p)
+{
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < p.n; j += (size_t)gridDim.x * blockDim.x) {
+        gf192 comb = gf_zero();
+        for (int m = 0; m < p.num_matrices; ++m) gf_add_to(comb, gf_mul(gf_load(p.mz[m], j), gf_load(p.r, m)));
+        gf192 acc = gf_mul(comb, gf_load(p.p1, j));
+        gf_add_to(acc, gf_mul(gf_load(p.fz, j), gf_load(p.p2, j)));
+        gf_store(p.out, j, acc);
+    }
+}
+
+// Both terms are data x data products (scale 2^181, see k_rowcheck_fp): one last product with 2^214 restores libff's form.
+__global__ void __launch_bounds__(256) k_lincheck_fp(LincheckParams p)
+{
+    const fp3 rescale = fp_load(p.r, p.num_matrices);
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < p.n; j += (size_t)gridDim.x * blockDim.x) {
+        fp3 comb = fp_zero();
+        for (int m = 0; m < p.num_matrices; ++m) comb = fp_add(comb, fp_mul(fp_load(p.mz[m], j), fp_load(p.r, m)));
+        const fp3 t = fp_sub(fp_mul(comb, fp_load(p.p1, j)), fp_mul(fp_load(p.fz, j), fp_load(p.p2, j)));
+        fp_store(p.out, j, fp_mul(t, rescale));
+    }
+}
+
 static int vo_grid(size_t n)
 {
     size_t g = (n + 255) / 256;
@@ -382,6 +418,46 @@ int iopx_sumcheck_g_fp3_dev(const uint64_t *d_f, const uint64_t *d_h, size_t log
                                                           (const uint64_t *)zlo.u64(), (const uint64_t *)ihi.u64(), (const uint64_t *)ilo.u64(), (const uint64_t *)dc.u64(), n); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
+}
+
+static int lincheck_common(const uint64_t *d_fz, const void *const *d_Mz, size_t num_matrices, const uint64_t *r_Mz, const uint64_t *d_p1,
+                           const uint64_t *d_p2, size_t n, uint64_t *d_out, bool prime_field)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_fz || !d_Mz || !r_Mz || !d_p1 || !d_p2 || !d_out) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (num_matrices == 0 || num_matrices > LINCHECK_MAX_MATRICES)
+        return fail(IOPX_ERR_INVALID_ARGUMENT, "multi_lincheck uses more constituent oracles than what was provided.");
+    std::vector<uint64_t> hr(r_Mz, r_Mz + 3 * num_matrices);
+    if (prime_field) {
+        for (size_t m = 0; m < num_matrices; ++m) { const hfp3 t = hfp3::from_words(r_Mz + 3 * m).table_form(); memcpy(&hr[3 * m], t.w, 24); }
+        const hfp3 k = hfp3::one().table_form().table_form();
+        hr.insert(hr.end(), k.w, k.w + 3);
+    }
+    TmpBuf dr;
+    if ((rc = dr.alloc(hr.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(dr.p, hr.data(), hr.size() * 8)) != IOPX_OK) return rc;
+    LincheckParams p;
+    memset(&p, 0, sizeof(p));
+    p.fz = d_fz; p.p1 = d_p1; p.p2 = d_p2; p.out = d_out; p.r = dr.u64();
+    for (size_t m = 0; m < num_matrices; ++m) p.mz[m] = (const uint64_t *)d_Mz[m];
+    p.num_matrices = (int)num_matrices; p.n = n;
+    if (prime_field) { ProfScope ps_("k_lincheck_fp"); hipLaunchKernelGGL(k_lincheck_fp, dim3(vo_grid(n)), dim3(256), 0, stream(), p); }
+    else { ProfScope ps_("k_lincheck_add"); hipLaunchKernelGGL(k_lincheck_add, dim3(vo_grid(n)), dim3(256), 0, stream(), p); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+int iopx_lincheck_gf192_dev(const uint64_t *d_fz, const void *const *d_Mz, size_t num_matrices, const uint64_t *r_Mz,
+                            const uint64_t *d_p_alpha_prime, const uint64_t *d_p_alpha_ABC, size_t n, uint64_t *d_out)
+{
+    return lincheck_common(d_fz, d_Mz, num_matrices, r_Mz, d_p_alpha_prime, d_p_alpha_ABC, n, d_out, false);
+}
+
+int iopx_lincheck_fp3_dev(const uint64_t *d_fz, const void *const *d_Mz, size_t num_matrices, const uint64_t *r_Mz,
+                          const uint64_t *d_p_alpha_prime, const uint64_t *d_p_alpha_ABC, size_t n, uint64_t *d_out)
+{
+    return lincheck_common(d_fz, d_Mz, num_matrices, r_Mz, d_p_alpha_prime, d_p_alpha_ABC, n, d_out, true);
 }
 
 } // extern "C"

@@ -608,3 +608,13 @@ def sumcheck_g_fp(f, h, shift, order_h, sshift, mu):
     out = np.empty_like(f)
     lib().oracle_sumcheck_g_fp(_p(f), _p(h), ctypes.c_size_t(f.shape[0]), _p(_c(shift)), ctypes.c_size_t(order_h), _p(_c(sshift)), _p(_c(mu)), _p(out))
     return out
+
+
+def lincheck_combine(fz, mz, r, p1, p2, prime_field=False):
+    fz, r, p1, p2 = _c(fz), _c(r), _c(p1), _c(p2)
+    mz = [_c(v) for v in mz]
+    out = np.empty_like(fz)
+    ptrs = (ctypes.c_void_p * len(mz))(*[v.ctypes.data for v in mz])
+    lib().oracle_lincheck_combine(0 if prime_field else fz.shape[1], _p(fz), ptrs, ctypes.c_size_t(len(mz)), _p(r), _p(p1), _p(p2),
+                                  ctypes.c_size_t(fz.shape[0]), _p(out))
+    return out

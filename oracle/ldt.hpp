@@ -212,4 +212,18 @@ std::vector<F> sumcheck_g_multiplicative(const std::vector<F> &f, const std::vec
     return result;
 }
 
+// libiop/protocols/encoded/lincheck/basic_lincheck_aux.tcc:102-144 — multi_lincheck_virtual_oracle::evaluated_contents given
+// p_alpha^1 / p_alpha^2 over the codeword domain (the reference extends them with FFT_over_field_subset, :112-118)
+template<typename F>
+std::vector<F> lincheck_combine(const std::vector<F> &fz, const std::vector<std::vector<F>> &Mz, const std::vector<F> &r_Mz,
+                                const std::vector<F> &p_alpha_prime, const std::vector<F> &p_alpha_ABC)
+{
+    const size_t n = fz.size();
+    std::vector<F> f_combined_Mz(n, F::zero());
+    for (size_t i = 0; i < n; ++i) for (size_t m = 0; m < Mz.size(); ++m) f_combined_Mz[i] += r_Mz[m] * Mz[m][i];       // :124-128
+    std::vector<F> result;
+    for (size_t i = 0; i < n; ++i) result.push_back(f_combined_Mz[i] * p_alpha_prime[i] - fz[i] * p_alpha_ABC[i]);      // :136-141
+    return result;
+}
+
 } // namespace oracle

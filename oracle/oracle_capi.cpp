@@ -515,4 +515,22 @@ void oracle_sumcheck_g_fp(const uint64_t *f, const uint64_t *h, size_t order, co
     store<FP>(out, sumcheck_g_multiplicative<FP>(load<FP>(f, order), load<FP>(h, order), load_coset(order, shift), order_h, ss, m));
 }
 
+// lincheck virtual oracle (basic_lincheck_aux.tcc:102-144); words == 0 selects the 181-bit prime field
+int oracle_lincheck_combine(int words, const uint64_t *fz, const uint64_t *const *mz, size_t num, const uint64_t *r, const uint64_t *p1,
+                            const uint64_t *p2, size_t n, uint64_t *out)
+{
+    if (words == 0) {
+        std::vector<std::vector<FP>> M;
+        for (size_t m = 0; m < num; ++m) M.push_back(load<FP>(mz[m], n));
+        store<FP>(out, lincheck_combine<FP>(load<FP>(fz, n), M, load<FP>(r, num), load<FP>(p1, n), load<FP>(p2, n)));
+        return 0;
+    }
+    DISPATCH(words, {
+        std::vector<std::vector<F>> M;
+        for (size_t m = 0; m < num; ++m) M.push_back(load<F>(mz[m], n));
+        store<F>(out, lincheck_combine<F>(load<F>(fz, n), M, load<F>(r, num), load<F>(p1, n), load<F>(p2, n)));
+    });
+    return 0;
+}
+
 } // extern "C"

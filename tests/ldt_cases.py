@@ -190,3 +190,15 @@ def check_sumcheck_g_multiplicative(lib, log_n, slog, seed):
     f, h, mu = _rand_fp(seed, n), _rand_fp(seed + 1, n), _rand_fp(seed + 2, 1)[0]
     got = lib.sumcheck_g_multiplicative(f, h, log_n, gen, shift, slog, ssh, mu)
     assert np.array_equal(got, oracle.sumcheck_g_fp(f, h, shift, 1 << slog, ssh, mu))
+
+
+# ---- lincheck virtual oracle (basic_lincheck_aux.tcc:102-144) -----------------------------------------------------------
+def check_lincheck(lib, n, k, seed, prime_field=False):
+    gen = (lambda s, c: _rand_fp(s, c)) if prime_field else (lambda s, c: rand_elems(s, c, W))
+    fz, p1, p2 = gen(seed, n), gen(seed + 1, n), gen(seed + 2, n)
+    mz = [gen(seed + 10 + m, n) for m in range(k)]
+    r = gen(seed + 3, k)
+    got = lib.lincheck(fz, mz, r, p1, p2, prime_field)
+    assert np.array_equal(got, oracle.lincheck_combine(fz, mz, r, p1, p2, prime_field))
+    with pytest.raises(ValueError):         # basic_lincheck_aux.tcc:32-34
+        lib.lincheck(fz, mz, r[:k - 1] if k > 1 else np.zeros((2, 3), dtype=np.uint64), p1, p2, prime_field)

@@ -418,3 +418,8 @@ def test_sumcheck_g_additive(gpu, m, sdim, seed, kind):
 @pytest.mark.parametrize("log_n,slog,seed", [(5, 2, 1), (9, 4, 2), (15, 10, 3), (6, 0, 4)])
 def test_sumcheck_g_multiplicative(gpu, log_n, slog, seed):
     lc.check_sumcheck_g_multiplicative(gpu, log_n, slog, seed)
+
+
+@pytest.mark.parametrize("n,k,seed,prime", [(16, 3, 1, False), (300, 1, 2, False), (1 << 16, 3, 3, False), (1 << 15, 3, 4, True), (7, 2, 5, True)])
+def test_lincheck(gpu, n, k, seed, prime):
+    lc.check_lincheck(gpu, n, k, seed, prime)

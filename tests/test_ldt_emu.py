@@ -105,3 +105,8 @@ def test_sumcheck_g_additive(m, sdim, seed, kind):
 @pytest.mark.parametrize("log_n,slog,seed", [(5, 2, 1), (9, 4, 2), (13, 3, 3), (6, 0, 4)])
 def test_sumcheck_g_multiplicative(log_n, slog, seed):
     lc.check_sumcheck_g_multiplicative(emu(), log_n, slog, seed)
+
+
+@pytest.mark.parametrize("n,k,seed,prime", [(16, 3, 1, False), (300, 1, 2, False), (1024, 3, 3, True), (7, 2, 4, True)])
+def test_lincheck(n, k, seed, prime):
+    lc.check_lincheck(emu(), n, k, seed, prime)
