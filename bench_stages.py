@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
 """Stage benchmarks of the prover hot path beyond bench.py's headline transform.
 
+  --config cfg5   Fractal 2^20 over the 181-bit prime field as a STAGE REPLAY: indexer (12 codeword FFTs 2^20 -> 2^25, one tree over 12
+                  oracles), prover (8 codeword FFTs from 2^22 coefficients, known-degree IFFT), FRI commit; --gpus N shards by
+                  residue class.
   --config cfg3   FRI prover commit phase (protocols/ldt/fri) on a degree-2^20 RS codeword over GF(2^192), 2^22-point
                   standard-basis domain, localization array [1,2x9], incl. the per-round BLAKE2b Merkle trees, 1 GPU.
   --config cfg4   Aurora 2^20 over GF(2^192) as a STAGE REPLAY (SURVEY.md §3.1 / §8d inventory; the protocol logic that
                   produces the real inputs is a 'next' row): 8 codeword LDEs 2^20 -> 2^25, IFFTs 6 x 2^20 + 1 x 2^21,
-                  Merkle round 0 (4 oracles, cosets of 2) and round 1 (1 oracle), FRI commit from 2^25.  With
+                  Merkle round 0 (4 oracles, cosets of 2) and round 1 (1 oracle), the virtual oracles (fz, row check, lincheck,
+                  sumcheck g), the LDT-reducer combination of 7 oracles, FRI commit from 2^25, the proof of work and (one
+                  GPU) the transcript of 32 queries.  With
                   --gpus N (torchrun) every oracle is sharded by contiguous blocks (libiop_amd/dist.py, no data-path
                   collective; N sub-roots all-gathered per tree).
 Prints one JSON line with per-stage milliseconds (wall, synchronised) and the per-kernel HIP-event times.
@@ -172,7 +177,7 @@ def main():
         extra = {"roots": [r.hex()[:16] for r in res.roots], "final_poly_len": int(res.final_polynomial.shape[0])}
     else:
         n_loc = (1 << m) // world
-        prewarm(torch, dev, 12, n_loc * 24)
+        prewarm(torch, dev, 16, n_loc * 24)
         coeffs = [rand_dev(1 << d, 0x2204 + k) for k in range(8)]
         lib.additive_LDE_dev(coeffs[0].data_ptr(), 1 << d, basis, shift, 0, 1, torch.empty((1 << d, 3), dtype=torch.int64, device=dev).data_ptr())
         cws = []
@@ -189,11 +194,27 @@ def main():
                 timed("ifft_6x2^20+1x2^21", lambda: lib.additive_IFFT_dev(cws[6].data_ptr(), b21, shift, tmp.data_ptr()))
         r0 = timed("merkle_round0(4 oracles,c=2)", lambda: idist.sharded_merkle_root(lib, torch, dist, cws[:4], n_loc, 2, rank, world))[0]
         r1 = timed("merkle_round1(1 oracle,c=2)", lambda: idist.sharded_merkle_root(lib, torch, dist, cws[7:8], n_loc, 2, rank, world))[0]
+        # virtual oracles evaluated over the whole codeword domain before the LDT reducer reads them (r1cs_rs_iop.tcc:181-222,
+        # rowcheck.tcc:16-88, basic_lincheck_aux.tcc:102-144, sumcheck.tcc:58-119); pointwise, so a rank works on its block over
+        # its local sub-domain.  Inputs are the replay's codewords (right sizes, synthetic values).
+        b_loc, s_loc = idist.local_subdomain(basis, shift, rank, world)
+        zero3, mu = np.zeros(3, dtype=np.uint64), np.array([5, 6, 7], dtype=np.uint64)
+        vo_out = [torch.empty_like(cws[0]) for _ in range(4)]
+        r3 = np.random.default_rng(8).integers(0, 2**63, size=(3, 3), dtype=np.uint64)
+
+        def virtual_oracles():
+            lib.fz_dev(cws[0].data_ptr(), cws[5].data_ptr(), b_loc, s_loc, basis[:4], zero3, vo_out[0].data_ptr())
+            lib.rowcheck_dev(cws[1].data_ptr(), cws[2].data_ptr(), cws[3].data_ptr(), b_loc, s_loc, d, zero3, vo_out[1].data_ptr())
+            lib.lincheck_dev(vo_out[0].data_ptr(), [cws[1].data_ptr(), cws[2].data_ptr(), cws[3].data_ptr()], r3, cws[5].data_ptr(),
+                             cws[6].data_ptr(), n_loc, vo_out[2].data_ptr())
+            lib.sumcheck_g_dev(vo_out[2].data_ptr(), cws[7].data_ptr(), b_loc, s_loc, basis[:d], zero3, mu, vo_out[3].data_ptr())
+        virtual_oracles()
+        timed("virtual_oracles(fz, rowcheck, lincheck, sumcheck g)", virtual_oracles)
+        del vo_out
         # LDT reducer: the random combination of the round's oracles that FRI is run on (ldt_reducer_aux.tcc:39-131); pointwise, so
         # a rank combines its own block over its local sub-domain.  Aurora-like degree spread (one maximal oracle).
         degrees = [(1 << (d + 1)) - 1, 1 << d, 1 << d, 1 << d, (1 << d) + 2 * 41 - 1, (1 << (d + 1)) - 2, (1 << d) - 1]
         rcoef = np.random.default_rng(7).integers(0, 2**63, size=(2 * len(degrees), 3), dtype=np.uint64)
-        b_loc, s_loc = idist.local_subdomain(basis, shift, rank, world)
         comb = torch.empty_like(cws[0])
         ldt = lambda: lib.ldt_combine_dev([c.data_ptr() for c in cws[:7]], degrees, rcoef, b_loc, s_loc, comb.data_ptr())
         ldt()
