@@ -204,6 +204,28 @@ __global__ void __launch_bounds__(256) k_lincheck_fp(LincheckParams p)
     }
 }
 
+// The subspace polynomial of span(basis[0..dim)): prod_{v in span} (X - v), a linearized polynomial (coeff[i] multiplies
+// X^(2^i)), built factor by factor as Z <- Z(X) (Z(X) + Z(b)) (libiop/algebra/polynomials/vanishing_polynomial.tcc:373-395).
+// The vanishing polynomial of the affine subspace span + shift is eval(X) + eval(shift).
+struct SubspacePoly {
+    std::vector<hgf192> coeff;
+    SubspacePoly(const uint64_t *basis, size_t dim) : coeff(1, hgf192::one())
+    {
+        for (size_t k = 0; k < dim; ++k) {
+            const hgf192 zb = eval(hgf192::from_words(basis + 3 * k));
+            std::vector<hgf192> nxt(coeff.size() + 1, hgf192::zero());
+            for (size_t i = 0; i < coeff.size(); ++i) { nxt[i + 1] += coeff[i].squared(); nxt[i] += coeff[i] * zb; }
+            coeff.swap(nxt);
+        }
+    }
+    hgf192 eval(const hgf192 &x) const
+    {
+        hgf192 r = hgf192::zero(), xp = x;
+        for (size_t i = 0; i < coeff.size(); ++i) { r += coeff[i] * xp; xp = xp.squared(); }
+        return r;
+    }
+};
+
 static int vo_grid(size_t n)
 {
     size_t g = (n + 255) / 256;
@@ -227,16 +249,8 @@ int iopx_rowcheck_gf192_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const ui
     const size_t h = constraint_dim, cosets = (size_t)1 << (m - h);
     // Z_H = prod_{v in H} (X - v): the subspace polynomial of span(basis[0..h)) built factor by factor, Z <- Z(X) (Z(X) + Z(b)),
     // shifted by its value at shift_H (vanishing_polynomial.tcc:373-395)
-    std::vector<hgf192> lin(1, hgf192::one());             // lin[i] multiplies X^(2^i)
-    for (size_t k = 0; k < h; ++k) {
-        const hgf192 b = hgf192::from_words(basis + 3 * k);
-        hgf192 zb = hgf192::zero(), bp = b;
-        for (size_t i = 0; i < lin.size(); ++i) { zb += lin[i] * bp; bp = bp.squared(); }
-        std::vector<hgf192> nxt(lin.size() + 1, hgf192::zero());
-        for (size_t i = 0; i < lin.size(); ++i) { nxt[i + 1] += lin[i].squared(); nxt[i] += lin[i] * zb; }
-        lin.swap(nxt);
-    }
-    auto eval = [&](const hgf192 &x) { hgf192 r = hgf192::zero(), xp = x; for (size_t i = 0; i < lin.size(); ++i) { r += lin[i] * xp; xp = xp.squared(); } return r; };
+    const SubspacePoly lin(basis, h);
+    auto eval = [&](const hgf192 &x) { return lin.eval(x); };
     const hgf192 z_shift = eval(hgf192::from_words(constraint_shift));
     std::vector<uint64_t> zinv(3 * cosets);
     for (size_t c = 0; c < cosets; ++c) {
@@ -298,16 +312,8 @@ int iopx_fz_gf192_dev(const uint64_t *d_fw, const uint64_t *d_f1v, const uint64_
     if (!d_fw || !d_f1v || !d_out || (m > 0 && !basis) || !shift || (input_dim > 0 && !input_basis) || !input_shift)
         return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
     if (input_dim > m || m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "Codeword domain must be bigger than the input variable domain.");
-    std::vector<hgf192> lin(1, hgf192::one());             // Z_I's linear part: lin[i] multiplies X^(2^i)
-    for (size_t k = 0; k < input_dim; ++k) {
-        const hgf192 b = hgf192::from_words(input_basis + 3 * k);
-        hgf192 zb = hgf192::zero(), bp = b;
-        for (size_t i = 0; i < lin.size(); ++i) { zb += lin[i] * bp; bp = bp.squared(); }
-        std::vector<hgf192> nxt(lin.size() + 1, hgf192::zero());
-        for (size_t i = 0; i < lin.size(); ++i) { nxt[i + 1] += lin[i].squared(); nxt[i] += lin[i] * zb; }
-        lin.swap(nxt);
-    }
-    auto eval = [&](const hgf192 &x) { hgf192 r = hgf192::zero(), xp = x; for (size_t i = 0; i < lin.size(); ++i) { r += lin[i] * xp; xp = xp.squared(); } return r; };
+    const SubspacePoly lin(input_basis, input_dim);       // Z_I's linear part
+    auto eval = [&](const hgf192 &x) { return lin.eval(x); };
     std::vector<uint64_t> tab(3 * (m + 1));
     const hgf192 t0 = eval(hgf192::from_words(shift)) + eval(hgf192::from_words(input_shift));      // Z_I(shift) = lin(shift) + lin(shift_I)
     memcpy(&tab[0], t0.w, 24);
@@ -352,18 +358,10 @@ int iopx_sumcheck_g_gf192_dev(const uint64_t *d_f, const uint64_t *d_h, const ui
     if (!d_f || !d_h || !d_out || (m > 0 && !basis) || !shift || (summation_dim > 0 && !summation_basis) || !summation_shift || !claimed_sum)
         return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
     if (m > 40 || summation_dim > 63) return fail(IOPX_ERR_INVALID_ARGUMENT, "domain dimension too large");
-    std::vector<hgf192> lin(1, hgf192::one());             // Z_H's linear part: lin[i] multiplies X^(2^i)
-    for (size_t k = 0; k < summation_dim; ++k) {
-        const hgf192 b = hgf192::from_words(summation_basis + 3 * k);
-        hgf192 zb = hgf192::zero(), bp = b;
-        for (size_t i = 0; i < lin.size(); ++i) { zb += lin[i] * bp; bp = bp.squared(); }
-        std::vector<hgf192> nxt(lin.size() + 1, hgf192::zero());
-        for (size_t i = 0; i < lin.size(); ++i) { nxt[i + 1] += lin[i].squared(); nxt[i] += lin[i] * zb; }
-        lin.swap(nxt);
-    }
-    auto eval = [&](const hgf192 &x) { hgf192 r = hgf192::zero(), xp = x; for (size_t i = 0; i < lin.size(); ++i) { r += lin[i] * xp; xp = xp.squared(); } return r; };
-    if (lin[0].is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the summation domain's basis is linearly dependent");
-    const hgf192 c = lin[0].inverse() * hgf192::from_words(claimed_sum);         // eps^-1 mu (sumcheck.tcc:52-54)
+    const SubspacePoly lin(summation_basis, summation_dim);   // Z_H's linear part
+    auto eval = [&](const hgf192 &x) { return lin.eval(x); };
+    if (lin.coeff[0].is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the summation domain's basis is linearly dependent");
+    const hgf192 c = lin.coeff[0].inverse() * hgf192::from_words(claimed_sum);   // eps^-1 mu (sumcheck.tcc:52-54)
     std::vector<uint64_t> xtab(3 * (m + 1)), htab(3 * (m + 1)), ztab(3 * (m + 1));
     for (size_t k = 0; k <= m; ++k) {
         const hgf192 v = hgf192::from_words(k == 0 ? shift : basis + 3 * (k - 1));
