@@ -180,18 +180,31 @@ def main():
         prewarm(torch, dev, 16, n_loc * 24)
         coeffs = [rand_dev(1 << d, 0x2204 + k) for k in range(8)]
         lib.additive_LDE_dev(coeffs[0].data_ptr(), 1 << d, basis, shift, 0, 1, torch.empty((1 << d, 3), dtype=torch.int64, device=dev).data_ptr())
-        cws = []
-        for k in range(8):
-            cws.append(timed("lde_fft_x8", lambda k=k: idist.sharded_lde(lib, torch, coeffs[k], (1 << d) - (16 if k == 0 else 0), basis, shift, rank, world)))
+        lib.synchronize()
+        # the eight codewords of the round share one domain: one batched call (phase 1 of the transforms runs once)
+        cws = timed("lde_fft_x8", lambda: idist.sharded_lde_batch(lib, torch, coeffs, 1 << d, basis, shift, rank, world))
+        # interpolation back to coefficients touches only the first 2^20 / 2^21 evaluations (rank 0's block); the stage is timed
+        # on every rank (timed() is collective)
+        b20, b21 = libiop_amd.standard_basis(d), libiop_amd.standard_basis(d + 1)
+        z3 = np.zeros(3, dtype=np.uint64)
         if rank == 0:
-            b20, b21 = libiop_amd.standard_basis(d), libiop_amd.standard_basis(d + 1)
-            tmp = torch.empty((1 << (d + 1), 3), dtype=torch.int64, device=dev)
-            lib.additive_IFFT_dev(cws[0].data_ptr(), b20, np.zeros(3, dtype=np.uint64), tmp.data_ptr())
-            for k in range(6):
-                timed("ifft_6x2^20+1x2^21", lambda k=k: lib.additive_IFFT_dev(cws[k].data_ptr(), b20, np.zeros(3, dtype=np.uint64), tmp.data_ptr()))
-            if n_loc >= (1 << (d + 1)):
-                lib.additive_IFFT_dev(cws[6].data_ptr(), b21, shift, tmp.data_ptr())
-                timed("ifft_6x2^20+1x2^21", lambda: lib.additive_IFFT_dev(cws[6].data_ptr(), b21, shift, tmp.data_ptr()))
+            tmp = torch.empty((6 << d, 3), dtype=torch.int64, device=dev)
+            tmp21 = torch.empty((1 << (d + 1), 3), dtype=torch.int64, device=dev)
+
+        def ifft6():            # six interpolations over the same 2^20-point domain, batched (inputs gathered back to back)
+            if rank != 0:
+                return
+            src = torch.cat([cws[k][: 1 << d] for k in range(6)], 0)
+            idist._torch_sync(torch, src)
+            lib.additive_IFFT_batch_dev(src.data_ptr(), 6, b20, z3, tmp.data_ptr())
+
+        def ifft21():
+            if rank == 0 and n_loc >= (1 << (d + 1)):
+                lib.additive_IFFT_dev(cws[6].data_ptr(), b21, shift, tmp21.data_ptr())
+        ifft6()
+        ifft21()
+        timed("ifft_6x2^20+1x2^21", ifft6)
+        timed("ifft_6x2^20+1x2^21", ifft21)
         r0 = timed("merkle_round0(4 oracles,c=2)", lambda: idist.sharded_merkle_root(lib, torch, dist, cws[:4], n_loc, 2, rank, world))[0]
         r1 = timed("merkle_round1(1 oracle,c=2)", lambda: idist.sharded_merkle_root(lib, torch, dist, cws[7:8], n_loc, 2, rank, world))[0]
         # virtual oracles evaluated over the whole codeword domain before the LDT reducer reads them (r1cs_rs_iop.tcc:181-222,

@@ -77,6 +77,15 @@ int iopx_add_ifft_gf192_dev(const uint64_t *d_evals, const uint64_t *basis, size
                             uint64_t *d_out);
 int iopx_add_ifft_gf192(const uint64_t *evals, const uint64_t *basis, size_t m, const uint64_t *shift,
                         uint64_t *out);
+/* Batched forms for several vectors over the SAME domain (Aurora transforms f_w, f_Az, f_Bz, f_Cz, ... one after the other,
+ * r1cs_rs_iop.tcc:459-568): a 2^20-point transform is latency-bound per pass, so the vectors share every launch.
+ *   iopx_add_ifft_gf192_batch_dev   `batch` inverse transforms, vectors back to back (batch * 2^m elements in and out)
+ *   iopx_add_lde_gf192_batch_dev    `batch` low-degree extensions: host arrays of device pointers, polynomial k with n_coeffs
+ *                                   coefficients -> the coset range of its transform at d_outs[k] (as iopx_add_lde_gf192_dev) */
+int iopx_add_ifft_gf192_batch_dev(const uint64_t *d_evals, size_t batch, const uint64_t *basis, size_t m, const uint64_t *shift,
+                                  uint64_t *d_out);
+int iopx_add_lde_gf192_batch_dev(const uint64_t *const *d_coeffs, size_t n_coeffs, size_t batch, const uint64_t *basis, size_t m,
+                                 const uint64_t *shift, size_t coset_begin, size_t coset_count, uint64_t *const *d_outs);
 
 /* Building blocks of ONE transform sharded across GPUs (libiop_amd/dist.py).  The top log2(N) levels of
  * additive_FFT touch index bits that live on different GPUs; dist.py runs them with these calls plus peer exchanges.

@@ -34,7 +34,7 @@ DOMAIN_MULTIPLICATIVE = 1
 EXPORTED_SYMBOLS = [
     "iopx_version", "iopx_last_error", "iopx_device_count", "iopx_init", "iopx_set_stream", "iopx_synchronize",
     "iopx_malloc", "iopx_free", "iopx_memcpy_h2d", "iopx_memcpy_d2h", "iopx_clear_plans",
-    "iopx_add_fft_gf192_dev", "iopx_add_fft_gf192", "iopx_add_lde_gf192_dev", "iopx_add_taylor_gf192_dev", "iopx_gf192_pow_table_dev", "iopx_add_combine_gf192_dev", "iopx_add_ifft_gf192_dev", "iopx_add_ifft_gf192",
+    "iopx_add_fft_gf192_dev", "iopx_add_fft_gf192", "iopx_add_lde_gf192_dev", "iopx_add_taylor_gf192_dev", "iopx_gf192_pow_table_dev", "iopx_add_combine_gf192_dev", "iopx_add_ifft_gf192_dev", "iopx_add_ifft_gf192", "iopx_add_ifft_gf192_batch_dev", "iopx_add_lde_gf192_batch_dev",
     "iopx_fri_fold_add_gf192_dev", "iopx_fri_fold_add_gf192",
     "iopx_mul_fft_fp3_dev", "iopx_mul_fft_fp3", "iopx_mul_ifft_fp3_dev", "iopx_mul_ifft_fp3",
     "iopx_mul_ifft_known_degree_fp3_dev", "iopx_fri_fold_mul_fp3_dev", "iopx_fri_fold_mul_fp3",
@@ -127,6 +127,8 @@ class Library:
         c.iopx_add_combine_gf192_dev.argtypes = [_vp, _vp, _vp, _sz, _sz, _u64p, _sz, _u64p, ctypes.c_int]
         c.iopx_add_ifft_gf192_dev.argtypes = [_vp, _u64p, _sz, _u64p, _vp]
         c.iopx_add_ifft_gf192.argtypes = [_u64p, _u64p, _sz, _u64p, _u64p]
+        c.iopx_add_ifft_gf192_batch_dev.argtypes = [_vp, _sz, _u64p, _sz, _u64p, _vp]
+        c.iopx_add_lde_gf192_batch_dev.argtypes = [ctypes.POINTER(_vp), _sz, _sz, _u64p, _sz, _u64p, _sz, _sz, ctypes.POINTER(_vp)]
         c.iopx_fri_fold_add_gf192_dev.argtypes = [_vp, _u64p, _sz, _u64p, _sz, _u64p, _vp]
         c.iopx_fri_fold_add_gf192.argtypes = [_u64p, _u64p, _sz, _u64p, _sz, _u64p, _u64p]
         c.iopx_mul_fft_fp3_dev.argtypes = [_vp, _sz, _sz, _u64p, _u64p, _vp]
@@ -538,6 +540,19 @@ class Library:
         basis, shift = _as_u64(basis), _as_u64(shift)
         self._check(self.c.iopx_add_lde_gf192_dev(_vp(d_coeffs), n_coeffs, basis.ctypes.data_as(_u64p), basis.shape[0],
                                                   shift.ctypes.data_as(_u64p), coset_begin, coset_count, _vp(d_out)))
+
+    def additive_IFFT_batch_dev(self, d_evals, batch, basis, shift, d_out):
+        """`batch` inverse transforms over one domain, vectors back to back."""
+        basis, shift = _as_u64(basis), _as_u64(shift)
+        self._check(self.c.iopx_add_ifft_gf192_batch_dev(_vp(d_evals), int(batch), basis.ctypes.data_as(_u64p), basis.shape[0],
+                                                         shift.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def additive_LDE_batch_dev(self, d_coeffs, n_coeffs, basis, shift, coset_begin, coset_count, d_outs):
+        """Low-degree extensions of several polynomials (lists of device pointers) over one domain; phase 1 runs once."""
+        basis, shift = _as_u64(basis), _as_u64(shift)
+        cin, cout = (_vp * len(d_coeffs))(*d_coeffs), (_vp * len(d_outs))(*d_outs)
+        self._check(self.c.iopx_add_lde_gf192_batch_dev(cin, int(n_coeffs), len(d_coeffs), basis.ctypes.data_as(_u64p), basis.shape[0],
+                                                        shift.ctypes.data_as(_u64p), int(coset_begin), int(coset_count), cout))
 
     def taylor_dev(self, d_S, log_n, d_twist=0):
         self._check(self.c.iopx_add_taylor_gf192_dev(_vp(d_S), log_n, _vp(d_twist)))

@@ -180,10 +180,11 @@ __global__ void __launch_bounds__(512) k_phase1(P1Params p)
     const size_t mid = o & (((size_t)1 << midbits) - 1), hi = o >> midbits;
     const size_t base = (hi << (p.h + p.A)) | (mid << p.c);
     const int cmask = (1 << p.c) - 1;
+    uint64_t *S = p.S + 3 * ((size_t)blockIdx.y << p.d);      // blockIdx.y: which vector of a batch (same domain, same tables)
 
     for (int li = tid; li < E; li += nt) {
         const size_t gi = base | ((size_t)(li >> p.c) << p.h) | (size_t)(li & cmask);
-        lds_put(s, E, li, gf_load(p.S, gi));
+        lds_put(s, E, li, gf_load(S, gi));
     }
     __syncthreads();
 
@@ -236,7 +237,7 @@ __global__ void __launch_bounds__(512) k_phase1(P1Params p)
 
     for (int li = tid; li < E; li += nt) {
         const size_t gi = base | ((size_t)(li >> p.c) << p.h) | (size_t)(li & cmask);
-        gf_store(p.S, gi, lds_get(s, E, li));
+        gf_store(S, gi, lds_get(s, E, li));
     }
 }
 
@@ -615,8 +616,10 @@ static std::vector<P1Pass> phase1_schedule(int d)
     return sched;
 }
 
+// `batch` vectors of 2^d elements stored back to back share every launch (grid.y): small transforms are latency-bound per
+// pass, so a batch costs little more than one
 template<bool INV>
-static int run_phase1(AddPlan &pl, uint64_t *S)
+static int run_phase1(AddPlan &pl, uint64_t *S, size_t batch = 1)
 {
     const int d = pl.d;
     if (d == 0) return IOPX_OK;
@@ -642,7 +645,7 @@ static int run_phase1(AddPlan &pl, uint64_t *S)
         static char names[64][2][32];
         char *nm = names[ps.j0 & 63][ps.k_start == d - 2 ? 1 : 0];
         if (!nm[0]) snprintf(nm, 32, getenv("IOPX_PROFILE_LEVELS") ? "k_phase1_L%02d_%s" : "k_phase1", ps.j0, ps.k_start == d - 2 ? "tw" : "x");
-        { ProfScope ps_(nm); hipLaunchKernelGGL(k_phase1<INV>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        { ProfScope ps_(nm); hipLaunchKernelGGL(k_phase1<INV>, dim3((unsigned)blocks, (unsigned)batch), dim3(threads), lds, stream(), p); }
     }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
@@ -741,10 +744,11 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
 
     int rc;
     if (INV) {
-        rc = launch_edge(src, dst, 0, 1, 0);
+        // nhi = 0: the "cosets" of the unit index are the vectors of a batch (identical twiddles)
+        rc = launch_edge(src, dst, 0, cosets, 0);
         if (rc != IOPX_OK) return rc;
         for (size_t i = ups.size(); i-- > 0; ) {
-            rc = launch_upper(ups[i], dst, dst, 0, 1, 0);
+            rc = launch_upper(ups[i], dst, dst, 0, cosets, 0);
             if (rc != IOPX_OK) return rc;
         }
     } else if (ups.empty()) {
@@ -885,6 +889,87 @@ int iopx_add_ifft_gf192_dev(const uint64_t *d_evals, const uint64_t *basis, size
     if (rc != IOPX_OK) return rc;
     rc = run_phase1<true>(*pl, d_out);
     if (rc != IOPX_OK) return rc;
+    return IOPX_OK;
+}
+
+// `batch` inverse transforms over the same domain, vectors stored back to back (d_evals and d_out: batch * 2^m elements)
+int iopx_add_ifft_gf192_batch_dev(const uint64_t *d_evals, size_t batch, const uint64_t *basis, size_t m, const uint64_t *shift,
+                                  uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    rc = check_basis_args(basis, m, shift);
+    if (rc != IOPX_OK) return rc;
+    if (!d_evals || !d_out) return fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
+    if (batch == 0 || batch > 65535) return fail(IOPX_ERR_INVALID_ARGUMENT, "batch size %zu outside 1..65535", batch);
+    const size_t bytes = (batch * 24) << m;
+    if (m == 0) {
+        IOPX_HIP(hipMemcpyAsync(d_out, d_evals, bytes, hipMemcpyDeviceToDevice, stream()));
+        return IOPX_OK;
+    }
+    AddPlan *pl = nullptr;
+    rc = get_plan(basis, (int)m, &pl);
+    if (rc != IOPX_OK) return rc;
+    rc = upload_rs(*pl, hgf192::from_words(shift), nullptr, 0);
+    if (rc != IOPX_OK) return rc;
+    const uint64_t *src = d_evals;
+    TmpBuf tmp;
+    if (d_evals == d_out) {     // the first pass permutes: it cannot run in place
+        rc = tmp.alloc(bytes);
+        if (rc != IOPX_OK) return rc;
+        IOPX_HIP(hipMemcpyAsync(tmp.p, d_evals, bytes, hipMemcpyDeviceToDevice, stream()));
+        src = tmp.u64();
+    }
+    rc = run_phase2<true>(*pl, src, d_out, 0, 0, batch);
+    if (rc != IOPX_OK) return rc;
+    return run_phase1<true>(*pl, d_out, batch);
+}
+
+// `batch` low-degree extensions over the same domain: polynomial k (n_coeffs coefficients at d_coeffs[k]) -> cosets
+// [coset_begin, +coset_count) of its transform at d_outs[k].  Phase 1 runs once for the whole batch.
+int iopx_add_lde_gf192_batch_dev(const uint64_t *const *d_coeffs, size_t n_coeffs, size_t batch, const uint64_t *basis, size_t m,
+                                 const uint64_t *shift, size_t coset_begin, size_t coset_count, uint64_t *const *d_outs)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    rc = check_basis_args(basis, m, shift);
+    if (rc != IOPX_OK) return rc;
+    if (!d_coeffs || !d_outs) return fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
+    if (batch == 0 || batch > 65535) return fail(IOPX_ERR_INVALID_ARGUMENT, "batch size %zu outside 1..65535", batch);
+    for (size_t k = 0; k < batch; ++k) if (!d_coeffs[k] || !d_outs[k]) return fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
+    const size_t n = (size_t)1 << m;
+    if (n_coeffs > n) return fail(IOPX_ERR_INVALID_ARGUMENT, "additive FFT: %zu coefficients exceed the domain size %zu", n_coeffs, n);
+    if (n_coeffs <= 1 || batch == 1) {
+        for (size_t k = 0; k < batch; ++k) {
+            rc = iopx_add_lde_gf192_dev(d_coeffs[k], n_coeffs, basis, m, shift, coset_begin, coset_count, d_outs[k]);
+            if (rc != IOPX_OK) return rc;
+        }
+        return IOPX_OK;
+    }
+    const int d = (int)ceil_log2(n_coeffs);
+    const int nhi = (int)m - d;
+    const size_t all_cosets = (size_t)1 << nhi;
+    if (coset_count == 0 || coset_begin >= all_cosets || coset_count > all_cosets - coset_begin)
+        return fail(IOPX_ERR_INVALID_ARGUMENT, "coset range [%zu, +%zu) outside the %zu cosets of the transform", coset_begin, coset_count, all_cosets);
+    AddPlan *pl = nullptr;
+    rc = get_plan(basis, d, &pl);
+    if (rc != IOPX_OK) return rc;
+    rc = upload_rs(*pl, hgf192::from_words(shift), basis + 3 * (size_t)d, nhi);
+    if (rc != IOPX_OK) return rc;
+    const size_t nd = (size_t)1 << d;
+    TmpBuf work;
+    rc = work.alloc(batch * nd * 24);
+    if (rc != IOPX_OK) return rc;
+    for (size_t k = 0; k < batch; ++k) {
+        ProfScope ps_("k_pad_copy");
+        hipLaunchKernelGGL(k_pad_copy, dim3(grid_for(3 * nd, 256)), dim3(256), 0, stream(), work.u64() + 3 * k * nd, d_coeffs[k], n_coeffs, nd);
+    }
+    rc = run_phase1<false>(*pl, work.u64(), batch);
+    if (rc != IOPX_OK) return rc;
+    for (size_t k = 0; k < batch; ++k) {
+        rc = run_phase2<false>(*pl, work.u64() + 3 * k * nd, d_outs[k], nhi, coset_begin, coset_count);
+        if (rc != IOPX_OK) return rc;
+    }
     return IOPX_OK;
 }
 

@@ -47,6 +47,19 @@ def sharded_lde(lib, torch, d_coeffs, n_coeffs, basis, shift, rank, world):
     return out
 
 
+def sharded_lde_batch(lib, torch, d_coeffs_list, n_coeffs, basis, shift, rank, world):
+    """sharded_lde for several polynomials over one domain: phase 1 of the transforms runs once for the batch."""
+    m = np.asarray(basis).shape[0]
+    d = 0 if n_coeffs <= 1 else int(n_coeffs - 1).bit_length()
+    cosets = 1 << (m - d)
+    if cosets % world:
+        raise ValueError("fewer cosets than ranks: use distributed_fft for this transform")
+    per = cosets // world
+    outs = [torch.empty((per << d, 3), dtype=torch.int64, device=c.device) for c in d_coeffs_list]
+    lib.additive_LDE_batch_dev([c.data_ptr() for c in d_coeffs_list], n_coeffs, basis, shift, rank * per, per, [o.data_ptr() for o in outs])
+    return outs
+
+
 def sharded_merkle_root(lib, torch, dist, d_oracles, n_local, coset_size, rank, world):
     """Merkle tree over oracles sharded by contiguous blocks: every rank builds the sub-tree over its leaves; the
     N sub-roots are all-gathered (32 bytes each) and the top log2(N) levels are finished on the host

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
+import libiop_amd
 from emu_lib import emu
 from helpers import rand_elems
 
@@ -168,3 +169,32 @@ def test_sharded_transform_building_blocks():
     for log_n in (1, 2, 5, 10, 12):
         c.check_taylor(emu(), log_n)
     c.check_combine(emu())
+
+
+@pytest.mark.parametrize("m,batch", [(1, 3), (5, 2), (9, 4), (12, 3)])
+def test_batched_ifft(m, batch):
+    lib = emu()
+    basis, shift = rand_elems(40 + m, m, W), rand_elems(41 + m, 1, W)[0]
+    ev = rand_elems(42 + m, batch << m, W)
+    out = np.empty_like(ev)
+    lib._check(lib.c.iopx_add_ifft_gf192_batch_dev(ev.ctypes.data, batch, basis.ctypes.data_as(libiop_amd._u64p), m,
+                                                   shift.ctypes.data_as(libiop_amd._u64p), out.ctypes.data))
+    for k in range(batch):
+        assert np.array_equal(out[k << m:(k + 1) << m], oracle.additive_ifft(ev[k << m:(k + 1) << m], basis, shift)), k
+    # in place
+    lib._check(lib.c.iopx_add_ifft_gf192_batch_dev(ev.ctypes.data, batch, basis.ctypes.data_as(libiop_amd._u64p), m,
+                                                   shift.ctypes.data_as(libiop_amd._u64p), ev.ctypes.data))
+    assert np.array_equal(ev, out)
+
+
+@pytest.mark.parametrize("m,ncoef,batch,cb,cc", [(8, 50, 3, 0, 4), (10, 64, 2, 3, 5), (7, 128, 3, 0, 1), (6, 1, 2, 0, 64), (12, 1000, 4, 1, 2)])
+def test_batched_lde(m, ncoef, batch, cb, cc):
+    lib = emu()
+    basis, shift = rand_elems(50 + m, m, W), rand_elems(51 + m, 1, W)[0]
+    d = 0 if ncoef <= 1 else int(np.ceil(np.log2(ncoef)))
+    polys = [rand_elems(60 + k, ncoef, W) for k in range(batch)]
+    outs = [np.zeros((cc << d, W), dtype=np.uint64) for _ in range(batch)]
+    lib.additive_LDE_batch_dev([p.ctypes.data for p in polys], ncoef, basis, shift, cb, cc, [o.ctypes.data for o in outs])
+    for k in range(batch):
+        full = oracle.additive_fft(polys[k], basis, shift)
+        assert np.array_equal(outs[k], full[cb << d:(cb + cc) << d]), k
