@@ -423,3 +423,41 @@ def test_sumcheck_g_multiplicative(gpu, log_n, slog, seed):
 @pytest.mark.parametrize("n,k,seed,prime", [(16, 3, 1, False), (300, 1, 2, False), (1 << 16, 3, 3, False), (1 << 15, 3, 4, True), (7, 2, 5, True)])
 def test_lincheck(gpu, n, k, seed, prime):
     lc.check_lincheck(gpu, n, k, seed, prime)
+
+
+# ---- batched transforms over one domain ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,batch", [(1, 3), (9, 4), (14, 3), (18, 2)])
+def test_batched_ifft(gpu, m, batch):
+    basis, shift = rand_elems(40 + m, m, W), rand_elems(41 + m, 1, W)[0]
+    ev = rand_elems(42 + m, batch << m, W)
+    d_in, d_out = gpu.malloc(ev.nbytes), gpu.malloc(ev.nbytes)
+    try:
+        gpu.h2d(d_in, ev)
+        gpu.additive_IFFT_batch_dev(d_in, batch, basis, shift, d_out)
+        out = np.empty_like(ev)
+        gpu.d2h(out, d_out)
+    finally:
+        gpu.free(d_in)
+        gpu.free(d_out)
+    for k in range(batch):
+        assert np.array_equal(out[k << m:(k + 1) << m], oracle.additive_ifft(ev[k << m:(k + 1) << m], basis, shift)), k
+
+
+@pytest.mark.parametrize("m,ncoef,batch,cb,cc", [(8, 50, 3, 0, 4), (10, 64, 2, 3, 5), (16, 1 << 12, 4, 1, 2), (6, 1, 2, 0, 64)])
+def test_batched_lde(gpu, m, ncoef, batch, cb, cc):
+    basis, shift = rand_elems(50 + m, m, W), rand_elems(51 + m, 1, W)[0]
+    d = 0 if ncoef <= 1 else int(ncoef - 1).bit_length()
+    polys = [rand_elems(60 + k, ncoef, W) for k in range(batch)]
+    ins = [gpu.malloc(p.nbytes) for p in polys]
+    outs = [gpu.malloc((cc << d) * 24) for _ in polys]
+    try:
+        for b, p in zip(ins, polys):
+            gpu.h2d(b, p)
+        gpu.additive_LDE_batch_dev(ins, ncoef, basis, shift, cb, cc, outs)
+        for k in range(batch):
+            got = np.empty((cc << d, W), dtype=np.uint64)
+            gpu.d2h(got, outs[k])
+            assert np.array_equal(got, oracle.additive_fft(polys[k], basis, shift)[cb << d:(cb + cc) << d]), k
+    finally:
+        for b in ins + outs:
+            gpu.free(b)
