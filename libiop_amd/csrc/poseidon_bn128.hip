@@ -14,6 +14,7 @@
 // is supplied by the caller as canonical integers — libiop holds them in poseidon_params (poseidon.tcc:311-520) — converted
 // to the internal form on the device and cached.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -453,6 +454,101 @@ __global__ void k_poseidon_top(PoseidonDev P, uint64_t *nodes, size_t count)
     }
 }
 
+// ---- small tree levels: one permutation spread over t lanes ------------------------------------------------------------
+// A level with few nodes runs at the LATENCY of one permutation (about 600 dependent field products on one lane).  Here lane
+// (node, e) owns state element e: the S-boxes of a full round and the t output rows of the mixing layer run side by side, the
+// elements cross lanes through LDS (two barriers per round).  About twice faster per level for the dense-MDS sets; partial
+// rounds still wait for the one S-box, so large levels keep the one-lane-per-node kernel (better throughput).
+#define POSEIDON_PAR_NODES 64           // nodes per workgroup (64 * t lanes = t waves: they spread over the CU's four SIMDs)
+
+__device__ __forceinline__ uint32_t *par_slot(uint32_t *lds, int T, int buf, int e, int node) { return lds + ((size_t)(buf * T + e) * 9) * POSEIDON_PAR_NODES + node; }
+__device__ __forceinline__ bn9 par_get(uint32_t *lds, int T, int buf, int e, int node)
+{
+    const uint32_t *q = par_slot(lds, T, buf, e, node);
+    bn9 r;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r.l[i] = q[i * POSEIDON_PAR_NODES];
+    return r;
+}
+__device__ __forceinline__ void par_put(uint32_t *lds, int T, int buf, int e, int node, const bn9 &v)
+{
+    uint32_t *q = par_slot(lds, T, buf, e, node);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) q[i * POSEIDON_PAR_NODES] = v.l[i];
+}
+
+// two-to-one hashes of nodes first .. first + nn - 1 (nn <= POSEIDON_PAR_NODES) by the whole workgroup
+template<int T>
+__device__ __forceinline__ void poseidon_nodes_par(const PoseidonDev &P, uint64_t *nodes, size_t first, int nn, uint32_t *lds)
+{
+    const int lanes = nn * T;
+    for (int t = threadIdx.x; t < lanes; t += blockDim.x) {
+        const int node = t % nn, e = t / nn;
+        // state[0] = left child, state[1] = right child (algebraic_sponge.tcc:256-265), the rest zero
+        par_put(lds, T, 0, e, node, e < 2 ? bn9_load_mont(nodes, 2 * (first + node) + 1 + e) : bn9_zero());
+    }
+    __syncthreads();
+    const int half = P.full_rounds / 2, total = P.full_rounds + P.partial_rounds;
+    const uint32_t *mds = P.consts + 9 * (size_t)total * T;
+    for (int round = 0; round < total; ++round) {
+        const bool full = round < half || round >= half + P.partial_rounds;
+        for (int t = threadIdx.x; t < lanes; t += blockDim.x) {                 // constants and S-boxes (poseidon.tcc:241-271)
+            const int node = t % nn, e = t / nn;
+            bn9 x = bn9_add(par_get(lds, T, 0, e, node), bn9_load_const(P.consts, (size_t)round * T + e));
+            if (P.near_mds || round == 0) x = bn9_reduce(x);
+            if (full || e == T - 1) x = poseidon_sbox(x, P.alpha);
+            else if (!P.near_mds) x = bn9_norm(x);
+            par_put(lds, T, 1, e, node, x);
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < lanes; t += blockDim.x) {                 // mixing layer, one output row per lane (:195-239)
+            const int node = t % nn, e = t / nn;
+            bn9 out;
+            if (P.near_mds) {
+                if constexpr (T == 3) {
+                    // new0 = s0 + s2, new1 = s1 + s0, new2 = s2 + s1
+                    out = bn9_add(par_get(lds, T, 1, e, node), par_get(lds, T, 1, (e + 2) % 3, node));
+                } else {
+                    out = bn9_zero();
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (c != e) out = bn9_add(out, par_get(lds, T, 1, c, node));
+                }
+            } else {
+                bn9 row[T], v[T];
+#pragma unroll
+                for (int c = 0; c < T; ++c) { row[c] = bn9_load_const(mds, e * T + c); v[c] = par_get(lds, T, 1, c, node); }
+                out = bn9_dot<T>(row, v);
+            }
+            par_put(lds, T, 0, e, node, out);
+        }
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < nn; t += blockDim.x) bn9_store_mont(nodes, first + t, par_get(lds, T, 0, 0, t));
+}
+
+template<int T>
+__global__ void __launch_bounds__(POSEIDON_PAR_NODES * T) k_poseidon_level_par(PoseidonDev P, uint64_t *nodes, size_t first, size_t count)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
+    for (size_t base = (size_t)blockIdx.x * POSEIDON_PAR_NODES; base < count; base += (size_t)gridDim.x * POSEIDON_PAR_NODES) {
+        const int nn = count - base < POSEIDON_PAR_NODES ? (int)(count - base) : POSEIDON_PAR_NODES;
+        poseidon_nodes_par<T>(P, nodes, first + base, nn, (uint32_t *)iopx_smem);
+        __syncthreads();
+    }
+}
+
+// the top of the tree in one workgroup: levels of `count`, count / 2, ..., 1 nodes
+template<int T>
+__global__ void __launch_bounds__(POSEIDON_PAR_NODES * T) k_poseidon_top_par(PoseidonDev P, uint64_t *nodes, size_t count)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
+    for (size_t c = count; c >= 1; c >>= 1) {
+        poseidon_nodes_par<T>(P, nodes, c - 1, (int)c, (uint32_t *)iopx_smem);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // Proof-of-work grind, algebraic digests (libiop/bcs/pow.tcc:73-84,129-141): candidate k is FieldT(k); it passes when word 0 of
 // the canonical integer of two_to_one(challenge, k) has its low `bitlen` bits zero.  One lane per candidate, smallest index wins.
 struct PowChallengeBn {
@@ -586,14 +682,30 @@ int iopx_merkle_poseidon_bn128_dev(const iopx_poseidon_params *params, const voi
     p.additive = (domain_type == IOPX_DOMAIN_ADDITIVE);
     { ProfScope ps_("k_poseidon_leaves"); if (P.t == 3) hipLaunchKernelGGL(k_poseidon_leaves<3>, dim3(pgrid(L, 64)), dim3(64), 0, stream(), P, p);
       else hipLaunchKernelGGL(k_poseidon_leaves<4>, dim3(pgrid(L, 64)), dim3(64), 0, stream(), P, p); }
+    // large levels: one lane per node (throughput); levels of at most 2^14 nodes: one permutation over t lanes (latency)
+    static const int par_from = getenv("IOPX_POSEIDON_PAR_BELOW") ? atoi(getenv("IOPX_POSEIDON_PAR_BELOW")) : (1 << 14);
+    const size_t par_lds = (size_t)2 * P.t * 9 * POSEIDON_PAR_NODES * 4;
+    if (P.t == 3) { IOPX_HIP(hipFuncSetAttribute((const void *)k_poseidon_level_par<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)par_lds));
+                    IOPX_HIP(hipFuncSetAttribute((const void *)k_poseidon_top_par<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)par_lds)); }
+    else { IOPX_HIP(hipFuncSetAttribute((const void *)k_poseidon_level_par<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)par_lds));
+           IOPX_HIP(hipFuncSetAttribute((const void *)k_poseidon_top_par<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)par_lds)); }
     size_t count = L / 2;
-    while (count > 256) {
-        { ProfScope ps_("k_poseidon_level"); if (P.t == 3) hipLaunchKernelGGL(k_poseidon_level<3>, dim3(pgrid(count, 64)), dim3(64), 0, stream(), P, d_nodes, count - 1, count);
-          else hipLaunchKernelGGL(k_poseidon_level<4>, dim3(pgrid(count, 64)), dim3(64), 0, stream(), P, d_nodes, count - 1, count); }
+    while (count > POSEIDON_PAR_NODES) {
+        if (count > (size_t)par_from) {
+            ProfScope ps_("k_poseidon_level");
+            if (P.t == 3) hipLaunchKernelGGL(k_poseidon_level<3>, dim3(pgrid(count, 64)), dim3(64), 0, stream(), P, d_nodes, count - 1, count);
+            else hipLaunchKernelGGL(k_poseidon_level<4>, dim3(pgrid(count, 64)), dim3(64), 0, stream(), P, d_nodes, count - 1, count);
+        } else {
+            ProfScope ps_("k_poseidon_level_par");
+            const unsigned grid = (unsigned)((count + POSEIDON_PAR_NODES - 1) / POSEIDON_PAR_NODES);
+            if (P.t == 3) hipLaunchKernelGGL(k_poseidon_level_par<3>, dim3(grid), dim3(POSEIDON_PAR_NODES * 3), par_lds, stream(), P, d_nodes, count - 1, count);
+            else hipLaunchKernelGGL(k_poseidon_level_par<4>, dim3(grid), dim3(POSEIDON_PAR_NODES * 4), par_lds, stream(), P, d_nodes, count - 1, count);
+        }
         count >>= 1;
     }
-    { ProfScope ps_("k_poseidon_top"); if (P.t == 3) hipLaunchKernelGGL(k_poseidon_top<3>, dim3(1), dim3(count >= 256 ? 256 : 64), 0, stream(), P, d_nodes, count);
-      else hipLaunchKernelGGL(k_poseidon_top<4>, dim3(1), dim3(count >= 256 ? 256 : 64), 0, stream(), P, d_nodes, count); }
+    { ProfScope ps_("k_poseidon_top_par");
+      if (P.t == 3) hipLaunchKernelGGL(k_poseidon_top_par<3>, dim3(1), dim3(POSEIDON_PAR_NODES * 3), par_lds, stream(), P, d_nodes, count);
+      else hipLaunchKernelGGL(k_poseidon_top_par<4>, dim3(1), dim3(POSEIDON_PAR_NODES * 4), par_lds, stream(), P, d_nodes, count); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
 }

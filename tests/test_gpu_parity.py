@@ -283,6 +283,8 @@ def test_poseidon_permutation(gpu, name):
     ("test_params", 1, 1, 2, False, False), ("test_params", 1, 2, 8, False, True), ("test_params", 3, 2, 4, True, False),
     ("starkware_alpha5_t3", 2, 4, 64, False, False), ("high_alpha17_t3", 1, 2, 512, False, True), ("high_alpha17_t4", 2, 3, 128, False, True),
     ("high_alpha17_t4", 1, 6, 2, True, False), ("high_alpha17_t3", 4, 2, 4096, False, False), ("starkware_alpha5_t3", 1, 2, 2048, True, True),
+    # 2^16 leaves: the first inner level (2^15 nodes) runs one lane per node, the rest one permutation over t lanes
+    ("starkware_alpha5_t3", 1, 1, 1 << 16, False, False), ("high_alpha17_t4", 1, 1, 1 << 16, False, False),
 ])
 def test_poseidon_merkle(gpu, name, r, cs, L, additive, zk):
     pc.check_merkle(gpu, name, r, cs, L, additive, zk)
