@@ -166,6 +166,7 @@ struct P1Params {
     int c, h, A;            // tile = columns on bits [0,c) x rows on bits [h, h+A)
     int j0, j1;             // levels handled by this pass
     int k_start, k_end;     // first op of level j0, last op of level j1 (ops run k = d-2 .. j)
+    int xcd_remap;
 };
 
 template<bool INV>
@@ -176,7 +177,9 @@ __global__ void __launch_bounds__(512) k_phase1(P1Params p)
     const int tid = threadIdx.x, nt = blockDim.x;
     const int E = 1 << (p.c + p.A);
     const int midbits = p.h - p.c;
-    const size_t o = blockIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Neighbouring tiles share cache lines when a tile
+    // row is narrower than a line (2^c * 24 bytes), so consecutive tiles are kept on one XCD: tile = (id % 8) * (grid / 8) + id / 8.
+    const size_t o = (p.xcd_remap && (gridDim.x & 7) == 0) ? (size_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (size_t)blockIdx.x;
     const size_t mid = o & (((size_t)1 << midbits) - 1), hi = o >> midbits;
     const size_t base = (hi << (p.h + p.A)) | (mid << p.c);
     const int cmask = (1 << p.c) - 1;
@@ -636,6 +639,7 @@ static int run_phase1(AddPlan &pl, uint64_t *S, size_t batch = 1)
         p.pow = INV ? pl.pow_inv.u64() : pl.pow_fwd.u64();
         p.d = d; p.c = ps.c; p.h = ps.h; p.A = ps.A;
         p.j0 = ps.j0; p.j1 = ps.j1; p.k_start = ps.k_start; p.k_end = ps.k_end;
+        p.xcd_remap = env_int("IOPX_XCD_REMAP", 1, 0, 1);
         const int tbits = ps.c + ps.A;
         const size_t lds = ((size_t)24) << tbits;
         const size_t blocks = (size_t)1 << (d - tbits);
@@ -1081,6 +1085,7 @@ int iopx_add_taylor_gf192_dev(uint64_t *d_S, size_t log_n, const uint64_t *d_twi
         p.S = d_S; p.pow = d_twist;
         p.d = d; p.c = ps.c; p.h = ps.h; p.A = ps.A;
         p.j0 = 0; p.j1 = 0; p.k_start = ps.k_start; p.k_end = ps.k_end;
+        p.xcd_remap = 0;
         const int tbits = ps.c + ps.A;
         const size_t lds = ((size_t)24) << tbits;
         const size_t blocks = (size_t)1 << (d - tbits);
