@@ -94,22 +94,33 @@ __global__ void k_merkle_leaves(LeafParams p)
 {
     const size_t words_total = p.num_oracles * p.coset_size * p.elem_words;
     const size_t bytes_total = words_total * 8;
-    const size_t cw = p.coset_size * p.elem_words;      // words contributed by one oracle
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.num_leaves; i += (size_t)gridDim.x * blockDim.x) {
         uint64_t h[8];
         b2b_init(h);
         size_t done = 0;                                // words consumed
+        // the serialisation cursor (oracle k, position j in the coset, word ww of the element) is the same for every lane: it
+        // advances by counting, never by dividing (a 64-bit division costs about as much as a BLAKE2b round)
+        uint32_t k = 0, j = 0, ww = 0;
+        const uint64_t *cur = p.oracles[0];
+        // position_by_coset_indices: subspace.tcc:86-91 / subgroup.tcc:191-197
+        size_t pos = p.additive ? i * p.coset_size : i;
+        const size_t pos_step = p.additive ? 1 : p.num_leaves;
         while (true) {
             uint64_t m[16];
 #pragma unroll
             for (int w = 0; w < 16; ++w) {
-                const size_t g = done + w;
                 uint64_t val = 0;
-                if (g < words_total) {
-                    const size_t k = g / cw, r = g % cw, j = r / p.elem_words, ww = r % p.elem_words;
-                    // position_by_coset_indices: subspace.tcc:86-91 / subgroup.tcc:191-197
-                    const size_t pos = p.additive ? i * p.coset_size + j : i + j * p.num_leaves;
-                    val = p.oracles[k][pos * p.elem_words + ww];
+                if (k < p.num_oracles) {
+                    val = cur[pos * p.elem_words + ww];
+                    if (++ww == p.elem_words) {
+                        ww = 0;
+                        pos += pos_step;
+                        if (++j == p.coset_size) {
+                            j = 0;
+                            pos = p.additive ? i * p.coset_size : i;
+                            if (++k < p.num_oracles) cur = p.oracles[k];
+                        }
+                    }
                 }
                 m[w] = val;
             }
