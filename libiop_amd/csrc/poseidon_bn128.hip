@@ -482,8 +482,9 @@ template<int T>
 __device__ __forceinline__ void poseidon_nodes_par(const PoseidonDev &P, uint64_t *nodes, size_t first, int nn, uint32_t *lds)
 {
     const int lanes = nn * T;
+    const int nn_log = 31 - __builtin_clz((unsigned)nn);        // nn is a power of two (tree levels are)
     for (int t = threadIdx.x; t < lanes; t += blockDim.x) {
-        const int node = t % nn, e = t / nn;
+        const int node = t & (nn - 1), e = t >> nn_log;
         // state[0] = left child, state[1] = right child (algebraic_sponge.tcc:256-265), the rest zero
         par_put(lds, T, 0, e, node, e < 2 ? bn9_load_mont(nodes, 2 * (first + node) + 1 + e) : bn9_zero());
     }
@@ -493,7 +494,7 @@ __device__ __forceinline__ void poseidon_nodes_par(const PoseidonDev &P, uint64_
     for (int round = 0; round < total; ++round) {
         const bool full = round < half || round >= half + P.partial_rounds;
         for (int t = threadIdx.x; t < lanes; t += blockDim.x) {                 // constants and S-boxes (poseidon.tcc:241-271)
-            const int node = t % nn, e = t / nn;
+            const int node = t & (nn - 1), e = t >> nn_log;
             bn9 x = bn9_add(par_get(lds, T, 0, e, node), bn9_load_const(P.consts, (size_t)round * T + e));
             if (P.near_mds || round == 0) x = bn9_reduce(x);
             if (full || e == T - 1) x = poseidon_sbox(x, P.alpha);
@@ -502,7 +503,7 @@ __device__ __forceinline__ void poseidon_nodes_par(const PoseidonDev &P, uint64_
         }
         __syncthreads();
         for (int t = threadIdx.x; t < lanes; t += blockDim.x) {                 // mixing layer, one output row per lane (:195-239)
-            const int node = t % nn, e = t / nn;
+            const int node = t & (nn - 1), e = t >> nn_log;
             bn9 out;
             if (P.near_mds) {
                 if constexpr (T == 3) {

@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) k_rowcheck_fp(uint64_t *out, const uint64
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
         const fp3 ab = fp_mul(fp_load(az, j), fp_load(bz, j));
         const fp3 c = fp_mul(fp_load(cz, j), one);
-        fp_store(out, j, fp_mul(fp_sub(ab, c), fp_load(zinv_scaled, j % num_cosets)));
+        fp_store(out, j, fp_mul(fp_sub(ab, c), fp_load(zinv_scaled, j & (num_cosets - 1))));
     }
 }
 
