@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libiop_amd.so")
+LIB_PATH = os.environ.get("IOPX_LIB_PATH") or os.path.join(_HERE, "lib", "libiop_amd.so")     # override: A/B runs of two builds
 
 IOPX_OK = 0
 IOPX_ERR_INVALID_ARGUMENT = -1
