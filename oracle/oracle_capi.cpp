@@ -11,6 +11,7 @@
 #include "poseidon.hpp"
 #include "pow.hpp"
 #include "ldt.hpp"
+#include "aurora.hpp"
 
 using namespace oracle;
 
@@ -531,6 +532,106 @@ int oracle_lincheck_combine(int words, const uint64_t *fz, const uint64_t *const
         store<F>(out, lincheck_combine<F>(load<F>(fz, n), M, load<F>(r, num), load<F>(p1, n), load<F>(p2, n)));
     });
     return 0;
+}
+
+
+// ---- Aurora SNARK, prover and verifier (aurora.hpp) ----------------------------------------------------------------
+// field: 1 = gf64, 3 = gf192 (additive arm), 0 = the 181-bit prime field edwards_Fr (multiplicative arm).
+// The instance is generate_r1cs_example(2^log_constraints, num_inputs, 2^log_constraints - 1) from `seed`, as
+// profiling/instrument_aurora_snark.cpp:108-110 calls it.
+} // extern "C"
+
+namespace {
+std::vector<uint8_t> g_last_transcript;
+
+#define AURORA_DISPATCH(field, CALL)                  \
+    switch (field) {                                  \
+    case 0: { typedef edwards_Fr F; CALL; } break;    \
+    case 1: { typedef gf64 F; CALL; } break;          \
+    case 3: { typedef gf192 F; CALL; } break;         \
+    default: return -1;                               \
+    }
+
+template<typename F>
+long aurora_prove_impl(size_t log_constraints, size_t num_inputs, uint64_t seed, size_t security, size_t rs_extra, size_t localization)
+{
+    const size_t n = (size_t)1 << log_constraints;
+    const r1cs_example<F> ex = generate_r1cs_example<F>(n, num_inputs, n - 1, seed);
+    const aurora_parameters<F> params(security, rs_extra, localization, n, n - 1, num_inputs);
+    g_last_transcript = aurora_snark_prover<F>(ex.cs, ex.primary_input, ex.auxiliary_input, params).serialize();
+    return (long)g_last_transcript.size();
+}
+template<typename F>
+int aurora_verify_impl(size_t log_constraints, size_t num_inputs, uint64_t seed, size_t security, size_t rs_extra, size_t localization,
+                       const uint8_t *bytes, size_t len, const uint64_t *primary_override)
+{
+    const size_t n = (size_t)1 << log_constraints;
+    r1cs_example<F> ex = generate_r1cs_example<F>(n, num_inputs, n - 1, seed);
+    if (primary_override) memcpy((void *)ex.primary_input.data(), primary_override, num_inputs * sizeof(F));
+    const aurora_parameters<F> params(security, rs_extra, localization, n, n - 1, num_inputs);
+    bcs_transcript<F> t;
+    try { t = bcs_transcript<F>::deserialize(bytes, len); } catch (const std::exception &) { return 0; }
+    return aurora_snark_verifier<F>(ex.cs, ex.primary_input, t, params) ? 1 : 0;
+}
+template<typename F>
+int aurora_params_impl(size_t log_constraints, size_t num_inputs, size_t security, size_t rs_extra, size_t localization, uint64_t *out, size_t cap)
+{
+    const size_t n = (size_t)1 << log_constraints;
+    const aurora_parameters<F> p(security, rs_extra, localization, n, n - 1, num_inputs);
+    std::vector<uint64_t> v = { p.codeword_domain_dim, p.pow_bits, p.query_soundness_error_bits, p.interactive_soundness_error_bits,
+                                p.max_tested_degree_bound, p.max_constraint_degree_bound, p.absolute_proximity_parameter, p.multi_lincheck_repetitions,
+                                p.num_output_LDT_instances, p.fri_interactive_repetitions, p.fri_query_repetitions, p.localization_parameters.size() };
+    for (size_t l : p.localization_parameters) v.push_back(l);
+    if (v.size() > cap) return -1;
+    memcpy(out, v.data(), v.size() * 8);
+    return (int)v.size();
+}
+// the instance itself, so tests can compare the product's generator: z = (primary, auxiliary) then the C coefficients
+template<typename F>
+int r1cs_example_impl(size_t log_constraints, size_t num_inputs, uint64_t seed, uint64_t *z_out, uint64_t *c_index_out, uint64_t *c_coeff_out)
+{
+    const size_t n = (size_t)1 << log_constraints;
+    const r1cs_example<F> ex = generate_r1cs_example<F>(n, num_inputs, n - 1, seed);
+    std::vector<F> z(ex.primary_input);
+    z.insert(z.end(), ex.auxiliary_input.begin(), ex.auxiliary_input.end());
+    memcpy(z_out, (const void *)z.data(), z.size() * sizeof(F));
+    for (size_t i = 0; i < n; ++i) {
+        c_index_out[i] = ex.cs.C[i][0].first;
+        memcpy((uint8_t *)c_coeff_out + i * sizeof(F), (const void *)&ex.cs.C[i][0].second, sizeof(F));
+    }
+    return 0;
+}
+} // namespace
+
+extern "C" {
+
+long oracle_aurora_prove(int field, size_t log_constraints, size_t num_inputs, uint64_t seed, size_t security, size_t rs_extra, size_t localization)
+{
+    try { AURORA_DISPATCH(field, return aurora_prove_impl<F>(log_constraints, num_inputs, seed, security, rs_extra, localization)); }
+    catch (const std::exception &e) { fprintf(stderr, "oracle_aurora_prove: %s\n", e.what()); return -2; }
+    return -1;
+}
+void oracle_aurora_fetch(uint8_t *dst) { if (!g_last_transcript.empty()) memcpy(dst, g_last_transcript.data(), g_last_transcript.size()); }
+
+// primary_override: NULL, or num_inputs elements replacing the instance's primary input (a wrong statement must be rejected)
+int oracle_aurora_verify(int field, size_t log_constraints, size_t num_inputs, uint64_t seed, size_t security, size_t rs_extra, size_t localization,
+                         const uint8_t *transcript, size_t len, const uint64_t *primary_override)
+{
+    try { AURORA_DISPATCH(field, return aurora_verify_impl<F>(log_constraints, num_inputs, seed, security, rs_extra, localization, transcript, len, primary_override)); }
+    catch (const std::exception &e) { fprintf(stderr, "oracle_aurora_verify: %s\n", e.what()); return -2; }
+    return -1;
+}
+int oracle_aurora_params(int field, size_t log_constraints, size_t num_inputs, size_t security, size_t rs_extra, size_t localization, uint64_t *out, size_t cap)
+{
+    try { AURORA_DISPATCH(field, return aurora_params_impl<F>(log_constraints, num_inputs, security, rs_extra, localization, out, cap)); }
+    catch (const std::exception &e) { fprintf(stderr, "oracle_aurora_params: %s\n", e.what()); return -2; }
+    return -1;
+}
+int oracle_r1cs_example(int field, size_t log_constraints, size_t num_inputs, uint64_t seed, uint64_t *z_out, uint64_t *c_index_out, uint64_t *c_coeff_out)
+{
+    try { AURORA_DISPATCH(field, return r1cs_example_impl<F>(log_constraints, num_inputs, seed, z_out, c_index_out, c_coeff_out)); }
+    catch (const std::exception &e) { fprintf(stderr, "oracle_r1cs_example: %s\n", e.what()); return -2; }
+    return -1;
 }
 
 } // extern "C"
