@@ -44,10 +44,16 @@ int         iopx_version(void);
 const char *iopx_last_error(void);
 /* Number of visible HIP devices (0 on a CPU-only host; never fails). */
 int         iopx_device_count(void);
-/* Bind the calling process to a device (one process per GPU). */
+/* Bind the calling process to a device (one process per GPU).  The binding is latched by the first call that touches the
+ * device: a later iopx_init with another device fails with IOPX_ERR_LOGIC.  Every entry point re-selects the bound device for
+ * the calling host thread, but the library keeps per-process state (plans, temporaries): call it from one thread at a time. */
 int         iopx_init(int device);
-/* Use the caller's hipStream_t for all subsequent work (NULL = the library's own stream). */
+/* Enqueue all subsequent work on the caller's hipStream_t, taken as given — NULL is the HIP legacy default stream (what
+ * torch.cuda.current_stream().cuda_stream is for torch's default stream), so library kernels and the caller's own work on that
+ * stream are ordered.  iopx_use_own_stream() goes back to the library's private non-blocking stream (the initial state): then
+ * the caller orders its producers / consumers against iopx_synchronize() itself. */
 int         iopx_set_stream(void *hip_stream);
+int         iopx_use_own_stream(void);
 int         iopx_synchronize(void);
 int         iopx_malloc(void **dptr, size_t bytes);
 int         iopx_free(void *dptr);
@@ -255,6 +261,38 @@ int iopx_lincheck_gf192_dev(const uint64_t *d_fz, const void *const *d_Mz, size_
                             const uint64_t *d_p_alpha_prime, const uint64_t *d_p_alpha_ABC, size_t n, uint64_t *d_out);
 int iopx_lincheck_fp3_dev(const uint64_t *d_fz, const void *const *d_Mz, size_t num_matrices, const uint64_t *r_Mz,
                           const uint64_t *d_p_alpha_prime, const uint64_t *d_p_alpha_ABC, size_t n, uint64_t *d_out);
+
+/* ---- encoded Aurora prover: the vector-sized steps between the transforms ---------------------------- */
+/* Sparse matrix x vector in CSR form (row_ptr: rows + 1 offsets, col: column of each entry, coeff: its field element), all on the
+ * device: out[r] (+)= scale * sum_t coeff[t] * vec[col[t]].  Replaces r1cs_constraint_system::create_Az_Bz_Cz_from_variable_assignment
+ * (libiop/relations/r1cs.tcc:236-268; vec = (1, primary, auxiliary)) and the p_alpha_ABC accumulation of
+ * multi_lincheck_virtual_oracle::set_challenge (libiop/protocols/encoded/lincheck/basic_lincheck_aux.tcc:64-88: the transposed
+ * matrix with rows already placed at their summation-domain index, vec = the alpha powers, scale = r_Mz[m], accumulate over m).
+ * scale: NULL or one host element. */
+int iopx_spmv_gf192_dev(const uint64_t *d_row_ptr, const uint32_t *d_col, const uint64_t *d_coeff, size_t rows, const uint64_t *d_vec,
+                        const uint64_t *scale, int accumulate, uint64_t *d_out);
+int iopx_spmv_fp3_dev(const uint64_t *d_row_ptr, const uint32_t *d_col, const uint64_t *d_coeff, size_t rows, const uint64_t *d_vec,
+                      const uint64_t *scale, int accumulate, uint64_t *d_out);
+/* polynomial_over_vanishing_polynomial(P, Z).first (libiop/algebra/polynomials/vanishing_polynomial.tcc:314-371,
+ * linearized_polynomial.tcc:238-289): the quotient of the n_coeffs-coefficient polynomial by the vanishing polynomial of the affine
+ * subspace (basis[dim], shift) / of the coset shift * <order 2^log_order>; writes n_coeffs - |domain| coefficients (nothing when
+ * n_coeffs <= |domain|).  Used for f_w = f_w' / Z_I (r1cs_rs_iop.tcc:563-565) and the sumcheck's h (sumcheck.tcc:359-365). */
+int iopx_poly_div_vanishing_gf192_dev(const uint64_t *d_poly, size_t n_coeffs, const uint64_t *basis, size_t dim, const uint64_t *shift,
+                                      uint64_t *d_quotient);
+int iopx_poly_div_vanishing_fp3_dev(const uint64_t *d_poly, size_t n_coeffs, size_t log_order, const uint64_t *shift, uint64_t *d_quotient);
+/* random_linear_combination_oracle::evaluated_contents (libiop/protocols/encoded/common/random_linear_combination.tcc:27-57):
+ * out[x] = sum_i coefficients[i] * oracle_i[x]; d_oracles is a host array of num_oracles (<= 16) device pointers. */
+int iopx_lincomb_gf192_dev(const void *const *d_oracles, size_t num_oracles, const uint64_t *coefficients, size_t n, uint64_t *d_out);
+int iopx_lincomb_fp3_dev(const void *const *d_oracles, size_t num_oracles, const uint64_t *coefficients, size_t n, uint64_t *d_out);
+/* Elementwise helpers on device vectors (the synthetic instance of libiop/relations/examples/r1cs_examples.tcc:40-64, and
+ * f_w' = z - f_1v over the variable domain, r1cs_rs_iop.tcc:406-430): sum / difference, product, inverse (zero stays zero),
+ * d_out[l] = init * base^l (the alpha powers of basic_lincheck_aux.tcc:37-45). */
+int iopx_gf192_add_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count);
+int iopx_gf192_inv_dev(const uint64_t *d_a, uint64_t *d_out, size_t count);
+int iopx_fp3_mul_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count);
+int iopx_fp3_sub_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count);
+int iopx_fp3_inv_dev(const uint64_t *d_a, uint64_t *d_out, size_t count);
+int iopx_fp3_pow_table_dev(uint64_t *d_out, size_t count, const uint64_t *base, const uint64_t *init);
 
 /* ---- proof of work ------------------------------------------------------------------------------ */
 /* pow<FieldT, binary_hash_digest>::solve_pow (libiop/bcs/pow.tcc:67-103) with the BLAKE2b two-to-one hash: returns the

@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("IOPX_LIB_PATH") or os.path.join(_HERE, "lib", "libiop_amd.so")     # override: A/B runs of two builds
+LIB_PATH = os.path.join(_HERE, "lib", "libiop_amd.so")
 
 IOPX_OK = 0
 IOPX_ERR_INVALID_ARGUMENT = -1
@@ -32,7 +32,7 @@ DOMAIN_MULTIPLICATIVE = 1
 
 # every symbol include/libiop_amd.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
-    "iopx_version", "iopx_last_error", "iopx_device_count", "iopx_init", "iopx_set_stream", "iopx_synchronize",
+    "iopx_version", "iopx_last_error", "iopx_device_count", "iopx_init", "iopx_set_stream", "iopx_use_own_stream", "iopx_synchronize",
     "iopx_malloc", "iopx_free", "iopx_memcpy_h2d", "iopx_memcpy_d2h", "iopx_clear_plans",
     "iopx_add_fft_gf192_dev", "iopx_add_fft_gf192", "iopx_add_lde_gf192_dev", "iopx_add_taylor_gf192_dev", "iopx_gf192_pow_table_dev", "iopx_add_combine_gf192_dev", "iopx_add_ifft_gf192_dev", "iopx_add_ifft_gf192", "iopx_add_ifft_gf192_batch_dev", "iopx_add_lde_gf192_batch_dev",
     "iopx_fri_fold_add_gf192_dev", "iopx_fri_fold_add_gf192",
@@ -45,6 +45,9 @@ EXPORTED_SYMBOLS = [
     "iopx_fz_gf192_dev", "iopx_fz_fp3_dev", "iopx_sumcheck_g_gf192_dev", "iopx_sumcheck_g_fp3_dev",
     "iopx_lincheck_gf192_dev", "iopx_lincheck_fp3_dev",
     "iopx_gf192_mul_dev", "iopx_gf192_mul_uniform_dev", "iopx_profile_begin", "iopx_profile_report",
+    "iopx_spmv_gf192_dev", "iopx_spmv_fp3_dev", "iopx_poly_div_vanishing_gf192_dev", "iopx_poly_div_vanishing_fp3_dev",
+    "iopx_lincomb_gf192_dev", "iopx_lincomb_fp3_dev", "iopx_gf192_add_dev", "iopx_gf192_inv_dev", "iopx_fp3_mul_dev", "iopx_fp3_sub_dev",
+    "iopx_fp3_inv_dev", "iopx_fp3_pow_table_dev",
 ]
 
 
@@ -163,6 +166,18 @@ class Library:
         c.iopx_pow_solve_poseidon_bn128.argtypes = [pp, _vp, _sz, _vp]
         c.iopx_gf192_mul_dev.argtypes = [_vp, _vp, _vp, _sz]
         c.iopx_gf192_mul_uniform_dev.argtypes = [_vp, _vp, _vp, _sz]
+        c.iopx_spmv_gf192_dev.argtypes = [_vp, _vp, _vp, _sz, _vp, _u64p, ctypes.c_int, _vp]
+        c.iopx_spmv_fp3_dev.argtypes = [_vp, _vp, _vp, _sz, _vp, _u64p, ctypes.c_int, _vp]
+        c.iopx_poly_div_vanishing_gf192_dev.argtypes = [_vp, _sz, _u64p, _sz, _u64p, _vp]
+        c.iopx_poly_div_vanishing_fp3_dev.argtypes = [_vp, _sz, _sz, _u64p, _vp]
+        c.iopx_lincomb_gf192_dev.argtypes = [ctypes.POINTER(_vp), _sz, _u64p, _sz, _vp]
+        c.iopx_lincomb_fp3_dev.argtypes = [ctypes.POINTER(_vp), _sz, _u64p, _sz, _vp]
+        c.iopx_gf192_add_dev.argtypes = [_vp, _vp, _vp, _sz]
+        c.iopx_gf192_inv_dev.argtypes = [_vp, _vp, _sz]
+        c.iopx_fp3_mul_dev.argtypes = [_vp, _vp, _vp, _sz]
+        c.iopx_fp3_sub_dev.argtypes = [_vp, _vp, _vp, _sz]
+        c.iopx_fp3_inv_dev.argtypes = [_vp, _vp, _sz]
+        c.iopx_fp3_pow_table_dev.argtypes = [_vp, _sz, _u64p, _u64p]
 
     # ---- error translation (the exception types the reference throws) ----
     def _check(self, rc):
@@ -188,7 +203,11 @@ class Library:
         self._check(self.c.iopx_init(device))
 
     def set_stream(self, hip_stream):
+        """All later work goes to this hipStream_t, taken as given: 0 is the legacy default stream (torch's default stream)."""
         self._check(self.c.iopx_set_stream(_vp(hip_stream)))
+
+    def use_own_stream(self):
+        self._check(self.c.iopx_use_own_stream())
 
     def synchronize(self):
         self._check(self.c.iopx_synchronize())
@@ -590,6 +609,50 @@ class Library:
     def merkle_inner_dev(self, d_nodes, num_leaves):
         """compute_inner_nodes (merkle_tree.tcc:200-229) over leaf digests already stored in the node array."""
         self._check(self.c.iopx_merkle_inner_blake2b_dev(_vp(d_nodes), int(num_leaves)))
+
+    # ---- encoded Aurora prover: vector-sized steps between the transforms (include/libiop_amd.h) ----
+    def spmv_dev(self, d_row_ptr, d_col, d_coeff, rows, d_vec, d_out, scale=None, accumulate=False, prime_field=False):
+        """out[r] (+)= scale * sum_t coeff[t] * vec[col[t]] over CSR rows (r1cs.tcc:236-268; basic_lincheck_aux.tcc:64-88)."""
+        sc = _as_u64(scale).ctypes.data_as(_u64p) if scale is not None else None
+        fn = self.c.iopx_spmv_fp3_dev if prime_field else self.c.iopx_spmv_gf192_dev
+        self._check(fn(_vp(d_row_ptr), _vp(d_col), _vp(d_coeff), int(rows), _vp(d_vec), sc, int(bool(accumulate)), _vp(d_out)))
+
+    def poly_div_vanishing_dev(self, d_poly, n_coeffs, basis, shift, d_quotient):
+        """Quotient by the vanishing polynomial of the affine subspace (basis, shift): n_coeffs - 2^dim coefficients."""
+        shift = _as_u64(shift)
+        b = np.ascontiguousarray(basis, dtype=np.uint64).reshape(-1, 3)
+        self._check(self.c.iopx_poly_div_vanishing_gf192_dev(_vp(d_poly), int(n_coeffs), b.ctypes.data_as(_u64p), b.shape[0],
+                                                             shift.ctypes.data_as(_u64p), _vp(d_quotient)))
+
+    def poly_div_vanishing_multiplicative_dev(self, d_poly, n_coeffs, log_order, shift, d_quotient):
+        shift = _as_u64(shift)
+        self._check(self.c.iopx_poly_div_vanishing_fp3_dev(_vp(d_poly), int(n_coeffs), int(log_order), shift.ctypes.data_as(_u64p), _vp(d_quotient)))
+
+    def lincomb_dev(self, d_oracles, coefficients, n, d_out, prime_field=False):
+        """random_linear_combination_oracle::evaluated_contents: out = sum_i coefficients[i] * oracle_i."""
+        co = _as_u64(coefficients)
+        if co.shape[0] != len(d_oracles):
+            raise ValueError("Random Linear Combination Oracle: Expected same number of random coefficients as oracles.")
+        ptrs = (_vp * len(d_oracles))(*d_oracles)
+        fn = self.c.iopx_lincomb_fp3_dev if prime_field else self.c.iopx_lincomb_gf192_dev
+        self._check(fn(ptrs, len(d_oracles), co.ctypes.data_as(_u64p), int(n), _vp(d_out)))
+
+    def field_add_dev(self, d_a, d_b, d_out, count):
+        self._check(self.c.iopx_gf192_add_dev(_vp(d_a), _vp(d_b), _vp(d_out), int(count)))
+
+    def field_inv_dev(self, d_a, d_out, count, prime_field=False):
+        fn = self.c.iopx_fp3_inv_dev if prime_field else self.c.iopx_gf192_inv_dev
+        self._check(fn(_vp(d_a), _vp(d_out), int(count)))
+
+    def fp3_mul_dev(self, d_a, d_b, d_out, count):
+        self._check(self.c.iopx_fp3_mul_dev(_vp(d_a), _vp(d_b), _vp(d_out), int(count)))
+
+    def fp3_sub_dev(self, d_a, d_b, d_out, count):
+        self._check(self.c.iopx_fp3_sub_dev(_vp(d_a), _vp(d_b), _vp(d_out), int(count)))
+
+    def fp3_pow_table_dev(self, d_out, count, base, init):
+        base, init = _as_u64(base), _as_u64(init)
+        self._check(self.c.iopx_fp3_pow_table_dev(_vp(d_out), int(count), base.ctypes.data_as(_u64p), init.ctypes.data_as(_u64p)))
 
     def profile_begin(self):
         self._check(self.c.iopx_profile_begin())

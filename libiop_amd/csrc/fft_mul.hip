@@ -411,6 +411,24 @@ int iopx_mul_fft_fp3_dev(const uint64_t *d_coeffs, size_t n_coeffs, size_t log_n
     return IOPX_OK;                                     // per-call tables are released in stream order
 }
 
+// d_out[l] = init * base^l for l < count, as ordinary libff elements (multi_lincheck's alpha powers, basic_lincheck_aux.tcc:37-45)
+int iopx_fp3_pow_table_dev(uint64_t *d_out, size_t count, const uint64_t *base, const uint64_t *init)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_out || !base || !init) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (count == 0) return IOPX_OK;
+    const int nb = (int)ceil_log2(count);
+    // fp_build_pow writes multipliers (x 2^203); data are x 2^192: start from init 2^-11
+    const hfp3 init_d = hfp3::from_words(init) * hfp3::from_uint(2048).inverse();
+    if (((size_t)1 << nb) == count) return fp_build_pow(d_out, hfp3::from_words(base), init_d, nb);
+    TmpBuf full;
+    if ((rc = full.alloc((((size_t)1) << nb) * 24)) != IOPX_OK) return rc;
+    if ((rc = fp_build_pow(full.u64(), hfp3::from_words(base), init_d, nb)) != IOPX_OK) return rc;
+    IOPX_HIP(hipMemcpyAsync(d_out, full.p, count * 24, hipMemcpyDeviceToDevice, stream()));
+    return IOPX_OK;
+}
+
 int iopx_mul_ifft_fp3_dev(const uint64_t *d_evals, size_t log_n, const uint64_t *gen, const uint64_t *shift, uint64_t *d_out)
 {
     int rc = ensure_device();

@@ -9,9 +9,11 @@
 namespace iopx {
 
 static thread_local char g_err[512] = "";
-static hipStream_t g_stream = nullptr;      // stream in use
+static hipStream_t g_stream = nullptr;      // stream in use (may legitimately be 0: the HIP legacy default stream)
 static hipStream_t g_own_stream = nullptr;  // created lazily
+static bool g_caller_stream = false;        // g_stream was chosen by iopx_set_stream
 static bool g_ready = false;
+static int g_device = -1;                   // the device this process is bound to (one process per GPU)
 static std::mutex g_mu;
 
 void set_error(const char *fmt, ...)
@@ -34,11 +36,20 @@ int fail(int code, const char *fmt, ...)
 const char *last_error() { return g_err; }
 
 hipStream_t stream() { return g_stream; }
+int bound_device();
 
 int ensure_device()
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_ready) return IOPX_OK;
+    if (g_ready) {
+        // a host thread other than the binding one starts on device 0: every entry point runs on the bound device
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != g_device) {
+            const hipError_t e = hipSetDevice(g_device);
+            if (e != hipSuccess) return fail(IOPX_ERR_RUNTIME, "hipSetDevice(%d) failed: %s", g_device, hipGetErrorString(e));
+        }
+        return IOPX_OK;
+    }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -50,19 +61,25 @@ int ensure_device()
         e = hipStreamCreateWithFlags(&g_own_stream, hipStreamNonBlocking);
         if (e != hipSuccess) return fail(IOPX_ERR_RUNTIME, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
-    if (!g_stream) g_stream = g_own_stream;
+    if (!g_caller_stream) g_stream = g_own_stream;
+    if (hipGetDevice(&g_device) != hipSuccess) return fail(IOPX_ERR_RUNTIME, "hipGetDevice failed");
     g_ready = true;
     return IOPX_OK;
 }
 
-int set_stream(void *s)
+int bound_device() { return g_ready ? g_device : -1; }
+
+// own = true: back to the library's private stream; otherwise the caller's handle as given, 0 included (the legacy default
+// stream, which is what torch's default stream is)
+int set_stream(void *s, bool own)
 {
     int rc = ensure_device();
     if (rc != IOPX_OK) return rc;
     // temporaries are recycled in stream order: drain the old stream before work moves to another one
-    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    (void)hipStreamSynchronize(g_stream);
     std::lock_guard<std::mutex> lk(g_mu);
-    g_stream = s ? (hipStream_t)s : g_own_stream;
+    g_caller_stream = !own;
+    g_stream = own ? g_own_stream : (hipStream_t)s;
     return IOPX_OK;
 }
 
@@ -232,11 +249,16 @@ int iopx_init(int device)
     int n = iopx_device_count();
     if (n <= 0) return iopx::fail(IOPX_ERR_NO_DEVICE, "no HIP device available; libiop_amd has no CPU fallback");
     if (device < 0 || device >= n) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "device %d out of range [0,%d)", device, n);
+    // the stream, the cached temporaries, the staging events and every plan belong to the first device used
+    const int bound = iopx::bound_device();
+    if (bound >= 0 && bound != device)
+        return iopx::fail(IOPX_ERR_LOGIC, "libiop_amd is bound to device %d (one process per GPU); cannot rebind to device %d", bound, device);
     IOPX_HIP(hipSetDevice(device));
     return iopx::ensure_device();
 }
 
-int iopx_set_stream(void *hip_stream) { return iopx::set_stream(hip_stream); }
+int iopx_set_stream(void *hip_stream) { return iopx::set_stream(hip_stream, false); }
+int iopx_use_own_stream(void) { return iopx::set_stream(nullptr, true); }
 
 int iopx_synchronize(void)
 {

@@ -618,3 +618,64 @@ def lincheck_combine(fz, mz, r, p1, p2, prime_field=False):
     lib().oracle_lincheck_combine(0 if prime_field else fz.shape[1], _p(fz), ptrs, ctypes.c_size_t(len(mz)), _p(r), _p(p1), _p(p2),
                                   ctypes.c_size_t(fz.shape[0]), _p(out))
     return out
+
+
+# ---- Aurora SNARK, prover and verifier (oracle/aurora.hpp) ----
+FIELD_EDWARDS, FIELD_GF64, FIELD_GF192 = 0, 1, 3
+_AURORA_PARAM_NAMES = ("codeword_domain_dim", "pow_bits", "query_soundness_error_bits", "interactive_soundness_error_bits",
+                       "max_tested_degree_bound", "max_constraint_degree_bound", "absolute_proximity_parameter", "multi_lincheck_repetitions",
+                       "num_output_LDT_instances", "fri_interactive_repetitions", "fri_query_repetitions")
+
+
+def _aurora_args(field, log_constraints, num_inputs, seed, security, rs_extra, localization):
+    sz = ctypes.c_size_t
+    return [ctypes.c_int(field), sz(log_constraints), sz(num_inputs), ctypes.c_uint64(seed), sz(security), sz(rs_extra), sz(localization)]
+
+
+def aurora_prove(field, log_constraints, num_inputs, seed, security=128, rs_extra=5, localization=2):
+    """The serialized transcript of aurora_snark_prover on generate_r1cs_example(2^log_constraints, num_inputs, 2^log_constraints - 1; seed)."""
+    l = lib()
+    l.oracle_aurora_prove.restype = ctypes.c_long
+    n = l.oracle_aurora_prove(*_aurora_args(field, log_constraints, num_inputs, seed, security, rs_extra, localization))
+    if n < 0:
+        raise RuntimeError("oracle_aurora_prove failed (%d)" % n)
+    buf = (ctypes.c_uint8 * n)()
+    l.oracle_aurora_fetch(buf)
+    return bytes(buf)
+
+
+def aurora_verify(field, log_constraints, num_inputs, seed, transcript, security=128, rs_extra=5, localization=2, primary_override=None):
+    """aurora_snark_verifier on the same seeded instance; primary_override replaces the statement's primary input."""
+    buf = (ctypes.c_uint8 * len(transcript)).from_buffer_copy(bytes(transcript))
+    po = None
+    if primary_override is not None:
+        po = np.ascontiguousarray(primary_override, dtype=np.uint64)
+    rc = lib().oracle_aurora_verify(*_aurora_args(field, log_constraints, num_inputs, seed, security, rs_extra, localization), buf,
+                                    ctypes.c_size_t(len(transcript)), _p(po) if po is not None else None)
+    if rc < 0:
+        raise RuntimeError("oracle_aurora_verify failed (%d)" % rc)
+    return bool(rc)
+
+
+def aurora_params(field, log_constraints, num_inputs, security=128, rs_extra=5, localization=2):
+    out = np.zeros(80, dtype=np.uint64)
+    sz = ctypes.c_size_t
+    n = lib().oracle_aurora_params(ctypes.c_int(field), sz(log_constraints), sz(num_inputs), sz(security), sz(rs_extra), sz(localization), _p(out), sz(80))
+    if n < 0:
+        raise RuntimeError("oracle_aurora_params failed (%d)" % n)
+    d = dict(zip(_AURORA_PARAM_NAMES, (int(v) for v in out[:11])))
+    d["localization_parameters"] = [int(v) for v in out[12:n]]
+    return d
+
+
+def r1cs_example(field, log_constraints, num_inputs, seed):
+    """(z = primary || auxiliary, C's column index per row, C's coefficient per row) of the seeded instance."""
+    words = {FIELD_EDWARDS: 3, FIELD_GF64: 1, FIELD_GF192: 3}[field]
+    n = 1 << log_constraints
+    z = np.zeros((n - 1, words), dtype=np.uint64)
+    idx = np.zeros(n, dtype=np.uint64)
+    coeff = np.zeros((n, words), dtype=np.uint64)
+    rc = lib().oracle_r1cs_example(ctypes.c_int(field), ctypes.c_size_t(log_constraints), ctypes.c_size_t(num_inputs), ctypes.c_uint64(seed),
+                                   _p(z), _p(idx), _p(coeff))
+    assert rc == 0
+    return z, idx, coeff

@@ -1,0 +1,84 @@
+"""Encoded Aurora prover on the device path, kernel sources compiled for the CPU (tests/emu): transcript byte-equality with
+the oracle's independent prover, acceptance by the oracle's verifier, rejection of tampered transcripts and of a wrong
+statement, parameter derivation, the synthetic instance.  The same cases run on the MI355X in tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+import aurora_cases as ac
+import emu_lib
+import oracle
+from libiop_amd import aurora, domains, r1cs
+
+CPU = torch.device("cpu")
+
+
+@pytest.mark.parametrize("field_name,log_n,num_inputs", [
+    ("gf192", 6, 3), ("gf192", 8, 15), ("gf192", 9, 1), ("gf192", 10, 15),
+    ("edwards_Fr", 6, 3), ("edwards_Fr", 8, 15), ("edwards_Fr", 9, 7), ("edwards_Fr", 10, 15),
+])
+def test_device_transcript_equals_oracle_prover(field_name, log_n, num_inputs):
+    ac.check_transcript_equals_oracle(emu_lib.emu(), torch, CPU, field_name, log_n, num_inputs, 0x2204)
+
+
+@pytest.mark.parametrize("field_name", ["gf192", "edwards_Fr"])
+def test_other_rates_and_localizations(field_name):
+    ac.check_transcript_equals_oracle(emu_lib.emu(), torch, CPU, field_name, 7, 3, 7, rs_extra=3, localization=3)
+    ac.check_transcript_equals_oracle(emu_lib.emu(), torch, CPU, field_name, 7, 7, 8, rs_extra=2, localization=1)
+
+
+@pytest.mark.parametrize("field_name", ["gf192", "edwards_Fr"])
+def test_oracle_verifier_rejects_tampering(field_name):
+    code = ac.FIELDS[field_name][0]
+    transcript, _ = ac.check_transcript_equals_oracle(emu_lib.emu(), torch, CPU, field_name, 7, 3, 11)
+    for label, data in ac.tamper_cases(transcript):
+        assert not oracle.aurora_verify(code, 7, 3, 11, data), label
+    good = transcript.serialize()
+    assert not oracle.aurora_verify(code, 7, 3, 11, good[:-1]), "truncated"
+    assert not oracle.aurora_verify(code, 7, 3, 12, good), "another instance"
+    z, _, _ = oracle.r1cs_example(code, 7, 3, 11)
+    wrong = z[:3].copy()
+    wrong[1, 0] ^= np.uint64(1) if field_name == "gf192" else np.uint64(0)
+    if field_name == "edwards_Fr":
+        wrong[1] = z[2]
+    assert not oracle.aurora_verify(code, 7, 3, 11, good, primary_override=wrong), "wrong primary input"
+    assert oracle.aurora_verify(code, 7, 3, 11, good, primary_override=z[:3].copy())
+
+
+@pytest.mark.parametrize("field_name,log_n", [("gf192", 8), ("gf192", 20), ("edwards_Fr", 12), ("edwards_Fr", 20)])
+def test_parameters_match_oracle(field_name, log_n):
+    code, cls = ac.FIELDS[field_name]
+    n = 1 << log_n
+    p = aurora.AuroraParameters(cls(), n, n - 1, 15)
+    ref = oracle.aurora_params(code, log_n, 15)
+    for name in ("codeword_domain_dim", "pow_bits", "query_soundness_error_bits", "max_tested_degree_bound", "max_constraint_degree_bound",
+                 "absolute_proximity_parameter", "multi_lincheck_repetitions", "num_output_LDT_instances", "fri_interactive_repetitions",
+                 "fri_query_repetitions", "localization_parameters"):
+        assert getattr(p, name) == ref[name], name
+    if log_n == 20:                     # cfg4 / cfg5 shapes
+        assert p.codeword_domain_dim == 25 and p.localization_parameters == [1] + [2] * 9 and p.pow_bits == 23 and p.fri_query_repetitions == 27
+
+
+@pytest.mark.parametrize("field_name", ["gf192", "edwards_Fr"])
+def test_synthetic_instance_matches_oracle(field_name):
+    code, cls = ac.FIELDS[field_name]
+    ops = domains.DeviceOps(emu_lib.emu(), torch, CPU, cls())
+    cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, 64, 3, 63, 99)
+    z, c_idx, c_coeff = oracle.r1cs_example(code, 6, 3, 99)
+    assert np.array_equal(np.concatenate([primary, auxiliary]), z)
+    assert np.array_equal(cs.C.col.astype(np.uint64), c_idx)
+    assert np.array_equal(ops.download(cs.C.d_coeff), c_coeff)
+    # the instance is satisfied: Az * Bz = Cz
+    one = np.array([[1, 0, 0]], dtype=np.uint64) if field_name == "gf192" else cls().from_int(1).reshape(1, 3)
+    d_z = ops.upload(np.concatenate([one, z]))
+    az, bz, cz = (ops.spmv(M, d_z) for M in (cs.A, cs.B, cs.C))
+    assert np.array_equal(ops.download(ops.mul(az, bz)), ops.download(cz))
+
+
+def test_argument_checks():
+    with pytest.raises(ValueError):
+        aurora.AuroraParameters(domains.GF192(), 100, 127, 15)
+    with pytest.raises(ValueError):
+        aurora.AuroraParameters(domains.GF192(), 128, 126, 15)
+    with pytest.raises(ValueError):
+        aurora.AuroraParameters(domains.GF192(), 128, 127, 14)
