@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the MI355X prover hot path (BASELINE.json metric: FFT field-ops/s).
+"""bench.py — headline benchmark of the MI355X prover hot path.
 
-Workload at N = 1 (BASELINE.json configs[1]): the standalone additive FFT over GF(2^192) of 2^22 random
-coefficients on the standard-basis subspace of dimension 22, shift 0 (libiop/profiling/
-instrument_algebra.cpp:84-94).  A "step" is one such transform with the coefficients already resident in HBM.
-field-ops are counted with the REFERENCE's operation count for this size (1.5 n m
-multiplications + (n/2) m (m-1)/2 + n m additions), whatever algorithm runs.
+BASELINE.json metric: "prover sec + FFT field-ops/s, Aurora 2^20 R1CS, 1/2/4/8 MI355X vs CPU".
 
-At N > 1 every rank transforms its own 2^22-coefficient polynomial (independent units, no data-path
-collective; "weak" scaling); the value is the sum over ranks divided by the slowest rank's time.
+Workload (BASELINE.json configs[3], run on as many GPUs as given): the Aurora SNARK prover for the synthetic
+2^20-constraint R1CS over GF(2^192) (generate_r1cs_example(2^20, 15, 2^20 - 1), profiling/instrument_aurora_snark.cpp:
+108-110; security 128, RS_extra_dimensions 5, FRI localization 2, non-zk, BLAKE2b).  A "step" is one complete proof —
+witness -> codewords -> lincheck / sumcheck -> LDT reducer -> FRI -> proof of work -> transcript — with the instance and
+the witness already resident in HBM (libiop_amd/aurora.py over the C ABI).
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
+`value` = the proof's FFT work in the REFERENCE's operation count (per 2^m-point transform 1.5 n m
+multiplications + (n/2) m (m-1)/2 + n m additions, summed over every transform the reference prover runs) divided by the
+prover's wall-clock seconds: prover seconds and FFT field-ops/s in one number; `ms_per_step` is the prover time itself.
+The roofline line is for the dominant kernel of THAT run; config.secondary holds configs[1] (one 2^22 FFT).
+
+N > 1 (one process per GPU): see libiop_amd/dist.py — the proof is sharded by contiguous cosets; "strong" scaling.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 import argparse
@@ -24,33 +30,46 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-LOG_N = 22
 ELEM = 24
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+SEED = 0x2204
 
 
-def ref_field_ops(m):
+def ref_fft_ops(m):
+    """(multiplications, additions) the reference's additive FFT / IFFT performs on a 2^m-point domain."""
     n = 1 << m
-    mults = 3 * n * m // 2
-    adds = (n // 2) * (m * (m - 1) // 2) + n * m
-    return mults, adds
+    return 3 * n * m // 2, (n // 2) * (m * (m - 1) // 2) + n * m
+
+
+def aurora_transform_inventory(log_n, rs_extra, final_dim):
+    """Every transform of the reference's non-zk Aurora prover as (what, domain dimension) — SURVEY.md §8d, confirmed there by
+    the size trace of the reference prover: 8 codeword FFTs, the interpolations over the 2^log_n domains, one 2^(log_n+1)
+    known-degree IFFT, the small input-domain and FRI-final transforms."""
+    L = log_n + rs_extra
+    inv = [("FFT f_w / f_Az / f_Bz / f_Cz / f_1v / p_alpha_prime / p_alpha_ABC / h -> codeword domain", L)] * 8
+    inv += [("IFFT f_w' over the variable domain", log_n), ("FFT f_1v over the variable domain", log_n)]
+    inv += [("IFFT Az / Bz / Cz over the constraint domain", log_n)] * 3
+    inv += [("IFFT p_alpha over the summation domain", log_n)] * 2
+    inv += [("IFFT_of_known_degree of the sumcheck polynomial", log_n + 1)]
+    inv += [("IFFT f_1v over the input domain", 4)] * 2 + [("IFFT of the last FRI codeword", final_dim)]
+    return inv
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--log-n", type=int, default=LOG_N)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log-n", type=int, default=20, help="log2 of the number of R1CS constraints")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sharded", action="store_true",
-                    help="N > 1: ONE 2^(log_n + log2 N)-point transform sharded across the ranks (libiop_amd/dist.py: all-to-all "
-                         "transpose + peer exchanges) instead of one independent transform per rank")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--cpu-log-n", type=int, default=12, help="size of the CPU-baseline sample (oracle prover)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import libiop_amd
+    from libiop_amd import aurora, domains, r1cs
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -60,43 +79,38 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    lib = libiop_amd.lib()
+    lib = libiop_amd.lib()                      # raises when the HIP library is missing: no fallback
     lib.init(local_rank)
-    stream = torch.cuda.current_stream()
-    lib.set_stream(stream.cuda_stream)
+    lib.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    m = args.log_n
-    n = 1 << m
-    basis = libiop_amd.standard_basis(m)
-    shift = np.zeros(3, dtype=np.uint64)
-    rng = np.random.Generator(np.random.PCG64(0x2201 + rank))
-    coeffs_h = rng.integers(0, 2**64, size=(n, 3), dtype=np.uint64)
-    # device-resident buffers owned by torch (int64 storage = raw words)
-    d_in = torch.from_numpy(coeffs_h.view(np.int64)).to(dev)
-    d_out = torch.empty_like(d_in)
+    field = domains.GF192()
+    ops = domains.DeviceOps(lib, torch, dev, field)
+    n = 1 << args.log_n
+    cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, n, 15, n - 1, SEED)         # untimed: the statement and witness
+    params = aurora.AuroraParameters(field, n, n - 1, 15)
+    d_assignment = ops.upload(aurora.assignment_vector(field, primary, auxiliary))      # resident in HBM before the timed region
+    torch.cuda.synchronize()
 
-    def step():
-        lib.additive_FFT_dev(d_in.data_ptr(), n, basis, shift, d_out.data_ptr())
-
-    total_m = m
-    if args.sharded and world > 1:
+    if world > 1:
         from libiop_amd import dist as idist
-        total_m = m + (world.bit_length() - 1)
-        big_basis = libiop_amd.standard_basis(total_m)
-        plan = idist.DistributedFFTPlan(lib, torch, big_basis, shift, rank, world, dev)
+        shard = idist.AuroraShard(dist, rank, world)
 
-        def step():          # noqa: F811 — the rank's block of the coefficients in, its block of the evaluations out
-            idist.distributed_fft(lib, torch, dist, plan, d_in)
+        def step():
+            return idist.sharded_aurora_snark_prover(ops, shard, cs, primary, params, d_assignment)
+    else:
+        def step():
+            return aurora.aurora_snark_prover(ops, cs, primary, None, params, d_assignment=d_assignment)
 
+    transcript = None
     for _ in range(args.warmup):
-        step()
+        transcript = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        transcript = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -106,76 +120,106 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    prover_s = dt / args.steps
 
-    # per-kernel durations, live, with HIP events on the stream the kernels are launched on
+    # per-kernel durations of one more proof, live, with HIP events on the stream the kernels are launched on
     lib.profile_begin()
-    for _ in range(args.steps):
-        step()
+    step()
     prof = lib.profile_report()
-    dom_name, (dom_cnt, dom_ms) = max(prof.items(), key=lambda kv: kv[1][1])
+    dom_name, (dom_cnt, dom_ms, dom_bytes) = max(prof.items(), key=lambda kv: kv[1][1])
     dom_avg_s = dom_ms / dom_cnt / 1e3
-    # every FFT pass kernel sweeps the whole vector once: algorithmic bytes per launch = read + write of n elements
-    alg_bytes = 2 * n * ELEM
-    achieved = alg_bytes / dom_avg_s / 1e9
-
-    # HBM traffic of the dominant kernel from the committed PMC run (profiles/), when it is for this kernel and size
+    alg_bytes_per_launch = dom_bytes / dom_cnt if dom_bytes else None
+    achieved = (dom_bytes / (dom_ms / 1e3) / 1e9) if dom_bytes else None
     traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if tj.get("log_n") == m and dom_name in tj.get("kernels", {}):
+    try:                                        # HBM bytes per launch of that kernel from the committed PMC run (profiles/)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic_aurora.json")))
+        if tj.get("log_n") == args.log_n and dom_name in tj.get("kernels", {}):
             traffic = tj["kernels"][dom_name]["traffic_bytes_per_launch"]
     except (OSError, ValueError):
         pass
+    fft_kernels = ("k_phase1", "k_bfly_upper", "k_bfly_edge", "k_pad_copy", "k_rs_combine", "k_fill")
+    fft_ms = sum(v[1] for k, v in prof.items() if k.startswith(fft_kernels))
 
-    mults, adds = ref_field_ops(total_m)
-    ms_per_step = dt / args.steps * 1e3
-    units = 1 if (args.sharded and world > 1) else world       # one big transform, or one transform per rank
-    value = units * (mults + adds) / (dt / args.steps)
+    final_dim = params.codeword_domain_dim - sum(params.localization_parameters)
+    inventory = aurora_transform_inventory(args.log_n, params.RS_extra_dimensions, final_dim)
+    mults = sum(ref_fft_ops(m)[0] for _, m in inventory)
+    adds = sum(ref_fft_ops(m)[1] for _, m in inventory)
+    value = (mults + adds) / prover_s
 
     out = {
-        "metric": "fft_field_ops_per_s",
+        "metric": "aurora_prover_fft_field_ops_per_s",
         "value": value,
         "unit": "field-ops/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
+        "ms_per_step": prover_s * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "gf2^192 (u32 VALU bit-ops)",
         "data": "synthetic",
-        "config": {"workload": "additive FFT over GF(2^192), 2^%d coefficients -> 2^%d-point standard-basis subspace, shift 0 "
-                               "(BASELINE configs[1]); one transform per GPU" % (m, m),
-                   "log_n": m, "field": "gf192", "ref_mults_per_step": mults, "ref_adds_per_step": adds,
-                   "field_mults_per_s": units * mults / (dt / args.steps),
-                   "multi_gpu": ("one 2^%d-point transform sharded over %d ranks (all-to-all transpose + peer exchanges)" % (total_m, world))
-                   if (args.sharded and world > 1) else "one independent transform per rank, no collective"},
+        "config": {
+            "workload": "Aurora SNARK prover, 2^%d-constraint synthetic R1CS over GF(2^192) (generate_r1cs_example(n, 15, n - 1), seed 0x%x), "
+                        "security 128, RS_extra_dimensions 5, FRI localization 2, non-zk, BLAKE2b: one complete proof per step, "
+                        "instance and witness resident in HBM" % (args.log_n, SEED),
+            "log_n": args.log_n, "field": "gf192", "prover_s": prover_s,
+            "codeword_domain_dim": params.codeword_domain_dim, "localization": params.localization_parameters,
+            "fri_query_repetitions": params.fri_query_repetitions, "pow_bits": params.pow_bits,
+            "argument_bytes": len(transcript.serialize()) if transcript is not None else None,
+            "ref_fft_mults_per_proof": mults, "ref_fft_adds_per_proof": adds,
+            "fft_stage": {"ms": fft_ms, "field_ops_per_s": (mults + adds) / (fft_ms / 1e3) if fft_ms else None,
+                          "note": "transform kernels only (k_phase1, k_bfly_upper, k_bfly_edge, padding): HIP-event time inside one proof"},
+            "multi_gpu": "one proof sharded over %d ranks by contiguous cosets of every codeword (libiop_amd/dist.py)" % world if world > 1
+                         else "single GPU",
+        },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": dom_name, "launches_per_step": dom_cnt / args.steps, "avg_launch_ms": dom_avg_s * 1e3,
-                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
+                     "kernel": dom_name, "launches_per_step": dom_cnt, "avg_launch_ms": dom_avg_s * 1e3,
+                     "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                      "note": "gfx950 has no carry-less multiply: the GF(2^192) butterflies are integer-ALU-bound, see DESIGN.md",
-                     "kernels_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
-                     # the bound that actually binds: GF(2^192) products per second of the dominant kernel (each launch that
-                     # twists multiplies every element once) against the measured rate of the in-register multiplier
-                     # (tools/ubench/mul_rates.hip: 4.4e10/s general operands)
-                     "valu": {"products_per_s": (n * (m if dom_name.startswith("k_phase1") else m / 2)) / (dom_ms / args.steps / 1e3),
-                              "multiplier_peak_per_s": 4.4e10,
-                              "frac": (n * (m if dom_name.startswith("k_phase1") else m / 2)) / (dom_ms / args.steps / 1e3) / 4.4e10}},
+                     "kernels_ms_per_step": {k: round(v[1], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+                     "kernel_launches_per_step": {k: v[0] for k, v in prof.items()}},
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # BASELINE configs[1]: one additive FFT of 2^22 random coefficients on the standard-basis subspace, shift 0
+        m = 22
+        basis, shift = libiop_amd.standard_basis(m), np.zeros(3, dtype=np.uint64)
+        d_in = ops.upload(np.random.Generator(np.random.PCG64(0x2201)).integers(0, 2**64, size=(1 << m, 3), dtype=np.uint64))
+        d_out = ops.empty(1 << m)
+        for _ in range(2):
+            lib.additive_FFT_dev(d_in.data_ptr(), 1 << m, basis, shift, d_out.data_ptr())
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ref = oracle.additive_fft(coeffs_h, basis, shift)
+        for _ in range(10):
+            lib.additive_FFT_dev(d_in.data_ptr(), 1 << m, basis, shift, d_out.data_ptr())
+        torch.cuda.synchronize()
+        s = (time.perf_counter() - t0) / 10
+        mu, ad = ref_fft_ops(m)
+        out["config"]["secondary"] = {"workload": "configs[1]: additive FFT over GF(2^192), 2^22 coefficients, shift 0", "ms_per_step": s * 1e3,
+                                      "field_ops_per_s": (mu + ad) / s}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU baseline: the oracle's literal restatement of the reference prover (PCLMUL gf192, one thread) on a bounded sample
+        # of the same workload — the same protocol and rate on a 2^cpu_log_n-constraint instance — checked against the device
+        # prover's transcript for that instance byte for byte before its time is accepted.
+        import oracle
+        k = args.cpu_log_n
+        nk = 1 << k
+        cs_k, prim_k, aux_k = r1cs.generate_r1cs_example(ops, nk, 15, nk - 1, SEED)
+        params_k = aurora.AuroraParameters(field, nk, nk - 1, 15)
+        mine = aurora.aurora_snark_prover(ops, cs_k, prim_k, aux_k, params_k).serialize()
+        t0 = time.perf_counter()
+        ref = oracle.aurora_prove(oracle.FIELD_GF192, k, 15, SEED)
         cpu_s = time.perf_counter() - t0
-        got = d_out.cpu().numpy().view(np.uint64)
-        assert np.array_equal(got, ref), "GPU output differs from the CPU oracle"
-        out["cpu_baseline"] = {"value": (mults + adds) / cpu_s, "unit": "field-ops/s", "cores": 1, "kind": "port",
-                               "sample": "the full workload once (2^%d-point additive FFT, PCLMUL gf192, 1 thread): %.2f s; "
-                                         "output compared bit-for-bit with the GPU result" % (m, cpu_s),
-                               "seconds": cpu_s}
+        assert mine == ref, "device transcript differs from the CPU oracle prover's"
+        inv_k = aurora_transform_inventory(k, params_k.RS_extra_dimensions, params_k.codeword_domain_dim - sum(params_k.localization_parameters))
+        ops_k = sum(sum(ref_fft_ops(m)) for _, m in inv_k)
+        out["cpu_baseline"] = {"value": ops_k / cpu_s, "unit": "field-ops/s", "cores": 1, "kind": "port",
+                               "sample": "the same prover on a 2^%d-constraint instance (same protocol, rate 1/32, seed): %.2f s on one core; its "
+                                         "transcript equals the device prover's byte for byte" % (k, cpu_s),
+                               "seconds": cpu_s, "sample_log_n": k}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -55,6 +55,25 @@ class NoDeviceError(RuntimeError):
     pass
 
 
+def _bind_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64 (same soname as /opt/rocm's) and looks it up by
+    file name, so if this library pulled in the system copy first, a later `import torch` would bring up a second runtime and
+    find no GPU.  Loading torch's copy first makes both bind to that one instance, whichever package is imported first; without
+    PyTorch installed the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 _sz = ctypes.c_size_t
@@ -114,6 +133,7 @@ class Library:
                 "libiop_amd: %s is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
         self.path = path
+        _bind_hip_runtime()
         self.c = ctypes.CDLL(path)
         c = self.c
         c.iopx_last_error.restype = ctypes.c_char_p
@@ -658,13 +678,13 @@ class Library:
         self._check(self.c.iopx_profile_begin())
 
     def profile_report(self):
-        """Returns {kernel: (launches, total_ms)} for the launches since profile_begin()."""
+        """Returns {kernel: (launches, total_ms, algorithmic_bytes)} for the launches since profile_begin()."""
         buf = ctypes.create_string_buffer(1 << 16)
         self._check(self.c.iopx_profile_report(buf, len(buf)))
         out = {}
         for line in buf.value.decode().splitlines():
-            name, cnt, ms = line.split()
-            out[name] = (int(cnt), float(ms))
+            f = line.split()
+            out[f[0]] = (int(f[1]), float(f[2]), float(f[3]) if len(f) > 3 else 0.0)
         return out
 
     def gf192_mul_dev(self, d_a, d_b, d_out, count):

@@ -321,17 +321,21 @@ class EncodedAuroraProtocol:
     def register_proof(self):
         self.multi_lincheck.register_proof()
 
-    def submit_witness_oracles(self, primary_input, auxiliary_input):
+    def submit_witness_oracles(self, primary_input, auxiliary_input, d_assignment=None):
         """:481-615.  f_w' interpolates z - f_1v over the variable domain (zero on the input positions, where f_1v already
-        equals z), is divided by Z_I and extended together with f_Az, f_Bz, f_Cz."""
+        equals z), is divided by Z_I and extended together with f_Az, f_Bz, f_Cz.  d_assignment: the variable assignment
+        (1, primary, auxiliary) already resident on the device (then auxiliary_input may be None)."""
         ops = self.ops
         primary_input = np.ascontiguousarray(primary_input, dtype=np.uint64).reshape(-1, 3)
-        auxiliary_input = np.ascontiguousarray(auxiliary_input, dtype=np.uint64).reshape(-1, 3)
         self.fz_oracle.set_primary_input(primary_input)                                                  # :485, :508-516
         f1v_over_variable_domain = ops.FFT(self.fz_oracle.d_f1v_coefficients, self.I.size, self.V)       # :517-518
-        one = np.array([[1, 0, 0]], dtype=np.uint64) if ops.field.additive else ops.field.from_int(1).reshape(1, 3)
-        z = np.concatenate([one, primary_input, auxiliary_input])                                        # :581-585
-        d_z = ops.upload(z)
+        if d_assignment is None:
+            auxiliary_input = np.ascontiguousarray(auxiliary_input, dtype=np.uint64).reshape(-1, 3)
+            d_z = ops.upload(assignment_vector(ops.field, primary_input, auxiliary_input))               # :581-585
+        else:
+            d_z = d_assignment
+        if d_z.shape[0] != self.cs.num_variables + 1:
+            raise ValueError("variable assignment of the wrong size")
         if self.V.additive:
             z_over_variable_domain = d_z
         else:
@@ -340,15 +344,18 @@ class EncodedAuroraProtocol:
             z_over_variable_domain = d_z[ops.upload_raw(order, ops.torch.int64)]
         fw_prime_evals = ops.sub(z_over_variable_domain, f1v_over_variable_domain)                       # :406-430
         fw_prime = ops.IFFT(fw_prime_evals, self.V)                                                      # :551-555
-        fw = ops.poly_div_vanishing(fw_prime, self.V.size, self.I)                                       # :563-565
-        Az, Bz, Cz = (ops.spmv(M, d_z) for M in (self.cs.A, self.cs.B, self.cs.C))                       # :586-592, r1cs.tcc:236-268
-        fA, fB, fC = ops.IFFT_batch([Az, Bz, Cz], self.C)                                                # :459-463
-        if fw.shape[0] < self.C.size and self.V.size == self.C.size:                                     # one batched extension (zero padded, fft.tcc:43-44)
-            fw_padded = ops.torch.zeros((self.C.size, 3), dtype=ops.torch.int64, device=ops.device)
-            fw_padded[: fw.shape[0]] = fw
-            codewords = ops.FFT_batch([fw_padded, fA, fB, fC], self.C.size, self.L)                     # :567-568, :474-478
+        nC = self.C.size
+        Mz = ops.empty(3 * nC)
+        for k, M in enumerate((self.cs.A, self.cs.B, self.cs.C)):                                        # :586-592, r1cs.tcc:236-268
+            ops.spmv(M, d_z, d_out=Mz[k * nC:(k + 1) * nC])
+        fA, fB, fC = ops.IFFT_batch_packed(Mz, 3, self.C)                                                # :459-463
+        if self.V.size == nC:                                                                            # one batched extension (zero padded, fft.tcc:43-44)
+            fw = ops.torch.zeros((nC, 3), dtype=ops.torch.int64, device=ops.device)
+            ops.poly_div_vanishing(fw_prime, self.V.size, self.I, out=fw)                                # :563-565
+            codewords = ops.FFT_batch([fw, fA, fB, fC], nC, self.L)                                      # :567-568, :474-478
         else:
-            codewords = [ops.FFT(fw, fw.shape[0], self.L)] + ops.FFT_batch([fA, fB, fC], self.C.size, self.L)
+            fw = ops.poly_div_vanishing(fw_prime, self.V.size, self.I)
+            codewords = [ops.FFT(fw, fw.shape[0], self.L)] + ops.FFT_batch([fA, fB, fC], nC, self.L)
         for handle, cw in zip((self.fw_handle, self.fAz_handle, self.fBz_handle, self.fCz_handle), codewords):
             self.IOP.submit_oracle(handle, cw)                                                           # :603-606
 
@@ -488,16 +495,23 @@ class AuroraIOP:
     def register_queries(self):
         self.LDT_reducer.register_queries()
 
-    def produce_proof(self, primary_input, auxiliary_input):                                             # :334-344
-        self.protocol.submit_witness_oracles(primary_input, auxiliary_input)
+    def produce_proof(self, primary_input, auxiliary_input, d_assignment=None):                          # :334-344
+        self.protocol.submit_witness_oracles(primary_input, auxiliary_input, d_assignment)
         self.IOP.signal_prover_round_done()
         self.protocol.calculate_and_submit_proof()
         self.IOP.signal_prover_round_done()
         self.LDT_reducer.calculate_and_submit_proof()
 
 
-def aurora_snark_prover(ops, constraint_system, primary_input, auxiliary_input, parameters, round_hook=None):
-    """aurora_snark_prover (aurora_snark.tcc:119-146): returns the Transcript (libiop_amd/bcs.py)."""
+def assignment_vector(field, primary_input, auxiliary_input):
+    """The variable assignment z = (1, primary, auxiliary) (r1cs_rs_iop.tcc:581-585) as host words."""
+    one = np.array([[1, 0, 0]], dtype=np.uint64) if field.additive else field.from_int(1).reshape(1, 3)
+    return np.concatenate([one, np.asarray(primary_input, dtype=np.uint64).reshape(-1, 3), np.asarray(auxiliary_input, dtype=np.uint64).reshape(-1, 3)])
+
+
+def aurora_snark_prover(ops, constraint_system, primary_input, auxiliary_input, parameters, round_hook=None, d_assignment=None):
+    """aurora_snark_prover (aurora_snark.tcc:119-146): returns the Transcript (libiop_amd/bcs.py).  With d_assignment (the
+    device-resident (1, primary, auxiliary) vector) the witness never crosses PCIe inside the call."""
     IOP = BCSProver(ops, parameters.pow_bits)
     if round_hook is not None:
         IOP.round_hooks.append(round_hook)
@@ -506,5 +520,5 @@ def aurora_snark_prover(ops, constraint_system, primary_input, auxiliary_input, 
     IOP.seal_interaction_registrations()
     full_protocol.register_queries()
     IOP.seal_query_registrations()
-    full_protocol.produce_proof(primary_input, auxiliary_input)
+    full_protocol.produce_proof(primary_input, auxiliary_input, d_assignment)
     return IOP.get_transcript()

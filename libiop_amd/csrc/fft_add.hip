@@ -649,7 +649,7 @@ static int run_phase1(AddPlan &pl, uint64_t *S, size_t batch = 1)
         static char names[64][2][32];
         char *nm = names[ps.j0 & 63][ps.k_start == d - 2 ? 1 : 0];
         if (!nm[0]) snprintf(nm, 32, getenv("IOPX_PROFILE_LEVELS") ? "k_phase1_L%02d_%s" : "k_phase1", ps.j0, ps.k_start == d - 2 ? "tw" : "x");
-        { ProfScope ps_(nm); hipLaunchKernelGGL(k_phase1<INV>, dim3((unsigned)blocks, (unsigned)batch), dim3(threads), lds, stream(), p); }
+        { ProfScope ps_(nm, (batch << d) * 48); hipLaunchKernelGGL(k_phase1<INV>, dim3((unsigned)blocks, (unsigned)batch), dim3(threads), lds, stream(), p); }
     }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
@@ -721,7 +721,7 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         p.rs_comb = comb_count ? rs_comb.u64() + 3 * (cbase - comb_base) * d : nullptr;
         int rc;
         if ((rc = set_lds(k_bfly_edge<INV, false>, lds)) != IOPX_OK) return rc;
-        { ProfScope ps_("k_bfly_edge"); hipLaunchKernelGGL((k_bfly_edge<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        { ProfScope ps_("k_bfly_edge", (ncos << d) * 48); hipLaunchKernelGGL((k_bfly_edge<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         return IOPX_OK;
     };
     auto launch_upper = [&](const Up &u, const uint64_t *s, uint64_t *dd, int shared, size_t ncos, size_t cbase) -> int {
@@ -738,10 +738,10 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         int rc;
         if (tuning().comb) {
             if ((rc = set_lds(k_bfly_upper<INV, true>, lds)) != IOPX_OK) return rc;
-            { ProfScope ps_("k_bfly_upper"); hipLaunchKernelGGL((k_bfly_upper<INV, true>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+            { ProfScope ps_("k_bfly_upper", (ncos << d) * 48); hipLaunchKernelGGL((k_bfly_upper<INV, true>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         } else {
             if ((rc = set_lds(k_bfly_upper<INV, false>, lds)) != IOPX_OK) return rc;
-            { ProfScope ps_("k_bfly_upper"); hipLaunchKernelGGL((k_bfly_upper<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+            { ProfScope ps_("k_bfly_upper", (ncos << d) * 48); hipLaunchKernelGGL((k_bfly_upper<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         }
         return IOPX_OK;
     };

@@ -89,9 +89,10 @@ struct TmpBuf {
 
 // Per-kernel timing with HIP events on the library's stream (iopx_profile_begin / iopx_profile_report).
 // Costs nothing when profiling is off.  Usage: { ProfScope ps("k_name"); hipLaunchKernelGGL(...); }
+// work_bytes: the launch's ALGORITHMIC bytes (elements swept x 24 x (read + write)), summed per kernel in the report.
 struct ProfScope {
     int slot;
-    explicit ProfScope(const char *name);
+    explicit ProfScope(const char *name, size_t work_bytes = 0);
     ~ProfScope();
 };
 

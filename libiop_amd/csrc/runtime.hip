@@ -166,15 +166,16 @@ int upload(void *dst_dev, const void *src_host, size_t bytes)
 }
 
 // ---- per-kernel profiling -----------------------------------------------------------------------
-struct ProfRec { const char *name; hipEvent_t a, b; };
+struct ProfRec { const char *name; hipEvent_t a, b; size_t bytes; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 
-ProfScope::ProfScope(const char *name) : slot(-1)
+ProfScope::ProfScope(const char *name, size_t work_bytes) : slot(-1)
 {
     if (!g_prof_on) return;
     ProfRec r;
     r.name = name;
+    r.bytes = work_bytes;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, g_stream);
     slot = (int)g_prof.size();
@@ -200,20 +201,22 @@ int iopx_profile_begin(void)
     return IOPX_OK;
 }
 
-// Stops profiling and writes one line per kernel name: "<name> <launches> <total_ms>\n".
+// Stops profiling and writes one line per kernel name: "<name> <launches> <total_ms> <algorithmic_bytes>\n".
 int iopx_profile_report(char *buf, size_t cap)
 {
     int rc = iopx::ensure_device();
     if (rc != IOPX_OK) return rc;
     iopx::g_prof_on = false;
     IOPX_HIP(hipStreamSynchronize(iopx::stream()));
-    std::map<std::string, std::pair<size_t, double>> agg;
+    struct Agg { size_t launches = 0; double ms = 0; double bytes = 0; };
+    std::map<std::string, Agg> agg;
     for (auto &r : iopx::g_prof) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             auto &e = agg[r.name];
-            e.first += 1;
-            e.second += ms;
+            e.launches += 1;
+            e.ms += ms;
+            e.bytes += (double)r.bytes;
         }
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -222,7 +225,7 @@ int iopx_profile_report(char *buf, size_t cap)
     std::string out;
     for (auto &kv : agg) {
         char line[256];
-        snprintf(line, sizeof(line), "%s %zu %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        snprintf(line, sizeof(line), "%s %zu %.6f %.0f\n", kv.first.c_str(), kv.second.launches, kv.second.ms, kv.second.bytes);
         out += line;
     }
     if (buf && cap) {

@@ -247,6 +247,15 @@ class DeviceOps:
             return [out[k * domain.size:(k + 1) * domain.size] for k in range(len(d_evals_list))]
         return [self.IFFT(t, domain) for t in d_evals_list]
 
+    def IFFT_batch_packed(self, packed, batch, domain):
+        """`batch` vectors stored back to back in one tensor: one batched inverse transform (phase-1 passes shared)."""
+        n = domain.size
+        if domain.additive and batch > 1:
+            out = self.empty(n * batch)
+            self.lib.additive_IFFT_batch_dev(packed.data_ptr(), batch, domain.basis, domain.shift, out.data_ptr())
+            return [out[k * n:(k + 1) * n] for k in range(batch)]
+        return [self.IFFT(packed[k * n:(k + 1) * n], domain) for k in range(batch)]
+
     def IFFT_of_known_degree(self, d_evals, degree, domain):
         """IFFT_of_known_degree_over_field_subset (fft.tcc:435-475): 2^ceil(log2 degree) coefficients."""
         k = _log2(degree)
@@ -362,9 +371,9 @@ class DeviceOps:
                           scale=scale, accumulate=accumulate, prime_field=not self.field.additive)
         return out
 
-    def poly_div_vanishing(self, d_poly, n_coeffs, domain):
-        """polynomial_over_vanishing_polynomial(P, Z_domain).first."""
-        out = self.empty(max(n_coeffs - domain.size, 0))
+    def poly_div_vanishing(self, d_poly, n_coeffs, domain, out=None):
+        """polynomial_over_vanishing_polynomial(P, Z_domain).first (written to the head of `out` when given)."""
+        out = self.empty(max(n_coeffs - domain.size, 0)) if out is None else out
         if n_coeffs > domain.size:
             if domain.additive:
                 self.lib.poly_div_vanishing_dev(d_poly.data_ptr(), n_coeffs, domain.basis, domain.shift, out.data_ptr())

@@ -463,3 +463,27 @@ def test_batched_lde(gpu, m, ncoef, batch, cb, cc):
     finally:
         for b in ins + outs:
             gpu.free(b)
+
+
+# ---- encoded Aurora prover: device transcript == the oracle prover's, byte for byte (configs 1 and 4's shapes) ------------------
+import aurora_cases as ac
+
+
+@pytest.mark.parametrize("field_name,log_n,num_inputs", [("gf192", 8, 15), ("gf192", 10, 15), ("gf192", 12, 15),      # cfg4's shape: RS 5, localization 2
+                                                         ("edwards_Fr", 8, 15), ("edwards_Fr", 12, 15)])               # cfg1: 2^12 over the 181-bit field
+def test_aurora_transcript_equals_oracle_prover(gpu, field_name, log_n, num_inputs):
+    import torch
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    transcript, params = ac.check_transcript_equals_oracle(gpu, torch, torch.device("cuda:0"), field_name, log_n, num_inputs, 0x2204)
+    assert params.RS_extra_dimensions == 5 and params.localization_parameters[:2] == [1, 2]
+    if log_n == 12:
+        code = ac.FIELDS[field_name][0]
+        for label, data in ac.tamper_cases(transcript):
+            assert not oracle.aurora_verify(code, log_n, num_inputs, 0x2204, data), label
+
+
+@pytest.mark.parametrize("field_name", ["gf192", "edwards_Fr"])
+def test_aurora_other_rates(gpu, field_name):
+    import torch
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    ac.check_transcript_equals_oracle(gpu, torch, torch.device("cuda:0"), field_name, 9, 7, 5, rs_extra=3, localization=3)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/r01_traffic.json from the FETCH_SIZE / WRITE_SIZE rocprofv3 passes (rocpd databases): per-launch HBM bytes of the
 phase-1 kernel with the guide's gfx950 correction (FETCH_SIZE counts half of a coalesced streaming read: doubled; WRITE_SIZE
-exact), both in KiB.  Usage: make_traffic_json.py <fetch_dir> <write_dir> <log_n> <out.json>"""
+exact), both in KiB.  Usage: make_traffic_json.py <fetch_dir> <write_dir> <log_n> <out.json> [kernel substring ...]"""
 import glob
 import json
 import sqlite3
@@ -18,14 +18,19 @@ def avg_counter(d, counter, kernel_like):
     return c.execute(q, (counter, kernel_like)).fetchone()
 
 
-fetch, nf = avg_counter(sys.argv[1], "FETCH_SIZE", "%k_phase1%")
-write, nw = avg_counter(sys.argv[2], "WRITE_SIZE", "%k_phase1%")
+kernels = sys.argv[5:] or ["k_phase1"]
 out = {
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 3 (summaries in profiles/r01_final_rocprofv3_bench_fft2p22.txt)",
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over bench.py (summaries next to this file in profiles/)",
     "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE reports 1/2 of the bytes of a coalesced streaming read on gfx950 -> doubled; WRITE_SIZE exact; both KiB",
     "log_n": int(sys.argv[3]),
-    "kernels": {"k_phase1": {"fetch_size_kib_avg": round(fetch, 1), "write_size_kib_avg": round(write, 1), "launches": nf,
-                             "traffic_bytes_per_launch": int(round((2 * fetch + write) * 1024))}},
+    "kernels": {},
 }
+for k in kernels:
+    fetch, nf = avg_counter(sys.argv[1], "FETCH_SIZE", "%" + k + "%")
+    write, nw = avg_counter(sys.argv[2], "WRITE_SIZE", "%" + k + "%")
+    if fetch is None or write is None:
+        continue
+    out["kernels"][k] = {"fetch_size_kib_avg": round(fetch, 1), "write_size_kib_avg": round(write, 1), "launches": nf,
+                         "traffic_bytes_per_launch": int(round((2 * fetch + write) * 1024))}
 json.dump(out, open(sys.argv[4], "w"), indent=1)
 print(json.dumps(out))

@@ -18,5 +18,5 @@ for name, fn in (("general", lambda: lib.gf192_mul_dev(da, db, do, n)),
     for _ in range(5):
         fn()
     rep = lib.profile_report()
-    for k, (cnt, ms) in rep.items():
+    for k, (cnt, ms, _bytes) in rep.items():
         print("%s: %s %.3f ms/launch  %.3e mult/s  (%.1f GB/s)" % (name, k, ms / cnt, n / (ms / cnt / 1e3), 3 * a.nbytes / (ms / cnt / 1e3) / 1e9))
