@@ -84,22 +84,19 @@ def main():
     lib.set_stream(torch.cuda.current_stream().cuda_stream)
 
     field = domains.GF192()
-    ops = domains.DeviceOps(lib, torch, dev, field)
+    if world > 1:
+        from libiop_amd import dist as idist
+        ops = idist.ShardedDeviceOps(lib, torch, dev, field, idist.AuroraShard(dist, rank, world))
+    else:
+        ops = domains.DeviceOps(lib, torch, dev, field)
     n = 1 << args.log_n
     cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, n, 15, n - 1, SEED)         # untimed: the statement and witness
     params = aurora.AuroraParameters(field, n, n - 1, 15)
     d_assignment = ops.upload(aurora.assignment_vector(field, primary, auxiliary))      # resident in HBM before the timed region
     torch.cuda.synchronize()
 
-    if world > 1:
-        from libiop_amd import dist as idist
-        shard = idist.AuroraShard(dist, rank, world)
-
-        def step():
-            return idist.sharded_aurora_snark_prover(ops, shard, cs, primary, params, d_assignment)
-    else:
-        def step():
-            return aurora.aurora_snark_prover(ops, cs, primary, None, params, d_assignment=d_assignment)
+    def step():          # with ShardedDeviceOps the same prover runs block-distributed (libiop_amd/dist.py)
+        return aurora.aurora_snark_prover(ops, cs, primary, None, params, d_assignment=d_assignment)
 
     transcript = None
     for _ in range(args.warmup):

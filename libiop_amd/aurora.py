@@ -142,7 +142,7 @@ class MultiLincheckVirtualOracle(VirtualOracle):
         if len(constituents) != len(self.matrices_T) + 1:
             raise ValueError("multi_lincheck uses more constituent oracles than what was provided.")
         p1, p2 = self.ops.FFT_batch([self.d_p_alpha_prime, self.d_p_alpha_ABC], self.S.size, self.L)      # :112-118
-        return self.ops.lincheck(constituents[0], constituents[1:], self.r_Mz, p1, p2, self.L.size)
+        return self.ops.lincheck(constituents[0], constituents[1:], self.r_Mz, p1, p2, constituents[0].shape[0])
 
 
 class RandomLinearCombinationOracle(VirtualOracle):
@@ -376,7 +376,8 @@ class FRIProtocol:
         self.localization, self.poly_degree_bound = list(localization_parameters), poly_degree_bound
         self.interactive_repetitions, self.query_repetitions = interactive_repetitions, query_repetitions
         self.num_reductions = len(self.localization)
-        self.domains = self.ops.field.fri_domains(IOP.get_domain(codeword_domain_handle), self.localization)          # compute_domains (:279-340)
+        self.domains = self.ops.mark_fri_domains(self.ops.field.fri_domains(IOP.get_domain(codeword_domain_handle), self.localization),
+                                                 self.localization)                                         # compute_domains (:279-340)
 
     def register_interactions(self):                                                                     # :342-398
         IOP, total = self.IOP, self.localization[0]
@@ -430,7 +431,7 @@ class FRIProtocol:
             for j in range(self.interactive_repetitions):
                 x_i = IOP.obtain_verifier_random_message(self.verifier_challenge_handles[i][j])[0]
                 for l in range(len(self.poly_handles)):
-                    by_interaction[j][l] = ops.fold(by_interaction[j][l], self.domains[i], cs, x_i)      # :522-526
+                    by_interaction[j][l] = ops.fold(by_interaction[j][l], self.domains[i], cs, x_i, self.domains[i + 1])      # :522-526
         for j in range(self.interactive_repetitions):
             for l in range(len(self.poly_handles)):
                 coeffs = ops.IFFT(by_interaction[j][l], self.domains[self.num_reductions])               # :538
@@ -478,7 +479,7 @@ class AuroraIOP:
         codeword_domain_shift = f.domain(1 << params.codeword_domain_dim).element_outside_of_subset()    # :282-283
         constraint_h = IOP.register_domain(f.domain(1 << params.constraint_domain_dim))
         variable_h = IOP.register_domain(f.domain(1 << params.variable_domain_dim))
-        self.codeword_domain_handle = IOP.register_domain(f.domain(1 << params.codeword_domain_dim, codeword_domain_shift))
+        self.codeword_domain_handle = IOP.register_domain(IOP.ops.mark_codeword_domain(f.domain(1 << params.codeword_domain_dim, codeword_domain_shift)))
         self.protocol = EncodedAuroraProtocol(IOP, constraint_h, variable_h, self.codeword_domain_handle, constraint_system,
                                               params.multi_lincheck_repetitions)
         self.LDT_reducer = LDTInstanceReducer(IOP, self.codeword_domain_handle, params.num_output_LDT_instances, params.max_tested_degree_bound)

@@ -97,7 +97,7 @@ class BCSProver:
         # run state
         self.oracles, self.prover_messages = [], []
         self.num_prover_rounds_done, self.processed_MTs = 0, 0
-        self.MT_nodes, self.MT_roots, self.MT_info = [], [], []
+        self.MT_trees, self.MT_roots, self.MT_info = [], [], []
         self.verifier_random_messages = {}
         self.virtual_contents_cache = {}
         self.pow_answer = None
@@ -182,7 +182,7 @@ class BCSProver:
         for round in range(self.num_interaction_rounds):
             for dom, ids in self.oracles_in_round_by_domain(round):
                 self.MT_info.append((round, dom, ids))
-                self.MT_nodes.append(None)
+                self.MT_trees.append(None)
                 self.MT_roots.append(None)
 
     def register_random_query_position(self, domain):
@@ -218,7 +218,7 @@ class BCSProver:
             raise ValueError("submitting an oracle for a previous round")
         if oid >= self.num_oracles_at_end_of_round[self.num_prover_rounds_done]:
             raise ValueError("submitting an oracle for a future round (did you forget to call signal_prover_round_done?)")
-        if self.domains[self.oracle_regs[oid][0]].size != d_contents.shape[0]:
+        if self.ops.local_size(self.domains[self.oracle_regs[oid][0]]) != d_contents.shape[0]:
             raise ValueError("oracle evaluations don't match the domain size")
         self.oracles[oid] = d_contents
 
@@ -252,9 +252,9 @@ class BCSProver:
         cs = self.get_round_parameters(ended)
         roots = []
         for dom, ids in mapping:
-            nodes = self.ops.merkle_tree([self.oracles[i] for i in ids], self.domains[dom], cs)
-            root = self.lib.read_digest(nodes.data_ptr())              # merkle_tree::get_root
-            self.MT_nodes[self.processed_MTs] = nodes
+            tree = self.ops.merkle_tree([self.oracles[i] for i in ids], self.domains[dom], cs)
+            root = tree.root()                                          # merkle_tree::get_root
+            self.MT_trees[self.processed_MTs] = tree
             self.MT_roots[self.processed_MTs] = root
             roots.append(root)
             self.processed_MTs += 1
@@ -338,7 +338,7 @@ class BCSProver:
             qpos, lpos = sorted(qset), sorted(lset)
             t.query_positions.append(qpos)
             t.MT_leaf_positions.append(lpos)
-            t.query_responses.append(self.lib.query_responses_dev([self.oracles[i].data_ptr() for i in ids], 24, domain.size, qpos))
-            t.MT_set_membership_proofs.append(self.lib.get_set_membership_proof_dev(self.MT_nodes[mt].data_ptr(), num_leaves, lpos))
+            t.query_responses.append(self.ops.query_responses([self.oracles[i] for i in ids], domain, qpos))
+            t.MT_set_membership_proofs.append(self.MT_trees[mt].membership_proof(lpos))
         t.proof_of_work = self.pow_answer
         return t

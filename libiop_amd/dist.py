@@ -416,3 +416,234 @@ def sharded_mul_fri_commit(lib, torch, dist, la, fri, d_f_local, log_n, gen_int,
                                            la._as_u64(_mont(la, sh)).ctypes.data_as(la._u64p), coeffs.data_ptr()))
     lib.synchronize()
     return roots, coeffs.cpu().numpy().view(np.uint64)[:final_degree_bound].copy()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The Aurora prover sharded over N = 2^r GPUs by contiguous cosets (BASELINE config 4).
+#
+# Every vector over the codeword domain L and over the FRI domains L^(i) is block-distributed: rank g holds positions
+# [g |D| / N, (g + 1) |D| / N), which is the affine sub-domain span(basis[0 .. m - r)) + element_by_index(g 2^(m-r)).  Hence
+#   * a low-degree extension is the rank's coset range of the transform (no exchange; phase 1 on the <= 2^20 coefficients
+#     is replicated),
+#   * virtual oracles, the LDT combination and the FRI fold are pointwise / coset-local on the sub-domain,
+#   * a Merkle tree is N sub-trees whose roots are all-gathered (N x 32 bytes) and finished on the host,
+#   * the sumcheck's known-degree IFFT needs the first 2^(log|H| + 1) evaluations only: they sit on rank 0, which interpolates
+#     and divides, and h's coefficients are broadcast (|H| x 24 bytes — the one codeword-derived exchange of a proof),
+#   * once an FRI domain has fewer than MIN_BLOCK elements per rank it is all-gathered and every rank finishes it,
+#   * queried values and authentication paths are collected from their owners at the end (a few hundred KB).
+# Everything over the small domains (constraint / variable / summation / input: <= 2^20 elements), the hashchain and the
+# proof of work are replicated: every rank derives the same challenges and the same transcript.
+# ---------------------------------------------------------------------------------------------------------------
+from .domains import DeviceOps, Domain, MerkleTree, ADDITIVE
+
+MIN_BLOCK = 64          # elements per rank below which an FRI domain is gathered
+
+
+class AuroraShard:
+    def __init__(self, dist, rank, world):
+        self.dist, self.rank, self.world = dist, rank, world
+        self.r = world.bit_length() - 1
+        if (1 << self.r) != world:
+            raise ValueError("world size must be a power of two")
+
+
+class ShardedMerkleTree:
+    """Global tree = top r levels (host, from the all-gathered sub-roots) over N device-resident sub-trees."""
+
+    def __init__(self, ops, sub_tree, num_leaves_global):
+        self.ops, self.sub, self.L = ops, sub_tree, num_leaves_global
+        sh = ops.shard
+        gathered = [None] * sh.world
+        sh.dist.all_gather_object(gathered, sub_tree.root())
+        # top levels in heap order: level r (sub-roots) up to the root
+        self.top = {}
+        level = gathered
+        for depth in range(sh.r, -1, -1):
+            for j, dg in enumerate(level):
+                self.top[(1 << depth) - 1 + j] = dg
+            level = [hashlib.blake2b(level[2 * i] + level[2 * i + 1], digest_size=32).digest() for i in range(len(level) // 2)]
+
+    def root(self):
+        return self.top[0]
+
+    def membership_proof(self, leaf_positions):
+        """merkle_tree::get_set_membership_proof (merkle_tree.tcc:242-336) over the distributed tree: the index walk on the host,
+        every auxiliary node fetched from the rank that owns it."""
+        sh, torch = self.ops.shard, self.ops.torch
+        idx = membership_proof_node_indices(self.L, leaf_positions)
+        r = sh.r
+        mine = {}
+        local_req = []
+        for node in idx:
+            depth = (node + 1).bit_length() - 1
+            if depth <= r:
+                continue
+            j = node - ((1 << depth) - 1)
+            owner, loc_depth = j >> (depth - r), depth - r
+            if owner == sh.rank:
+                local_req.append((node, (1 << loc_depth) - 1 + (j & ((1 << loc_depth) - 1))))
+        if local_req:
+            sel = self.ops.upload_raw(np.array([l for _, l in local_req], dtype=np.int64), torch.int64)
+            got = self.sub.nodes[sel].cpu().numpy()
+            for (node, _), dg in zip(local_req, got):
+                mine[node] = bytes(dg)
+        everyone = [None] * sh.world
+        sh.dist.all_gather_object(everyone, mine)
+        table = dict(self.top)
+        for d in everyone:
+            table.update(d)
+        return np.frombuffer(b"".join(table[node] for node in idx), dtype=np.uint8).reshape(-1, 32).copy()
+
+
+def membership_proof_node_indices(num_leaves, positions):
+    """Heap indices of the auxiliary hashes of merkle_tree::get_set_membership_proof, in the reference's order
+    (merkle_tree.tcc:256-336): level by level from the leaves, a left node whose right sibling is not queried takes the
+    sibling, a right node takes its left sibling."""
+    out = []
+    S = sorted(set(int(p) for p in positions))
+    if not S:
+        return out
+    for p in S:
+        if p >= num_leaves:
+            raise ValueError("All positions must be between 0 and num_leaves-1.")
+    S = [p + num_leaves - 1 for p in S]
+    while not (len(S) == 1 and S[0] == 0):
+        new_S, i = [], 0
+        while i < len(S):
+            pos, nxt = S[i], i + 1
+            new_S.append((pos - 1) // 2)
+            if pos % 2 == 0:
+                out.append(pos - 1)
+            elif nxt == len(S) or S[nxt] != pos + 1:
+                out.append(pos + 1)
+            else:
+                nxt += 1
+            i = nxt
+        S = new_S
+    return out
+
+
+class ShardedDeviceOps(DeviceOps):
+    """DeviceOps with the codeword-domain vectors block-distributed over the ranks of `shard` (additive domains)."""
+
+    def __init__(self, lib, torch, device, field, shard):
+        super().__init__(lib, torch, device, field)
+        if not field.additive:
+            raise ValueError("contiguous-coset sharding is for affine subspaces (multiplicative cosets shard by residue class)")
+        self.shard = shard
+
+    # ---- layout ----
+    def _is_sharded(self, domain):
+        return getattr(domain, "sharded", False)
+
+    def local_size(self, domain):
+        return domain.size // self.shard.world if self._is_sharded(domain) else domain.size
+
+    def local_domain(self, domain):
+        """The rank's block as an affine subspace (local_subdomain above)."""
+        if not self._is_sharded(domain):
+            return domain
+        b, s = local_subdomain(domain.basis, domain.shift, self.shard.rank, self.shard.world)
+        return Domain(self.field, ADDITIVE, basis=b, shift=s)
+
+    def mark_codeword_domain(self, domain):
+        if domain.size // self.shard.world < MIN_BLOCK:
+            raise ValueError("codeword domain too small for %d ranks" % self.shard.world)
+        domain.sharded = True
+        return domain
+
+    def mark_fri_domains(self, domains, localization):
+        """L^(i+1) stays distributed while it keeps MIN_BLOCK elements per rank (folds are local: cosets are contiguous)."""
+        for i in range(1, len(domains)):
+            domains[i].sharded = self._is_sharded(domains[i - 1]) and domains[i].size // self.shard.world >= MIN_BLOCK
+        return domains
+
+    def _all_gather(self, d_local):
+        parts = [self.torch.empty_like(d_local) for _ in range(self.shard.world)]
+        self.shard.dist.all_gather(parts, d_local.contiguous())
+        return self.torch.cat(parts, 0)
+
+    # ---- transforms ----
+    def FFT(self, d_coeffs, n_coeffs, domain):
+        if not self._is_sharded(domain):
+            return super().FFT(d_coeffs, n_coeffs, domain)
+        return self.FFT_batch([d_coeffs], n_coeffs, domain)[0]
+
+    def FFT_batch(self, d_coeffs_list, n_coeffs, domain):
+        if not self._is_sharded(domain):
+            return super().FFT_batch(d_coeffs_list, n_coeffs, domain)
+        return sharded_lde_batch(self.lib, self.torch, d_coeffs_list, int(n_coeffs), domain.basis, domain.shift, self.shard.rank, self.shard.world)
+
+    def IFFT(self, d_evals, domain):
+        if self._is_sharded(domain):
+            raise ValueError("inverse transform of a distributed vector: gather it first")
+        return super().IFFT(d_evals, domain)
+
+    def IFFT_of_known_degree(self, d_evals, degree, domain):
+        """fft.tcc:458-475 needs the first 2^ceil(log2 degree) evaluations: rank 0's head.  Rank 0 interpolates, the
+        coefficients are broadcast."""
+        if not self._is_sharded(domain):
+            return super().IFFT_of_known_degree(d_evals, degree, domain)
+        k = max(int(degree) - 1, 0).bit_length()
+        if (1 << k) > self.local_size(domain):
+            full = self._all_gather(d_evals)
+            return super().IFFT(full[: 1 << k], domain.get_subset_of_order(1 << k))
+        if self.shard.rank == 0:
+            out = super().IFFT(d_evals[: 1 << k], domain.get_subset_of_order(1 << k))
+        else:
+            out = self.empty(1 << k)
+        self.shard.dist.broadcast(out, src=0)
+        return out
+
+    # ---- FRI / Merkle ----
+    def fold(self, d_f, domain, coset_size, x_i, next_domain=None):
+        if not self._is_sharded(domain):
+            return super().fold(d_f, domain, coset_size, x_i)
+        nxt = super().fold(d_f, self.local_domain(domain), coset_size, x_i)
+        if next_domain is not None and self._is_sharded(next_domain):
+            return nxt
+        return self._all_gather(nxt)
+
+    def merkle_tree(self, d_oracles, domain, coset_size):
+        if not self._is_sharded(domain):
+            return super().merkle_tree(d_oracles, domain, coset_size)
+        loc = self.local_domain(domain)
+        return ShardedMerkleTree(self, super().merkle_tree(d_oracles, loc, coset_size), domain.size // coset_size)
+
+    def query_responses(self, d_oracles, domain, positions):
+        if not self._is_sharded(domain):
+            return super().query_responses(d_oracles, domain, positions)
+        block = self.local_size(domain)
+        lo = self.shard.rank * block
+        mine_pos = [p for p in positions if lo <= p < lo + block]
+        mine = {}
+        if mine_pos:
+            vals = self.lib.query_responses_dev([t.data_ptr() for t in d_oracles], 24, block, [p - lo for p in mine_pos])
+            mine = {p: vals[i] for i, p in enumerate(mine_pos)}
+        everyone = [None] * self.shard.world
+        self.shard.dist.all_gather_object(everyone, mine)
+        table = {}
+        for d in everyone:
+            table.update(d)
+        return np.stack([table[p] for p in positions]) if positions else np.zeros((0, len(d_oracles), 3), dtype=np.uint64)
+
+    # ---- pointwise operators: the rank's block is the sub-domain ----
+    def rowcheck(self, d_az, d_bz, d_cz, codeword_domain, constraint_domain):
+        return super().rowcheck(d_az, d_bz, d_cz, self.local_domain(codeword_domain), constraint_domain)
+
+    def fz(self, d_fw, d_f1v, codeword_domain, input_domain):
+        return super().fz(d_fw, d_f1v, self.local_domain(codeword_domain), input_domain)
+
+    def sumcheck_g(self, d_f, d_h, codeword_domain, summation_domain, claimed_sum):
+        return super().sumcheck_g(d_f, d_h, self.local_domain(codeword_domain), summation_domain, claimed_sum)
+
+    def ldt_combine(self, d_oracles, degrees, random_coefficients, domain):
+        return super().ldt_combine(d_oracles, degrees, random_coefficients, self.local_domain(domain))
+
+
+def sharded_aurora_snark_prover(ops, constraint_system, primary_input, parameters, d_assignment, auxiliary_input=None, round_hook=None):
+    """aurora_snark_prover with `ops` a ShardedDeviceOps: every rank calls it with the same (replicated) instance and witness
+    and returns the same transcript, byte-identical to the single-GPU prover's."""
+    from . import aurora
+    return aurora.aurora_snark_prover(ops, constraint_system, primary_input, auxiliary_input, parameters, round_hook=round_hook,
+                                      d_assignment=d_assignment)

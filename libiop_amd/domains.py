@@ -124,7 +124,8 @@ class GF192:
 
     def fri_domains(self, domain, localization):
         """FRI_protocol::compute_domains, additive branch (fri_ldt.tcc:310-338)."""
-        return [Domain(self, ADDITIVE, basis=b, shift=s) for b, s in host.fri_additive_domains(domain.basis, domain.shift, localization)]
+        chain = host.fri_additive_domains(domain.basis, domain.shift, localization)
+        return [domain] + [Domain(self, ADDITIVE, basis=b, shift=s) for b, s in chain[1:]]
 
 
 class EdwardsFr:
@@ -177,12 +178,41 @@ class EdwardsFr:
         return out
 
 
+class MerkleTree:
+    """A BCS Merkle tree resident on the device: (2L - 1, 32) uint8 nodes in heap order (merkle_tree.tcc:92-229)."""
+
+    def __init__(self, lib, nodes, num_leaves):
+        self.lib, self.nodes, self.num_leaves = lib, nodes, num_leaves
+
+    def root(self):
+        """merkle_tree::get_root, read on the library's stream."""
+        return self.lib.read_digest(self.nodes.data_ptr())
+
+    def membership_proof(self, leaf_positions):
+        """merkle_tree::get_set_membership_proof (merkle_tree.tcc:242-336): the auxiliary hashes as a (count, 32) uint8 array."""
+        return self.lib.get_set_membership_proof_dev(self.nodes.data_ptr(), self.num_leaves, leaf_positions)
+
+
 class DeviceOps:
     """The device operators of the path, dispatched on the domain type.  Vectors are (count, 3) int64 torch tensors on the
     device the library is bound to; every call enqueues on the library's stream and returns without synchronising."""
 
     def __init__(self, lib, torch, device, field):
         self.lib, self.torch, self.device, self.field = lib, torch, device, field
+
+    # ---- layout: one GPU holds every vector whole (libiop_amd/dist.py overrides these for contiguous-coset sharding) ----
+    def local_size(self, domain):
+        return domain.size
+
+    def mark_codeword_domain(self, domain):
+        return domain
+
+    def mark_fri_domains(self, domains, localization):
+        return domains
+
+    def query_responses(self, d_oracles, domain, positions):
+        """values[p][k] = oracle_k[positions[p]] (bcs_prover.tcc:187-197) as a (positions, oracles, 3) uint64 array."""
+        return self.lib.query_responses_dev([t.data_ptr() for t in d_oracles], 24, domain.size, positions)
 
     def empty(self, n):
         return self.torch.empty((max(int(n), 1), 3), dtype=self.torch.int64, device=self.device)[: int(n)]
@@ -267,7 +297,7 @@ class DeviceOps:
         return out
 
     # ---- FRI / Merkle ----
-    def fold(self, d_f, domain, coset_size, x_i):
+    def fold(self, d_f, domain, coset_size, x_i, next_domain=None):
         """evaluate_next_f_i_over_entire_domain (fri_aux.tcc:5-34)."""
         out = self.empty(domain.size // coset_size)
         if domain.additive:
@@ -278,11 +308,11 @@ class DeviceOps:
         return out
 
     def merkle_tree(self, d_oracles, domain, coset_size):
-        """construct_with_leaves_serialized_by_cosets + compute_inner_nodes: (2L-1, 32) uint8 node array on the device."""
+        """construct_with_leaves_serialized_by_cosets + compute_inner_nodes over device-resident oracles."""
         leaves = domain.size // coset_size
         nodes = self.torch.empty((2 * leaves - 1, 32), dtype=self.torch.uint8, device=self.device)
         self.lib.merkle_tree_dev([t.data_ptr() for t in d_oracles], 24, domain.size, coset_size, nodes.data_ptr(), domain_type=domain.domain_type)
-        return nodes
+        return MerkleTree(self.lib, nodes, leaves)
 
     # ---- virtual oracles ----
     def rowcheck(self, d_az, d_bz, d_cz, codeword_domain, constraint_domain):

@@ -219,3 +219,51 @@ def test_sharded_fri_commit_equals_single_process(world):
     mp.spawn(_commit_worker, args=(world, port, ret), nprocs=world, join=True)
     for r in range(world):
         assert ret[r] == (True, True), (r, ret[r])
+
+
+# ---- the whole Aurora prover block-distributed over the ranks (libiop_amd/dist.py ShardedDeviceOps) ----
+def _aurora_worker(rank, world, port, ret, log_n, num_inputs):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from emu_lib import emu
+        from libiop_amd import aurora, domains, r1cs
+        from libiop_amd import dist as idist
+        field = domains.GF192()
+        ops = idist.ShardedDeviceOps(emu(), torch, torch.device("cpu"), field, idist.AuroraShard(dist, rank, world))
+        n = 1 << log_n
+        cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, n, num_inputs, n - 1, 0x2204)
+        params = aurora.AuroraParameters(field, n, n - 1, num_inputs)
+        d_z = ops.upload(aurora.assignment_vector(field, primary, auxiliary))
+        transcript = idist.sharded_aurora_snark_prover(ops, cs, primary, params, d_z)
+        ret[rank] = transcript.serialize()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,log_n", [(2, 7), (4, 8), (2, 9)])
+def test_sharded_aurora_prover_equals_oracle(world, log_n):
+    """Every rank returns the transcript of the single-process oracle prover, byte for byte."""
+    import oracle
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_aurora_worker, args=(world, port, ret, log_n, 15), nprocs=world, join=True)
+    ref = oracle.aurora_prove(oracle.FIELD_GF192, log_n, 15, 0x2204)
+    for r in range(world):
+        assert ret[r] == ref, "rank %d" % r
+
+
+def test_membership_proof_node_indices_match_oracle():
+    import oracle
+    from libiop_amd import dist as idist
+    rng = np.random.default_rng(3)
+    for num_leaves in (2, 8, 64, 1024):
+        for _ in range(20):
+            pos = sorted(set(int(p) for p in rng.integers(0, num_leaves, size=int(rng.integers(1, 12)))))
+            assert idist.membership_proof_node_indices(num_leaves, pos) == [int(v) for v in oracle.membership_proof_indices(num_leaves, pos)]
