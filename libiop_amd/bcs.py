@@ -49,7 +49,8 @@ class Transcript:
         self.proof_of_work = b""
 
     def serialize(self):
-        """The canonical byte form the parity tests compare (same layout as oracle/iop.hpp bcs_transcript::serialize)."""
+        """The canonical byte form the parity tests compare (counts and positions as 8-byte little-endian integers, elements and
+        digests raw, in the field order of this class; the reference's own serialisation is text, bcs_common.tcc:96-390)."""
         out = bytearray()
         u64 = lambda v: out.extend(int(v).to_bytes(8, "little"))
         u64(len(self.prover_messages))
