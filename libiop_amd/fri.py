@@ -1,6 +1,7 @@
-"""FRI prover commit phase on device-resident codewords (additive domains, GF(2^192)).
+"""FRI on device-resident codewords: the FRI-only SNARK of BASELINE config 3 on the BCS round driver (fri_snark_prover), and
+the bare commit-phase loops the sharded pipelines of libiop_amd/dist.py and the stage benches reuse (fri_commit*).
 
-Host-side mirror of FRI_protocol::calculate_and_submit_proof (libiop/protocols/ldt/fri/fri_ldt.tcc:475-548)
+The commit-phase functions are a host-side mirror of FRI_protocol::calculate_and_submit_proof (libiop/protocols/ldt/fri/fri_ldt.tcc:475-548)
 together with the per-round work bcs_prover::signal_prover_round_done does for it (bcs_prover.tcc:23-60: one
 Merkle tree per round over the round's oracle, leaves serialised by cosets of size 2^eta_i; bcs_common.tcc:550-614:
 absorb the root, absorb the round's prover messages, squeeze the verifier challenge).  The codeword never leaves
@@ -57,56 +58,69 @@ def fri_commit(lib, torch, d_codeword, basis, shift, localization_parameters, fi
     return res
 
 
-class FRIProof:
-    """What the BCS transformation of the FRI protocol sends (bcs_common.hpp:36-106), for one oracle / one interaction:
-    per round the Merkle root, the queried leaf positions, the codeword values of the queried cosets and a pruned
-    set-membership proof; the final polynomial; the proof-of-work answer."""
+class FRISnarkParameters:
+    """FRI_snark_parameters / FRI_iop_protocol_parameters (libiop/snark/fri_snark.hpp, protocols/fri_iop.hpp): codeword
+    domain dimension, RS_extra_dimensions, the localization array (or parameter), the interactive and query repetitions the
+    harness overrides FRI's own parameterisation with (fri_iop.tcc:59-73); pow parameter = dim + 3 (fri_snark.tcc:26-28,
+    common_bcs_parameters.tcc:23-25)."""
 
-    def __init__(self):
-        self.roots = []
-        self.final_polynomial = None
-        self.proof_of_work = None
-        self.leaf_positions = []        # per round: sorted unique leaf (coset) indices
-        self.query_responses = []       # per round: (len(leaf_positions), coset_size, 3) uint64
-        self.membership_proofs = []     # per round: (count, 32) uint8 auxiliary hashes
-
-
-def fri_query_positions(hashchain, num_queries, domain_size):
-    """One squeezed position per query repetition in the codeword domain (bcs_common.tcc:536-548)."""
-    return [hashchain.squeeze_query_positions(1, domain_size)[0] for _ in range(num_queries)]
+    def __init__(self, codeword_domain_dim, RS_extra_dimensions, localization_parameter=2, num_interactive_repetitions=1,
+                 num_query_repetitions=10, localization_parameter_array=None):
+        self.codeword_domain_dim, self.RS_extra_dimensions = codeword_domain_dim, RS_extra_dimensions
+        self.localization_parameters = list(localization_parameter_array) if localization_parameter_array else \
+            host.localization_parameter_to_array(localization_parameter, codeword_domain_dim, RS_extra_dimensions)
+        self.num_interactive_repetitions, self.num_query_repetitions = num_interactive_repetitions, num_query_repetitions
+        self.pow_bits = codeword_domain_dim + 3
+        self.poly_degree_bound = 1 << (codeword_domain_dim - RS_extra_dimensions)
 
 
-def fri_prove(lib, torch, d_codeword, basis, shift, localization_parameters, final_degree_bound, num_queries, pow_bitlen,
-              domains=None):
-    """Non-interactive FRI prover for one device-resident codeword over an affine subspace of GF(2^192): commit phase
-    (fri_commit), proof of work on the hashchain's root-type squeeze (bcs_prover.tcc:52-59), query positions from the
-    hashchain, then transcript extraction straight from the device-resident trees and codewords (bcs_prover.tcc:136-233).
-    Round i's leaves are the cosets of size 2^eta_i of L^(i); a query at position s of L^(0) touches leaf s >> (eta_0 + .. +
-    eta_i) of round i (fri_aux.tcc:355-387 for affine subspaces)."""
-    hc = host.Blake2bHashchain()
-    com = fri_commit(lib, torch, d_codeword, basis, shift, localization_parameters, final_degree_bound, hashchain=hc,
-                     keep_codewords=True, domains=domains)
-    proof = FRIProof()
-    proof.roots = com.roots
-    proof.final_polynomial = com.final_polynomial
-    hc.absorb(None)                                       # the last round's prover message: the final polynomial (F8: state only)
-    challenge = hc.squeeze_root_type()
-    proof.proof_of_work = lib.solve_pow(challenge, pow_bitlen)
-    hc.absorb(proof.proof_of_work)
-    n0 = d_codeword.shape[0]
-    positions = fri_query_positions(hc, num_queries, n0)
-    shift_bits = 0
-    for i, eta in enumerate(localization_parameters):
-        shift_bits += eta
-        f_i, nodes = com.codewords[i], com.trees[i]
-        cs = 1 << eta
-        leaves = sorted(set(p >> shift_bits for p in positions))
-        elems = [leaf * cs + k for leaf in leaves for k in range(cs)]
-        vals = lib.query_responses_dev([f_i.data_ptr()], 24, f_i.shape[0], elems)
-        proof.leaf_positions.append(leaves)
-        proof.query_responses.append(vals.reshape(len(leaves), cs, 3))
-        proof.membership_proofs.append(lib.get_set_membership_proof_dev(nodes.data_ptr(), f_i.shape[0] // cs, leaves))
-    return proof
+class FRIIopProtocol:
+    """FRI_iop_protocol (libiop/protocols/fri_iop.tcc:3-101): one oracle over the unshifted default codeword domain (:13), the
+    LDT instance reducer with one instance over it, FRI with the given repetitions; round-0 leaves hold cosets of 2^eta_0 (:55-57).
+
+    Reference quirk: dummy_oracle::evaluated_contents (protocols/encoded/dummy_protocol.tcc:14-32) reserves its result and then
+    loops over its still-zero size, so the virtual oracle the reference hands to the LDT reducer is EMPTY and the reference's
+    FRI_snark_prover folds out-of-bounds memory (no reference test runs it).  BASELINE config 3 states the intent — the FRI prover
+    on a degree-2^20 Reed-Solomon codeword — so the reducer here takes the submitted oracle itself."""
+
+    def __init__(self, IOP, params):
+        from .aurora import LDTInstanceReducer
+        self.IOP, self.params = IOP, params
+        domain = IOP.ops.mark_codeword_domain(IOP.field.domain(1 << params.codeword_domain_dim))
+        self.codeword_domain_handle = IOP.register_domain(domain)
+        self.oracle = IOP.register_oracle("dummy", self.codeword_domain_handle, params.poly_degree_bound, False)
+        self.LDT = LDTInstanceReducer(IOP, self.codeword_domain_handle, 1, params.poly_degree_bound)
+        IOP.set_round_parameters(domain.get_subset_of_order(1 << params.localization_parameters[0]))
+
+    def register_interactions(self):
+        self.LDT.register_interactions([self.oracle], self.params.localization_parameters, self.params.num_interactive_repetitions,
+                                       self.params.num_query_repetitions)
+
+    def register_queries(self):
+        self.LDT.register_queries()
+
+    def produce_proof(self, d_codeword):                                                   # :82-89
+        self.IOP.submit_oracle(self.oracle, d_codeword)
+        self.IOP.signal_prover_round_done()
+        self.LDT.calculate_and_submit_proof()
+
+
+def fri_snark_prover(ops, params, d_poly_coeffs=None, d_codeword=None, round_hook=None):
+    """FRI_snark_prover (libiop/snark/fri_snark.tcc:43-77) on the BCS round driver: the codeword (given, or the extension of
+    the given coefficients, dummy_protocol.tcc:91-107) is committed, reduced and folded on the device; returns the Transcript."""
+    from .bcs import BCSProver
+    IOP = BCSProver(ops, params.pow_bits)
+    if round_hook is not None:
+        IOP.round_hooks.append(round_hook)
+    protocol = FRIIopProtocol(IOP, params)
+    protocol.register_interactions()
+    IOP.seal_interaction_registrations()
+    protocol.register_queries()
+    IOP.seal_query_registrations()
+    if d_codeword is None:
+        d_codeword = ops.FFT(d_poly_coeffs, d_poly_coeffs.shape[0], IOP.get_domain(protocol.codeword_domain_handle))
+    protocol.produce_proof(d_codeword)
+    return IOP.get_transcript()
 
 
 def squeeze_edwards_fr(hc):
@@ -165,32 +179,3 @@ def fri_commit_multiplicative(lib, torch, d_codeword, log_n, shift_int, localiza
     lib.synchronize()
     res.final_polynomial = coeffs.cpu().numpy().view(np.uint64)[:final_degree_bound].copy()
     return res
-
-
-def fri_prove_multiplicative(lib, torch, d_codeword, log_n, shift_int, localization_parameters, final_degree_bound, num_queries, pow_bitlen):
-    """fri_prove over multiplicative cosets of the 181-bit prime field.  Round i's leaf j is the coset {j + k * n_i / 2^eta_i} of
-    L^(i) (subgroup.tcc:175-197); a query at position p of L^(i) lands in leaf p mod (n_i / 2^eta_i), which is also its position
-    in L^(i+1) (fri_aux.tcc:355-387 for multiplicative cosets)."""
-    hc = host.Blake2bHashchain()
-    com = fri_commit_multiplicative(lib, torch, d_codeword, log_n, shift_int, localization_parameters, final_degree_bound, hashchain=hc,
-                                    keep_codewords=True)
-    proof = FRIProof()
-    proof.roots = com.roots
-    proof.final_polynomial = com.final_polynomial
-    hc.absorb(None)
-    import hashlib
-    challenge = hashlib.blake2b(squeeze_edwards_fr(hc).tobytes(), digest_size=32).digest()     # squeeze_root_type (blake2b.tcc:105-110)
-    proof.proof_of_work = lib.solve_pow(challenge, pow_bitlen)
-    hc.absorb(proof.proof_of_work)
-    positions = fri_query_positions(hc, num_queries, 1 << log_n)
-    for i, eta in enumerate(localization_parameters):
-        f_i, nodes = com.codewords[i], com.trees[i]
-        cs = 1 << eta
-        num_leaves = f_i.shape[0] // cs
-        positions = [p % num_leaves for p in positions]
-        leaves = sorted(set(positions))
-        vals = lib.query_responses_dev([f_i.data_ptr()], 24, f_i.shape[0], [leaf + k * num_leaves for leaf in leaves for k in range(cs)])
-        proof.leaf_positions.append(leaves)
-        proof.query_responses.append(vals.reshape(len(leaves), cs, 3))
-        proof.membership_proofs.append(lib.get_set_membership_proof_dev(nodes.data_ptr(), num_leaves, leaves))
-    return proof

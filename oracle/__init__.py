@@ -679,3 +679,26 @@ def r1cs_example(field, log_constraints, num_inputs, seed):
                                    _p(z), _p(idx), _p(coeff))
     assert rc == 0
     return z, idx, coeff
+
+
+def fri_snark_prove(field, codeword_domain_dim, rs_extra, localization, interactions, queries, seed):
+    """Serialized transcript of the FRI-only SNARK (oracle/aurora.hpp FRI_snark_prover) on the seeded degree-2^(dim - rs_extra) polynomial."""
+    l = lib()
+    l.oracle_fri_snark_prove.restype = ctypes.c_long
+    sz = ctypes.c_size_t
+    n = l.oracle_fri_snark_prove(ctypes.c_int(field), sz(codeword_domain_dim), sz(rs_extra), sz(localization), sz(interactions), sz(queries), ctypes.c_uint64(seed))
+    if n < 0:
+        raise RuntimeError("oracle_fri_snark_prove failed (%d)" % n)
+    buf = (ctypes.c_uint8 * n)()
+    l.oracle_aurora_fetch(buf)
+    return bytes(buf)
+
+
+def fri_snark_verify(field, codeword_domain_dim, rs_extra, localization, interactions, queries, transcript):
+    sz = ctypes.c_size_t
+    buf = (ctypes.c_uint8 * len(transcript)).from_buffer_copy(bytes(transcript))
+    rc = lib().oracle_fri_snark_verify(ctypes.c_int(field), sz(codeword_domain_dim), sz(rs_extra), sz(localization), sz(interactions), sz(queries),
+                                       buf, sz(len(transcript)))
+    if rc < 0:
+        raise RuntimeError("oracle_fri_snark_verify failed (%d)" % rc)
+    return bool(rc)

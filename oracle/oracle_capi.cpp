@@ -634,4 +634,52 @@ int oracle_r1cs_example(int field, size_t log_constraints, size_t num_inputs, ui
     return -1;
 }
 
+
+// FRI-only SNARK (aurora.hpp FRI_snark_*): the polynomial's coefficients are seeded_element(seed, i), i < 2^(dim - rs_extra)
+} // extern "C"
+
+namespace {
+template<typename F>
+FRI_snark_parameters<F> make_fri_params(size_t dim, size_t rs_extra, size_t localization, size_t interactions, size_t queries)
+{
+    FRI_snark_parameters<F> p;
+    p.codeword_domain_dim = dim; p.RS_extra_dimensions = rs_extra; p.num_interactive_repetitions = interactions; p.num_query_repetitions = queries;
+    p.localization_parameters = localization_parameter_to_array(localization, dim, rs_extra);
+    return p;
+}
+template<typename F>
+long fri_prove_impl(size_t dim, size_t rs_extra, size_t localization, size_t interactions, size_t queries, uint64_t seed)
+{
+    const FRI_snark_parameters<F> p = make_fri_params<F>(dim, rs_extra, localization, interactions, queries);
+    std::vector<F> coeffs(p.poly_degree_bound());
+    for (size_t i = 0; i < coeffs.size(); ++i) coeffs[i] = seeded_element(seed, i, (const F *)nullptr);
+    g_last_transcript = FRI_snark_prover<F>(coeffs, p).serialize();
+    return (long)g_last_transcript.size();
+}
+template<typename F>
+int fri_verify_impl(size_t dim, size_t rs_extra, size_t localization, size_t interactions, size_t queries, const uint8_t *bytes, size_t len)
+{
+    const FRI_snark_parameters<F> p = make_fri_params<F>(dim, rs_extra, localization, interactions, queries);
+    bcs_transcript<F> t;
+    try { t = bcs_transcript<F>::deserialize(bytes, len); } catch (const std::exception &) { return 0; }
+    return FRI_snark_verifier<F>(t, p) ? 1 : 0;
+}
+} // namespace
+
+extern "C" {
+
+long oracle_fri_snark_prove(int field, size_t dim, size_t rs_extra, size_t localization, size_t interactions, size_t queries, uint64_t seed)
+{
+    try { AURORA_DISPATCH(field, return fri_prove_impl<F>(dim, rs_extra, localization, interactions, queries, seed)); }
+    catch (const std::exception &e) { fprintf(stderr, "oracle_fri_snark_prove: %s\n", e.what()); return -2; }
+    return -1;
+}
+int oracle_fri_snark_verify(int field, size_t dim, size_t rs_extra, size_t localization, size_t interactions, size_t queries,
+                            const uint8_t *transcript, size_t len)
+{
+    try { AURORA_DISPATCH(field, return fri_verify_impl<F>(dim, rs_extra, localization, interactions, queries, transcript, len)); }
+    catch (const std::exception &e) { fprintf(stderr, "oracle_fri_snark_verify: %s\n", e.what()); return -2; }
+    return -1;
+}
+
 } // extern "C"

@@ -1,18 +1,16 @@
-"""End-to-end FRI (prover through the C ABI on the CPU build of the kernels, independent oracle verifier)."""
+"""FRI-only SNARK end to end (prover through the C ABI on the CPU build of the kernels): transcripts byte-equal to the oracle's
+independent prover, accepted by its verifier; tampering and high-degree codewords rejected."""
 import pytest
+import torch
 
 import fri_cases as fc
 from emu_lib import emu
 
-
-@pytest.mark.parametrize("m,rs_extra,loc_param,queries,pow_bits,kind", [(8, 2, 2, 6, 6, "standard"), (10, 3, 2, 10, 9, "random"), (7, 2, 1, 4, 0, "random"),
-                                                                       (9, 2, 3, 8, 10, "standard")])
-def test_prove_and_verify(m, rs_extra, loc_param, queries, pow_bits, kind):
-    torch, to_device = fc.host_env()
-    assert fc.prove_and_verify(emu(), torch, to_device, m, rs_extra, loc_param, queries, pow_bits, 5, kind)
+CPU = torch.device("cpu")
 
 
-@pytest.mark.parametrize("log_n,rs_extra,loc_param,queries,pow_bits", [(8, 2, 2, 6, 5), (9, 3, 1, 8, 7), (10, 2, 3, 10, 0)])
-def test_prove_and_verify_multiplicative(log_n, rs_extra, loc_param, queries, pow_bits):
-    torch, to_device = fc.host_env()
-    assert fc.prove_and_verify_multiplicative(emu(), torch, to_device, log_n, rs_extra, loc_param, queries, pow_bits, 7)
+@pytest.mark.parametrize("field_name,dim,rs_extra,loc_param,interactions,queries", [
+    ("gf192", 8, 2, 2, 1, 6), ("gf192", 10, 3, 2, 1, 10), ("gf192", 7, 2, 1, 2, 4), ("gf192", 9, 2, 3, 1, 8),
+    ("edwards_Fr", 8, 2, 2, 1, 6), ("edwards_Fr", 9, 3, 1, 1, 8), ("edwards_Fr", 10, 2, 3, 2, 10)])
+def test_fri_snark(field_name, dim, rs_extra, loc_param, interactions, queries):
+    assert fc.prove_and_verify(emu(), torch, CPU, field_name, dim, rs_extra, loc_param, interactions, queries, 5)

@@ -1,0 +1,217 @@
+"""Correctness at BASELINE.json's full sizes (configs 4 and 5: 2^20-constraint instances, 2^25-point codeword domains) on the
+MI355X, through the C ABI: what the stage timings and bench.py run is checked here at the size they run it — sampled values
+against the oracle's point formulas (Horner evaluation, single-coset fold, hashlib digests, the LDT combination at a point),
+whole-vector identities computed on the device (interpolate o evaluate, re-extension of a folded codeword), and the complete
+2^20 Aurora proof accepted by the oracle's independent verifier."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import rand_elems
+
+pytestmark = pytest.mark.gpu
+W = 3
+M, D = 25, 20                       # codeword domain 2^25, polynomials of 2^20 coefficients (rate 1/32)
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import libiop_amd
+    from libiop_amd import domains
+    lib = libiop_amd.lib()
+    lib.init(0)
+    lib.set_stream(torch.cuda.current_stream().cuda_stream)
+    dev = torch.device("cuda:0")
+    return lib, torch, dev, domains.DeviceOps(lib, torch, dev, domains.GF192()), domains.DeviceOps(lib, torch, dev, domains.EdwardsFr())
+
+
+def _sample_positions(n, coset, seed):
+    """First / last element of several cosets, the two ends of the vector, positions >= n/2, plus random ones."""
+    rng = np.random.default_rng(seed)
+    pos = {0, 1, coset - 1, coset, n // 2 - 1, n // 2, n - coset, n - 1, (n // 2) + coset * 5, n - 2 * coset - 1}
+    pos.update(int(p) for p in rng.integers(0, n, size=12))
+    pos.update(int(c) * coset for c in rng.integers(0, n // coset, size=4))
+    return sorted(pos)
+
+
+def test_lde_2p20_to_2p25_horner(env):
+    """additive LDE with Aurora's shift x^25: sampled evaluations equal Horner evaluation of the polynomial at the domain point."""
+    lib, torch, dev, ops, _ = env
+    field = ops.field
+    L = field.domain(1 << M, np.array([1 << M, 0, 0], dtype=np.uint64))
+    coeffs = rand_elems(0x2504, 1 << D, W)
+    cw = ops.FFT(ops.upload(coeffs), 1 << D, L)
+    pos = _sample_positions(1 << M, 1 << D, 1)
+    assert max(pos) >= (1 << 24)
+    vals = lib.query_responses_dev([cw.data_ptr()], 24, 1 << M, pos)[:, 0, :]
+    for p, v in zip(pos, vals):
+        point = np.array([p ^ (1 << M), 0, 0], dtype=np.uint64)            # shift + sum of basis bits: all in word 0
+        assert np.array_equal(v, oracle.poly_eval(coeffs, point)), p
+    # batched extension of four polynomials: equal to four single extensions
+    polys = [ops.upload(rand_elems(0x2510 + k, 1 << D, W)) for k in range(3)] + [ops.upload(coeffs)]
+    batch = ops.FFT_batch(polys, 1 << D, L)
+    assert torch.equal(batch[3], cw)
+    single = ops.FFT(polys[1], 1 << D, L)
+    assert torch.equal(batch[1], single)
+    # interpolation of the systematic part returns the coefficients (IFFT_of_known_degree on the first 2^20 evaluations)
+    back = ops.IFFT_of_known_degree(cw, 1 << D, L)
+    assert np.array_equal(ops.download(back), coeffs)
+
+
+def _check_tree(lib, torch, nodes, oracles_host_getter, num_oracles, n, coset, additive, sample_leaves):
+    """Sampled leaf digests against hashlib over the reference's serialisation (merkle_tree.tcc:127-134), the root against a
+    recomputation from the device's level-8 nodes, sampled inner nodes against their children."""
+    L = n // coset
+    nodes_h = nodes.cpu().numpy()
+    for leaf in sample_leaves:
+        cols = []
+        for j in range(coset):
+            p = leaf * coset + j if additive else leaf + j * L
+            cols.append(oracles_host_getter(p))                      # (num_oracles, 3)
+        cols = np.stack(cols)                                        # [j][k]
+        msg = b"".join(cols[j, k].tobytes() for k in range(num_oracles) for j in range(coset))      # slice[j + k * coset]
+        assert hashlib.blake2b(msg, digest_size=32).digest() == bytes(nodes_h[L - 1 + leaf]), leaf
+    level = [bytes(nodes_h[(1 << 8) - 1 + i]) for i in range(1 << 8)]
+    while len(level) > 1:
+        level = [hashlib.blake2b(level[2 * i] + level[2 * i + 1], digest_size=32).digest() for i in range(len(level) // 2)]
+    assert level[0] == bytes(nodes_h[0])
+    rng = np.random.default_rng(9)
+    for j in [0, 1, L - 2, (L - 1) // 2] + [int(v) for v in rng.integers(0, L - 1, size=16)]:
+        assert hashlib.blake2b(bytes(nodes_h[2 * j + 1]) + bytes(nodes_h[2 * j + 2]), digest_size=32).digest() == bytes(nodes_h[j]), j
+
+
+def test_merkle_2p24_leaves_four_oracles(env):
+    """cfg4 round 0: 4 oracles x 2^25 elements, cosets of 2 -> 2^24 leaves of 192 bytes."""
+    lib, torch, dev, ops, _ = env
+    n = 1 << M
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4)
+    oracles = [torch.randint(-2**62, 2**62, (n, 3), dtype=torch.int64, device=dev, generator=gen) for _ in range(4)]
+    torch.cuda.synchronize()
+    tree = ops.merkle_tree(oracles, ops.field.domain(n), 2)
+    lib.synchronize()
+    get = lambda p: np.stack([o[p].cpu().numpy().view(np.uint64) for o in oracles])
+    L = n // 2
+    _check_tree(lib, torch, tree.nodes, get, 4, n, 2, True, [0, 1, L // 2, L - 1, 12345678, (1 << 23) + 77])
+
+
+def test_merkle_2p24_leaves_twelve_oracles_multiplicative(env):
+    """cfg5 index round: 12 oracles, multiplicative position map, cosets of 2 -> 2^24 leaves of 576 bytes."""
+    lib, torch, dev, _, ops = env
+    n = 1 << M
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    oracles = [torch.randint(0, 2**62, (n, 3), dtype=torch.int64, device=dev, generator=gen) for _ in range(12)]
+    torch.cuda.synchronize()
+    tree = ops.merkle_tree(oracles, ops.field.domain(n), 2)
+    lib.synchronize()
+    get = lambda p: np.stack([o[p].cpu().numpy().view(np.uint64) for o in oracles])
+    L = n // 2
+    _check_tree(lib, torch, tree.nodes, get, 12, n, 2, False, [0, 1, L // 2, L - 1, 7654321, (1 << 23) + 5])
+
+
+def test_fold_chain_2p25(env):
+    """FRI folds 2^25 -> 2^24 -> 2^22 of an LDE codeword: sampled cosets against the oracle's single-coset fold
+    (fri_aux.tcc:270-303), and the twice-folded codeword is again a codeword of degree < 2^17 over the derived domain
+    (interpolating its first 2^17 evaluations and re-extending reproduces all 2^22)."""
+    lib, torch, dev, ops, _ = env
+    field = ops.field
+    L0 = field.domain(1 << M, np.array([1 << M, 0, 0], dtype=np.uint64))
+    doms = field.fri_domains(L0, [1, 2])
+    f0 = ops.FFT(ops.upload(rand_elems(0x2511, 1 << D, W)), 1 << D, L0)
+    x0, x1 = rand_elems(0x2512, 1, W)[0], rand_elems(0x2513, 1, W)[0]
+    f1 = ops.fold(f0, doms[0], 2, x0)
+    f2 = ops.fold(f1, doms[1], 4, x1)
+    for f, g, dom, cs, x in ((f0, f1, doms[0], 2, x0), (f1, f2, doms[1], 4, x1)):
+        ncos = dom.size // cs
+        for c in [0, 1, ncos // 2, ncos - 1, 3333333 % ncos, (ncos // 2) + 12345]:
+            evals = lib.query_responses_dev([f.data_ptr()], 24, dom.size, [c * cs + k for k in range(cs)])[:, 0, :]
+            # the coset's first element: shift + sum of the high basis vectors selected by c
+            first = np.array(dom.shift, dtype=np.uint64).copy()
+            eta = cs.bit_length() - 1
+            for k in range(dom.dim - eta):
+                if (c >> k) & 1:
+                    first ^= dom.basis[eta + k]
+            want = oracle.fri_fold_at_coset(evals, dom.basis[:eta], first, x)
+            got = lib.query_responses_dev([g.data_ptr()], 24, ncos, [c])[0, 0]
+            assert np.array_equal(got, want), (cs, c)
+    coeffs = ops.IFFT_of_known_degree(f2, 1 << (D - 3), doms[2])
+    again = ops.FFT(coeffs, 1 << (D - 3), doms[2])
+    assert torch.equal(again, f2)
+
+
+def test_multiplicative_fft_2p22_to_2p25_round_trip(env):
+    """cfg5's prover transforms: 2^22 coefficients onto the 2^25 coset with shift = the field's generator, back through the strided
+    known-degree IFFT (fft.tcc:435-456); sampled evaluations against Horner."""
+    lib, torch, dev, _, ops = env
+    import libiop_amd as la
+    field = ops.field
+    L = field.domain(1 << M, la.EDWARDS_FR_GENERATOR)
+    ncoef = 1 << 22
+    rng = np.random.default_rng(0x2505)
+    raw = rng.integers(0, 2**63, size=(ncoef, 3), dtype=np.uint64)
+    raw[:, 2] &= np.uint64((1 << 50) - 1)                                   # below p: valid Montgomery representatives
+    d_coeffs = ops.upload(raw)
+    cw = ops.FFT(d_coeffs, ncoef, L)
+    back = ops.IFFT_of_known_degree(cw, ncoef, L)
+    assert torch.equal(back, d_coeffs)
+    pos = [0, 1, (1 << 24) + 3, (1 << M) - 1, 23456789]
+    vals = lib.query_responses_dev([cw.data_ptr()], 24, 1 << M, pos)[:, 0, :]
+    g = field.to_int(L.gen)
+    for p, v in zip(pos, vals):
+        x = field.from_int(L.shift_int * pow(g, p, field.P))
+        assert np.array_equal(v, oracle.fp_poly_eval(raw, x)), p
+
+
+def test_ldt_combination_2p25_sampled(env):
+    """combined_LDT_virtual_oracle over 7 oracles of 2^25 elements with Aurora's degrees: sampled positions against the point
+    formula sum_i c_i f_i(x) + sum_submaximal c'_i x^(max - deg_i) f_i(x) (ldt_reducer_aux.tcc:133-170)."""
+    from libiop_amd import host
+    lib, torch, dev, ops, _ = env
+    n = 1 << M
+    L = ops.field.domain(n, np.array([n, 0, 0], dtype=np.uint64))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(6)
+    oracles = [torch.randint(-2**62, 2**62, (n, 3), dtype=torch.int64, device=dev, generator=gen) for _ in range(7)]
+    degrees = [(1 << D) - 1, (1 << D) - 1, (1 << D) - 16, 1 << D, 1 << D, 1 << D, (1 << D) - 1]       # h, g, fw, fAz, fBz, fCz, rowcheck
+    coeffs = rand_elems(0x2514, 14, W)
+    out = ops.ldt_combine(oracles, degrees, coeffs, L)
+    pos = _sample_positions(n, 1 << D, 2)
+    got = lib.query_responses_dev([out.data_ptr()], 24, n, pos)[:, 0, :]
+    vals = lib.query_responses_dev([o.data_ptr() for o in oracles], 24, n, pos)
+    c = [1] + [host.gf_from_words(w) for w in coeffs]                       # coefficients_ = {1, r...} (ldt_reducer_aux.tcc:34-36)
+    submax = [i for i, d in enumerate(degrees) if d < max(degrees)]
+    for q, p in enumerate(pos):
+        x = p ^ n
+        acc = 0
+        for i in range(7):
+            acc ^= host.gf_mul(c[i], host.gf_from_words(vals[q, i]))
+        for s, i in enumerate(submax):
+            e, xp, r = max(degrees) - degrees[i], x, 1
+            while e:
+                if e & 1:
+                    r = host.gf_mul(r, xp)
+                xp = host.gf_sq(xp)
+                e >>= 1
+            acc ^= host.gf_mul(host.gf_mul(c[7 + s], r), host.gf_from_words(vals[q, i]))
+        assert host.gf_from_words(got[q]) == acc, p
+
+
+def test_aurora_2p20_proof_accepted_by_the_oracle_verifier(env):
+    """The complete Aurora proof bench.py times (2^20 constraints, 2^25-point codewords, 10 Merkle trees, 27 queries) is accepted
+    by the oracle's independent verifier, which re-derives the instance from the seed; a flipped answer is rejected."""
+    from libiop_amd import aurora, r1cs
+    lib, torch, dev, ops, _ = env
+    n = 1 << D
+    cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, n, 15, n - 1, 0x2204)
+    params = aurora.AuroraParameters(ops.field, n, n - 1, 15)
+    transcript = aurora.aurora_snark_prover(ops, cs, primary, auxiliary, params)
+    data = transcript.serialize()
+    assert len(transcript.MT_roots) == 11 and params.codeword_domain_dim == 25
+    assert oracle.aurora_verify(oracle.FIELD_GF192, D, 15, 0x2204, data)
+    transcript.query_responses[0] = transcript.query_responses[0].copy()
+    transcript.query_responses[0][3, 2, 1] ^= np.uint64(4)
+    assert not oracle.aurora_verify(oracle.FIELD_GF192, D, 15, 0x2204, transcript.serialize())

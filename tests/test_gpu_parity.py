@@ -358,27 +358,17 @@ def test_query_responses(gpu):
     tc.check_query_responses(gpu, 1 << 16, 4, 5)
 
 
-# ---- end-to-end FRI: device prover, independent oracle verifier ---------------------------------------------------
+# ---- FRI-only SNARK (config 3's shape): device transcript == the oracle prover's; the oracle's verifier accepts / rejects ----
 import fri_cases as fc
 
 
-@pytest.mark.parametrize("m,rs_extra,loc_param,queries,pow_bits,kind", [(10, 3, 2, 10, 9, "random"), (16, 2, 2, 24, 16, "standard"),
-                                                                       (22, 2, 2, 32, 20, "standard")])
-def test_fri_prove_and_verify(gpu, m, rs_extra, loc_param, queries, pow_bits, kind):
+@pytest.mark.parametrize("field_name,dim,rs_extra,loc_param,interactions,queries", [
+    ("gf192", 10, 3, 2, 1, 10), ("gf192", 16, 2, 2, 1, 10), ("gf192", 13, 2, 2, 2, 6),
+    ("edwards_Fr", 10, 3, 2, 1, 10), ("edwards_Fr", 16, 2, 2, 1, 10)])
+def test_fri_snark(gpu, field_name, dim, rs_extra, loc_param, interactions, queries):
     import torch
-    dev = torch.device("cuda:0")
     gpu.set_stream(torch.cuda.current_stream().cuda_stream)
-    to_device = lambda arr: torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).to(dev)
-    assert fc.prove_and_verify(gpu, torch, to_device, m, rs_extra, loc_param, queries, pow_bits, 5, kind)
-
-
-@pytest.mark.parametrize("log_n,rs_extra,loc_param,queries,pow_bits", [(10, 3, 2, 10, 8), (16, 2, 2, 24, 14), (20, 3, 2, 32, 18)])
-def test_fri_prove_and_verify_multiplicative(gpu, log_n, rs_extra, loc_param, queries, pow_bits):
-    import torch
-    dev = torch.device("cuda:0")
-    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
-    to_device = lambda arr: torch.from_numpy(np.ascontiguousarray(arr).view(np.int64)).to(dev)
-    assert fc.prove_and_verify_multiplicative(gpu, torch, to_device, log_n, rs_extra, loc_param, queries, pow_bits, 7)
+    assert fc.prove_and_verify(gpu, torch, torch.device("cuda:0"), field_name, dim, rs_extra, loc_param, interactions, queries, 0x2203)
 
 
 # ---- R1CS row check (rowcheck.tcc:16-88) -------------------------------------------------------------------------
