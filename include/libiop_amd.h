@@ -132,6 +132,16 @@ int iopx_fri_fold_mul_fp3_dev(const uint64_t *d_f_i, size_t log_n, const uint64_
 int iopx_fri_fold_mul_fp3(const uint64_t *f_i, size_t log_n, const uint64_t *gen, const uint64_t *shift,
                           size_t coset_size, const uint64_t *x_i, uint64_t *next);
 
+/* Host-side scalars of the 181-bit prime field for the domain metadata of the template boundary (no device needed):
+ *   iopx_fp3_subgroup_generator        multiplicative_generator^((p - 1) / 2^log_order), the generator of the order-2^log_order
+ *                                      subgroup (multiplicative_subgroup_base::construct_internal, subgroup.tcc:55-59)
+ *   iopx_fp3_multiplicative_generator  FieldT::multiplicative_generator (element_outside_of_subset, subgroup.tcc:311-315)
+ *   iopx_fp3_host_mul / _host_pow      a * b, a^exponent (shift^(2^eta) of the FRI domain chain, fri_ldt.tcc:292-308) */
+int iopx_fp3_subgroup_generator(size_t log_order, uint64_t *gen);
+int iopx_fp3_multiplicative_generator(uint64_t *gen);
+int iopx_fp3_host_mul(const uint64_t *a, const uint64_t *b, uint64_t *out);
+int iopx_fp3_host_pow(const uint64_t *a, uint64_t exponent, uint64_t *out);
+
 /* ---- FRI fold over GF(2^192) -------------------------------------------------------------------- */
 /* evaluate_next_f_i_over_entire_domain for affine subspaces:
  * libiop/protocols/ldt/fri/fri_aux.tcc:5-34 -> :36-103.  f_i has 2^m evaluations over (basis, shift);
@@ -178,6 +188,10 @@ typedef struct iopx_poseidon_params {
     const uint64_t *mds;
 } iopx_poseidon_params;
 
+/* get_poseidon_parameters (libiop/bcs/hashing/hash_enum.tcc:12-24): the shipped parameter set of a bcs_hash_type
+ * (2 = starkware_poseidon_type, 3 = high_alpha_poseidon_type; state_size 0 / 3, or 4 for the high-alpha set, poseidon.hpp:56).
+ * The ark / mds pointers refer to static tables inside the library. */
+int iopx_poseidon_shipped_params(int bcs_hash_type, size_t state_size, iopx_poseidon_params *out);
 /* FieldT(bigint): canonical 4-word integers -> Montgomery words (libff Fp_model::mont_repr), on the device. */
 int iopx_bn128_to_montgomery_dev(const uint64_t *d_canonical, uint64_t *d_out, size_t count);
 /* poseidon::apply_permutation (poseidon.tcc:273-297) on `count` states of state_size Montgomery elements, in place. */

@@ -48,6 +48,7 @@ EXPORTED_SYMBOLS = [
     "iopx_spmv_gf192_dev", "iopx_spmv_fp3_dev", "iopx_poly_div_vanishing_gf192_dev", "iopx_poly_div_vanishing_fp3_dev",
     "iopx_lincomb_gf192_dev", "iopx_lincomb_fp3_dev", "iopx_gf192_add_dev", "iopx_gf192_inv_dev", "iopx_fp3_mul_dev", "iopx_fp3_sub_dev",
     "iopx_fp3_inv_dev", "iopx_fp3_pow_table_dev",
+    "iopx_fp3_subgroup_generator", "iopx_fp3_multiplicative_generator", "iopx_fp3_host_mul", "iopx_fp3_host_pow", "iopx_poseidon_shipped_params",
 ]
 
 

@@ -411,6 +411,40 @@ int iopx_mul_fft_fp3_dev(const uint64_t *d_coeffs, size_t n_coeffs, size_t log_n
     return IOPX_OK;                                     // per-call tables are released in stream order
 }
 
+// ---- host-side scalars of the prime field (domain metadata of the template boundary; no device needed) ----
+// multiplicative_subgroup_base::construct_internal (subgroup.tcc:55-59): multiplicative_generator^((p - 1) / 2^log_order)
+int iopx_fp3_subgroup_generator(size_t log_order, uint64_t *gen)
+{
+    if (!gen) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (log_order > 31) return fail(IOPX_ERR_INVALID_ARGUMENT, "log_order %zu exceeds the 2-adicity of the field", log_order);
+    uint64_t e[3] = { hfp3::P[0] - 1, hfp3::P[1], hfp3::P[2] };
+    for (size_t s = 0; s < log_order; ++s) { e[0] = (e[0] >> 1) | (e[1] << 63); e[1] = (e[1] >> 1) | (e[2] << 63); e[2] >>= 1; }
+    const hfp3 g = hfp3::from_uint(19).pow_limbs(e, 3);
+    memcpy(gen, g.w, 24);
+    return IOPX_OK;
+}
+int iopx_fp3_multiplicative_generator(uint64_t *gen)           // libff edwards_Fr::multiplicative_generator = 19 (recalled)
+{
+    if (!gen) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    const hfp3 g = hfp3::from_uint(19);
+    memcpy(gen, g.w, 24);
+    return IOPX_OK;
+}
+int iopx_fp3_host_mul(const uint64_t *a, const uint64_t *b, uint64_t *out)
+{
+    if (!a || !b || !out) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    const hfp3 r = hfp3::from_words(a) * hfp3::from_words(b);
+    memcpy(out, r.w, 24);
+    return IOPX_OK;
+}
+int iopx_fp3_host_pow(const uint64_t *a, uint64_t exponent, uint64_t *out)
+{
+    if (!a || !out) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    const hfp3 r = hfp3::from_words(a).pow(exponent);
+    memcpy(out, r.w, 24);
+    return IOPX_OK;
+}
+
 // d_out[l] = init * base^l for l < count, as ordinary libff elements (multi_lincheck's alpha powers, basic_lincheck_aux.tcc:37-45)
 int iopx_fp3_pow_table_dev(uint64_t *d_out, size_t count, const uint64_t *base, const uint64_t *init)
 {

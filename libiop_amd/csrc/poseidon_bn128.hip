@@ -21,6 +21,7 @@
 #include <mutex>
 #include <vector>
 #include "runtime.h"
+#include "poseidon_tables.h"
 
 namespace iopx {
 
@@ -635,6 +636,26 @@ static int get_poseidon(const iopx_poseidon_params *pp, PoseidonDev *out)
 using namespace iopx;
 
 extern "C" {
+
+// get_poseidon_parameters (hash_enum.tcc:12-24): 2 = starkware_poseidon_type (alpha 5, t = 3), 3 = high_alpha_poseidon_type
+// (alpha 17, state_size 3 by default, 4 on request: poseidon.hpp:56).  Host-only: the tables are static data of the library.
+int iopx_poseidon_shipped_params(int bcs_hash_type, size_t state_size, iopx_poseidon_params *out)
+{
+    if (!out) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    const char *want = nullptr;
+    if (bcs_hash_type == 2 && (state_size == 0 || state_size == 3)) want = "starkware_alpha5_t3";
+    else if (bcs_hash_type == 3 && (state_size == 0 || state_size == 3)) want = "high_alpha17_t3";
+    else if (bcs_hash_type == 3 && state_size == 4) want = "high_alpha17_t4";
+    else if (bcs_hash_type == 3) return fail(IOPX_ERR_INVALID_ARGUMENT, "high_alpha_128_bit_altbn_poseidon_params only supports state size 3 or 4");
+    else return fail(IOPX_ERR_INVALID_ARGUMENT, "Not a poseidon hash type");
+    for (const ShippedPoseidon &s : SHIPPED_POSEIDON) {
+        if (strcmp(s.name, want) != 0) continue;
+        out->alpha = s.alpha; out->full_rounds = s.full_rounds; out->partial_rounds = s.partial_rounds;
+        out->rate = s.rate; out->state_size = s.state_size; out->near_mds = s.near_mds; out->ark = s.ark; out->mds = s.mds;
+        return IOPX_OK;
+    }
+    return fail(IOPX_ERR_LOGIC, "parameter set %s missing from the library", want);
+}
 
 int iopx_bn128_to_montgomery_dev(const uint64_t *d_canonical, uint64_t *d_out, size_t count)
 {

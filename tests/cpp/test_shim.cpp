@@ -17,8 +17,19 @@
 #include "../../oracle/mult.hpp"
 #include "../../oracle/ldt.hpp"
 #include "../../oracle/pow.hpp"
+#include "../../oracle/poseidon.hpp"
+#include "../../oracle/domain.hpp"
 
 typedef oracle::gf192 FieldT;
+typedef oracle::edwards_Fr Fr;
+typedef oracle::alt_bn128_Fr BnFr;
+
+// what an integration writes once per field type (libff::is_additive / is_multiplicative in the reference)
+namespace libiop_amd {
+template<> struct field_kind<FieldT> { static const field_subset_type type = affine_subspace_type; };
+template<> struct field_kind<Fr> { static const field_subset_type type = multiplicative_coset_type; };
+template<> struct field_kind<BnFr> { static const field_subset_type type = multiplicative_coset_type; };
+}
 
 static std::mt19937_64 rng(12345);
 static FieldT rnd() { FieldT r; for (int i = 0; i < 3; ++i) r.w[i] = rng(); return r; }
@@ -35,6 +46,40 @@ static int run_nodevice()
     threw = false;
     try { libiop_amd::merkle_tree<FieldT> t(3); } catch (const std::invalid_argument &) { threw = true; }   // merkle_tree.tcc:27-31
     CHECK(threw);
+    {   // the tagged union's host metadata needs no device: both arms against the oracle's domain restatement
+        const libiop_amd::field_subset<FieldT> add(1 << 10);
+        CHECK(add.type() == libiop_amd::affine_subspace_type && add.shift() == FieldT(0));
+        CHECK(add.element_outside_of_subset() == FieldT(1 << 10));                                           // subspace.tcc:219-227
+        CHECK(add.reindex_by_subset(4, 77) == 77);
+        const libiop_amd::field_subset<Fr> mul(1 << 10);
+        const oracle::mult_coset<Fr> omul(1 << 10);
+        CHECK(mul.type() == libiop_amd::multiplicative_coset_type && mul.shift() == Fr::one());
+        CHECK(mul.generator() == omul.g);                                                                    // subgroup.tcc:55-59
+        CHECK(mul.element_outside_of_subset() == oracle::dom_element_outside(omul));                        // subgroup.tcc:311-315
+        for (size_t idx : { 0, 3, 15, 16, 17, 500, 1023 }) CHECK(mul.reindex_by_subset(4, idx) == oracle::dom_reindex_by_subset(omul, 4, idx));
+        const libiop_amd::field_subset<Fr> shifted(1 << 10, mul.element_outside_of_subset());
+        const libiop_amd::field_subset<Fr> sub = shifted.get_subset_of_order(16);                            // field_subset.tcc:217-237
+        CHECK(sub.num_elements() == 16 && sub.shift() == shifted.shift() && sub.generator() == oracle::mult_coset<Fr>(16).g);
+        CHECK(shifted.element_by_index(37) == oracle::dom_element(oracle::mult_coset<Fr>(1 << 10, shifted.shift()), 37));
+        CHECK(shifted.coset_index(700, 4) == 700 % 256 && shifted.intra_coset_index(700, 4) == 700 / 256 && shifted.position_by_coset_indices(188, 2, 4) == 700);
+        threw = false;
+        try { libiop_amd::field_subset<Fr> z(16, Fr::zero()); } catch (const std::invalid_argument &) { threw = true; }   // field_subset.tcc:37-39
+        CHECK(threw);
+        // hash factories (hash_enum.tcc:73-171): the digest type picks the family, a mismatch throws
+        threw = false;
+        try { libiop_amd::get_leafhash<FieldT, libiop_amd::binary_hash_digest>(libiop_amd::starkware_poseidon_type, 128, 2); } catch (const std::invalid_argument &) { threw = true; }
+        CHECK(threw);
+        threw = false;
+        try { libiop_amd::get_two_to_one_hash<BnFr, BnFr>(libiop_amd::blake2b_type, 128); } catch (const std::invalid_argument &) { threw = true; }
+        CHECK(threw);
+        threw = false;
+        try { libiop_amd::get_leafhash<BnFr, BnFr>(libiop_amd::high_alpha_poseidon_type, 100, 2); } catch (const std::invalid_argument &) { threw = true; }
+        CHECK(threw);
+        iopx_poseidon_params pp;
+        CHECK(iopx_poseidon_shipped_params(2, 0, &pp) == IOPX_OK && pp.alpha == 5 && pp.partial_rounds == 56 && pp.state_size == 3);
+        CHECK(iopx_poseidon_shipped_params(3, 4, &pp) == IOPX_OK && pp.alpha == 17 && pp.partial_rounds == 30 && pp.state_size == 4);
+        CHECK(iopx_poseidon_shipped_params(1, 0, &pp) != IOPX_OK);
+    }
     libiop_amd::merkle_tree<FieldT> t(4);
     threw = false;
     try { t.get_root(); } catch (const std::logic_error &) { threw = true; }                                 // merkle_tree.tcc:234-237
@@ -81,7 +126,6 @@ static int run_gpu()
         CHECK(threw);
     }
     {   // test_fft.cpp:88-121: multiplicative coset FFT == naive, IFFT inverts (edwards_Fr, shift = generator)
-        typedef oracle::edwards_Fr Fr;
         for (size_t dim = 1; dim <= 10; ++dim) {
             const size_t n = (size_t)1 << dim;
             const oracle::mult_coset<Fr> od(n, Fr::multiplicative_generator());
@@ -106,7 +150,7 @@ static int run_gpu()
         for (uint64_t subset : { 0x1ull, 0x8000000000000000ull, 0xF0F0ull, 0x123456789ABCDEFull, ~0ull }) {
             std::vector<size_t> pos;
             for (size_t k = 0; k < n; ++k) if (subset >> k & 1) pos.push_back(k);
-            const libiop_amd::merkle_tree_set_membership_proof mp = tree.get_set_membership_proof(pos);
+            const libiop_amd::merkle_tree_set_membership_proof<libiop_amd::binary_hash_digest> mp = tree.get_set_membership_proof(pos);
             const std::vector<size_t> idx = oracle::membership_proof_node_indices(n, pos);
             CHECK(mp.auxiliary_hashes.size() == idx.size());
             std::vector<std::vector<uint8_t>> leaf_hashes, aux;
@@ -135,6 +179,94 @@ static int run_gpu()
         bool threw = false;
         try { vo.set_random_coefficients(rnd_vec(3)); } catch (const std::invalid_argument &) { threw = true; }     // ldt_reducer_aux.tcc:29-32
         CHECK(threw);
+    }
+    {   // the type-dispatching entry points on a prime-field domain (fft.tcc:407-475, fri_aux.tcc:5-34)
+        const size_t dim = 9, n = (size_t)1 << dim;
+        const libiop_amd::field_subset<Fr> unshifted(n);
+        const libiop_amd::field_subset<Fr> domain(n, unshifted.element_outside_of_subset());
+        const oracle::mult_coset<Fr> od(n, domain.shift());
+        std::vector<Fr> coeffs;
+        for (size_t i = 0; i < 100; ++i) { uint64_t c[3] = { rng(), rng(), rng() & 0xfffffffffull }; coeffs.push_back(Fr::from_canonical(c)); }
+        const std::vector<Fr> evals = libiop_amd::FFT_over_field_subset<Fr>(coeffs, domain);
+        CHECK(evals == oracle::multiplicative_FFT_degree_aware<Fr>(coeffs, od));
+        std::vector<Fr> back = libiop_amd::IFFT_over_field_subset<Fr>(evals, domain);
+        back.resize(coeffs.size());
+        CHECK(back == coeffs);
+        CHECK(libiop_amd::IFFT_of_known_degree_over_field_subset<Fr>(evals, 100, domain) == oracle::multiplicative_IFFT_of_known_degree<Fr>(evals, 100, od));
+        uint64_t xc[3] = { rng(), rng(), 5 };
+        const Fr x = Fr::from_canonical(xc);
+        auto shared = std::make_shared<std::vector<Fr>>(evals);
+        CHECK(*libiop_amd::evaluate_next_f_i_over_entire_domain<Fr>(shared, domain, 4, x) == oracle::multiplicative_evaluate_next_f_i_over_entire_domain<Fr>(evals, od, 4, x));
+        // and on a binary-field domain through the same names
+        const libiop_amd::field_subset<FieldT> adom(n, FieldT(n));
+        const oracle::affine_subspace<FieldT> oad = oracle::affine_subspace<FieldT>::standard(dim, FieldT(n));
+        const std::vector<FieldT> ac = rnd_vec(77);
+        const std::vector<FieldT> ae = libiop_amd::FFT_over_field_subset<FieldT>(ac, adom);
+        CHECK(ae == oracle::additive_FFT<FieldT>(ac, oad));
+        CHECK(libiop_amd::IFFT_of_known_degree_over_field_subset<FieldT>(ae, 77, adom) == oracle::additive_IFFT_of_known_degree<FieldT>(ae, 77, oad));
+        auto ashared = std::make_shared<std::vector<FieldT>>(ae);
+        const FieldT ax = rnd();
+        CHECK(*libiop_amd::evaluate_next_f_i_over_entire_domain<FieldT>(ashared, adom, 4, ax) == oracle::additive_evaluate_next_f_i_over_entire_domain<FieldT>(ae, oad, 4, ax));
+        // the LDT combination on the prime-field domain
+        const std::vector<size_t> degrees = { 60, 33, 60, 1 };
+        std::vector<std::shared_ptr<std::vector<Fr>>> ev;
+        std::vector<std::vector<Fr>> oev;
+        for (size_t k = 0; k < degrees.size(); ++k) {
+            std::vector<Fr> v;
+            for (size_t i = 0; i < n; ++i) { uint64_t c[3] = { rng(), rng(), rng() & 0xfffffffffull }; v.push_back(Fr::from_canonical(c)); }
+            oev.push_back(v); ev.push_back(std::make_shared<std::vector<Fr>>(v));
+        }
+        std::vector<Fr> r;
+        for (size_t i = 0; i < 2 * degrees.size(); ++i) { uint64_t c[3] = { rng(), rng(), 1 }; r.push_back(Fr::from_canonical(c)); }
+        libiop_amd::combined_LDT_virtual_oracle<Fr> vo(domain, degrees);
+        vo.set_random_coefficients(r);
+        oracle::combined_LDT_virtual_oracle<Fr> ovo(degrees);
+        ovo.set_random_coefficients(r);
+        CHECK(*vo.evaluated_contents(ev) == ovo.evaluated_contents(od, oev));
+    }
+    {   // merkle_tree<FieldT, FieldT> with the hashers the hash_enum factories inject (hash_enum.tcc:73-171): Poseidon tree over alt_bn128 Fr
+        for (libiop_amd::bcs_hash_type he : { libiop_amd::starkware_poseidon_type, libiop_amd::high_alpha_poseidon_type }) {
+            const size_t n = 256, cs = 2;
+            std::vector<std::shared_ptr<std::vector<BnFr>>> cols;
+            std::vector<std::vector<BnFr>> ocols;
+            for (int k = 0; k < 3; ++k) {
+                std::vector<BnFr> v;
+                for (size_t i = 0; i < n; ++i) { uint64_t c[4] = { rng(), rng(), rng(), rng() & 0xfffffffffffffffull }; v.push_back(BnFr::from_canonical(c)); }
+                ocols.push_back(v); cols.push_back(std::make_shared<std::vector<BnFr>>(v));
+            }
+            libiop_amd::merkle_tree<BnFr, BnFr> tree(n / cs, libiop_amd::get_leafhash<BnFr, BnFr>(he, 128, 2), libiop_amd::get_two_to_one_hash<BnFr, BnFr>(he, 128),
+                                                   32, false, 128);
+            tree.construct_with_leaves_serialized_by_cosets(cols, cs);
+            iopx_poseidon_params pp;
+            CHECK(iopx_poseidon_shipped_params((int)he, 0, &pp) == IOPX_OK);
+            oracle::poseidon_params<BnFr> op;
+            op.alpha = pp.alpha; op.full_rounds = pp.full_rounds; op.partial_rounds = pp.partial_rounds; op.rate = pp.rate; op.state_size = pp.state_size;
+            op.near_mds = pp.near_mds != 0;
+            for (size_t r = 0; r < pp.full_rounds + pp.partial_rounds; ++r) {
+                std::vector<BnFr> row;
+                for (size_t c = 0; c < pp.state_size; ++c) row.push_back(BnFr::from_canonical(pp.ark + 4 * (r * pp.state_size + c)));
+                op.ark.push_back(row);
+            }
+            for (size_t r = 0; r < pp.state_size; ++r) {
+                std::vector<BnFr> row;
+                for (size_t c = 0; c < pp.state_size; ++c) row.push_back(BnFr::from_canonical(pp.mds + 4 * (r * pp.state_size + c)));
+                op.mds.push_back(row);
+            }
+            const size_t L = n / cs;                                   // merkle_tree.tcc:92-229 with the algebraic hashes, multiplicative position map
+            std::vector<BnFr> want(2 * L - 1);
+            for (size_t i = 0; i < L; ++i) {
+                std::vector<BnFr> slice(ocols.size() * cs);
+                for (size_t j = 0; j < cs; ++j) for (size_t k = 0; k < ocols.size(); ++k) slice[j + k * cs] = ocols[k][oracle::position_by_coset_indices(false, n, i, j, cs)];
+                want[L - 1 + i] = oracle::poseidon_leafhash<BnFr>(op, slice);
+            }
+            for (size_t j = L - 1; j-- > 0; ) want[j] = oracle::poseidon_two_to_one<BnFr>(op, want[2 * j + 1], want[2 * j + 2]);
+            CHECK(tree.get_root() == want[0]);
+            CHECK(tree.node(n / cs - 1) == want[n / cs - 1] && tree.node(2 * (n / cs) - 2) == want[2 * (n / cs) - 2]);
+            const libiop_amd::merkle_tree_set_membership_proof<BnFr> mp = tree.get_set_membership_proof({ 1, 3, 6, 7 });
+            const std::vector<size_t> idx = oracle::membership_proof_node_indices(n / cs, { 1, 3, 6, 7 });
+            CHECK(mp.auxiliary_hashes.size() == idx.size());
+            for (size_t i = 0; i < idx.size(); ++i) CHECK(mp.auxiliary_hashes[i] == want[idx[i]]);
+        }
     }
     {   // tests/snark/test_pow.cpp:13-33
         const libiop_amd::pow_parameters params(20, 1);
