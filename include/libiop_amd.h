@@ -151,6 +151,13 @@ int iopx_fri_fold_add_gf192_dev(const uint64_t *d_f_i, const uint64_t *basis, si
 int iopx_fri_fold_add_gf192(const uint64_t *f_i, const uint64_t *basis, size_t m, const uint64_t *shift,
                             size_t coset_size, const uint64_t *x_i, uint64_t *next);
 
+/* FRI_protocol::compute_domains for affine subspaces (libiop/protocols/ldt/fri/fri_ldt.tcc:310-338): the chain of derived
+ * domains L^(1), L^(2), ... — basis q(basis[eta_i..]), shift q(shift) with q the subspace polynomial of the first eta_i basis
+ * vectors.  Host-only metadata; out_bases holds the derived bases back to back (sum of their dimensions), out_shifts one
+ * element per derived domain. */
+int iopx_fri_domains_gf192(const uint64_t *basis, size_t m, const uint64_t *shift, const size_t *localization, size_t num_reductions,
+                           uint64_t *out_bases, uint64_t *out_shifts);
+
 /* ---- BCS Merkle tree, BLAKE2b ------------------------------------------------------------------- */
 /* merkle_tree::construct_with_leaves_serialized_by_cosets + compute_inner_nodes:
  * libiop/bcs/merkle_tree.tcc:92-151, 200-229 with blake2b_leafhash / blake2b_two_to_one_hash

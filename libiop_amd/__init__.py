@@ -48,7 +48,7 @@ EXPORTED_SYMBOLS = [
     "iopx_spmv_gf192_dev", "iopx_spmv_fp3_dev", "iopx_poly_div_vanishing_gf192_dev", "iopx_poly_div_vanishing_fp3_dev",
     "iopx_lincomb_gf192_dev", "iopx_lincomb_fp3_dev", "iopx_gf192_add_dev", "iopx_gf192_inv_dev", "iopx_fp3_mul_dev", "iopx_fp3_sub_dev",
     "iopx_fp3_inv_dev", "iopx_fp3_pow_table_dev",
-    "iopx_fp3_subgroup_generator", "iopx_fp3_multiplicative_generator", "iopx_fp3_host_mul", "iopx_fp3_host_pow", "iopx_poseidon_shipped_params",
+    "iopx_fp3_subgroup_generator", "iopx_fp3_multiplicative_generator", "iopx_fp3_host_mul", "iopx_fp3_host_pow", "iopx_poseidon_shipped_params", "iopx_fri_domains_gf192",
 ]
 
 
@@ -674,6 +674,26 @@ class Library:
     def fp3_pow_table_dev(self, d_out, count, base, init):
         base, init = _as_u64(base), _as_u64(init)
         self._check(self.c.iopx_fp3_pow_table_dev(_vp(d_out), int(count), base.ctypes.data_as(_u64p), init.ctypes.data_as(_u64p)))
+
+    def fri_additive_domains(self, basis, shift, localization):
+        """FRI_protocol::compute_domains, additive branch (fri_ldt.tcc:310-338): [(basis_i, shift_i)] for L^(0), L^(1), ..."""
+        basis, shift = _as_u64(basis), _as_u64(shift)
+        m = basis.shape[0]
+        dims, d = [], m
+        for eta in localization:
+            d -= int(eta)
+            dims.append(d)
+        ob = np.zeros((max(sum(dims), 1), 3), dtype=np.uint64)
+        osh = np.zeros((max(len(dims), 1), 3), dtype=np.uint64)
+        loc = (_sz * max(len(localization), 1))(*[int(e) for e in localization])
+        self.c.iopx_fri_domains_gf192.argtypes = [_u64p, _sz, _u64p, ctypes.POINTER(_sz), _sz, _u64p, _u64p]
+        self._check(self.c.iopx_fri_domains_gf192(basis.ctypes.data_as(_u64p), m, shift.ctypes.data_as(_u64p), loc, len(localization),
+                                                  ob.ctypes.data_as(_u64p), osh.ctypes.data_as(_u64p)))
+        out, off = [(basis, shift.reshape(3))], 0
+        for i, dm in enumerate(dims):
+            out.append((ob[off:off + dm].copy(), osh[i].copy()))
+            off += dm
+        return out
 
     def profile_begin(self):
         self._check(self.c.iopx_profile_begin())

@@ -309,7 +309,7 @@ class EncodedAuroraProtocol:
         # the matrices as set_challenge walks them: column c of M lands at summation index reindex(reindex(c)) (:80-84)
         S = self.C if self.C.dim > self.V.dim else self.V
         col_to_summation = S.reindex_by_subset_array(self.V.dim, self.V.size)[self.V.reindex_by_subset_array(self.I.dim, self.cs.num_variables + 1)]
-        transposed = [M.transposed_onto(self.ops, S.size, col_to_summation) for M in (self.cs.A, self.cs.B, self.cs.C)]
+        transposed = self.cs.lincheck_matrices(self.ops, S.size, col_to_summation, (S.kind, S.dim, self.V.dim, self.I.dim))
         self.multi_lincheck = MultiLincheck(IOP, codeword_domain_handle, constraint_domain_handle, variable_domain_handle, self.I.dim, transposed,
                                             self.fz_handle, Mz_handles, lincheck_repetitions)
         self.rowcheck_oracle = RowcheckVirtualOracle(self.ops, self.L, self.C)
@@ -376,7 +376,7 @@ class FRIProtocol:
         self.localization, self.poly_degree_bound = list(localization_parameters), poly_degree_bound
         self.interactive_repetitions, self.query_repetitions = interactive_repetitions, query_repetitions
         self.num_reductions = len(self.localization)
-        self.domains = self.ops.mark_fri_domains(self.ops.field.fri_domains(IOP.get_domain(codeword_domain_handle), self.localization),
+        self.domains = self.ops.mark_fri_domains(self.ops.field.fri_domains(IOP.get_domain(codeword_domain_handle), self.localization, self.ops.lib),
                                                  self.localization)                                         # compute_domains (:279-340)
 
     def register_interactions(self):                                                                     # :342-398

@@ -134,4 +134,37 @@ int iopx_fri_fold_add_gf192(const uint64_t *f_i, const uint64_t *basis, size_t m
     return IOPX_OK;
 }
 
+// FRI_protocol::compute_domains, additive branch (libiop/protocols/ldt/fri/fri_ldt.tcc:310-338): L^(i+1) has basis q(basis[eta_i..])
+// and shift q(shift), q = the subspace polynomial of span(basis[0..eta_i)) (localizer_polynomial.tcc:3-27,
+// vanishing_polynomial.tcc:373-395).  Host-only metadata: out_bases receives the bases of L^(1), L^(2), ... back to back
+// (sum_i dim(L^(i)) elements), out_shifts one element per derived domain.
+int iopx_fri_domains_gf192(const uint64_t *basis, size_t m, const uint64_t *shift, const size_t *localization, size_t num_reductions,
+                           uint64_t *out_bases, uint64_t *out_shifts)
+{
+    if ((m > 0 && !basis) || !shift || (num_reductions > 0 && (!localization || !out_bases || !out_shifts))) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    std::vector<hgf192> b(m);
+    for (size_t i = 0; i < m; ++i) b[i] = hgf192::from_words(basis + 3 * i);
+    hgf192 s = hgf192::from_words(shift);
+    size_t off = 0;
+    for (size_t r = 0; r < num_reductions; ++r) {
+        const size_t eta = localization[r];
+        if (eta > b.size()) return fail(IOPX_ERR_INVALID_ARGUMENT, "localization parameters exceed the domain dimension");
+        std::vector<hgf192> q(1, hgf192::one());                 // coefficient i multiplies X^(2^i)
+        auto eval = [&](const hgf192 &x) { hgf192 v = hgf192::zero(), xp = x; for (size_t i = 0; i < q.size(); ++i) { v += q[i] * xp; xp = xp.squared(); } return v; };
+        for (size_t k = 0; k < eta; ++k) {
+            const hgf192 qb = eval(b[k]);
+            std::vector<hgf192> nxt(q.size() + 1, hgf192::zero());
+            for (size_t i = 0; i < q.size(); ++i) { nxt[i + 1] += q[i].squared(); nxt[i] += q[i] * qb; }
+            q.swap(nxt);
+        }
+        std::vector<hgf192> nb;
+        for (size_t k = eta; k < b.size(); ++k) nb.push_back(eval(b[k]));
+        s = eval(s);
+        b.swap(nb);
+        for (const hgf192 &v : b) { memcpy(out_bases + 3 * off, v.w, 24); ++off; }
+        memcpy(out_shifts + 3 * r, s.w, 24);
+    }
+    return IOPX_OK;
+}
+
 } // extern "C"

@@ -156,6 +156,21 @@ __global__ void __launch_bounds__(256, 2) k_sumcheck_g_add(SumcheckAddParams p)
     }
 }
 
+// mu = 0 (every sum the shipped protocols claim: lincheck attaches its oracle with claimed sum 0, basic_lincheck.tcc:213-214): the
+// middle term eps^-1 mu x^(|H| - 1) is identically zero, so p'(x) = f(x) - Z_H(x) h(x) — no inversions at all
+__global__ void __launch_bounds__(256) k_sumcheck_g_add_zero_sum(SumcheckAddParams p)
+{
+    for (size_t base = (size_t)blockIdx.x * 256; base < p.n; base += (size_t)gridDim.x * 256) {
+        const uint32_t jhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 8));
+        const size_t end = base + 256 < p.n ? base + 256 : p.n;
+        for (size_t j = base + threadIdx.x; j < end; j += blockDim.x) {
+            gf192 acc = gf_load(p.f, j);
+            gf_add_to(acc, gf_mul(vo_subset_sum(p.ztab, p.m, (uint32_t)(j & 255), jhi), gf_load(p.h, j)));
+            gf_store(p.out, j, acc);
+        }
+    }
+}
+
 // multiplicative arm (sumcheck.tcc:96-117): p'(x) = (f(x) - |H|^-1 mu - Z_H(x) h(x)) / x
 __global__ void __launch_bounds__(256) k_sumcheck_g_fp(uint64_t *out, const uint64_t *f, const uint64_t *h, const uint64_t *zhi, const uint64_t *zlo,
                                                        const uint64_t *ihi, const uint64_t *ilo, const uint64_t *consts, size_t n)
@@ -384,6 +399,11 @@ int iopx_sumcheck_g_gf192_dev(const uint64_t *d_f, const uint64_t *d_h, const ui
     p.f = d_f; p.h = d_h; p.out = d_out;
     p.xtab = dx.u64(); p.htab = dh.u64(); p.ztab = dz.u64(); p.c = dc.u64();
     p.m = (int)m; p.n = (size_t)1 << m;
+    if (c.is_zero()) {
+        { ProfScope ps_("k_sumcheck_g_add_zero_sum"); hipLaunchKernelGGL(k_sumcheck_g_add_zero_sum, dim3(vo_grid(p.n)), dim3(256), 0, stream(), p); }
+        IOPX_HIP(hipGetLastError());
+        return IOPX_OK;
+    }
     size_t g = (p.n + 256 * SUMCHECK_BATCH - 1) / (256 * SUMCHECK_BATCH);
     if (g > 16384) g = 16384;
     { ProfScope ps_("k_sumcheck_g_add"); hipLaunchKernelGGL(k_sumcheck_g_add, dim3((unsigned)(g ? g : 1)), dim3(256), 0, stream(), p); }

@@ -122,9 +122,9 @@ class GF192:
     def squeeze(self, hashchain, n):
         return hashchain.squeeze_gf192(n)
 
-    def fri_domains(self, domain, localization):
-        """FRI_protocol::compute_domains, additive branch (fri_ldt.tcc:310-338)."""
-        chain = host.fri_additive_domains(domain.basis, domain.shift, localization)
+    def fri_domains(self, domain, localization, lib):
+        """FRI_protocol::compute_domains, additive branch (fri_ldt.tcc:310-338), by the library's host-side helper."""
+        chain = lib.fri_additive_domains(domain.basis, domain.shift, localization)
         return [domain] + [Domain(self, ADDITIVE, basis=b, shift=s) for b, s in chain[1:]]
 
 
@@ -169,7 +169,7 @@ class EdwardsFr:
             out[i] = [(raw >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(3)]
         return out
 
-    def fri_domains(self, domain, localization):
+    def fri_domains(self, domain, localization, lib=None):
         """fri_ldt.tcc:292-308: size >>= eta, shift <- shift^(2^eta)."""
         out, sh, logn = [domain], domain.shift_int, domain.dim
         for eta in localization:

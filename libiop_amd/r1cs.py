@@ -40,6 +40,15 @@ class R1CS:
     def __init__(self, A, B, C, num_inputs, num_variables):
         self.A, self.B, self.C = A, B, C
         self.num_inputs, self.num_variables = int(num_inputs), int(num_variables)
+        self._lincheck_matrices = {}
+
+    def lincheck_matrices(self, ops, num_rows_out, col_to_summation, key):
+        """A^T, B^T, C^T with their rows placed at the summation-domain index of each column — the form multi_lincheck's
+        set_challenge walks (basic_lincheck_aux.tcc:64-88).  Part of the instance's device-resident representation: built on
+        first use for a domain layout (`key`) and kept, like the CSR arrays themselves."""
+        if key not in self._lincheck_matrices:
+            self._lincheck_matrices[key] = [M.transposed_onto(ops, num_rows_out, col_to_summation) for M in (self.A, self.B, self.C)]
+        return self._lincheck_matrices[key]
 
     def num_constraints(self):
         return self.A.rows

@@ -180,6 +180,8 @@ def check_sumcheck_g_additive(lib, m, sdim, seed, kind="aurora"):
     f, h, mu = rand_elems(seed + 5, n, W), rand_elems(seed + 6, n, W), rand_elems(seed + 7, 1, W)[0]
     got = lib.sumcheck_g(f, h, basis, shift, sb, ssh, mu)
     assert np.array_equal(got, oracle.sumcheck_g_additive(f, h, basis, shift, sb, ssh, mu))
+    zero = np.zeros(W, dtype=np.uint64)     # the claimed sum of every lincheck instance: the inversion-free kernel
+    assert np.array_equal(lib.sumcheck_g(f, h, basis, shift, sb, ssh, zero), oracle.sumcheck_g_additive(f, h, basis, shift, sb, ssh, zero))
 
 
 def check_sumcheck_g_multiplicative(lib, log_n, slog, seed):

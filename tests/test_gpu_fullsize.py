@@ -120,7 +120,7 @@ def test_fold_chain_2p25(env):
     lib, torch, dev, ops, _ = env
     field = ops.field
     L0 = field.domain(1 << M, np.array([1 << M, 0, 0], dtype=np.uint64))
-    doms = field.fri_domains(L0, [1, 2])
+    doms = field.fri_domains(L0, [1, 2], lib)
     f0 = ops.FFT(ops.upload(rand_elems(0x2511, 1 << D, W)), 1 << D, L0)
     x0, x1 = rand_elems(0x2512, 1, W)[0], rand_elems(0x2513, 1, W)[0]
     f1 = ops.fold(f0, doms[0], 2, x0)
