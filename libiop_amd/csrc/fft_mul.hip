@@ -210,6 +210,33 @@ __global__ void k_fri_fold2_mul(MfoldParams p)
     }
 }
 
+// One kernel per FRI round for cosets of 2^ETA: output j (j < n / 2^ETA) needs f[j + t q], q = n / 2^ETA, t < 2^ETA (the
+// strided coset of subgroup.tcc:175-197): a lane loads them, folds ETA times in registers and writes one element.  Level e
+// works on an array of n >> e values: entry u pairs with u + (n >> (e + 1)), multiplier (x / shift)^(2^e) * g^-(u << e).
+template<int ETA>
+__global__ void __launch_bounds__(256) k_fri_fold_fused_mul(MfoldParams p)        // p.half = number of outputs q; p.consts: (xs_e, 1/2) per level
+{
+    const size_t q = p.half;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < q; j += (size_t)gridDim.x * blockDim.x) {
+        fp3 v[1 << ETA];
+#pragma unroll
+        for (int t = 0; t < (1 << ETA); ++t) v[t] = fp_load(p.src, j + (size_t)t * q);
+#pragma unroll
+        for (int e = 0; e < ETA; ++e) {
+            const fp3 xs = fp_load(p.consts, 2 * e), inv2 = fp_load(p.consts, 2 * e + 1);
+            const int pairs = 1 << (ETA - 1 - e);
+#pragma unroll
+            for (int t = 0; t < pairs; ++t) {
+                const size_t u = j + (size_t)t * q;                             // index in the level-e array
+                const fp3 c = fp_mul(xs, fp_load(p.ginv, u << e));
+                const fp3 a = v[t], b = v[t + pairs];
+                v[t] = fp_mul(fp_add(fp_add(a, b), fp_mul(fp_sub(a, b), c)), inv2);
+            }
+        }
+        fp_store(p.dst, j, v[0]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -555,6 +582,16 @@ int iopx_fri_fold_mul_fp3_dev(const uint64_t *d_f_i, size_t log_n, const uint64_
     if ((rc = dc.alloc(hc.size() * 8)) != IOPX_OK) return rc;
     { int urc_ = upload(dc.p, hc.data(), hc.size() * 8); if (urc_ != IOPX_OK) return urc_; }
     const uint64_t *ginv_top = pl->cache_inv.u64() + 3 * ((n >> 1) - 1);
+    if (eta <= 3 && getenv("IOPX_FOLD_UNFUSED") == nullptr) {
+        MfoldParams p;
+        p.src = d_f_i; p.dst = d_next; p.ginv = ginv_top; p.consts = dc.u64(); p.half = n >> eta; p.stride_log = 0;
+        const size_t bytes = (n + p.half) * 24;
+        if (eta == 1) { ProfScope ps_("k_fri_fold_fused_mul", bytes); hipLaunchKernelGGL(k_fri_fold_fused_mul<1>, dim3(mgrid(p.half, 256)), dim3(256), 0, stream(), p); }
+        else if (eta == 2) { ProfScope ps_("k_fri_fold_fused_mul", bytes); hipLaunchKernelGGL(k_fri_fold_fused_mul<2>, dim3(mgrid(p.half, 256)), dim3(256), 0, stream(), p); }
+        else { ProfScope ps_("k_fri_fold_fused_mul", bytes); hipLaunchKernelGGL(k_fri_fold_fused_mul<3>, dim3(mgrid(p.half, 256)), dim3(256), 0, stream(), p); }
+        IOPX_HIP(hipGetLastError());
+        return IOPX_OK;
+    }
     TmpBuf tmp[2];
     const uint64_t *src = d_f_i;
     size_t cur = n;

@@ -11,6 +11,8 @@
 // m-1 host-prepared constants.  When x lies in the coset the formula returns f at x, which is what
 // the reference's special case (:77-86) returns.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "gf192_dev.h"
 #include "gf192_host.h"
@@ -37,6 +39,69 @@ __global__ void k_fri_fold2(FoldParams p)
         gf192 r = gf_mul(gf_add(f0, f1), mult);
         gf_add_to(r, f0);
         gf_store(p.dst, J, r);
+    }
+}
+
+// One kernel per FRI round for cosets of 2^eta elements, eta <= 3: a lane reads its whole coset (2^eta consecutive elements),
+// folds it eta times in registers and writes one element, so a round moves (1 + 2^-eta) n elements instead of the
+// (1 + 2 (1/2 + ... )) n of eta chained launches.  The level-e multiplier of pair J_e = C 2^(eta-1-e) + p of coset C is
+//     A_e + sum_k bit_k(J_e) D_e[k] = [A_e + sum_k' bit_k'(C) D_e[eta-1-e+k']] + sum_{k < eta-1-e} bit_k(p) D_e[k] :
+// the bracket splits into bits 0-5 of C — the lane id when a wave owns 64 consecutive cosets: computed once per kernel — and the
+// wave-uniform bits >= 6 (uniform branches); the tail depends on the in-coset pair p only.
+#define FOLD_MAX_ETA 3
+struct FusedFoldParams {
+    const uint64_t *src;
+    uint64_t *dst;
+    const uint64_t *consts[FOLD_MAX_ETA];   // level e: [0] = A_e, [1 + k] = D_e[k]
+    int nbits[FOLD_MAX_ETA];                // number of D_e entries
+    int eta;
+    size_t n_out;
+};
+
+template<int ETA>
+__global__ void __launch_bounds__(256) k_fri_fold_fused(FusedFoldParams p)
+{
+    // per-lane part of every level's multiplier: bits 0-5 of the coset index — the lane id within the wave for every iteration
+    // of the grid-stride loop (workgroups are multiples of 64 lanes), so it is computed once
+    gf192 lane_part[ETA];
+    uint32_t have_low = 0xffffffffu;
+    for (size_t base = (size_t)blockIdx.x * blockDim.x; base < p.n_out; base += (size_t)gridDim.x * blockDim.x) {
+        const size_t C = base + threadIdx.x;
+        const uint32_t low = (uint32_t)(C & 63);
+        if (low != have_low) {
+#pragma unroll
+            for (int e = 0; e < ETA; ++e) {
+                const int skip = ETA - 1 - e;           // D_e entries owned by the in-coset pair index
+                gf192 t = gf_zero();
+                for (int k = 0; k < 6 && skip + k < p.nbits[e]; ++k) if ((low >> k) & 1) gf_add_to(t, gf_load(p.consts[e], 1 + skip + k));
+                lane_part[e] = t;
+            }
+            have_low = low;
+        }
+        const uint32_t chi = __builtin_amdgcn_readfirstlane((uint32_t)(C >> 6));       // bits >= 6: wave-uniform
+        gf192 v[1 << ETA];
+        if (C < p.n_out) {
+#pragma unroll
+            for (int i = 0; i < (1 << ETA); ++i) v[i] = gf_load(p.src, (C << ETA) + i);
+        }
+#pragma unroll
+        for (int e = 0; e < ETA; ++e) {
+            const int skip = ETA - 1 - e;
+            gf192 m = gf_add(gf_load(p.consts[e], 0), lane_part[e]);
+            for (int k = 6; skip + k < p.nbits[e]; ++k) if ((chi >> (k - 6)) & 1) gf_add_to(m, gf_load(p.consts[e], 1 + skip + k));
+            if (C < p.n_out) {
+#pragma unroll
+                for (int q = 0; q < (1 << skip); ++q) {
+                    gf192 mq = m;
+#pragma unroll
+                    for (int k = 0; k < skip; ++k) if ((q >> k) & 1) gf_add_to(mq, gf_load(p.consts[e], 1 + k));
+                    gf192 r = gf_mul(gf_add(v[2 * q], v[2 * q + 1]), mq);
+                    gf_add_to(r, v[2 * q]);
+                    v[q] = r;
+                }
+            }
+        }
+        if (C < p.n_out) gf_store(p.dst, C, v[0]);
     }
 }
 
@@ -90,6 +155,21 @@ int iopx_fri_fold_add_gf192_dev(const uint64_t *d_f_i, const uint64_t *basis, si
     if ((rc = dc.alloc(hc.size() * 8)) != IOPX_OK) return rc;
     { int urc_ = upload(dc.p, hc.data(), hc.size() * 8); if (urc_ != IOPX_OK) return urc_; }
 
+    if (eta <= FOLD_MAX_ETA && getenv("IOPX_FOLD_UNFUSED") == nullptr) {
+        FusedFoldParams fp;
+        memset(&fp, 0, sizeof(fp));
+        fp.src = d_f_i; fp.dst = d_next; fp.eta = eta; fp.n_out = n >> eta;
+        for (int e = 0; e < eta; ++e) { fp.consts[e] = dc.u64() + 3 * off[e]; fp.nbits[e] = (int)m - 1 - e; }
+        size_t grid = (fp.n_out + 255) / 256;
+        if (grid > 16384) grid = 16384;
+        if (grid < 1) grid = 1;
+        const size_t bytes = (n + fp.n_out) * 24;
+        if (eta == 1) { ProfScope ps_("k_fri_fold_fused", bytes); hipLaunchKernelGGL(k_fri_fold_fused<1>, dim3((unsigned)grid), dim3(256), 0, stream(), fp); }
+        else if (eta == 2) { ProfScope ps_("k_fri_fold_fused", bytes); hipLaunchKernelGGL(k_fri_fold_fused<2>, dim3((unsigned)grid), dim3(256), 0, stream(), fp); }
+        else { ProfScope ps_("k_fri_fold_fused", bytes); hipLaunchKernelGGL(k_fri_fold_fused<3>, dim3((unsigned)grid), dim3(256), 0, stream(), fp); }
+        IOPX_HIP(hipGetLastError());
+        return IOPX_OK;
+    }
     TmpBuf tmp[2];
     const uint64_t *src = d_f_i;
     size_t cur = n;
