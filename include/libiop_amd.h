@@ -93,6 +93,14 @@ int iopx_add_ifft_gf192_batch_dev(const uint64_t *d_evals, size_t batch, const u
 int iopx_add_lde_gf192_batch_dev(const uint64_t *const *d_coeffs, size_t n_coeffs, size_t batch, const uint64_t *basis, size_t m,
                                  const uint64_t *shift, size_t coset_begin, size_t coset_count, uint64_t *const *d_outs);
 
+/* FFT_over_field_subset(IFFT_over_field_subset(evals, H), L) for `batch` vectors stored back to back (2^d_dim elements each),
+ * H = span(basis[0..d_dim)) + eval_shift, L = span(basis[0..m)) + shift: the composite the reference uses to move evaluations over
+ * a systematic domain onto the codeword domain (r1cs_rs_iop.tcc:459-478, basic_lincheck_aux.tcc:94-118, fractal_indexer.tcc:123-156).
+ * Writes cosets [coset_begin, +coset_count) of vector k's codeword to d_outs[k] (as iopx_add_lde_gf192_dev).  The coefficient form
+ * is never materialised: the shift-independent halves of the two transforms cancel exactly, the outputs are the same field elements. */
+int iopx_add_reextend_gf192_batch_dev(const uint64_t *d_evals, size_t batch, const uint64_t *basis, size_t m, size_t d_dim, const uint64_t *eval_shift,
+                                      const uint64_t *shift, size_t coset_begin, size_t coset_count, uint64_t *const *d_outs);
+
 /* Building blocks of ONE transform sharded across GPUs (libiop_amd/dist.py).  The top log2(N) levels of
  * additive_FFT touch index bits that live on different GPUs; dist.py runs them with these calls plus peer exchanges.
  *   iopx_add_taylor_gf192_dev   in place: S[i] *= d_twist[i] (optional), then the Taylor-expansion network of one

@@ -48,7 +48,7 @@ EXPORTED_SYMBOLS = [
     "iopx_spmv_gf192_dev", "iopx_spmv_fp3_dev", "iopx_poly_div_vanishing_gf192_dev", "iopx_poly_div_vanishing_fp3_dev",
     "iopx_lincomb_gf192_dev", "iopx_lincomb_fp3_dev", "iopx_gf192_add_dev", "iopx_gf192_inv_dev", "iopx_fp3_mul_dev", "iopx_fp3_sub_dev",
     "iopx_fp3_inv_dev", "iopx_fp3_pow_table_dev",
-    "iopx_fp3_subgroup_generator", "iopx_fp3_multiplicative_generator", "iopx_fp3_host_mul", "iopx_fp3_host_pow", "iopx_poseidon_shipped_params", "iopx_fri_domains_gf192",
+    "iopx_fp3_subgroup_generator", "iopx_fp3_multiplicative_generator", "iopx_fp3_host_mul", "iopx_fp3_host_pow", "iopx_poseidon_shipped_params", "iopx_fri_domains_gf192", "iopx_add_reextend_gf192_batch_dev",
 ]
 
 
@@ -593,6 +593,15 @@ class Library:
         cin, cout = (_vp * len(d_coeffs))(*d_coeffs), (_vp * len(d_outs))(*d_outs)
         self._check(self.c.iopx_add_lde_gf192_batch_dev(cin, int(n_coeffs), len(d_coeffs), basis.ctypes.data_as(_u64p), basis.shape[0],
                                                         shift.ctypes.data_as(_u64p), int(coset_begin), int(coset_count), cout))
+
+    def additive_reextend_batch_dev(self, d_evals, batch, basis, d_dim, eval_shift, shift, coset_begin, coset_count, d_outs):
+        """FFT_over_field_subset(IFFT_over_field_subset(evals, H), L) for `batch` back-to-back vectors over H = span(basis[:d_dim]) +
+        eval_shift onto cosets of L = span(basis) + shift, without materialising the coefficients."""
+        basis, shift, es = _as_u64(basis), _as_u64(shift), _as_u64(eval_shift)
+        self.c.iopx_add_reextend_gf192_batch_dev.argtypes = [_vp, _sz, _u64p, _sz, _sz, _u64p, _u64p, _sz, _sz, ctypes.POINTER(_vp)]
+        cout = (_vp * len(d_outs))(*d_outs)
+        self._check(self.c.iopx_add_reextend_gf192_batch_dev(_vp(d_evals), int(batch), basis.ctypes.data_as(_u64p), basis.shape[0], int(d_dim),
+                                                             es.ctypes.data_as(_u64p), shift.ctypes.data_as(_u64p), int(coset_begin), int(coset_count), cout))
 
     def taylor_dev(self, d_S, log_n, d_twist=0):
         self._check(self.c.iopx_add_taylor_gf192_dev(_vp(d_S), log_n, _vp(d_twist)))

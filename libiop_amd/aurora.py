@@ -116,7 +116,7 @@ class MultiLincheckVirtualOracle(VirtualOracle):
     def __init__(self, ops, codeword_domain, constraint_domain, variable_domain, summation_domain, input_variable_dim, transposed_matrices):
         self.ops, self.L, self.C, self.V, self.S = ops, codeword_domain, constraint_domain, variable_domain, summation_domain
         self.input_variable_dim, self.matrices_T = input_variable_dim, transposed_matrices
-        self.r_Mz = self.d_p_alpha_prime = self.d_p_alpha_ABC = None
+        self.r_Mz = self.d_p_alpha_evals = None
 
     def set_challenge(self, alpha, r_Mz):
         """:29-99 — alpha powers, p_alpha_prime (the powers at the constraint positions of the summation domain), p_alpha_ABC
@@ -133,15 +133,18 @@ class MultiLincheckVirtualOracle(VirtualOracle):
             idx = ops.upload_raw(self.S.reindex_by_subset_array(self.C.dim, self.C.size), ops.torch.int64)
             prime_evals = ops.torch.zeros((self.S.size, 3), dtype=ops.torch.int64, device=ops.device)
             prime_evals[idx] = alpha_powers                                                    # :50-58
-        abc_evals = ops.empty(self.S.size)
+        # the two p_alpha evaluation vectors over the summation domain, back to back; the reference interpolates them here (:94-98)
+        # and extends them in evaluated_contents (:112-118): both happen there, as one re-extension
+        self.d_p_alpha_evals = ops.empty(2 * self.S.size)
+        self.d_p_alpha_evals[: self.S.size].copy_(prime_evals)
+        abc_evals = self.d_p_alpha_evals[self.S.size:]
         for m, MT in enumerate(self.matrices_T):                                               # :64-88
             ops.spmv(MT, alpha_powers, d_out=abc_evals, scale=r_Mz[m], accumulate=m > 0)
-        self.d_p_alpha_ABC, self.d_p_alpha_prime = ops.IFFT(abc_evals, self.S), ops.IFFT(prime_evals, self.S)     # :94-98
 
     def evaluated_contents(self, constituents):
         if len(constituents) != len(self.matrices_T) + 1:
             raise ValueError("multi_lincheck uses more constituent oracles than what was provided.")
-        p1, p2 = self.ops.FFT_batch([self.d_p_alpha_prime, self.d_p_alpha_ABC], self.S.size, self.L)      # :112-118
+        p1, p2 = self.ops.reextend_packed(self.d_p_alpha_evals, 2, self.S, self.L)             # :94-98 + :112-118
         return self.ops.lincheck(constituents[0], constituents[1:], self.r_Mz, p1, p2, constituents[0].shape[0])
 
 
@@ -348,14 +351,8 @@ class EncodedAuroraProtocol:
         Mz = ops.empty(3 * nC)
         for k, M in enumerate((self.cs.A, self.cs.B, self.cs.C)):                                        # :586-592, r1cs.tcc:236-268
             ops.spmv(M, d_z, d_out=Mz[k * nC:(k + 1) * nC])
-        fA, fB, fC = ops.IFFT_batch_packed(Mz, 3, self.C)                                                # :459-463
-        if self.V.size == nC:                                                                            # one batched extension (zero padded, fft.tcc:43-44)
-            fw = ops.torch.zeros((nC, 3), dtype=ops.torch.int64, device=ops.device)
-            ops.poly_div_vanishing(fw_prime, self.V.size, self.I, out=fw)                                # :563-565
-            codewords = ops.FFT_batch([fw, fA, fB, fC], nC, self.L)                                      # :567-568, :474-478
-        else:
-            fw = ops.poly_div_vanishing(fw_prime, self.V.size, self.I)
-            codewords = [ops.FFT(fw, fw.shape[0], self.L)] + ops.FFT_batch([fA, fB, fC], nC, self.L)
+        fw = ops.poly_div_vanishing(fw_prime, self.V.size, self.I)                                       # :563-565
+        codewords = [ops.FFT(fw, fw.shape[0], self.L)] + ops.reextend_packed(Mz, 3, self.C, self.L)      # :567-568; :459-478
         for handle, cw in zip((self.fw_handle, self.fAz_handle, self.fBz_handle, self.fCz_handle), codewords):
             self.IOP.submit_oracle(handle, cw)                                                           # :603-606
 

@@ -977,6 +977,53 @@ int iopx_add_lde_gf192_batch_dev(const uint64_t *const *d_coeffs, size_t n_coeff
     return IOPX_OK;
 }
 
+// FFT_over_field_subset(IFFT_over_field_subset(evals, H), L) for `batch` vectors at once, H = span(basis[0..d)) + eval_shift and
+// L = span(basis[0..m)) + shift — how the reference moves a vector of evaluations over a systematic domain onto the codeword
+// domain (r1cs_rs_iop.tcc:459-478, basic_lincheck_aux.tcc:94-118, fractal_indexer.tcc:123-156).  Gao-Mateer's phase 1 (twists and
+// Taylor expansions) depends on the basis only, not on the shift, so the inverse transform's last half and the forward
+// transform's first half cancel exactly: the butterflies of H are undone into block order and the butterflies of every coset of L
+// are applied to that — no phase-1 pass at all, same field elements.
+int iopx_add_reextend_gf192_batch_dev(const uint64_t *d_evals, size_t batch, const uint64_t *basis, size_t m, size_t d_dim, const uint64_t *eval_shift,
+                                      const uint64_t *shift, size_t coset_begin, size_t coset_count, uint64_t *const *d_outs)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    rc = check_basis_args(basis, m, shift);
+    if (rc != IOPX_OK) return rc;
+    if (!d_evals || !d_outs || !eval_shift) return fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
+    if (batch == 0 || batch > 65535) return fail(IOPX_ERR_INVALID_ARGUMENT, "batch size %zu outside 1..65535", batch);
+    if (d_dim > m) return fail(IOPX_ERR_INVALID_ARGUMENT, "the evaluation domain must be spanned by the first basis vectors of the codeword domain");
+    for (size_t k = 0; k < batch; ++k) if (!d_outs[k]) return fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
+    const int d = (int)d_dim, nhi = (int)m - d;
+    const size_t all_cosets = (size_t)1 << nhi, nd = (size_t)1 << d;
+    if (coset_count == 0 || coset_begin >= all_cosets || coset_count > all_cosets - coset_begin)
+        return fail(IOPX_ERR_INVALID_ARGUMENT, "coset range [%zu, +%zu) outside the %zu cosets of the transform", coset_begin, coset_count, all_cosets);
+    if (d == 0) {       // a constant: every evaluation equals it
+        for (size_t k = 0; k < batch; ++k) {
+            rc = iopx_add_lde_gf192_dev(d_evals + 3 * k, 1, basis, m, shift, coset_begin, coset_count, d_outs[k]);
+            if (rc != IOPX_OK) return rc;
+        }
+        return IOPX_OK;
+    }
+    AddPlan *pl = nullptr;
+    rc = get_plan(basis, d, &pl);
+    if (rc != IOPX_OK) return rc;
+    rc = upload_rs(*pl, hgf192::from_words(eval_shift), nullptr, 0);
+    if (rc != IOPX_OK) return rc;
+    TmpBuf work;
+    rc = work.alloc(batch * nd * 24);
+    if (rc != IOPX_OK) return rc;
+    rc = run_phase2<true>(*pl, d_evals, work.u64(), 0, 0, batch);                  // H's butterflies undone: natural order -> block order
+    if (rc != IOPX_OK) return rc;
+    rc = upload_rs(*pl, hgf192::from_words(shift), basis + 3 * (size_t)d, nhi);    // stream-ordered: after the inverse passes
+    if (rc != IOPX_OK) return rc;
+    for (size_t k = 0; k < batch; ++k) {
+        rc = run_phase2<false>(*pl, work.u64() + 3 * k * nd, d_outs[k], nhi, coset_begin, coset_count);
+        if (rc != IOPX_OK) return rc;
+    }
+    return IOPX_OK;
+}
+
 int iopx_add_fft_gf192(const uint64_t *coeffs, size_t n_coeffs, const uint64_t *basis, size_t m,
                        const uint64_t *shift, uint64_t *out)
 {

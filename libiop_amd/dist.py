@@ -574,6 +574,15 @@ class ShardedDeviceOps(DeviceOps):
             return super().FFT_batch(d_coeffs_list, n_coeffs, domain)
         return sharded_lde_batch(self.lib, self.torch, d_coeffs_list, int(n_coeffs), domain.basis, domain.shift, self.shard.rank, self.shard.world)
 
+    def _coset_range(self, codeword_domain, d):
+        if not self._is_sharded(codeword_domain):
+            return super()._coset_range(codeword_domain, d)
+        cosets = 1 << (codeword_domain.dim - d)
+        if cosets % self.shard.world:
+            raise ValueError("fewer cosets than ranks")
+        per = cosets // self.shard.world
+        return self.shard.rank * per, per
+
     def IFFT(self, d_evals, domain):
         if self._is_sharded(domain):
             raise ValueError("inverse transform of a distributed vector: gather it first")

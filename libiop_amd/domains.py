@@ -286,6 +286,23 @@ class DeviceOps:
             return [out[k * n:(k + 1) * n] for k in range(batch)]
         return [self.IFFT(packed[k * n:(k + 1) * n], domain) for k in range(batch)]
 
+    def reextend_packed(self, packed, batch, eval_domain, codeword_domain):
+        """FFT_over_field_subset(IFFT_over_field_subset(v, eval_domain), codeword_domain) for `batch` vectors stored back to back.
+        When the evaluation domain is spanned by the first basis vectors of the codeword domain the coefficient form is skipped
+        (iopx_add_reextend_gf192_batch_dev); otherwise the two transforms run one after the other."""
+        n = eval_domain.size
+        if codeword_domain.additive and np.array_equal(eval_domain.basis, codeword_domain.basis[: eval_domain.dim]):
+            lo, cnt = self._coset_range(codeword_domain, eval_domain.dim)
+            outs = [self.empty(cnt << eval_domain.dim) for _ in range(batch)]
+            self.lib.additive_reextend_batch_dev(packed.data_ptr(), batch, codeword_domain.basis, eval_domain.dim, eval_domain.shift,
+                                                 codeword_domain.shift, lo, cnt, [o.data_ptr() for o in outs])
+            return outs
+        return self.FFT_batch(self.IFFT_batch_packed(packed, batch, eval_domain), n, codeword_domain)
+
+    def _coset_range(self, codeword_domain, d):
+        """The cosets of span(basis[:d]) this process holds: all of them on one GPU."""
+        return 0, 1 << (codeword_domain.dim - d)
+
     def IFFT_of_known_degree(self, d_evals, degree, domain):
         """IFFT_of_known_degree_over_field_subset (fft.tcc:435-475): 2^ceil(log2 degree) coefficients."""
         k = _log2(degree)

@@ -1,4 +1,6 @@
 """Transcript extraction on the CPU (product .hip sources compiled by tests/emu) against the oracle."""
+import pytest
+
 import transcript_cases as tc
 from emu_lib import emu
 from transcript_cases import test_hash_count_expectation  # noqa: F401
@@ -19,3 +21,9 @@ def test_empty_and_errors():
 
 def test_query_responses():
     tc.check_query_responses(emu(), 256, 3, 5)
+
+
+@pytest.mark.parametrize("m,d,batch", [(6, 3, 1), (9, 5, 3), (8, 8, 2), (10, 1, 2), (12, 7, 2)])
+def test_reextend_equals_ifft_then_fft(m, d, batch):
+    import torch
+    tc.check_reextend(emu(), torch, torch.device("cpu"), m, d, batch, 40 + m)

@@ -80,3 +80,20 @@ def check_query_responses(lib, n, r, seed):
 def test_hash_count_expectation():
     # test_merkle_tree.cpp:178-199
     assert oracle.count_hashes_to_verify(8, [1, 3, 6, 7]) == 6
+
+
+def check_reextend(lib, torch, device, m, d, batch, seed):
+    """iopx_add_reextend_gf192_batch_dev == FFT_over_field_subset(IFFT_over_field_subset(evals, H), L) of the oracle, for random
+    shifts of both domains (bases: a shared random basis, H on its first d vectors)."""
+    from helpers import rand_elems
+    from libiop_amd import domains
+    ops = domains.DeviceOps(lib, torch, device, domains.GF192())
+    basis = rand_elems(seed, m, 3)
+    es, sh = rand_elems(seed + 1, 1, 3)[0], rand_elems(seed + 2, 1, 3)[0]
+    H = domains.Domain(ops.field, domains.ADDITIVE, basis=basis[:d], shift=es)
+    L = domains.Domain(ops.field, domains.ADDITIVE, basis=basis, shift=sh)
+    evals = rand_elems(seed + 3, batch << d, 3)
+    outs = ops.reextend_packed(ops.upload(evals), batch, H, L)
+    for k in range(batch):
+        coeffs = oracle.additive_ifft(evals[k << d:(k + 1) << d], basis[:d], es)
+        assert np.array_equal(ops.download(outs[k]), oracle.additive_fft(coeffs, basis, sh)), k
