@@ -326,6 +326,8 @@ class Library:
         evals, shift = _as_u64(evals), _as_u64(shift)
         n = evals.shape[0]
         log_n = n.bit_length() - 1
+        if n != 1 << log_n:
+            raise ValueError("multiplicative IFFT of known degree: %d evaluations is not a power of two" % n)
         k = max(int(degree) - 1, 0).bit_length()
         gen = _as_u64(edwards_subgroup_generator(log_n))
         d_in, d_out = self.malloc(evals.nbytes), self.malloc(24 << k)
@@ -345,6 +347,8 @@ class Library:
         f, shift, x = _as_u64(f_i_evals), _as_u64(shift), _as_u64(x_i)
         n = f.shape[0]
         log_n = n.bit_length() - 1
+        if n != 1 << log_n:
+            raise ValueError("multiplicative fold: %d evaluations is not a power of two" % n)
         gen = _as_u64(edwards_subgroup_generator(log_n) if gen is None else gen)
         out = np.empty((n // max(int(coset_size), 1), 3), dtype=np.uint64)
         self._check(self.c.iopx_fri_fold_mul_fp3(f.ctypes.data_as(_u64p), log_n, gen.ctypes.data_as(_u64p), shift.ctypes.data_as(_u64p),
@@ -365,6 +369,8 @@ class Library:
         ptrs = (_vp * len(oracles))(*[o.ctypes.data for o in oracles])
         if salts is not None:
             salts = np.ascontiguousarray(salts, dtype=np.uint8)
+            if salts.ndim != 2 or salts.shape[0] != L:
+                raise ValueError("zk salts: expected one row per leaf (%d), got shape %s" % (L, salts.shape))
             sp, sb = _vp(salts.ctypes.data), salts.shape[1]
         else:
             sp, sb = _vp(0), 0
@@ -412,6 +418,8 @@ class Library:
         ptrs = (_vp * len(oracles))(*[o.ctypes.data for o in oracles])
         if salts is not None:
             salts = np.ascontiguousarray(salts, dtype=np.uint8).reshape(-1, 32)
+            if salts.shape[0] != L:
+                raise ValueError("zk salts: expected %d rows of 32 bytes, got %d" % (L, salts.shape[0]))
             sp = _vp(salts.ctypes.data)
         else:
             sp = _vp(0)

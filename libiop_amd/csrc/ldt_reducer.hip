@@ -281,8 +281,11 @@ int iopx_ldt_combine_gf192_dev(const void *const *d_oracles, size_t num_oracles,
         q.a = p;
         q.slot_bits = dbits.u64(); q.slot_parent = (const int *)dparent.p; q.oracle_slot = (const int *)dslot.p;
         q.num_slots = (int)(distinct.empty() ? 0 : ns);
-        ProfScope ps_("k_ldt_combine_add_slots");
-        hipLaunchKernelGGL(k_ldt_combine_add_slots, dim3(ldt_grid(p.n)), dim3(256), ns * 6 * 256 * 4, stream(), q);
+        const size_t lds_bytes = ns * 6 * 256 * 4;           // 11..16 distinct degree gaps exceed the 64 KiB default
+        if (lds_bytes > 64 * 1024)
+            IOPX_HIP(hipFuncSetAttribute((const void *)k_ldt_combine_add_slots, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        ProfScope ps_("k_ldt_combine_add_slots", (p.num_oracles + 1) * p.n * 24);
+        hipLaunchKernelGGL(k_ldt_combine_add_slots, dim3(ldt_grid(p.n)), dim3(256), lds_bytes, stream(), q);
     }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;

@@ -55,6 +55,9 @@ ADDITIVE = [
     (5, [200] + [200 - 3 * k - 1 for k in range(20)], 7, "random"),
     # all multi-bit exponents identical to the common set
     (6, [100, 100 - 7, 100 - 7, 100 - 15], 8, "random"),
+    # 11..16 distinct degree gaps: the shared-power slots need more than 64 KiB of LDS (hipFuncSetAttribute path)
+    (9, [400] + [400 - (1 << k) for k in range(8)] + [400 - 3, 400 - 5, 400 - 9, 400 - 17, 400 - 33], 9, "standard"),
+    (9, [400] + [400 - 3 * k - 1 for k in range(15)], 10, "random"),
 ]
 MULTIPLICATIVE = [(1, [1], 0, True), (5, [20, 20], 1, True), (8, [100, 37, 100, 1], 2, True), (13, [5000, 4097, 3], 3, False)]
 
