@@ -323,6 +323,56 @@ int iopx_fp3_sub_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, 
 int iopx_fp3_inv_dev(const uint64_t *d_a, uint64_t *d_out, size_t count);
 int iopx_fp3_pow_table_dev(uint64_t *d_out, size_t count, const uint64_t *base, const uint64_t *init);
 
+/* ---- holographic (Fractal) prover: the vector-sized steps Aurora's entry points do not cover ---------- */
+/* sum_i coefficients[i] * oracle_i[x] + constant: single_matrix_denominator::evaluated_contents
+ * (libiop/protocols/encoded/lincheck/holographic_lincheck_aux.tcc:117-143) with (row, col, row*col) and the coefficients
+ * (-col_query, -row_query, 1), constant row_query * col_query. */
+int iopx_lincomb_affine_gf192_dev(const void *const *d_oracles, size_t num_oracles, const uint64_t *coefficients, const uint64_t *constant, size_t n,
+                                  uint64_t *d_out);
+int iopx_lincomb_affine_fp3_dev(const void *const *d_oracles, size_t num_oracles, const uint64_t *coefficients, const uint64_t *constant, size_t n,
+                                uint64_t *d_out);
+/* Elementwise quotient d_out[l] = d_num[l] / d_den[l] by batch inversion (libiop/algebra/utils.tcc:57-118 batch_inverse /
+ * batch_inverse_and_mul); d_num NULL: plain inverses; a zero denominator yields zero.  d_out must not alias an input.
+ * Callers: lagrange_polynomial::evaluations_over_field_subset (algebra/polynomials/lagrange_polynomial.tcc:66-136),
+ * single_boundary_constraint::evaluated_contents (protocols/encoded/common/boundary_constraint.tcc:22-63),
+ * rational_linear_combination::evaluated_contents (common/rational_linear_combination.tcc:183-209). */
+int iopx_gf192_div_dev(const uint64_t *d_num, const uint64_t *d_den, uint64_t *d_out, size_t count);
+int iopx_fp3_div_dev(const uint64_t *d_num, const uint64_t *d_den, uint64_t *d_out, size_t count);
+/* d_out[j] = point - x_j over the whole domain (affine subspace basis[m] + shift / coset shift * <gen> of order 2^log_n): the
+ * denominators x - y of lagrange_polynomial.tcc:72-87 and the shifted elements of boundary_constraint.tcc:31-47 (negated). */
+int iopx_domain_offsets_gf192_dev(const uint64_t *basis, size_t m, const uint64_t *shift, const uint64_t *point, uint64_t *d_out);
+int iopx_domain_offsets_fp3_dev(size_t log_n, const uint64_t *gen, const uint64_t *shift, const uint64_t *point, uint64_t *d_out);
+/* d_out[j] = constant - Z_S(x_j) over the whole domain, Z_S the vanishing polynomial of the subspace vanishing_basis[vanishing_dim] +
+ * vanishing_shift / of the coset vanishing_shift * <order 2^vanishing_log_order> (vanishing_polynomial::evaluations_over_field_subset,
+ * libiop/algebra/polynomials/vanishing_polynomial.tcc:97-137): with constant = Z_S(alpha) the numerator of lagrange_polynomial.tcc:124-131. */
+int iopx_vanishing_evals_gf192_dev(const uint64_t *basis, size_t m, const uint64_t *shift, const uint64_t *vanishing_basis, size_t vanishing_dim,
+                                   const uint64_t *vanishing_shift, const uint64_t *constant, uint64_t *d_out);
+int iopx_vanishing_evals_fp3_dev(size_t log_n, const uint64_t *gen, const uint64_t *shift, size_t vanishing_log_order, const uint64_t *vanishing_shift,
+                                 const uint64_t *constant, uint64_t *d_out);
+/* combined_numerator / combined_denominator::evaluated_contents (libiop/protocols/encoded/common/rational_linear_combination.tcc:13-108):
+ * N[x] = sum_i coefficients[i] N_i[x] prod_{k != i} D_k[x], D[x] = prod_k D_k[x] for num_rationals (<= 4) rationals; host arrays of
+ * device pointers. */
+int iopx_rational_combine_gf192_dev(const void *const *d_numerators, const void *const *d_denominators, size_t num_rationals, const uint64_t *coefficients,
+                                    size_t n, uint64_t *d_numerator_out, uint64_t *d_denominator_out);
+int iopx_rational_combine_fp3_dev(const void *const *d_numerators, const void *const *d_denominators, size_t num_rationals, const uint64_t *coefficients,
+                                  size_t n, uint64_t *d_numerator_out, uint64_t *d_denominator_out);
+/* sumcheck_constraint_oracle::evaluated_contents (libiop/protocols/encoded/sumcheck/rational_sumcheck.tcc:58-112) over the whole
+ * codeword domain, K the summation (index) domain:
+ *   subspaces: (D (p + eps^-1 mu x^(|K| - 1)) - N) / Z_K, K = span(basis[0..summation_dim)) + summation_shift, d_xinv = 1 / x over the
+ *              codeword domain (iopx_gf192_div_dev of iopx_domain_offsets_gf192_dev with point 0);
+ *   cosets:    (D (x p + mu / |K|) - N) / Z_K, K = summation_shift * <order 2^summation_log_order>. */
+int iopx_rational_sumcheck_constraint_gf192_dev(const uint64_t *d_p, const uint64_t *d_N, const uint64_t *d_D, const uint64_t *d_xinv, const uint64_t *basis,
+                                                size_t m, const uint64_t *shift, size_t summation_dim, const uint64_t *summation_shift,
+                                                const uint64_t *claimed_sum, uint64_t *d_out);
+int iopx_rational_sumcheck_constraint_fp3_dev(const uint64_t *d_p, const uint64_t *d_N, const uint64_t *d_D, size_t log_n, const uint64_t *gen,
+                                              const uint64_t *shift, size_t summation_log_order, const uint64_t *summation_shift,
+                                              const uint64_t *claimed_sum, uint64_t *d_out);
+/* Host helpers (no device work): Z_S(x) and Z_S's linear coefficient — its formal derivative, vanishing_polynomial.tcc:55-74 — for
+ * S = span(basis[dim]) + shift (either output may be NULL); the inverse of one element. */
+int iopx_gf192_vanishing_host(const uint64_t *basis, size_t dim, const uint64_t *shift, const uint64_t *x, uint64_t *value_out,
+                              uint64_t *linear_coefficient_out);
+int iopx_gf192_inverse_host(const uint64_t *x, uint64_t *out);
+
 /* ---- proof of work ------------------------------------------------------------------------------ */
 /* pow<FieldT, binary_hash_digest>::solve_pow (libiop/bcs/pow.tcc:67-103) with the BLAKE2b two-to-one hash: returns the
  * FIRST candidate in the reference's order (the challenge itself, then the challenge with its last 8-byte word set to

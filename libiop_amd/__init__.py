@@ -48,6 +48,10 @@ EXPORTED_SYMBOLS = [
     "iopx_spmv_gf192_dev", "iopx_spmv_fp3_dev", "iopx_poly_div_vanishing_gf192_dev", "iopx_poly_div_vanishing_fp3_dev",
     "iopx_lincomb_gf192_dev", "iopx_lincomb_fp3_dev", "iopx_gf192_add_dev", "iopx_gf192_inv_dev", "iopx_fp3_mul_dev", "iopx_fp3_sub_dev",
     "iopx_fp3_inv_dev", "iopx_fp3_pow_table_dev",
+    "iopx_lincomb_affine_gf192_dev", "iopx_lincomb_affine_fp3_dev", "iopx_gf192_div_dev", "iopx_fp3_div_dev", "iopx_domain_offsets_gf192_dev",
+    "iopx_domain_offsets_fp3_dev", "iopx_vanishing_evals_gf192_dev", "iopx_vanishing_evals_fp3_dev", "iopx_rational_combine_gf192_dev",
+    "iopx_rational_combine_fp3_dev", "iopx_rational_sumcheck_constraint_gf192_dev", "iopx_rational_sumcheck_constraint_fp3_dev",
+    "iopx_gf192_vanishing_host", "iopx_gf192_inverse_host",
     "iopx_fp3_subgroup_generator", "iopx_fp3_multiplicative_generator", "iopx_fp3_host_mul", "iopx_fp3_host_pow", "iopx_poseidon_shipped_params", "iopx_fri_domains_gf192", "iopx_add_reextend_gf192_batch_dev",
 ]
 
@@ -199,6 +203,21 @@ class Library:
         c.iopx_fp3_sub_dev.argtypes = [_vp, _vp, _vp, _sz]
         c.iopx_fp3_inv_dev.argtypes = [_vp, _vp, _sz]
         c.iopx_fp3_pow_table_dev.argtypes = [_vp, _sz, _u64p, _u64p]
+        pv = ctypes.POINTER(_vp)
+        c.iopx_lincomb_affine_gf192_dev.argtypes = [pv, _sz, _u64p, _u64p, _sz, _vp]
+        c.iopx_lincomb_affine_fp3_dev.argtypes = [pv, _sz, _u64p, _u64p, _sz, _vp]
+        c.iopx_gf192_div_dev.argtypes = [_vp, _vp, _vp, _sz]
+        c.iopx_fp3_div_dev.argtypes = [_vp, _vp, _vp, _sz]
+        c.iopx_domain_offsets_gf192_dev.argtypes = [_u64p, _sz, _u64p, _u64p, _vp]
+        c.iopx_domain_offsets_fp3_dev.argtypes = [_sz, _u64p, _u64p, _u64p, _vp]
+        c.iopx_vanishing_evals_gf192_dev.argtypes = [_u64p, _sz, _u64p, _u64p, _sz, _u64p, _u64p, _vp]
+        c.iopx_vanishing_evals_fp3_dev.argtypes = [_sz, _u64p, _u64p, _sz, _u64p, _u64p, _vp]
+        c.iopx_rational_combine_gf192_dev.argtypes = [pv, pv, _sz, _u64p, _sz, _vp, _vp]
+        c.iopx_rational_combine_fp3_dev.argtypes = [pv, pv, _sz, _u64p, _sz, _vp, _vp]
+        c.iopx_rational_sumcheck_constraint_gf192_dev.argtypes = [_vp, _vp, _vp, _vp, _u64p, _sz, _u64p, _sz, _u64p, _u64p, _vp]
+        c.iopx_rational_sumcheck_constraint_fp3_dev.argtypes = [_vp, _vp, _vp, _sz, _u64p, _u64p, _sz, _u64p, _u64p, _vp]
+        c.iopx_gf192_vanishing_host.argtypes = [_u64p, _sz, _u64p, _u64p, _u64p, _u64p]
+        c.iopx_gf192_inverse_host.argtypes = [_u64p, _u64p]
 
     # ---- error translation (the exception types the reference throws) ----
     def _check(self, rc):
@@ -674,6 +693,77 @@ class Library:
         ptrs = (_vp * len(d_oracles))(*d_oracles)
         fn = self.c.iopx_lincomb_fp3_dev if prime_field else self.c.iopx_lincomb_gf192_dev
         self._check(fn(ptrs, len(d_oracles), co.ctypes.data_as(_u64p), int(n), _vp(d_out)))
+
+    def lincomb_affine_dev(self, d_oracles, coefficients, constant, n, d_out, prime_field=False):
+        """sum_i coefficients[i] * oracle_i + constant (single_matrix_denominator::evaluated_contents)."""
+        co, c0 = _as_u64(coefficients), _as_u64(constant)
+        if co.shape[0] != len(d_oracles):
+            raise ValueError("Expected same number of coefficients as oracles.")
+        ptrs = (_vp * len(d_oracles))(*d_oracles)
+        fn = self.c.iopx_lincomb_affine_fp3_dev if prime_field else self.c.iopx_lincomb_affine_gf192_dev
+        self._check(fn(ptrs, len(d_oracles), co.ctypes.data_as(_u64p), c0.ctypes.data_as(_u64p), int(n), _vp(d_out)))
+
+    def field_div_dev(self, d_num, d_den, d_out, count, prime_field=False):
+        """d_out = d_num / d_den elementwise by batch inversion (d_num None: inverses); zero denominators give zero."""
+        fn = self.c.iopx_fp3_div_dev if prime_field else self.c.iopx_gf192_div_dev
+        self._check(fn(_vp(d_num) if d_num is not None else None, _vp(d_den), _vp(d_out), int(count)))
+
+    def domain_offsets_dev(self, basis, shift, point, d_out):
+        """d_out[j] = point - x_j over the affine subspace (basis, shift)."""
+        basis, shift, point = _as_u64(basis).reshape(-1, 3), _as_u64(shift), _as_u64(point)
+        self._check(self.c.iopx_domain_offsets_gf192_dev(basis.ctypes.data_as(_u64p), basis.shape[0], shift.ctypes.data_as(_u64p),
+                                                         point.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def domain_offsets_multiplicative_dev(self, log_n, gen, shift, point, d_out):
+        gen, shift, point = _as_u64(gen), _as_u64(shift), _as_u64(point)
+        self._check(self.c.iopx_domain_offsets_fp3_dev(int(log_n), gen.ctypes.data_as(_u64p), shift.ctypes.data_as(_u64p), point.ctypes.data_as(_u64p),
+                                                       _vp(d_out)))
+
+    def vanishing_evals_dev(self, basis, shift, vanishing_basis, vanishing_shift, constant, d_out):
+        """d_out[j] = constant - Z_S(x_j), S = span(vanishing_basis) + vanishing_shift, x over the subspace (basis, shift)."""
+        basis, vb = _as_u64(basis).reshape(-1, 3), _as_u64(vanishing_basis).reshape(-1, 3)
+        shift, vs, c0 = _as_u64(shift), _as_u64(vanishing_shift), _as_u64(constant)
+        self._check(self.c.iopx_vanishing_evals_gf192_dev(basis.ctypes.data_as(_u64p), basis.shape[0], shift.ctypes.data_as(_u64p), vb.ctypes.data_as(_u64p),
+                                                          vb.shape[0], vs.ctypes.data_as(_u64p), c0.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def vanishing_evals_multiplicative_dev(self, log_n, gen, shift, vanishing_log_order, vanishing_shift, constant, d_out):
+        gen, shift, vs, c0 = _as_u64(gen), _as_u64(shift), _as_u64(vanishing_shift), _as_u64(constant)
+        self._check(self.c.iopx_vanishing_evals_fp3_dev(int(log_n), gen.ctypes.data_as(_u64p), shift.ctypes.data_as(_u64p), int(vanishing_log_order),
+                                                        vs.ctypes.data_as(_u64p), c0.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def rational_combine_dev(self, d_numerators, d_denominators, coefficients, n, d_numerator_out, d_denominator_out, prime_field=False):
+        """combined_numerator / combined_denominator::evaluated_contents for up to 4 rationals."""
+        co = _as_u64(coefficients)
+        if co.shape[0] != len(d_numerators) or len(d_numerators) != len(d_denominators):
+            raise ValueError("Expected same number of random coefficients as oracles.")
+        pn, pd = (_vp * len(d_numerators))(*d_numerators), (_vp * len(d_denominators))(*d_denominators)
+        fn = self.c.iopx_rational_combine_fp3_dev if prime_field else self.c.iopx_rational_combine_gf192_dev
+        self._check(fn(pn, pd, len(d_numerators), co.ctypes.data_as(_u64p), int(n), _vp(d_numerator_out), _vp(d_denominator_out)))
+
+    def rational_sumcheck_constraint_dev(self, d_p, d_N, d_D, d_xinv, basis, shift, summation_dim, summation_shift, claimed_sum, d_out):
+        basis, shift, ss, mu = _as_u64(basis).reshape(-1, 3), _as_u64(shift), _as_u64(summation_shift), _as_u64(claimed_sum)
+        self._check(self.c.iopx_rational_sumcheck_constraint_gf192_dev(_vp(d_p), _vp(d_N), _vp(d_D), _vp(d_xinv), basis.ctypes.data_as(_u64p), basis.shape[0],
+                                                                       shift.ctypes.data_as(_u64p), int(summation_dim), ss.ctypes.data_as(_u64p),
+                                                                       mu.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def rational_sumcheck_constraint_multiplicative_dev(self, d_p, d_N, d_D, log_n, gen, shift, summation_log_order, summation_shift, claimed_sum, d_out):
+        gen, shift, ss, mu = _as_u64(gen), _as_u64(shift), _as_u64(summation_shift), _as_u64(claimed_sum)
+        self._check(self.c.iopx_rational_sumcheck_constraint_fp3_dev(_vp(d_p), _vp(d_N), _vp(d_D), int(log_n), gen.ctypes.data_as(_u64p),
+                                                                     shift.ctypes.data_as(_u64p), int(summation_log_order), ss.ctypes.data_as(_u64p),
+                                                                     mu.ctypes.data_as(_u64p), _vp(d_out)))
+
+    def gf192_vanishing_host(self, basis, shift, x):
+        """(Z_S(x), Z_S's linear coefficient) for S = span(basis) + shift, on the host."""
+        basis, shift, x = _as_u64(basis).reshape(-1, 3), _as_u64(shift), _as_u64(x)
+        value, lin = np.zeros(3, dtype=np.uint64), np.zeros(3, dtype=np.uint64)
+        self._check(self.c.iopx_gf192_vanishing_host(basis.ctypes.data_as(_u64p), basis.shape[0], shift.ctypes.data_as(_u64p), x.ctypes.data_as(_u64p),
+                                                     value.ctypes.data_as(_u64p), lin.ctypes.data_as(_u64p)))
+        return value, lin
+
+    def gf192_inverse_host(self, x):
+        x, out = _as_u64(x), np.zeros(3, dtype=np.uint64)
+        self._check(self.c.iopx_gf192_inverse_host(x.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p)))
+        return out
 
     def field_add_dev(self, d_a, d_b, d_out, count):
         self._check(self.c.iopx_gf192_add_dev(_vp(d_a), _vp(d_b), _vp(d_out), int(count)))

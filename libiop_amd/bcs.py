@@ -60,7 +60,7 @@ class Transcript:
         u64(len(self.MT_roots))
         for r in self.MT_roots:
             out.extend(r)
-        for t in range(len(self.MT_roots)):
+        for t in range(len(self.query_positions)):      # one entry per tree: a holographic transcript has more trees than roots
             u64(len(self.query_positions[t]))
             for p in self.query_positions[t]:
                 u64(p)
@@ -77,11 +77,21 @@ class Transcript:
         return bytes(out)
 
 
-class BCSProver:
-    """bcs_prover<FieldT, binary_hash_digest>."""
+class ProverIndex:
+    """bcs_prover_index (bcs/bcs_common.hpp): the index round's oracles and their Merkle trees, device resident, plus whatever the
+    protocol's indexer wants the prover to find next to them (iop_prover_index::all_oracle_evals_ and, here, `extra`)."""
 
-    def __init__(self, ops, pow_work_parameter):
+    def __init__(self, oracles, trees, roots, prover_messages, extra=None):
+        self.oracles, self.trees, self.roots, self.prover_messages, self.extra = oracles, trees, roots, prover_messages, extra
+
+
+class BCSProver:
+    """bcs_prover<FieldT, binary_hash_digest>; without interactions registered after the index round it is the bcs_indexer
+    (bcs/bcs_indexer.tcc): signal_index_submissions_done then Merkleises the submitted index oracles."""
+
+    def __init__(self, ops, pow_work_parameter, index=None):
         self.ops, self.lib, self.field = ops, ops.lib, ops.field
+        self.index, self.is_holographic = index, False            # bcs_prover.tcc:12-21
         self.pow_bitlen = pow_work_parameter            # pow_parameters(dim_h + 3, cost 1).pow_bitlen() (pow.tcc:21-32)
         self.hashchain = host.Blake2bHashchain()
         # registrations
@@ -137,9 +147,28 @@ class BCSProver:
         if make_zk:
             raise ValueError("zero-knowledge oracles are out of scope (salts and masks are not reproducible)")
         self._update_rounds_and_direction(True)
+        if self.is_holographic and self.num_interaction_rounds == 0:
+            raise ValueError("Cannot register non-index oracles in round 0 of a holographic IOP")
         self.oracle_regs.append((domain, degree, name))
         self.oracles.append(None)
         return OracleHandle(len(self.oracle_regs) - 1)
+
+    def register_index_oracle(self, domain, degree):
+        """iop.tcc:106-125."""
+        self._assert_can_register(domain, degree)
+        if self.num_prover_rounds_done != 0:
+            raise ValueError("index oracles must be created in the 0th round")
+        self._update_rounds_and_direction(True)
+        self.is_holographic = True
+        self.oracle_regs.append((domain, degree, "index"))
+        self.oracles.append(None)
+        return OracleHandle(len(self.oracle_regs) - 1)
+
+    def signal_index_registrations_done(self):
+        """iop.tcc:377-386."""
+        if not self.is_holographic or self.num_interaction_rounds != 0:
+            raise ValueError("Should only be used to end round 0 of a holographic IOP")
+        self._update_rounds_and_direction(False)
 
     def register_virtual_oracle(self, domain, degree, constituents, contents, cache_evaluated_contents=False):
         self._assert_can_register(domain, degree)
@@ -168,6 +197,9 @@ class BCSProver:
 
     def get_round_parameters(self, round):
         return self.round_params[round] if round < len(self.round_params) else 1
+
+    def get_oracle_domain(self, handle):
+        return self.virtual_regs[handle.id][0] if handle.virtual else self.oracle_regs[handle.id][0]
 
     def get_oracle_degree(self, handle):
         return self.virtual_regs[handle.id][1] if handle.virtual else self.oracle_regs[handle.id][1]
@@ -231,7 +263,42 @@ class BCSProver:
             raise ValueError("prover message submission does not match its registered size")
         self.prover_messages[handle] = contents
 
+    def submit_prover_index(self, index):
+        """iop_protocol::submit_prover_index (iop.tcc:309-341) + bcs_prover::signal_index_submissions_done (bcs_prover.tcc:68-80):
+        round 0's oracles, messages and trees come from the index; only the hashchain runs."""
+        if self.num_prover_rounds_done != 0:
+            raise ValueError("The IOP prover index should only be for round 0")
+        count = self.num_oracles_at_end_of_round[0]
+        if len(index.oracles) != count:
+            raise ValueError("The IOP prover index provided the wrong number of evaluations")
+        for oid in range(count):
+            self.submit_oracle(OracleHandle(oid), index.oracles[oid])
+        for mid in range(self.num_prover_messages_at_end_of_round[0]):
+            self.submit_prover_message(mid, index.prover_messages[mid])
+        self.signal_index_submissions_done()
+
+    def signal_index_submissions_done(self):
+        """bcs_indexer.tcc:17-53 when no index was given (the trees are built here), bcs_prover.tcc:68-80 otherwise."""
+        if self.num_prover_rounds_done != 0:
+            raise ValueError("Index submissions should be round 0")
+        self._finish_round(build_trees=self.index is None)
+
+    def get_prover_index(self, extra=None):
+        """bcs_indexer::get_bcs_prover_index (bcs_indexer.tcc:80-103)."""
+        k = len(self.oracles_in_round_by_domain(0))
+        count = self.num_oracles_at_end_of_round[0]
+        return ProverIndex(self.oracles[:count], self.MT_trees[:k], self.MT_roots[:k],
+                           self.prover_messages[: self.num_prover_messages_at_end_of_round[0]], extra)
+
+    def get_verifier_index(self):
+        """bcs_indexer::get_verifier_index (bcs_indexer.tcc:67-77): the index trees' roots (and the indexed messages)."""
+        k = len(self.oracles_in_round_by_domain(0))
+        return list(self.MT_roots[:k]), self.prover_messages[: self.num_prover_messages_at_end_of_round[0]]
+
     def signal_prover_round_done(self):
+        self._finish_round(build_trees=True)
+
+    def _finish_round(self, build_trees):
         if self.num_prover_rounds_done >= self.num_interaction_rounds:
             raise AssertionError("attempting to signal end of a round after protocol already finished")
         ended = self.num_prover_rounds_done
@@ -253,14 +320,18 @@ class BCSProver:
         cs = self.get_round_parameters(ended)
         roots = []
         for dom, ids in mapping:
-            tree = self.ops.merkle_tree([self.oracles[i] for i in ids], self.domains[dom], cs)
-            root = tree.root()                                          # merkle_tree::get_root
+            if build_trees:
+                tree = self.ops.merkle_tree([self.oracles[i] for i in ids], self.domains[dom], cs)
+                root = tree.root()                                      # merkle_tree::get_root
+            else:                                                       # "The Merkle trees are already filled in by the preprocessor."
+                tree, root = self.index.trees[self.processed_MTs], self.index.roots[self.processed_MTs]
             self.MT_trees[self.processed_MTs] = tree
             self.MT_roots[self.processed_MTs] = root
             roots.append(root)
             self.processed_MTs += 1
         self._run_hashchain_for_round(ended, roots)
-        if self.num_prover_rounds_done == self.num_interaction_rounds:  # bcs_prover.tcc:52-59
+        # bcs_prover.tcc:52-59; the indexer's one-round protocol registers no proof of work (bcs_common.tcc:426-431)
+        if self.num_prover_rounds_done == self.num_interaction_rounds and not (self.is_holographic and self.num_interaction_rounds == 1):
             challenge = self._squeeze_root_type()
             self.pow_answer = self.lib.solve_pow(challenge, self.pow_bitlen)
         for hook in self.round_hooks:
@@ -341,5 +412,8 @@ class BCSProver:
             t.MT_leaf_positions.append(lpos)
             t.query_responses.append(self.ops.query_responses([self.oracles[i] for i in ids], domain, qpos))
             t.MT_set_membership_proofs.append(self.MT_trees[mt].membership_proof(lpos))
+        if self.is_holographic:                                        # remove_index_info_from_transcript (bcs_prover.tcc:119-134)
+            t.prover_messages = t.prover_messages[self.num_prover_messages_at_end_of_round[0]:]
+            t.MT_roots = t.MT_roots[len(self.oracles_in_round_by_domain(0)):]
         t.proof_of_work = self.pow_answer
         return t

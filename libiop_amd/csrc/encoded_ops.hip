@@ -84,16 +84,17 @@ __global__ void __launch_bounds__(256) k_fp3_inv(uint64_t *out, const uint64_t *
 #define LINCOMB_MAX 16
 struct LincombParams {
     const uint64_t *o[LINCOMB_MAX];
-    const uint64_t *c;          // num coefficients (fp3: 2^203 form)
+    const uint64_t *c;          // num coefficients (fp3: 2^203 form), then the constant term (libff's form) when has_constant
     uint64_t *out;
-    int num;
+    int num, has_constant;
     size_t n;
 };
 
 __global__ void __launch_bounds__(256) k_lincomb_gf192(LincombParams p)
 {
+    const gf192 c0 = p.has_constant ? gf_load(p.c, p.num) : gf_zero();
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < p.n; j += (size_t)gridDim.x * blockDim.x) {
-        gf192 acc = gf_zero();
+        gf192 acc = c0;
         for (int i = 0; i < p.num; ++i) gf_add_to(acc, gf_mul_uniform(gf_load(p.o[i], j), gf_load(p.c, i)));
         gf_store(p.out, j, acc);
     }
@@ -101,8 +102,9 @@ __global__ void __launch_bounds__(256) k_lincomb_gf192(LincombParams p)
 
 __global__ void __launch_bounds__(256) k_lincomb_fp3(LincombParams p)
 {
+    const fp3 c0 = p.has_constant ? fp_load(p.c, p.num) : fp_zero();
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < p.n; j += (size_t)gridDim.x * blockDim.x) {
-        fp3 acc = fp_zero();
+        fp3 acc = c0;
         for (int i = 0; i < p.num; ++i) acc = fp_add(acc, fp_mul(fp_load(p.o[i], j), fp_load(p.c, i)));
         fp_store(p.out, j, acc);
     }
@@ -280,7 +282,8 @@ int iopx_fp3_mul_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, 
 int iopx_fp3_sub_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count) { return fp3_elementwise(1, d_a, d_b, d_out, count); }
 int iopx_fp3_inv_dev(const uint64_t *d_a, uint64_t *d_out, size_t count) { return fp3_elementwise(2, d_a, nullptr, d_out, count); }
 
-static int lincomb_common(const void *const *d_oracles, size_t num, const uint64_t *coeffs, size_t n, uint64_t *d_out, bool prime_field)
+static int lincomb_common(const void *const *d_oracles, size_t num, const uint64_t *coeffs, const uint64_t *constant, size_t n, uint64_t *d_out,
+                          bool prime_field)
 {
     int rc = ensure_device();
     if (rc != IOPX_OK) return rc;
@@ -288,13 +291,14 @@ static int lincomb_common(const void *const *d_oracles, size_t num, const uint64
     if (num == 0 || num > LINCOMB_MAX) return fail(IOPX_ERR_INVALID_ARGUMENT, "Random Linear Combination Oracle: Expected same number of evaluations as in registration.");
     std::vector<uint64_t> hc(coeffs, coeffs + 3 * num);
     if (prime_field) for (size_t i = 0; i < num; ++i) { const hfp3 t = hfp3::from_words(coeffs + 3 * i).table_form(); memcpy(&hc[3 * i], t.w, 24); }
+    if (constant) hc.insert(hc.end(), constant, constant + 3);
     TmpBuf dc;
     if ((rc = dc.alloc(hc.size() * 8)) != IOPX_OK) return rc;
     if ((rc = upload(dc.p, hc.data(), hc.size() * 8)) != IOPX_OK) return rc;
     LincombParams p;
     memset(&p, 0, sizeof(p));
     for (size_t i = 0; i < num; ++i) { if (!d_oracles[i]) return fail(IOPX_ERR_INVALID_ARGUMENT, "null oracle"); p.o[i] = (const uint64_t *)d_oracles[i]; }
-    p.c = dc.u64(); p.out = d_out; p.num = (int)num; p.n = n;
+    p.c = dc.u64(); p.out = d_out; p.num = (int)num; p.n = n; p.has_constant = constant ? 1 : 0;
     if (prime_field) { ProfScope ps_("k_lincomb_fp3"); hipLaunchKernelGGL(k_lincomb_fp3, dim3(eo_grid(n)), dim3(256), 0, stream(), p); }
     else { ProfScope ps_("k_lincomb_gf192"); hipLaunchKernelGGL(k_lincomb_gf192, dim3(eo_grid(n)), dim3(256), 0, stream(), p); }
     IOPX_HIP(hipGetLastError());
@@ -303,11 +307,24 @@ static int lincomb_common(const void *const *d_oracles, size_t num, const uint64
 
 int iopx_lincomb_gf192_dev(const void *const *d_oracles, size_t num_oracles, const uint64_t *coefficients, size_t n, uint64_t *d_out)
 {
-    return lincomb_common(d_oracles, num_oracles, coefficients, n, d_out, false);
+    return lincomb_common(d_oracles, num_oracles, coefficients, nullptr, n, d_out, false);
 }
 int iopx_lincomb_fp3_dev(const void *const *d_oracles, size_t num_oracles, const uint64_t *coefficients, size_t n, uint64_t *d_out)
 {
-    return lincomb_common(d_oracles, num_oracles, coefficients, n, d_out, true);
+    return lincomb_common(d_oracles, num_oracles, coefficients, nullptr, n, d_out, true);
+}
+// sum_i c_i o_i + constant: single_matrix_denominator::evaluated_contents (libiop/protocols/encoded/lincheck/holographic_lincheck_aux.tcc:117-143)
+int iopx_lincomb_affine_gf192_dev(const void *const *d_oracles, size_t num_oracles, const uint64_t *coefficients, const uint64_t *constant, size_t n,
+                                  uint64_t *d_out)
+{
+    if (!constant) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    return lincomb_common(d_oracles, num_oracles, coefficients, constant, n, d_out, false);
+}
+int iopx_lincomb_affine_fp3_dev(const void *const *d_oracles, size_t num_oracles, const uint64_t *coefficients, const uint64_t *constant, size_t n,
+                                uint64_t *d_out)
+{
+    if (!constant) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    return lincomb_common(d_oracles, num_oracles, coefficients, constant, n, d_out, true);
 }
 
 static int spmv_common(const uint64_t *d_row_ptr, const uint32_t *d_col, const uint64_t *d_coeff, size_t rows, const uint64_t *d_vec,

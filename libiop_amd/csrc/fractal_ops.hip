@@ -1,0 +1,494 @@
+// The vector-sized steps of the holographic (Fractal) prover that Aurora's kernels do not already cover, on gfx950:
+//
+//   iopx_*_div_dev                          batch_inverse / batch_inverse_and_mul (libiop/algebra/utils.tcc:57-118) as an elementwise
+//                                           quotient: lagrange_polynomial::evaluations_over_field_subset (algebra/polynomials/
+//                                           lagrange_polynomial.tcc:66-136), single_boundary_constraint::evaluated_contents (protocols/
+//                                           encoded/common/boundary_constraint.tcc:22-63), rational_linear_combination::evaluated_contents
+//                                           (common/rational_linear_combination.tcc:183-209)
+//   iopx_domain_offsets_*_dev               point - x over a domain: the denominators of the two quotients above
+//   iopx_vanishing_evals_*_dev              c - Z_H(x) over a domain (vanishing_polynomial::evaluations_over_field_subset,
+//                                           algebra/polynomials/vanishing_polynomial.tcc:97-137), the Lagrange numerator
+//   iopx_rational_combine_*_dev             combined_numerator / combined_denominator::evaluated_contents (rational_linear_combination.tcc:13-108)
+//   iopx_rational_sumcheck_constraint_*_dev sumcheck_constraint_oracle::evaluated_contents (protocols/encoded/sumcheck/rational_sumcheck.tcc:58-112)
+//
+// Montgomery's trick runs per lane over the positions tid, tid + T, tid + 2T, ... (T = threads of the launch): the running
+// products are parked in the OUTPUT buffer on the way up and consumed on the way down, so a lane amortises one field inversion
+// over n / T elements (64 at the 2^25-element codeword size) with coalesced traffic and no LDS.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <vector>
+#include "gf192_dev.h"
+#include "gf192_host.h"
+#include "fp3_dev.h"
+#include "fp3_host.h"
+#include "runtime.h"
+
+namespace iopx {
+
+static int fo_grid(size_t n, size_t cap = 16384)
+{
+    size_t g = (n + 255) / 256;
+    if (g > cap) g = cap;
+    return (int)(g ? g : 1);
+}
+
+struct DivParams {
+    const uint64_t *num;        // nullable: plain inverses
+    const uint64_t *den;
+    uint64_t *out;              // distinct from num and den
+    const uint64_t *consts;     // fp3: 2^214, 2^192 (raw), p - 2, 2^203
+    size_t n;
+};
+
+__global__ void __launch_bounds__(256) k_div_gf192(DivParams p)
+{
+    const size_t T = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    gf192 one = gf_zero();
+    one.w[0] = 1;
+    gf192 run = one;
+    size_t count = 0;
+    for (size_t j = tid; j < p.n; j += T, ++count) {
+        gf192 d = gf_load(p.den, j);
+        if (gf_is_zero(d)) d = one;
+        run = gf_mul(run, d);
+        gf_store(p.out, j, run);
+    }
+    if (count == 0) return;
+    gf192 inv = gf_inv(run);
+    for (size_t i = count; i-- > 0; ) {
+        const size_t j = tid + i * T;
+        gf192 d = gf_load(p.den, j);
+        const bool zero = gf_is_zero(d);
+        if (zero) d = one;
+        const gf192 before = i ? gf_load(p.out, j - T) : one;
+        gf192 q = gf_mul(before, inv);                      // 1 / d
+        inv = gf_mul(inv, d);
+        if (p.num) q = gf_mul(q, gf_load(p.num, j));
+        gf_store(p.out, j, zero ? gf_zero() : q);           // a zero denominator yields zero (utils.tcc:79-97)
+    }
+}
+
+// F_p: denominators are brought to the 2^203 form (closed under fp_mul, fp3_dev.h), the lane's product is inverted there by
+// x^(p-2), and the last product with a numerator in libff's form (or with the raw 2^192) lands in libff's form.
+__global__ void __launch_bounds__(256) k_div_fp3(DivParams p)
+{
+    const size_t T = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const fp3 k214 = fp_load(p.consts, 0), k192 = fp_load(p.consts, 1), one_t = fp_load(p.consts, 3);
+    const uint64_t e0 = p.consts[6], e1 = p.consts[7], e2 = p.consts[8];
+    fp3 run = one_t;
+    size_t count = 0;
+    for (size_t j = tid; j < p.n; j += T, ++count) {
+        const fp3 d = fp_load(p.den, j);
+        const bool zero = (d.w[0] | d.w[1] | d.w[2] | d.w[3] | d.w[4] | d.w[5]) == 0;
+        run = fp_mul(run, zero ? one_t : fp_mul(d, k214));
+        fp_store(p.out, j, run);
+    }
+    if (count == 0) return;
+    fp3 inv = run;                                          // the exponent's top bit (bit 180) is set
+    for (int bit = 179; bit >= 0; --bit) {
+        inv = fp_mul(inv, inv);
+        const uint64_t w = bit >= 128 ? e2 : (bit >= 64 ? e1 : e0);
+        if ((w >> (bit & 63)) & 1) inv = fp_mul(inv, run);
+    }
+    for (size_t i = count; i-- > 0; ) {
+        const size_t j = tid + i * T;
+        const fp3 d = fp_load(p.den, j);
+        const bool zero = (d.w[0] | d.w[1] | d.w[2] | d.w[3] | d.w[4] | d.w[5]) == 0;
+        const fp3 before = i ? fp_load(p.out, j - T) : one_t;
+        const fp3 q = fp_mul(before, inv);                  // (1 / d) 2^203
+        inv = fp_mul(inv, zero ? one_t : fp_mul(d, k214));
+        fp_store(p.out, j, zero ? fp_zero() : fp_mul(p.num ? fp_load(p.num, j) : k192, q));
+    }
+}
+
+// ---- subset sums over an affine subspace: out[j] = tab[0] + sum_{bit k of j} tab[1 + k] --------------------------------------
+__device__ __forceinline__ gf192 fo_subset_sum(const uint64_t *t, int m, uint32_t jlo, uint32_t jhi_uniform)
+{
+    gf192 v = gf_load(t, 0);
+    const int lo_bits = m < 8 ? m : 8;
+    for (int k = 0; k < lo_bits; ++k) {
+        const uint32_t mask = 0u - ((jlo >> k) & 1u);
+        const gf192 b = gf_load(t, 1 + k);
+#pragma unroll
+        for (int w = 0; w < 6; ++w) v.w[w] = xor_and(v.w[w], mask, b.w[w]);
+    }
+    for (int k = 8; k < m; ++k) if ((jhi_uniform >> (k - 8)) & 1u) gf_add_to(v, gf_load(t, 1 + k));
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_subset_sums_gf192(uint64_t *out, const uint64_t *tab, int m, size_t n)
+{
+    for (size_t base = (size_t)blockIdx.x * 256; base < n; base += (size_t)gridDim.x * 256) {
+        const uint32_t jhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 8));
+        const size_t end = base + 256 < n ? base + 256 : n;
+        for (size_t j = base + threadIdx.x; j < end; j += blockDim.x) gf_store(out, j, fo_subset_sum(tab, m, (uint32_t)(j & 255), jhi));
+    }
+}
+
+// ---- c - init base^j over a multiplicative coset (two-level table, hi pre-divided by 2^11 so the product is in libff's form) ----
+__global__ void __launch_bounds__(256) k_geometric_offsets_fp3(uint64_t *out, const uint64_t *hi, const uint64_t *lo, const uint64_t *c, size_t n)
+{
+    const fp3 cst = fp_load(c, 0);
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x)
+        fp_store(out, j, fp_sub(cst, fp_mul(fp_load(hi, j >> 12), fp_load(lo, j & 4095))));
+}
+
+// ---- rational linear combination: N = sum_i c_i N_i prod_{k != i} D_k, D = prod_k D_k ----------------------------------------
+#define RATIONAL_MAX 4
+struct RationalParams {
+    const uint64_t *N[RATIONAL_MAX], *D[RATIONAL_MAX];
+    const uint64_t *c;          // num coefficients (fp3: 2^203 form), then (fp3) the raw 2^214
+    uint64_t *outN, *outD;
+    int num;
+    size_t n;
+};
+
+__global__ void __launch_bounds__(256) k_rational_combine_gf192(RationalParams p)
+{
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < p.n; j += (size_t)gridDim.x * blockDim.x) {
+        gf192 d[RATIONAL_MAX];
+        for (int k = 0; k < p.num; ++k) d[k] = gf_load(p.D[k], j);
+        gf192 numer = gf_zero(), denom = d[0];
+        for (int k = 1; k < p.num; ++k) denom = gf_mul(denom, d[k]);
+        for (int i = 0; i < p.num; ++i) {
+            gf192 cur = gf_mul_uniform(gf_load(p.N[i], j), gf_load(p.c, i));
+            for (int k = 0; k < p.num; ++k) if (k != i) cur = gf_mul(cur, d[k]);
+            gf_add_to(numer, cur);
+        }
+        gf_store(p.outN, j, numer);
+        gf_store(p.outD, j, denom);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rational_combine_fp3(RationalParams p)
+{
+    const fp3 k214 = fp_load(p.c, p.num);
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < p.n; j += (size_t)gridDim.x * blockDim.x) {
+        fp3 t[RATIONAL_MAX];                                // the denominators in the 2^203 form
+        for (int k = 0; k < p.num; ++k) t[k] = fp_mul(fp_load(p.D[k], j), k214);
+        fp3 numer = fp_zero(), denom = fp_load(p.D[0], j);
+        for (int k = 1; k < p.num; ++k) denom = fp_mul(denom, t[k]);
+        for (int i = 0; i < p.num; ++i) {
+            fp3 cur = fp_mul(fp_load(p.N[i], j), fp_load(p.c, i));
+            for (int k = 0; k < p.num; ++k) if (k != i) cur = fp_mul(cur, t[k]);
+            numer = fp_add(numer, cur);
+        }
+        fp_store(p.outN, j, numer);
+        fp_store(p.outD, j, denom);
+    }
+}
+
+// ---- rational sumcheck constraint oracle ------------------------------------------------------------------------------------
+// affine subspaces: q(x) = (D(x) (p(x) + eps^-1 mu x^(|K| - 1)) - N(x)) / Z_K(x); x^(|K| - 1) = x^|K| / x with x^|K| a subset sum
+// and 1 / x supplied by the caller (iopx_gf192_div_dev over iopx_domain_offsets_gf192_dev); Z_K is constant on the cosets of K,
+// which are contiguous blocks of the codeword domain (K is spanned by a prefix of its basis), so 1 / Z_K is a small table.
+struct ConstraintAddParams {
+    const uint64_t *p, *N, *D, *xinv;
+    const uint64_t *ktab;       // (m + 1)-entry subset-sum table of x^|K|
+    const uint64_t *zinv;       // 2^(m - k) entries
+    const uint64_t *c;          // eps^-1 mu
+    uint64_t *out;
+    int m, k;
+    size_t n;
+};
+
+__global__ void __launch_bounds__(256) k_sumcheck_constraint_gf192(ConstraintAddParams a)
+{
+    const gf192 cst = gf_load(a.c, 0);
+    for (size_t base = (size_t)blockIdx.x * 256; base < a.n; base += (size_t)gridDim.x * 256) {
+        const uint32_t jhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 8));
+        const size_t end = base + 256 < a.n ? base + 256 : a.n;
+        for (size_t j = base + threadIdx.x; j < end; j += blockDim.x) {
+            const gf192 xk = fo_subset_sum(a.ktab, a.m, (uint32_t)(j & 255), jhi);
+            gf192 s = gf_mul(gf_mul_uniform(xk, cst), gf_load(a.xinv, j));
+            gf_add_to(s, gf_load(a.p, j));
+            gf192 t = gf_mul(gf_load(a.D, j), s);
+            gf_add_to(t, gf_load(a.N, j));
+            gf_store(a.out, j, gf_mul(t, gf_load(a.zinv, j >> a.k)));
+        }
+    }
+}
+
+// multiplicative cosets: q(x) = (D(x) (x p(x) + mu / |K|) - N(x)) / Z_K(x); position j lies in coset j mod (|L| / |K|).
+// D (x p + c) is a data x data product (scale 2^181): N is brought to the same scale by the stored 1 and the inverse table
+// carries 2^214 (as in k_rowcheck_fp).
+__global__ void __launch_bounds__(256) k_sumcheck_constraint_fp3(uint64_t *out, const uint64_t *pp, const uint64_t *N, const uint64_t *D,
+                                                                 const uint64_t *xhi, const uint64_t *xlo, const uint64_t *zinv_scaled,
+                                                                 const uint64_t *consts, size_t num_cosets, size_t n)
+{
+    const fp3 c = fp_load(consts, 0), one = fp_load(consts, 1);
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        const fp3 x = fp_mul(fp_load(xhi, j >> 12), fp_load(xlo, j & 4095));         // 2^203 form
+        const fp3 s = fp_add(fp_mul(fp_load(pp, j), x), c);
+        const fp3 t = fp_sub(fp_mul(fp_load(D, j), s), fp_mul(fp_load(N, j), one));
+        fp_store(out, j, fp_mul(t, fp_load(zinv_scaled, j & (num_cosets - 1))));
+    }
+}
+
+static void fo_fp_consts(uint64_t (&c)[12])
+{
+    const hfp3 k192 = hfp3::one(), k203 = k192.table_form(), k214 = k203.table_form();
+    memcpy(c, k214.w, 24); memcpy(c + 3, k192.w, 24);
+    c[6] = hfp3::P[0] - 2; c[7] = hfp3::P[1]; c[8] = hfp3::P[2];
+    memcpy(c + 9, k203.w, 24);
+}
+
+static int div_common(const uint64_t *d_num, const uint64_t *d_den, uint64_t *d_out, size_t n, bool prime_field)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (n == 0) return IOPX_OK;
+    if (!d_den || !d_out) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (d_out == d_den || d_out == d_num) return fail(IOPX_ERR_INVALID_ARGUMENT, "the quotient buffer holds the running products: it cannot alias an input");
+    DivParams p;
+    p.num = d_num; p.den = d_den; p.out = d_out; p.consts = nullptr; p.n = n;
+    TmpBuf dc;
+    if (prime_field) {
+        uint64_t c[12];
+        fo_fp_consts(c);
+        if ((rc = dc.alloc(sizeof(c))) != IOPX_OK) return rc;
+        if ((rc = upload(dc.p, c, sizeof(c))) != IOPX_OK) return rc;
+        p.consts = dc.u64();
+    }
+    const int grid = fo_grid(n, 2048);
+    const size_t bytes = n * 24 * (d_num ? 5 : 4);
+    if (prime_field) { ProfScope ps_("k_div_fp3", bytes); hipLaunchKernelGGL(k_div_fp3, dim3(grid), dim3(256), 0, stream(), p); }
+    else { ProfScope ps_("k_div_gf192", bytes); hipLaunchKernelGGL(k_div_gf192, dim3(grid), dim3(256), 0, stream(), p); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+static int subset_sums(const std::vector<uint64_t> &tab, size_t m, uint64_t *d_out)
+{
+    int rc;
+    TmpBuf dt;
+    if ((rc = dt.alloc(tab.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(dt.p, tab.data(), tab.size() * 8)) != IOPX_OK) return rc;
+    const size_t n = (size_t)1 << m;
+    { ProfScope ps_("k_subset_sums_gf192", n * 24); hipLaunchKernelGGL(k_subset_sums_gf192, dim3(fo_grid(n)), dim3(256), 0, stream(), d_out, (const uint64_t *)dt.u64(), (int)m, n); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+static int geometric_offsets(const hfp3 &base, const hfp3 &init, const hfp3 &c, size_t log_n, uint64_t *d_out)
+{
+    int rc;
+    TmpBuf hi, lo, dc;
+    const hfp3 unscale = hfp3::from_uint(2048).inverse();     // hi * lo comes out as value 2^203; libff's form is value 2^192
+    if ((rc = build_two_level(base, init * unscale, (int)log_n, hi, lo)) != IOPX_OK) return rc;
+    if ((rc = dc.alloc(24)) != IOPX_OK) return rc;
+    if ((rc = upload(dc.p, c.w, 24)) != IOPX_OK) return rc;
+    const size_t n = (size_t)1 << log_n;
+    { ProfScope ps_("k_geometric_offsets_fp3", n * 24); hipLaunchKernelGGL(k_geometric_offsets_fp3, dim3(fo_grid(n)), dim3(256), 0, stream(), d_out,
+                                                                          (const uint64_t *)hi.u64(), (const uint64_t *)lo.u64(), (const uint64_t *)dc.u64(), n); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+static int rational_common(const void *const *d_N, const void *const *d_D, size_t num, const uint64_t *coeffs, size_t n, uint64_t *d_outN,
+                           uint64_t *d_outD, bool prime_field)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_N || !d_D || !coeffs || !d_outN || !d_outD) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (num == 0 || num > RATIONAL_MAX) return fail(IOPX_ERR_INVALID_ARGUMENT, "Expected same number of evaluations as in registration.");
+    std::vector<uint64_t> hc(coeffs, coeffs + 3 * num);
+    if (prime_field) {
+        for (size_t i = 0; i < num; ++i) { const hfp3 t = hfp3::from_words(coeffs + 3 * i).table_form(); memcpy(&hc[3 * i], t.w, 24); }
+        const hfp3 k214 = hfp3::one().table_form().table_form();
+        hc.insert(hc.end(), k214.w, k214.w + 3);
+    }
+    TmpBuf dc;
+    if ((rc = dc.alloc(hc.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(dc.p, hc.data(), hc.size() * 8)) != IOPX_OK) return rc;
+    RationalParams p;
+    memset(&p, 0, sizeof(p));
+    for (size_t i = 0; i < num; ++i) {
+        if (!d_N[i] || !d_D[i]) return fail(IOPX_ERR_INVALID_ARGUMENT, "null oracle");
+        p.N[i] = (const uint64_t *)d_N[i]; p.D[i] = (const uint64_t *)d_D[i];
+    }
+    p.c = dc.u64(); p.outN = d_outN; p.outD = d_outD; p.num = (int)num; p.n = n;
+    const size_t bytes = n * 24 * (2 * num + 2);
+    if (prime_field) { ProfScope ps_("k_rational_combine_fp3", bytes); hipLaunchKernelGGL(k_rational_combine_fp3, dim3(fo_grid(n)), dim3(256), 0, stream(), p); }
+    else { ProfScope ps_("k_rational_combine_gf192", bytes); hipLaunchKernelGGL(k_rational_combine_gf192, dim3(fo_grid(n)), dim3(256), 0, stream(), p); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+} // namespace iopx
+
+using namespace iopx;
+
+extern "C" {
+
+int iopx_gf192_div_dev(const uint64_t *d_num, const uint64_t *d_den, uint64_t *d_out, size_t count) { return div_common(d_num, d_den, d_out, count, false); }
+int iopx_fp3_div_dev(const uint64_t *d_num, const uint64_t *d_den, uint64_t *d_out, size_t count) { return div_common(d_num, d_den, d_out, count, true); }
+
+int iopx_domain_offsets_gf192_dev(const uint64_t *basis, size_t m, const uint64_t *shift, const uint64_t *point, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if ((m > 0 && !basis) || !shift || !point || !d_out) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "domain dimension too large");
+    std::vector<uint64_t> tab(3 * (m + 1));
+    for (int w = 0; w < 3; ++w) tab[w] = shift[w] ^ point[w];               // point - x = point + shift + sum of basis vectors
+    if (m) memcpy(&tab[3], basis, 24 * m);
+    return subset_sums(tab, m, d_out);
+}
+
+int iopx_domain_offsets_fp3_dev(size_t log_n, const uint64_t *gen, const uint64_t *shift, const uint64_t *point, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!gen || !shift || !point || !d_out) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (log_n > 31) return fail(IOPX_ERR_INVALID_ARGUMENT, "log_n %zu exceeds the 2-adicity of the field", log_n);
+    return geometric_offsets(hfp3::from_words(gen), hfp3::from_words(shift), hfp3::from_words(point), log_n, d_out);
+}
+
+int iopx_vanishing_evals_gf192_dev(const uint64_t *basis, size_t m, const uint64_t *shift, const uint64_t *vanishing_basis, size_t vanishing_dim,
+                                   const uint64_t *vanishing_shift, const uint64_t *constant, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if ((m > 0 && !basis) || !shift || (vanishing_dim > 0 && !vanishing_basis) || !vanishing_shift || !constant || !d_out)
+        return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (m > 40 || vanishing_dim > 63) return fail(IOPX_ERR_INVALID_ARGUMENT, "domain dimension too large");
+    const SubspacePoly lin(vanishing_basis, vanishing_dim);
+    std::vector<uint64_t> tab(3 * (m + 1));
+    const hgf192 t0 = hgf192::from_words(constant) + lin.eval(hgf192::from_words(shift)) + lin.eval(hgf192::from_words(vanishing_shift));
+    memcpy(&tab[0], t0.w, 24);
+    for (size_t k = 0; k < m; ++k) { const hgf192 t = lin.eval(hgf192::from_words(basis + 3 * k)); memcpy(&tab[3 * (k + 1)], t.w, 24); }
+    return subset_sums(tab, m, d_out);
+}
+
+int iopx_vanishing_evals_fp3_dev(size_t log_n, const uint64_t *gen, const uint64_t *shift, size_t vanishing_log_order, const uint64_t *vanishing_shift,
+                                 const uint64_t *constant, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!gen || !shift || !vanishing_shift || !constant || !d_out) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (log_n > 31 || vanishing_log_order > 62) return fail(IOPX_ERR_INVALID_ARGUMENT, "domain dimension too large");
+    const uint64_t order = (uint64_t)1 << vanishing_log_order;
+    // c - Z_H(x) = (c + shift_H^|H|) - x^|H|
+    const hfp3 vp_shift = hfp3::from_words(vanishing_shift).pow(order);
+    const hfp3 zero = hfp3();
+    const hfp3 c = hfp3::from_words(constant) - (zero - vp_shift);
+    return geometric_offsets(hfp3::from_words(gen).pow(order), hfp3::from_words(shift).pow(order), c, log_n, d_out);
+}
+
+int iopx_rational_combine_gf192_dev(const void *const *d_numerators, const void *const *d_denominators, size_t num_rationals, const uint64_t *coefficients,
+                                    size_t n, uint64_t *d_numerator_out, uint64_t *d_denominator_out)
+{
+    return rational_common(d_numerators, d_denominators, num_rationals, coefficients, n, d_numerator_out, d_denominator_out, false);
+}
+int iopx_rational_combine_fp3_dev(const void *const *d_numerators, const void *const *d_denominators, size_t num_rationals, const uint64_t *coefficients,
+                                  size_t n, uint64_t *d_numerator_out, uint64_t *d_denominator_out)
+{
+    return rational_common(d_numerators, d_denominators, num_rationals, coefficients, n, d_numerator_out, d_denominator_out, true);
+}
+
+int iopx_rational_sumcheck_constraint_gf192_dev(const uint64_t *d_p, const uint64_t *d_N, const uint64_t *d_D, const uint64_t *d_xinv, const uint64_t *basis,
+                                                size_t m, const uint64_t *shift, size_t summation_dim, const uint64_t *summation_shift,
+                                                const uint64_t *claimed_sum, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_p || !d_N || !d_D || !d_xinv || !d_out || (m > 0 && !basis) || !shift || !summation_shift || !claimed_sum)
+        return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (summation_dim > m || m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "the summation domain must be spanned by a prefix of the codeword domain's basis");
+    const size_t k = summation_dim, cosets = (size_t)1 << (m - k);
+    const SubspacePoly lin(basis, k);
+    if (lin.coeff[0].is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the summation domain's basis is linearly dependent");
+    const hgf192 c = lin.coeff[0].inverse() * hgf192::from_words(claimed_sum);          // eps^-1 mu (rational_sumcheck.tcc:52-56)
+    const hgf192 z_shift = lin.eval(hgf192::from_words(summation_shift));
+    std::vector<uint64_t> ktab(3 * (m + 1)), zinv(3 * cosets);
+    for (size_t i = 0; i <= m; ++i) {
+        hgf192 v = hgf192::from_words(i == 0 ? shift : basis + 3 * (i - 1));
+        for (size_t s = 0; s < k; ++s) v = v.squared();                                // v^|K|
+        memcpy(&ktab[3 * i], v.w, 24);
+    }
+    for (size_t cidx = 0; cidx < cosets; ++cidx) {
+        hgf192 x = hgf192::from_words(shift);
+        for (size_t b = k; b < m; ++b) if ((cidx >> (b - k)) & 1) x += hgf192::from_words(basis + 3 * b);
+        const hgf192 z = lin.eval(x) + z_shift;
+        if (z.is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the codeword domain intersects the summation domain");
+        const hgf192 zi = z.inverse();
+        memcpy(&zinv[3 * cidx], zi.w, 24);
+    }
+    TmpBuf dk, dz, dc;
+    if ((rc = dk.alloc(ktab.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = dz.alloc(zinv.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = dc.alloc(24)) != IOPX_OK) return rc;
+    if ((rc = upload(dk.p, ktab.data(), ktab.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(dz.p, zinv.data(), zinv.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(dc.p, c.w, 24)) != IOPX_OK) return rc;
+    ConstraintAddParams a;
+    a.p = d_p; a.N = d_N; a.D = d_D; a.xinv = d_xinv; a.ktab = dk.u64(); a.zinv = dz.u64(); a.c = dc.u64(); a.out = d_out;
+    a.m = (int)m; a.k = (int)k; a.n = (size_t)1 << m;
+    { ProfScope ps_("k_sumcheck_constraint_gf192", a.n * 24 * 5); hipLaunchKernelGGL(k_sumcheck_constraint_gf192, dim3(fo_grid(a.n)), dim3(256), 0, stream(), a); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+int iopx_rational_sumcheck_constraint_fp3_dev(const uint64_t *d_p, const uint64_t *d_N, const uint64_t *d_D, size_t log_n, const uint64_t *gen,
+                                              const uint64_t *shift, size_t summation_log_order, const uint64_t *summation_shift,
+                                              const uint64_t *claimed_sum, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_p || !d_N || !d_D || !d_out || !gen || !shift || !summation_shift || !claimed_sum) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (summation_log_order > log_n || log_n > 31) return fail(IOPX_ERR_INVALID_ARGUMENT, "the summation domain must be a sub-domain of the codeword domain");
+    const uint64_t order_k = (uint64_t)1 << summation_log_order;
+    const size_t cosets = (size_t)1 << (log_n - summation_log_order);
+    const hfp3 g = hfp3::from_words(gen), s = hfp3::from_words(shift), ks = hfp3::from_words(summation_shift);
+    const hfp3 vp_shift = ks.pow(order_k), g_k = g.pow(order_k);
+    hfp3 cur = s.pow(order_k);
+    std::vector<uint64_t> zinv(3 * cosets);
+    for (size_t j = 0; j < cosets; ++j) {
+        const hfp3 z = cur - vp_shift;
+        if (z.is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the codeword domain intersects the summation domain");
+        const hfp3 zi = z.inverse().table_form().table_form();
+        memcpy(&zinv[3 * j], zi.w, 24);
+        cur = cur * g_k;
+    }
+    const hfp3 c = hfp3::from_uint(order_k).inverse() * hfp3::from_words(claimed_sum);     // mu / |K| (rational_sumcheck.tcc:47-51)
+    const hfp3 one = hfp3::one();
+    uint64_t consts[6];
+    memcpy(consts, c.w, 24); memcpy(consts + 3, one.w, 24);
+    TmpBuf xhi, xlo, dz, dc;
+    if ((rc = build_two_level(g, s, (int)log_n, xhi, xlo)) != IOPX_OK) return rc;
+    if ((rc = dz.alloc(zinv.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = dc.alloc(sizeof(consts))) != IOPX_OK) return rc;
+    if ((rc = upload(dz.p, zinv.data(), zinv.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(dc.p, consts, sizeof(consts))) != IOPX_OK) return rc;
+    const size_t n = (size_t)1 << log_n;
+    { ProfScope ps_("k_sumcheck_constraint_fp3", n * 24 * 4); hipLaunchKernelGGL(k_sumcheck_constraint_fp3, dim3(fo_grid(n)), dim3(256), 0, stream(), d_out, d_p, d_N, d_D,
+                                                                             (const uint64_t *)xhi.u64(), (const uint64_t *)xlo.u64(), (const uint64_t *)dz.u64(),
+                                                                             (const uint64_t *)dc.u64(), cosets, n); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+// ---- host helpers: O(dim) field operations for the handful of scalars the protocol layer needs ----
+// Z_S(x) and Z_S's linear coefficient (its formal derivative, vanishing_polynomial.tcc:55-74) for S = span(basis) + shift
+int iopx_gf192_vanishing_host(const uint64_t *basis, size_t dim, const uint64_t *shift, const uint64_t *x, uint64_t *value_out, uint64_t *linear_coefficient_out)
+{
+    if ((dim > 0 && !basis) || !shift || !x) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (dim > 63) return fail(IOPX_ERR_INVALID_ARGUMENT, "domain dimension too large");
+    const SubspacePoly lin(basis, dim);
+    if (value_out) { const hgf192 v = lin.eval(hgf192::from_words(x)) + lin.eval(hgf192::from_words(shift)); memcpy(value_out, v.w, 24); }
+    if (linear_coefficient_out) memcpy(linear_coefficient_out, lin.coeff[0].w, 24);
+    return IOPX_OK;
+}
+
+int iopx_gf192_inverse_host(const uint64_t *x, uint64_t *out)
+{
+    if (!x || !out) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    const hgf192 v = hgf192::from_words(x);
+    if (v.is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "inverse of zero");
+    const hgf192 r = v.inverse();
+    memcpy(out, r.w, 24);
+    return IOPX_OK;
+}
+
+} // extern "C"

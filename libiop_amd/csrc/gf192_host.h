@@ -104,4 +104,26 @@ inline hgf192 linearized_eval(const std::vector<hgf192> &c, const hgf192 &x)
     return r;
 }
 
+// The subspace polynomial of span(basis[0..dim)): prod_{v in span} (X - v), a linearized polynomial (coeff[i] multiplies
+// X^(2^i)), built factor by factor as Z <- Z(X) (Z(X) + Z(b)) (libiop/algebra/polynomials/vanishing_polynomial.tcc:373-395).
+// The vanishing polynomial of the affine subspace span + shift is eval(X) + eval(shift).
+struct SubspacePoly {
+    std::vector<hgf192> coeff;
+    SubspacePoly(const uint64_t *basis, size_t dim) : coeff(1, hgf192::one())
+    {
+        for (size_t k = 0; k < dim; ++k) {
+            const hgf192 zb = eval(hgf192::from_words(basis + 3 * k));
+            std::vector<hgf192> nxt(coeff.size() + 1, hgf192::zero());
+            for (size_t i = 0; i < coeff.size(); ++i) { nxt[i + 1] += coeff[i].squared(); nxt[i] += coeff[i] * zb; }
+            coeff.swap(nxt);
+        }
+    }
+    hgf192 eval(const hgf192 &x) const
+    {
+        hgf192 r = hgf192::zero(), xp = x;
+        for (size_t i = 0; i < coeff.size(); ++i) { r += coeff[i] * xp; xp = xp.squared(); }
+        return r;
+    }
+};
+
 } // namespace iopx

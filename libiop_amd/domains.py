@@ -119,6 +119,32 @@ class GF192:
     def add(self, a, b):
         return np.bitwise_xor(np.asarray(a, dtype=np.uint64), np.asarray(b, dtype=np.uint64))
 
+    def sub(self, a, b):
+        return self.add(a, b)
+
+    def neg(self, a):
+        return np.asarray(a, dtype=np.uint64)
+
+    def one(self):
+        return np.array([1, 0, 0], dtype=np.uint64)
+
+    def inv(self, a, lib):
+        return lib.gf192_inverse_host(a)
+
+    def vanishing_eval(self, domain, x, lib):
+        """Z_S(x) for the affine subspace S (vanishing_polynomial::evaluation_at_point)."""
+        return lib.gf192_vanishing_host(domain.basis, domain.shift, x)[0]
+
+    def vanishing_derivative(self, domain, x, lib):
+        """(DZ_S)(x): the linear coefficient (vanishing_polynomial.tcc:63-72)."""
+        return lib.gf192_vanishing_host(domain.basis, domain.shift, x)[1]
+
+    def element_in_domain(self, domain, x):
+        v = host.gf_from_words(self.add(x, domain.shift))
+        if not np.array_equal(domain.basis, la.standard_basis(domain.dim)):
+            raise NotImplementedError("membership test for a non-standard basis")
+        return v < (1 << domain.dim)
+
     def squeeze(self, hashchain, n):
         return hashchain.squeeze_gf192(n)
 
@@ -151,6 +177,29 @@ class EdwardsFr:
 
     def add(self, a, b):
         return self.from_int(self.to_int(a) + self.to_int(b))
+
+    def sub(self, a, b):
+        return self.from_int(self.to_int(a) - self.to_int(b))
+
+    def neg(self, a):
+        return self.from_int(-self.to_int(a))
+
+    def one(self):
+        return self.from_int(1)
+
+    def inv(self, a, lib=None):
+        return self.from_int(pow(self.to_int(a), -1, self.P))
+
+    def vanishing_eval(self, domain, x, lib=None):
+        """Z_S(x) = x^|S| - shift^|S| (vanishing_polynomial.tcc:14-25)."""
+        return self.from_int(pow(self.to_int(x), domain.size, self.P) - pow(domain.shift_int, domain.size, self.P))
+
+    def vanishing_derivative(self, domain, x, lib=None):
+        """|S| x^(|S| - 1) (vanishing_polynomial.tcc:57-62)."""
+        return self.from_int(domain.size * pow(self.to_int(x), domain.size - 1, self.P))
+
+    def element_in_domain(self, domain, x):
+        return pow(self.to_int(x) * pow(domain.shift_int, -1, self.P) % self.P, domain.size, self.P) == 1
 
     def squeeze(self, hashchain, n):
         """blake2b_FieldT_randomness_extractor for Fp (blake2b.tcc:187-257): keyed BLAKE2b straight into mont_repr, bits above
@@ -416,6 +465,74 @@ class DeviceOps:
         out = self.empty(csr.rows) if d_out is None else d_out
         self.lib.spmv_dev(csr.d_row_ptr.data_ptr(), csr.d_col.data_ptr(), csr.d_coeff.data_ptr(), csr.rows, d_vec.data_ptr(), out.data_ptr(),
                           scale=scale, accumulate=accumulate, prime_field=not self.field.additive)
+        return out
+
+    # ---- vector-sized steps of the holographic prover ----
+    def div(self, d_num, d_den):
+        """d_num / d_den elementwise by batch inversion (d_num None: the inverses)."""
+        out = self.empty(d_den.shape[0])
+        self.lib.field_div_dev(d_num.data_ptr() if d_num is not None else None, d_den.data_ptr(), out.data_ptr(), d_den.shape[0],
+                               prime_field=not self.field.additive)
+        return out
+
+    def domain_offsets(self, domain, point):
+        """point - x over the whole domain."""
+        out = self.empty(domain.size)
+        if domain.additive:
+            self.lib.domain_offsets_dev(domain.basis, domain.shift, point, out.data_ptr())
+        else:
+            self.lib.domain_offsets_multiplicative_dev(domain.dim, domain.gen, domain.shift, point, out.data_ptr())
+        return out
+
+    def domain_elements(self, domain):
+        """field_subset::all_elements on the device."""
+        if domain.additive:
+            return self.domain_offsets(domain, self.field.zero())
+        return self.pow_table(domain.size, domain.gen, domain.shift)
+
+    def vanishing_evals(self, vanishing_domain, domain, constant):
+        """constant - Z_S(x) over the whole domain (S = vanishing_domain)."""
+        out = self.empty(domain.size)
+        S = vanishing_domain
+        if domain.additive:
+            self.lib.vanishing_evals_dev(domain.basis, domain.shift, S.basis, S.shift, constant, out.data_ptr())
+        else:
+            self.lib.vanishing_evals_multiplicative_dev(domain.dim, domain.gen, domain.shift, S.dim, S.shift, constant, out.data_ptr())
+        return out
+
+    def lagrange_evals(self, x, S, evaldomain):
+        """lagrange_polynomial(x, S, normalized = false).evaluations_over_field_subset(evaldomain) (lagrange_polynomial.tcc:66-136):
+        (Z_S(x) - Z_S(y)) / (x - y) for y over evaldomain.  The reference patches the position y = x (probability |evaldomain| / |F|
+        for a sampled x) with the formal derivative; here that case is refused instead of silently differing."""
+        if self.field.element_in_domain(evaldomain, x):
+            raise NotImplementedError("the evaluation point lies in the evaluation domain")
+        numerator = self.vanishing_evals(S, evaldomain, self.field.vanishing_eval(S, x, self.lib))
+        return self.div(numerator, self.domain_offsets(evaldomain, x))
+
+    def lincomb_affine(self, d_oracles, coefficients, constant, n):
+        out = self.empty(n)
+        self.lib.lincomb_affine_dev([t.data_ptr() for t in d_oracles], coefficients, constant, n, out.data_ptr(), prime_field=not self.field.additive)
+        return out
+
+    def rational_combine(self, d_numerators, d_denominators, coefficients, n):
+        """(combined numerator, combined denominator) of sum_i c_i N_i / D_i."""
+        N, D = self.empty(n), self.empty(n)
+        self.lib.rational_combine_dev([t.data_ptr() for t in d_numerators], [t.data_ptr() for t in d_denominators], coefficients, n,
+                                      N.data_ptr(), D.data_ptr(), prime_field=not self.field.additive)
+        return N, D
+
+    def rational_sumcheck_constraint(self, d_p, d_N, d_D, codeword_domain, summation_domain, claimed_sum):
+        out = self.empty(codeword_domain.size)
+        L, K = codeword_domain, summation_domain
+        if L.additive:
+            if not np.array_equal(K.basis, L.basis[: K.dim]):
+                raise ValueError("the summation domain must be spanned by a prefix of the codeword domain's basis")
+            xinv = self.div(None, self.domain_offsets(L, self.field.zero()))
+            self.lib.rational_sumcheck_constraint_dev(d_p.data_ptr(), d_N.data_ptr(), d_D.data_ptr(), xinv.data_ptr(), L.basis, L.shift, K.dim, K.shift,
+                                                      claimed_sum, out.data_ptr())
+        else:
+            self.lib.rational_sumcheck_constraint_multiplicative_dev(d_p.data_ptr(), d_N.data_ptr(), d_D.data_ptr(), L.dim, L.gen, L.shift, K.dim, K.shift,
+                                                                     claimed_sum, out.data_ptr())
         return out
 
     def poly_div_vanishing(self, d_poly, n_coeffs, domain, out=None):

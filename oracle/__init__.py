@@ -702,3 +702,64 @@ def fri_snark_verify(field, codeword_domain_dim, rs_extra, localization, interac
     if rc < 0:
         raise RuntimeError("oracle_fri_snark_verify failed (%d)" % rc)
     return bool(rc)
+
+
+# ---- Fractal preprocessing SNARK (oracle/fractal.hpp) ----
+_FRACTAL_PARAM_NAMES = ["codeword_domain_dim", "pow_bits", "query_soundness_error_bits", "interactive_soundness_error_bits",
+                        "max_LDT_tested_degree_bound", "max_constraint_degree_bound", "absolute_proximity_parameter", "holographic_lincheck_repetitions",
+                        "num_output_LDT_instances", "fri_interactive_repetitions", "fri_query_repetitions", "index_domain_dim", "matrix_domain_dim"]
+
+
+def fractal_prove(field, log_constraints, num_inputs, seed, security=128, rs_extra=3, localization=2):
+    """(serialized transcript, index Merkle roots) of fractal_snark_indexer + fractal_snark_prover on the seeded instance
+    generate_r1cs_example(2^log_constraints, num_inputs, 2^log_constraints - 1; seed) (profiling/instrument_fractal_snark.cpp:93-160)."""
+    l = lib()
+    l.oracle_fractal_prove.restype = ctypes.c_long
+    l.oracle_fractal_index_roots.restype = ctypes.c_long
+    n = l.oracle_fractal_prove(*_aurora_args(field, log_constraints, num_inputs, seed, security, rs_extra, localization))
+    if n < 0:
+        raise RuntimeError("oracle_fractal_prove failed (%d)" % n)
+    buf = (ctypes.c_uint8 * n)()
+    l.oracle_aurora_fetch(buf)
+    k = l.oracle_fractal_index_roots(None)
+    roots = (ctypes.c_uint8 * (32 * k))()
+    l.oracle_fractal_index_roots(roots)
+    return bytes(buf), [bytes(roots[32 * i:32 * i + 32]) for i in range(k)]
+
+
+def fractal_verify(field, log_constraints, num_inputs, seed, transcript, index_roots, security=128, rs_extra=3, localization=2, primary_override=None):
+    """fractal_snark_verifier with the verifier index (the index trees' roots) on the same seeded instance."""
+    buf = (ctypes.c_uint8 * len(transcript)).from_buffer_copy(bytes(transcript))
+    flat = b"".join(index_roots)
+    rbuf = (ctypes.c_uint8 * max(1, len(flat))).from_buffer_copy(flat if flat else b"\0")
+    po = None
+    if primary_override is not None:
+        po = np.ascontiguousarray(primary_override, dtype=np.uint64)
+    rc = lib().oracle_fractal_verify(*_aurora_args(field, log_constraints, num_inputs, seed, security, rs_extra, localization), buf,
+                                     ctypes.c_size_t(len(transcript)), rbuf, ctypes.c_size_t(len(index_roots)), _p(po) if po is not None else None)
+    if rc < 0:
+        raise RuntimeError("oracle_fractal_verify failed (%d)" % rc)
+    return bool(rc)
+
+
+def fractal_params(field, log_constraints, num_inputs, security=128, rs_extra=3, localization=2):
+    out = np.zeros(80, dtype=np.uint64)
+    sz = ctypes.c_size_t
+    n = lib().oracle_fractal_params(ctypes.c_int(field), sz(log_constraints), sz(num_inputs), sz(security), sz(rs_extra), sz(localization), _p(out), sz(80))
+    if n < 0:
+        raise RuntimeError("oracle_fractal_params failed (%d)" % n)
+    d = dict(zip(_FRACTAL_PARAM_NAMES, (int(v) for v in out[:13])))
+    d["localization_parameters"] = [int(v) for v in out[14:n]]
+    return d
+
+
+def fractal_index_oracle(field, log_constraints, num_inputs, seed, matrix, which, security=128, rs_extra=3, localization=2):
+    """Index oracle `which` (0 row, 1 col, 2 val, 3 row*col) of matrix 0..2 (A, B, C) over the codeword domain."""
+    words = {FIELD_EDWARDS: 3, FIELD_GF64: 1, FIELD_GF192: 3}[field]
+    dim = fractal_params(field, log_constraints, num_inputs, security, rs_extra, localization)["codeword_domain_dim"]
+    out = np.zeros((1 << dim, words), dtype=np.uint64)
+    sz = ctypes.c_size_t
+    rc = lib().oracle_fractal_index_oracle(*_aurora_args(field, log_constraints, num_inputs, seed, security, rs_extra, localization), sz(matrix), sz(which), _p(out))
+    if rc != 0:
+        raise RuntimeError("oracle_fractal_index_oracle failed (%d)" % rc)
+    return out

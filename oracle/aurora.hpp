@@ -508,6 +508,7 @@ struct encoded_aurora_protocol {
     std::shared_ptr<rowcheck_ABC_virtual_oracle<F>> rowcheck_oracle;
     std::shared_ptr<multi_lincheck<F>> lincheck;
 
+    // lincheck_repetitions == 0: the holographic arm (r1cs_rs_iop.tcc:344-357) — oracle/fractal.hpp attaches its own lincheck
     encoded_aurora_protocol(bcs_protocol<F> &iop, size_t constraint_h, size_t variable_h, size_t codeword_h, const r1cs_system<F> &system,
                             size_t lincheck_repetitions)
         : IOP(iop), constraint_domain_handle(constraint_h), variable_domain_handle(variable_h), codeword_domain_handle(codeword_h), cs(system),
@@ -524,9 +525,10 @@ struct encoded_aurora_protocol {
         fz_oracle = std::make_shared<fz_virtual_oracle<F>>(k, input_variable_domain, codeword_domain);
         fz_handle = IOP.register_virtual_oracle(codeword_h, fw_degree + k + 1, { fw_handle }, fz_oracle);
         const std::vector<oracle_handle> Mz_handles = { fAz_handle, fBz_handle, fCz_handle };
-        lincheck = std::make_shared<multi_lincheck<F>>(IOP, codeword_h, constraint_h, variable_h, dom_dim(input_variable_domain),
-                                                       std::vector<const typename multi_lincheck<F>::matrix *>{ &cs.A, &cs.B, &cs.C }, fz_handle, Mz_handles,
-                                                       lincheck_repetitions);
+        if (lincheck_repetitions)
+            lincheck = std::make_shared<multi_lincheck<F>>(IOP, codeword_h, constraint_h, variable_h, dom_dim(input_variable_domain),
+                                                           std::vector<const typename multi_lincheck<F>::matrix *>{ &cs.A, &cs.B, &cs.C }, fz_handle, Mz_handles,
+                                                           lincheck_repetitions);
         rowcheck_oracle = std::make_shared<rowcheck_ABC_virtual_oracle<F>>(codeword_domain, constraint_domain);
         rowcheck_handle = IOP.register_virtual_oracle(codeword_h, dom_size(constraint_domain) - 1, Mz_handles, rowcheck_oracle);
     }

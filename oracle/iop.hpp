@@ -93,7 +93,7 @@ struct bcs_transcript {
         for (auto &m : prover_messages) { u64(m.size()); raw(m.data(), m.size() * sizeof(F)); }
         u64(MT_roots.size());
         for (auto &r : MT_roots) raw(r.data(), r.size());
-        for (size_t t = 0; t < MT_roots.size(); ++t) {
+        for (size_t t = 0; t < query_positions.size(); ++t) {      // one entry per tree; a holographic transcript has more trees than roots
             u64(query_positions[t].size());
             for (size_t p : query_positions[t]) u64(p);
             u64(MT_leaf_positions[t].size());
@@ -106,7 +106,8 @@ struct bcs_transcript {
         raw(proof_of_work.data(), proof_of_work.size());
         return out;
     }
-    static bcs_transcript deserialize(const uint8_t *p, size_t len)
+    // index_trees: the trees of the index round, whose roots a holographic transcript does not carry (bcs_prover.tcc:119-134)
+    static bcs_transcript deserialize(const uint8_t *p, size_t len, size_t index_trees = 0)
     {
         size_t off = 0;
         auto need = [&](size_t n) { if (n > len - off) throw std::invalid_argument("truncated transcript"); };
@@ -118,7 +119,7 @@ struct bcs_transcript {
         for (size_t i = 0; i < num_messages; ++i) { const size_t n = u64(); t.prover_messages.push_back(elems(n)); }
         const size_t num_roots = u64();
         for (size_t i = 0; i < num_roots; ++i) t.MT_roots.push_back(digest());
-        for (size_t i = 0; i < num_roots; ++i) {
+        for (size_t i = 0; i < num_roots + index_trees; ++i) {
             std::vector<size_t> qp(u64());
             for (size_t &v : qp) { need(8); uint64_t x; memcpy(&x, p + off, 8); off += 8; v = (size_t)x; }
             std::vector<size_t> lp(u64());
@@ -146,6 +147,15 @@ public:
     explicit bcs_protocol(size_t pow_work_parameter) : pow_bitlen_(pow_bitlen(pow_work_parameter, 1)) {}
     bcs_protocol(size_t pow_work_parameter, const bcs_transcript<F> &transcript)
         : pow_bitlen_(pow_bitlen(pow_work_parameter, 1)), verifier_(true), transcript_(transcript) {}
+    // preprocessing verifier (bcs_verifier.tcc:13-33): the index's roots (and messages) go in front of the transcript's
+    bcs_protocol(size_t pow_work_parameter, const bcs_transcript<F> &transcript, const std::vector<digest_t> &index_MT_roots,
+                 const std::vector<std::vector<F>> &indexed_messages = {})
+        : pow_bitlen_(pow_bitlen(pow_work_parameter, 1)), verifier_(true), transcript_(transcript), num_index_roots_given_(index_MT_roots.size()),
+          num_index_messages_given_(indexed_messages.size()), preprocessing_verifier_(true)
+    {
+        transcript_.MT_roots.insert(transcript_.MT_roots.begin(), index_MT_roots.begin(), index_MT_roots.end());
+        transcript_.prover_messages.insert(transcript_.prover_messages.begin(), indexed_messages.begin(), indexed_messages.end());
+    }
 
     // ---- registration (iop.tcc:22-263) ----
     size_t register_domain(const D &d) { domains_.push_back(d); return domains_.size() - 1; }
@@ -155,11 +165,29 @@ public:
     {
         assert_can_register(domain, degree);
         update_rounds_and_direction(true);
+        if (is_holographic_ && num_interaction_rounds_ == 0) throw std::invalid_argument("Cannot register non-index oracles in round 0 of a holographic IOP");
         oracle_regs_.push_back({ domain, degree, make_zk });
         oracles_.emplace_back();
         oracles_present_.push_back(false);
         return { false, oracle_regs_.size() - 1 };
     }
+    oracle_handle register_index_oracle(size_t domain, size_t degree)                                // iop.tcc:106-125
+    {
+        assert_can_register(domain, degree);
+        if (num_prover_rounds_done_ != 0) throw std::invalid_argument("index oracles must be created in the 0th round");
+        update_rounds_and_direction(true);
+        is_holographic_ = true;
+        oracle_regs_.push_back({ domain, degree, false });
+        oracles_.emplace_back();
+        oracles_present_.push_back(false);
+        return { false, oracle_regs_.size() - 1 };
+    }
+    void signal_index_registrations_done()                                                           // iop.tcc:377-386
+    {
+        if (!is_holographic_ || num_interaction_rounds_ != 0) throw std::invalid_argument("Should only be used to end round 0 of a holographic IOP");
+        update_rounds_and_direction(false);
+    }
+    bool is_holographic() const { return is_holographic_; }
     oracle_handle register_virtual_oracle(size_t domain, size_t degree, const std::vector<oracle_handle> &constituents,
                                           std::shared_ptr<virtual_oracle<F>> contents, bool cache_evaluated_contents = false)
     {
@@ -265,7 +293,8 @@ public:
             ++processed_MTs_;
         }
         run_hashchain_for_round(ended_round, roots, prover_messages_);
-        if (num_prover_rounds_done_ == num_interaction_rounds_) {                          // bcs_prover.tcc:52-59
+        // bcs_prover.tcc:52-59; the indexer's one-round protocol has no proof of work (bcs_common.tcc:426-431, bcs_indexer.tcc:17-53)
+        if (num_prover_rounds_done_ == num_interaction_rounds_ && !(is_holographic_ && num_interaction_rounds_ == 1)) {
             const digest_t challenge = squeeze_root_type();
             pow_answer_.resize(DIGEST_LEN);
             pow_solve_blake2b(challenge.data(), pow_bitlen_, pow_answer_.data());
@@ -328,9 +357,22 @@ public:
                 ++MT_idx;
             }
         }
+        if (is_holographic_) {                                                             // remove_index_info_from_transcript (bcs_prover.tcc:119-134)
+            const size_t index_trees = oracles_in_round_by_domain(0).size();
+            result.prover_messages.erase(result.prover_messages.begin(), result.prover_messages.begin() + num_prover_messages_at_end_of_round_[0]);
+            result.MT_roots.erase(result.MT_roots.begin(), result.MT_roots.begin() + index_trees);
+        }
         result.proof_of_work = pow_answer_;
         return result;
     }
+    // bcs_indexer.tcc:67-77: what the verifier keeps of the index
+    std::vector<digest_t> get_index_MT_roots() const
+    {
+        std::vector<digest_t> roots;
+        for (size_t i = 0; i < processed_MTs_ && i < oracles_in_round_by_domain(0).size(); ++i) roots.push_back(digest_t(MT_nodes_[i].begin(), MT_nodes_[i].begin() + DIGEST_LEN));
+        return roots;
+    }
+    std::vector<F> take_oracle(const oracle_handle &h) { return std::move(oracles_[h.id]); }
 
     // ---- shared by prover and verifier (iop.tcc:480-565, 669-714) ----
     size_t obtain_query_position(const position_handle &p)
@@ -476,6 +518,10 @@ private:
             for (size_t round = 0; round < num_interaction_rounds_; ++round) {
                 const auto mapping = oracles_in_round_by_domain(round);
                 const size_t num_domains = mapping.size();
+                if (preprocessing_verifier_ && round == 0) {                                 // bcs_verifier.tcc:47-59
+                    if (num_domains != num_index_roots_given_) throw std::invalid_argument("Index had an incorrect number of MT roots");
+                    if (num_prover_messages_at_end_of_round_[0] != num_index_messages_given_) throw std::invalid_argument("Index had an incorrect number of prover messages");
+                }
                 if (processed + num_domains > transcript_.MT_roots.size()) throw std::invalid_argument("transcript has too few Merkle roots");
                 std::vector<digest_t> roots(transcript_.MT_roots.begin() + processed, transcript_.MT_roots.begin() + processed + num_domains);
                 if (transcript_.prover_messages.size() != prover_message_sizes_.size()) throw std::invalid_argument("transcript has the wrong number of prover messages");
@@ -524,7 +570,7 @@ private:
     std::vector<size_t> prover_message_sizes_, verifier_message_sizes_;
     std::vector<size_t> num_oracles_at_end_of_round_, num_prover_messages_at_end_of_round_, num_verifier_messages_at_end_of_round_;
     std::vector<size_t> round_params_;
-    bool from_prover_ = false, sealed_interactions_ = false;
+    bool from_prover_ = false, sealed_interactions_ = false, is_holographic_ = false;
     size_t num_interaction_rounds_ = 0;
     std::vector<size_t> random_position_domains_;
     std::vector<det_position> deterministic_positions_;
@@ -548,6 +594,8 @@ private:
     // verifier state
     bool verifier_ = false, transcript_is_valid_ = false;
     bcs_transcript<F> transcript_;
+    size_t num_index_roots_given_ = 0, num_index_messages_given_ = 0;
+    bool preprocessing_verifier_ = false;
     std::map<std::pair<size_t, size_t>, F> oracle_id_and_pos_to_value_;
 };
 

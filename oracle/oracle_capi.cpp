@@ -12,6 +12,7 @@
 #include "pow.hpp"
 #include "ldt.hpp"
 #include "aurora.hpp"
+#include "fractal.hpp"
 
 using namespace oracle;
 
@@ -586,6 +587,74 @@ int aurora_params_impl(size_t log_constraints, size_t num_inputs, size_t securit
     memcpy(out, v.data(), v.size() * 8);
     return (int)v.size();
 }
+// ---- Fractal SNARK (fractal.hpp): indexer + prover; the index's Merkle roots are kept for oracle_fractal_index_roots ----
+std::vector<uint8_t> g_last_index_roots;
+template<typename F>
+long fractal_prove_impl(size_t log_constraints, size_t num_inputs, uint64_t seed, size_t security, size_t rs_extra, size_t localization)
+{
+    const size_t n = (size_t)1 << log_constraints;
+    const r1cs_example<F> ex = generate_r1cs_example<F>(n, num_inputs, n - 1, seed);
+    const fractal_parameters<F> params(security, rs_extra, localization, ex.cs);
+    const fractal_index<F> index = fractal_snark_indexer<F>(ex.cs, params);
+    g_last_index_roots.clear();
+    for (auto &r : index.MT_roots) g_last_index_roots.insert(g_last_index_roots.end(), r.begin(), r.end());
+    g_last_transcript = fractal_snark_prover<F>(index, ex.cs, ex.primary_input, ex.auxiliary_input, params).serialize();
+    return (long)g_last_transcript.size();
+}
+template<typename F>
+int fractal_verify_impl(size_t log_constraints, size_t num_inputs, uint64_t seed, size_t security, size_t rs_extra, size_t localization,
+                        const uint8_t *bytes, size_t len, const uint8_t *roots, size_t num_roots, const uint64_t *primary_override)
+{
+    const size_t n = (size_t)1 << log_constraints;
+    r1cs_example<F> ex = generate_r1cs_example<F>(n, num_inputs, n - 1, seed);
+    if (primary_override) memcpy((void *)ex.primary_input.data(), primary_override, num_inputs * sizeof(F));
+    const fractal_parameters<F> params(security, rs_extra, localization, ex.cs);
+    std::vector<digest_t> index_roots;
+    for (size_t i = 0; i < num_roots; ++i) index_roots.push_back(digest_t(roots + i * DIGEST_LEN, roots + (i + 1) * DIGEST_LEN));
+    bcs_transcript<F> t;
+    try { t = bcs_transcript<F>::deserialize(bytes, len, num_roots); } catch (const std::exception &) { return 0; }
+    return fractal_snark_verifier<F>(index_roots, ex.cs, ex.primary_input, t, params) ? 1 : 0;
+}
+template<typename F>
+int fractal_params_impl(size_t log_constraints, size_t num_inputs, size_t security, size_t rs_extra, size_t localization, uint64_t *out, size_t cap)
+{
+    const size_t n = (size_t)1 << log_constraints;
+    r1cs_system<F> shape;                           // the parameters read sizes and non-zero counts only: one entry per row, as the example has
+    shape.num_inputs = num_inputs; shape.num_variables = n - 1;
+    shape.A.assign(n, typename r1cs_system<F>::row(1, { 0, F::one() }));
+    shape.B = shape.A; shape.C = shape.A;
+    const fractal_parameters<F> p(security, rs_extra, localization, shape);
+    std::vector<uint64_t> v = { p.codeword_domain_dim, p.pow_bits, p.query_soundness_error_bits, p.interactive_soundness_error_bits,
+                                p.max_LDT_tested_degree_bound, p.max_constraint_degree_bound, p.absolute_proximity_parameter, p.holographic_lincheck_repetitions_,
+                                p.num_output_LDT_instances, p.fri_interactive_repetitions, p.fri_query_repetitions, p.index_domain_dim, p.matrix_domain_dim,
+                                p.localization_parameters.size() };
+    for (size_t l : p.localization_parameters) v.push_back(l);
+    if (v.size() > cap) return -1;
+    memcpy(out, v.data(), v.size() * 8);
+    return (int)v.size();
+}
+// one index oracle (matrix 0..2, which 0..3 = row, col, val, row*col) over the codeword domain; the twelve are computed once per
+// argument tuple and kept
+template<typename F>
+int fractal_index_oracle_impl(size_t log_constraints, size_t num_inputs, uint64_t seed, size_t security, size_t rs_extra, size_t localization,
+                              size_t matrix, size_t which, uint64_t *out)
+{
+    static std::vector<size_t> cached_key;
+    static std::vector<std::vector<F>> cached;
+    const std::vector<size_t> key = { log_constraints, num_inputs, (size_t)seed, security, rs_extra, localization };
+    if (key != cached_key) {
+        const size_t n = (size_t)1 << log_constraints;
+        const r1cs_example<F> ex = generate_r1cs_example<F>(n, num_inputs, n - 1, seed);
+        const fractal_parameters<F> params(security, rs_extra, localization, ex.cs);
+        bcs_protocol<F> IOP(params.pow_bits);
+        fractal_iop<F> full_protocol(IOP, ex.cs, params);
+        cached = full_protocol.compute_index_oracles();
+        cached_key = key;
+    }
+    const std::vector<F> &v = cached.at(4 * matrix + which);
+    memcpy(out, (const void *)v.data(), v.size() * sizeof(F));
+    return 0;
+}
 // the instance itself, so tests can compare the product's generator: z = (primary, auxiliary) then the C coefficients
 template<typename F>
 int r1cs_example_impl(size_t log_constraints, size_t num_inputs, uint64_t seed, uint64_t *z_out, uint64_t *c_index_out, uint64_t *c_coeff_out)
@@ -634,6 +703,39 @@ int oracle_r1cs_example(int field, size_t log_constraints, size_t num_inputs, ui
     return -1;
 }
 
+
+long oracle_fractal_prove(int field, size_t log_constraints, size_t num_inputs, uint64_t seed, size_t security, size_t rs_extra, size_t localization)
+{
+    try { AURORA_DISPATCH(field, return fractal_prove_impl<F>(log_constraints, num_inputs, seed, security, rs_extra, localization)); }
+    catch (const std::exception &e) { fprintf(stderr, "oracle_fractal_prove: %s\n", e.what()); return -2; }
+    return -1;
+}
+// the index Merkle roots of the last oracle_fractal_prove: returns their number, copies 32 bytes each when dst is not null
+long oracle_fractal_index_roots(uint8_t *dst)
+{
+    if (dst && !g_last_index_roots.empty()) memcpy(dst, g_last_index_roots.data(), g_last_index_roots.size());
+    return (long)(g_last_index_roots.size() / DIGEST_LEN);
+}
+int oracle_fractal_verify(int field, size_t log_constraints, size_t num_inputs, uint64_t seed, size_t security, size_t rs_extra, size_t localization,
+                          const uint8_t *transcript, size_t len, const uint8_t *roots, size_t num_roots, const uint64_t *primary_override)
+{
+    try { AURORA_DISPATCH(field, return fractal_verify_impl<F>(log_constraints, num_inputs, seed, security, rs_extra, localization, transcript, len, roots, num_roots, primary_override)); }
+    catch (const std::exception &e) { fprintf(stderr, "oracle_fractal_verify: %s\n", e.what()); return -2; }
+    return -1;
+}
+int oracle_fractal_params(int field, size_t log_constraints, size_t num_inputs, size_t security, size_t rs_extra, size_t localization, uint64_t *out, size_t cap)
+{
+    try { AURORA_DISPATCH(field, return fractal_params_impl<F>(log_constraints, num_inputs, security, rs_extra, localization, out, cap)); }
+    catch (const std::exception &e) { fprintf(stderr, "oracle_fractal_params: %s\n", e.what()); return -2; }
+    return -1;
+}
+int oracle_fractal_index_oracle(int field, size_t log_constraints, size_t num_inputs, uint64_t seed, size_t security, size_t rs_extra, size_t localization,
+                                size_t matrix, size_t which, uint64_t *out)
+{
+    try { AURORA_DISPATCH(field, return fractal_index_oracle_impl<F>(log_constraints, num_inputs, seed, security, rs_extra, localization, matrix, which, out)); }
+    catch (const std::exception &e) { fprintf(stderr, "oracle_fractal_index_oracle: %s\n", e.what()); return -2; }
+    return -1;
+}
 
 // FRI-only SNARK (aurora.hpp FRI_snark_*): the polynomial's coefficients are seeded_element(seed, i), i < 2^(dim - rs_extra)
 } // extern "C"

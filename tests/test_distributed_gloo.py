@@ -177,14 +177,13 @@ def _commit_worker(rank, world, port, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        import fri_cases as fc
         import libiop_amd as la
         import oracle
         from emu_lib import emu
         from helpers import rand_elems
         from libiop_amd import dist as idist, fri, host
         lib = emu()
-        htorch, to_dev = fc.host_env()
+        htorch, to_dev = torch, (lambda arr: torch.from_numpy(np.ascontiguousarray(arr).view(np.int64).copy()))
         # additive: contiguous blocks
         m, rs = 10, 2
         basis, shift = oracle.standard_basis(m, W), np.array([1 << m, 0, 0], dtype=np.uint64)
