@@ -91,3 +91,54 @@ def tamper_cases(transcript):
     variant("index authentication path", flip_aux)
     variant("proof of work", flip_pow)
     return out
+
+
+# ---- the kernels behind the holographic virtual oracles, one by one, against plain field arithmetic on the host ----
+def _rand(field, rng, n):
+    if field.additive:
+        return rng.integers(0, 1 << 63, size=(n, 3), dtype=np.uint64)
+    return np.stack([field.from_int(int(rng.integers(0, 1 << 62)) ** 3 + 1) for _ in range(n)])
+
+
+def check_div_kernel(lib, torch, device, field_name, n):
+    """num / den by batch inversion: q * den == num, inv * den == 1, a zero denominator yields zero."""
+    field = FIELDS[field_name][1]()
+    ops = domains.DeviceOps(lib, torch, device, field)
+    rng = np.random.default_rng(n)
+    num, den = _rand(field, rng, n), _rand(field, rng, n)
+    if n > 3:
+        den[3] = 0
+    d_num, d_den = ops.upload(num), ops.upload(den)
+    q, inv = ops.div(d_num, d_den), ops.div(None, d_den)
+    back, ones = ops.download(ops.mul(q, d_den)), ops.download(ops.mul(inv, d_den))
+    q, inv = ops.download(q), ops.download(inv)
+    expect_back, expect_ones = num.copy(), np.broadcast_to(field.one(), (n, 3)).copy()
+    if n > 3:
+        assert not q[3].any() and not inv[3].any()
+        expect_back[3] = 0
+        expect_ones[3] = 0
+    assert np.array_equal(back, expect_back) and np.array_equal(ones, expect_ones)
+
+
+def check_domain_kernels(lib, torch, device, field_name, log_l, log_h, samples=(0, 1, 2, 17, 255, 256)):
+    """point - x, point - Z_H(x) and the unnormalised Lagrange polynomial over a shifted codeword domain, at sampled positions."""
+    field = FIELDS[field_name][1]()
+    ops = domains.DeviceOps(lib, torch, device, field)
+    L = field.domain(1 << log_l, field.domain(1 << log_l).element_outside_of_subset())
+    H = field.domain(1 << log_h)
+    xs = ops.download(ops.domain_elements(L))
+    point = _rand(field, np.random.default_rng(1), 1)[0]
+    offs = ops.download(ops.domain_offsets(L, point))
+    van = ops.download(ops.vanishing_evals(H, L, point))
+    lag = ops.download(ops.lagrange_evals(point, H, L))
+    z_at_point = field.vanishing_eval(H, point, lib)
+    for j in list(samples) + [L.size - 1, L.size // 2, L.size // 2 + 5]:
+        assert np.array_equal(offs[j], field.sub(point, xs[j]))
+        assert np.array_equal(van[j], field.sub(point, field.vanishing_eval(H, xs[j], lib)))
+        expect = field.mul(field.sub(z_at_point, field.vanishing_eval(H, xs[j], lib)), field.inv(field.sub(point, xs[j]), lib))
+        assert np.array_equal(lag[j], expect)
+    try:
+        ops.lagrange_evals(xs[5], H, L)
+    except NotImplementedError:
+        return
+    raise AssertionError("an evaluation point inside the evaluation domain must be refused")

@@ -109,49 +109,12 @@ def test_argument_checks():
 
 
 # ---- the kernels behind the holographic virtual oracles, one by one, against plain field arithmetic on the host ----
-def _rand(field, rng, n):
-    if field.additive:
-        return rng.integers(0, 1 << 63, size=(n, 3), dtype=np.uint64)
-    return np.stack([field.from_int(int(rng.integers(0, 1 << 62)) ** 3 + 1) for _ in range(n)])
-
-
 @pytest.mark.parametrize("field_name", ["gf192", "edwards_Fr"])
 @pytest.mark.parametrize("n", [1, 7, 300, 2500])
 def test_div_kernel(field_name, n):
-    field = fc.FIELDS[field_name][1]()
-    ops = domains.DeviceOps(emu_lib.emu(), torch, CPU, field)
-    rng = np.random.default_rng(n)
-    num, den = _rand(field, rng, n), _rand(field, rng, n)
-    if n > 3:
-        den[3] = 0                                  # a zero denominator yields zero
-    q = ops.download(ops.div(ops.upload(num), ops.upload(den)))
-    inv = ops.download(ops.div(None, ops.upload(den)))
-    back = ops.download(ops.mul(ops.upload(q), ops.upload(den)))
-    ones = ops.download(ops.mul(ops.upload(inv), ops.upload(den)))
-    for i in range(n):
-        if n > 3 and i == 3:
-            assert not q[i].any() and not inv[i].any()
-        else:
-            assert np.array_equal(back[i], num[i]) and np.array_equal(ones[i], field.one())
+    fc.check_div_kernel(emu_lib.emu(), torch, CPU, field_name, n)
 
 
 @pytest.mark.parametrize("field_name", ["gf192", "edwards_Fr"])
 def test_domain_kernels(field_name):
-    field = fc.FIELDS[field_name][1]()
-    lib = emu_lib.emu()
-    ops = domains.DeviceOps(lib, torch, CPU, field)
-    L = field.domain(1 << 9, field.domain(1 << 9).element_outside_of_subset())
-    H = field.domain(1 << 4)
-    xs = ops.download(ops.domain_elements(L))
-    point = _rand(field, np.random.default_rng(1), 1)[0]
-    offs = ops.download(ops.domain_offsets(L, point))
-    van = ops.download(ops.vanishing_evals(H, L, point))
-    lag = ops.download(ops.lagrange_evals(point, H, L))
-    z_at_point = field.vanishing_eval(H, point, lib)
-    for j in (0, 1, 2, 17, 255, 256, 511):
-        assert np.array_equal(offs[j], field.sub(point, xs[j]))
-        assert np.array_equal(van[j], field.sub(point, field.vanishing_eval(H, xs[j], lib)))
-        expect = field.mul(field.sub(z_at_point, field.vanishing_eval(H, xs[j], lib)), field.inv(field.sub(point, xs[j]), lib))
-        assert np.array_equal(lag[j], expect)
-    with pytest.raises(NotImplementedError):
-        ops.lagrange_evals(xs[5], H, L)
+    fc.check_domain_kernels(emu_lib.emu(), torch, CPU, field_name, 9, 4)

@@ -215,3 +215,26 @@ def test_aurora_2p20_proof_accepted_by_the_oracle_verifier(env):
     transcript.query_responses[0] = transcript.query_responses[0].copy()
     transcript.query_responses[0][3, 2, 1] ^= np.uint64(4)
     assert not oracle.aurora_verify(oracle.FIELD_GF192, D, 15, 0x2204, transcript.serialize())
+
+
+def test_fractal_2p20_proof_accepted_by_the_oracle_verifier(env):
+    """BASELINE config 5 at full size: the Fractal index (twelve 2^25-point oracles, one Merkle tree) and proof of the 2^20-constraint
+    instance over the 181-bit field are accepted by the oracle's independent verifier, which holds only the index tree's root; a
+    flipped index-oracle answer and a wrong root are rejected."""
+    from libiop_amd import fractal, r1cs
+    lib, torch, dev, _, ops = env
+    n = 1 << D
+    cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, n, 0, n - 1, 0x2205)
+    params = fractal.FractalParameters(ops.field, cs)
+    assert params.codeword_domain_dim == 25 and params.index_domain_dim == 20 and params.localization_parameters == [1] + [2] * 10
+    prover_index, (roots, _) = fractal.fractal_snark_indexer(ops, cs, params)
+    roots = [bytes(r) for r in roots]
+    transcript = fractal.fractal_snark_prover(ops, prover_index, cs, primary, auxiliary, params)
+    data = transcript.serialize()
+    assert len(transcript.MT_roots) == 13 and len(transcript.query_positions) == 14
+    assert oracle.fractal_verify(oracle.FIELD_EDWARDS, D, 0, 0x2205, data, roots)
+    bad_root = bytearray(roots[0]); bad_root[9] ^= 2
+    assert not oracle.fractal_verify(oracle.FIELD_EDWARDS, D, 0, 0x2205, data, [bytes(bad_root)])
+    transcript.query_responses[0] = transcript.query_responses[0].copy()
+    transcript.query_responses[0][3, 6, 1] ^= np.uint64(4)
+    assert not oracle.fractal_verify(oracle.FIELD_EDWARDS, D, 0, 0x2205, transcript.serialize(), roots)

@@ -484,3 +484,45 @@ def test_reextend_equals_ifft_then_fft(gpu, m, d, batch):
     import torch
     gpu.set_stream(torch.cuda.current_stream().cuda_stream)
     tc.check_reextend(gpu, torch, torch.device("cuda:0"), m, d, batch, 60 + m)
+
+
+# ---- Fractal indexer and prover: device index root and transcript == the oracle's, byte for byte (config 5's shape) ---------------
+import fractal_cases as frc
+
+
+@pytest.mark.parametrize("field_name,log_n,num_inputs", [("edwards_Fr", 8, 0), ("edwards_Fr", 10, 0), ("edwards_Fr", 12, 0),   # cfg5: k = 0, RS 3, localization 2
+                                                         ("edwards_Fr", 9, 15), ("gf192", 7, 15), ("gf192", 9, 15)])
+def test_fractal_transcript_equals_oracle_prover(gpu, field_name, log_n, num_inputs):
+    import torch
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    transcript, roots, params = frc.check_transcript_equals_oracle(gpu, torch, torch.device("cuda:0"), field_name, log_n, num_inputs, 0x2205)
+    assert params.RS_extra_dimensions == 3 and params.localization_parameters[:2] == [1, 2] and len(roots) == 1
+    if log_n == 12:
+        code = frc.FIELDS[field_name][0]
+        for label, data in frc.tamper_cases(transcript):
+            assert not oracle.fractal_verify(code, log_n, num_inputs, 0x2205, data, roots), label
+
+
+@pytest.mark.parametrize("field_name", ["gf192", "edwards_Fr"])
+def test_fractal_index_oracles_and_other_rates(gpu, field_name):
+    import torch
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    frc.check_index_oracles(gpu, torch, torch.device("cuda:0"), field_name, 6, 3, 0x2205)
+    frc.check_transcript_equals_oracle(gpu, torch, torch.device("cuda:0"), field_name, 7, 3, 5, rs_extra=2, localization=3)
+
+
+@pytest.mark.parametrize("field_name", ["gf192", "edwards_Fr"])
+@pytest.mark.parametrize("n", [1, 300, 70000, 1 << 20])
+def test_fractal_div_kernel(gpu, field_name, n):
+    import torch
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    if n > 100000 and field_name == "edwards_Fr":
+        n = 200000                                   # the host side builds its inputs with Python integers
+    frc.check_div_kernel(gpu, torch, torch.device("cuda:0"), field_name, n)
+
+
+@pytest.mark.parametrize("field_name,log_l,log_h", [("gf192", 9, 4), ("gf192", 18, 12), ("edwards_Fr", 9, 4), ("edwards_Fr", 18, 12)])
+def test_fractal_domain_kernels(gpu, field_name, log_l, log_h):
+    import torch
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    frc.check_domain_kernels(gpu, torch, torch.device("cuda:0"), field_name, log_l, log_h, samples=(0, 1, 255, 256, 4095, 4096, 70001))

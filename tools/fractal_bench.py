@@ -1,0 +1,78 @@
+"""Fractal indexer and prover on one MI355X at a given size (BASELINE config 5: 2^20 constraints over the 181-bit field): wall-clock
+of the indexer, of the prover per round, and per kernel (library HIP events)."""
+import argparse, json, os, sys, time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import libiop_amd
+from libiop_amd import domains, fractal, r1cs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--field", default="edwards_Fr")
+    ap.add_argument("--inputs", type=int, default=None)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="check the last transcript with the oracle verifier (needs oracle/liboracle.so)")
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    lib = libiop_amd.lib()
+    lib.init(0)
+    dev = torch.device("cuda:0")
+    lib.set_stream(torch.cuda.current_stream().cuda_stream)
+    field = domains.GF192() if a.field == "gf192" else domains.EdwardsFr()
+    k = a.inputs if a.inputs is not None else (15 if field.additive else 0)            # instrument_fractal_snark.cpp:104-110
+    ops = domains.DeviceOps(lib, torch, dev, field)
+    n = 1 << a.log_n
+    t0 = time.time()
+    cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, n, k, n - 1, 0x2205)
+    torch.cuda.synchronize()
+    print("instance generated in %.2f s" % (time.time() - t0), flush=True)
+    params = fractal.FractalParameters(field, cs)
+    res = {"log_n": a.log_n, "field": a.field, "num_inputs": k, "codeword_domain_dim": params.codeword_domain_dim,
+           "fri_query_repetitions": params.fri_query_repetitions, "localization_parameters": params.localization_parameters, "runs": []}
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        index, (roots, _) = fractal.fractal_snark_indexer(ops, cs, params)
+        torch.cuda.synchronize()
+        res.setdefault("indexer_s", []).append(time.time() - t0)
+    print("indexer: %s s" % res["indexer_s"], flush=True)
+    tr = None
+    for rep in range(a.reps):
+        marks = []
+        torch.cuda.synchronize()
+        if a.profile and rep == a.reps - 1:
+            lib.profile_begin()
+        t0 = time.time()
+        def hook(r):
+            lib.synchronize()
+            marks.append((r, time.time() - t0))
+        tr = fractal.fractal_snark_prover(ops, index, cs, primary, auxiliary, params, round_hook=hook)
+        torch.cuda.synchronize()
+        total = time.time() - t0
+        run = {"prover_s": total, "round_marks": marks, "argument_bytes": len(tr.serialize())}
+        if a.profile and rep == a.reps - 1:
+            prof = lib.profile_report()
+            run["kernels"] = {kk: {"launches": v[0], "ms": v[1], "bytes": v[2]} for kk, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+        res["runs"].append(run)
+        print(json.dumps(run)[:3000], flush=True)
+    if a.verify:
+        import oracle
+        code = oracle.FIELD_GF192 if field.additive else oracle.FIELD_EDWARDS
+        t0 = time.time()
+        ok = oracle.fractal_verify(code, a.log_n, k, 0x2205, tr.serialize(), [bytes(r) for r in roots])
+        res["oracle_verifier_accepts"] = bool(ok)
+        print("oracle verifier: %s (%.1f s)" % (ok, time.time() - t0), flush=True)
+    if a.out:
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        with open(a.out, "w") as f:
+            json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
