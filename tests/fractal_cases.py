@@ -132,13 +132,13 @@ def check_domain_kernels(lib, torch, device, field_name, log_l, log_h, samples=(
     van = ops.download(ops.vanishing_evals(H, L, point))
     lag = ops.download(ops.lagrange_evals(point, H, L))
     z_at_point = field.vanishing_eval(H, point, lib)
-    for j in list(samples) + [L.size - 1, L.size // 2, L.size // 2 + 5]:
+    for j in [j for j in samples if j < L.size] + [L.size - 1, L.size // 2, L.size // 2 + 5]:
         assert np.array_equal(offs[j], field.sub(point, xs[j]))
         assert np.array_equal(van[j], field.sub(point, field.vanishing_eval(H, xs[j], lib)))
         expect = field.mul(field.sub(z_at_point, field.vanishing_eval(H, xs[j], lib)), field.inv(field.sub(point, xs[j]), lib))
         assert np.array_equal(lag[j], expect)
     try:
-        ops.lagrange_evals(xs[5], H, L)
+        ops.lagrange_evals(xs[5], H, L)                          # the reference patches this position; the device path refuses
     except NotImplementedError:
         return
     raise AssertionError("an evaluation point inside the evaluation domain must be refused")
