@@ -12,7 +12,8 @@ the witness already resident in HBM (libiop_amd/aurora.py over the C ABI).
 `value` = the proof's FFT work in the REFERENCE's operation count (per 2^m-point transform 1.5 n m
 multiplications + (n/2) m (m-1)/2 + n m additions, summed over every transform the reference prover runs) divided by the
 prover's wall-clock seconds: prover seconds and FFT field-ops/s in one number; `ms_per_step` is the prover time itself.
-The roofline line is for the dominant kernel of THAT run; config.secondary holds configs[1] (one 2^22 FFT).
+The roofline line is for the dominant kernel of THAT run; config.secondary holds configs[1] (one 2^22 FFT) and
+config.secondary_fractal configs[4]'s Fractal prover on this GPU.
 
 N > 1 (one process per GPU): see libiop_amd/dist.py — the proof is sharded by contiguous cosets; "strong" scaling.
 
@@ -196,6 +197,34 @@ def main():
         mu, ad = ref_fft_ops(m)
         out["config"]["secondary"] = {"workload": "configs[1]: additive FFT over GF(2^192), 2^22 coefficients, shift 0", "ms_per_step": s * 1e3,
                                       "field_ops_per_s": (mu + ad) / s}
+
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # BASELINE configs[4] on one GPU: the Fractal prover for a 2^20-constraint instance over the 181-bit field (k = 0 inputs, RS_extra 3,
+        # localization 2: profiling/instrument_fractal_snark.cpp:93-120), the index (twelve 2^25-point oracles + their Merkle tree) built once
+        # by the indexer and resident in HBM, as the reference's prover receives it (snark/fractal_snark.tcc:135-162)
+        from libiop_amd import fractal
+        f5 = domains.EdwardsFr()
+        ops5 = domains.DeviceOps(lib, torch, dev, f5)
+        cs5, prim5, aux5 = r1cs.generate_r1cs_example(ops5, n, 0, n - 1, 0x2205)
+        params5 = fractal.FractalParameters(f5, cs5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        index5, _ = fractal.fractal_snark_indexer(ops5, cs5, params5)
+        torch.cuda.synchronize()
+        indexer_s = time.perf_counter() - t0
+        d_z5 = ops5.upload(aurora.assignment_vector(f5, prim5, aux5))
+        times5 = []
+        for it in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tr5 = fractal.fractal_snark_prover(ops5, index5, cs5, prim5, None, params5, d_assignment=d_z5)
+            torch.cuda.synchronize()
+            times5.append(time.perf_counter() - t0)
+        out["config"]["secondary_fractal"] = {
+            "workload": "configs[4] on 1 GPU: Fractal prover, 2^%d-constraint R1CS over the 181-bit field, k=0, codeword 2^%d" % (args.log_n, params5.codeword_domain_dim),
+            "prover_ms": sorted(times5[1:])[len(times5[1:]) // 2] * 1e3, "indexer_ms_first_call": indexer_s * 1e3,
+            "argument_bytes": len(tr5.serialize()), "fri_query_repetitions": params5.fri_query_repetitions}
+        del index5, tr5, cs5, d_z5
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle's literal restatement of the reference prover (PCLMUL gf192, one thread) on a bounded sample

@@ -649,6 +649,17 @@ class ShardedDeviceOps(DeviceOps):
     def ldt_combine(self, d_oracles, degrees, random_coefficients, domain):
         return super().ldt_combine(d_oracles, degrees, random_coefficients, self.local_domain(domain))
 
+    # the holographic (Fractal) prover's domain-dependent steps; its elementwise ones (div, lincomb_affine, rational_combine,
+    # lincheck) act on whatever block they are handed
+    def domain_offsets(self, domain, point):
+        return super().domain_offsets(self.local_domain(domain), point)
+
+    def vanishing_evals(self, vanishing_domain, domain, constant):
+        return super().vanishing_evals(vanishing_domain, self.local_domain(domain), constant)
+
+    def rational_sumcheck_constraint(self, d_p, d_N, d_D, codeword_domain, summation_domain, claimed_sum):
+        return super().rational_sumcheck_constraint(d_p, d_N, d_D, self.local_domain(codeword_domain), summation_domain, claimed_sum)
+
 
 def sharded_aurora_snark_prover(ops, constraint_system, primary_input, parameters, d_assignment, auxiliary_input=None, round_hook=None):
     """aurora_snark_prover with `ops` a ShardedDeviceOps: every rank calls it with the same (replicated) instance and witness
@@ -656,3 +667,18 @@ def sharded_aurora_snark_prover(ops, constraint_system, primary_input, parameter
     from . import aurora
     return aurora.aurora_snark_prover(ops, constraint_system, primary_input, auxiliary_input, parameters, round_hook=round_hook,
                                       d_assignment=d_assignment)
+
+
+def sharded_fractal_snark_indexer(ops, constraint_system, parameters):
+    """fractal_snark_indexer with `ops` a ShardedDeviceOps: each rank holds its block of the twelve index oracles and the sub-tree over
+    it (the root is assembled from the ranks' sub-roots); the evaluations over the index domain are replicated."""
+    from . import fractal
+    return fractal.fractal_snark_indexer(ops, constraint_system, parameters)
+
+
+def sharded_fractal_snark_prover(ops, index, constraint_system, primary_input, parameters, d_assignment, auxiliary_input=None, round_hook=None):
+    """fractal_snark_prover on block-distributed oracles: every rank calls it with the same (replicated) instance and witness and its
+    own part of the index, and returns the same transcript, byte-identical to the single-GPU prover's."""
+    from . import fractal
+    return fractal.fractal_snark_prover(ops, index, constraint_system, primary_input, auxiliary_input, parameters, round_hook=round_hook,
+                                        d_assignment=d_assignment)
