@@ -661,6 +661,157 @@ class ShardedDeviceOps(DeviceOps):
         return super().rational_sumcheck_constraint(d_p, d_N, d_D, self.local_domain(codeword_domain), summation_domain, claimed_sum)
 
 
+class ResidueShardedDeviceOps(DeviceOps):
+    """DeviceOps with the codeword-domain vectors distributed over the ranks of `shard` by RESIDUE CLASS (multiplicative cosets): rank
+    r of N holds the positions p = r (mod N), at local index p // N — the sub-coset (shift g^r) <g^N>, itself a multiplicative coset, so
+    every per-domain operator runs unchanged on the rank's sub-coset.  A Merkle leaf (the coset {j + k n / 2^eta}) lies on rank j mod N
+    whole; leaf digests are exchanged once per tree (all-to-all) so that each rank builds a contiguous sub-tree.  FRI cosets are local."""
+
+    def __init__(self, lib, torch, device, field, shard):
+        super().__init__(lib, torch, device, field)
+        if field.additive:
+            raise ValueError("residue-class sharding is for multiplicative cosets (affine subspaces shard by contiguous cosets)")
+        self.shard = shard
+
+    # ---- layout ----
+    def _is_sharded(self, domain):
+        return getattr(domain, "sharded", False)
+
+    def local_size(self, domain):
+        return domain.size // self.shard.world if self._is_sharded(domain) else domain.size
+
+    def local_domain(self, domain, rank=None):
+        """The rank's sub-coset: order |domain| / N (its default generator is g^N), shift * g^rank."""
+        if not self._is_sharded(domain):
+            return domain
+        f = self.field
+        r = self.shard.rank if rank is None else rank
+        shift = domain.shift_int * pow(f.to_int(domain.gen), r, f.P) % f.P
+        return Domain(f, "multiplicative_coset", shift=shift, log_n=domain.dim - self.shard.r)
+
+    def _can_shard(self, size, coset_size):
+        """Enough elements per rank, and at least N leaves per rank so that the digest exchange splits evenly."""
+        W = self.shard.world
+        return size // W >= MIN_BLOCK and (size // coset_size) % (W * W) == 0
+
+    def mark_codeword_domain(self, domain, coset_size=2):
+        if not self._can_shard(domain.size, coset_size):
+            raise ValueError("codeword domain too small for %d ranks" % self.shard.world)
+        domain.sharded = True
+        return domain
+
+    def mark_fri_domains(self, domains, localization):
+        """L^(i+1) stays distributed while its own Merkle tree (cosets of 2^eta_(i+1)) can be exchanged evenly."""
+        for i in range(1, len(domains)):
+            cs = 1 << localization[i] if i < len(localization) else 1
+            domains[i].sharded = self._is_sharded(domains[i - 1]) and i < len(localization) and self._can_shard(domains[i].size, cs)
+        return domains
+
+    def _gather(self, d_local):
+        return gather_residues(self.torch, self.shard.dist, d_local, self.shard.world)
+
+    # ---- transforms ----
+    def FFT(self, d_coeffs, n_coeffs, domain):
+        if not self._is_sharded(domain):
+            return super().FFT(d_coeffs, n_coeffs, domain)
+        if int(n_coeffs) > self.local_size(domain):
+            raise ValueError("more coefficients than a residue class holds")
+        return super().FFT(d_coeffs, n_coeffs, self.local_domain(domain))
+
+    def IFFT(self, d_evals, domain):
+        if self._is_sharded(domain):
+            raise ValueError("inverse transform of a distributed vector: gather it first")
+        return super().IFFT(d_evals, domain)
+
+    def IFFT_of_known_degree(self, d_evals, degree, domain):
+        """fft.tcc:435-456 reads every (|domain| / 2^k)-th evaluation: while that stride is a multiple of N they are all rank 0's, at
+        stride / N in its sub-coset (whose shift is the domain's) — rank 0 interpolates, the coefficients are broadcast."""
+        if not self._is_sharded(domain):
+            return super().IFFT_of_known_degree(d_evals, degree, domain)
+        k = max(int(degree) - 1, 0).bit_length()
+        if (domain.size >> k) % self.shard.world:
+            return super().IFFT_of_known_degree(self._gather(d_evals), degree, domain)
+        if self.shard.rank == 0:
+            out = super().IFFT_of_known_degree(d_evals, degree, self.local_domain(domain, 0))
+        else:
+            out = self.empty(1 << k)
+        self.shard.dist.broadcast(out, src=0)
+        return out
+
+    # ---- FRI / Merkle ----
+    def fold(self, d_f, domain, coset_size, x_i, next_domain=None):
+        if not self._is_sharded(domain):
+            return super().fold(d_f, domain, coset_size, x_i)
+        nxt = super().fold(d_f, self.local_domain(domain), coset_size, x_i)
+        if next_domain is not None and self._is_sharded(next_domain):
+            return nxt
+        return self._gather(nxt)
+
+    def merkle_tree(self, d_oracles, domain, coset_size):
+        if not self._is_sharded(domain):
+            return super().merkle_tree(d_oracles, domain, coset_size)
+        sh, torch = self.shard, self.torch
+        W = sh.world
+        n_local = self.local_size(domain)
+        leaves_loc = n_local // coset_size
+        if leaves_loc % W:
+            raise ValueError("fewer leaves per rank than ranks")
+        nodes = torch.empty((2 * leaves_loc - 1, 32), dtype=torch.uint8, device=self.device)
+        # local leaf l' is global leaf rank + N l' (the sub-coset's own coset structure): digests first, then the exchange
+        self.lib.merkle_leaves_dev([t.data_ptr() for t in d_oracles], 24, n_local, coset_size, nodes.data_ptr(), domain_type=domain.domain_type)
+        self.lib.synchronize()
+        mine = nodes[leaves_loc - 1:].contiguous()              # chunk q holds the leaves that fall into rank q's contiguous run
+        got = torch.empty_like(mine)
+        sh.dist.all_to_all_single(got.view(-1), mine.view(-1))
+        nodes[leaves_loc - 1:] = got.reshape(W, leaves_loc // W, 32).permute(1, 0, 2).contiguous().reshape(leaves_loc, 32)
+        _torch_sync(torch, nodes)
+        self.lib.merkle_inner_dev(nodes.data_ptr(), leaves_loc)
+        return ShardedMerkleTree(self, MerkleTree(self.lib, nodes, leaves_loc), domain.size // coset_size)
+
+    def query_responses(self, d_oracles, domain, positions):
+        if not self._is_sharded(domain):
+            return super().query_responses(d_oracles, domain, positions)
+        W, rank = self.shard.world, self.shard.rank
+        mine_pos = [p for p in positions if p % W == rank]
+        mine = {}
+        if mine_pos:
+            vals = self.lib.query_responses_dev([t.data_ptr() for t in d_oracles], 24, self.local_size(domain), [p // W for p in mine_pos])
+            mine = {p: vals[i] for i, p in enumerate(mine_pos)}
+        everyone = [None] * W
+        self.shard.dist.all_gather_object(everyone, mine)
+        table = {}
+        for d in everyone:
+            table.update(d)
+        return np.stack([table[p] for p in positions]) if positions else np.zeros((0, len(d_oracles), 3), dtype=np.uint64)
+
+    # ---- pointwise operators: the rank's residue class is a coset in its own right ----
+    def rowcheck(self, d_az, d_bz, d_cz, codeword_domain, constraint_domain):
+        return super().rowcheck(d_az, d_bz, d_cz, self.local_domain(codeword_domain), constraint_domain)
+
+    def fz(self, d_fw, d_f1v, codeword_domain, input_domain):
+        return super().fz(d_fw, d_f1v, self.local_domain(codeword_domain), input_domain)
+
+    def sumcheck_g(self, d_f, d_h, codeword_domain, summation_domain, claimed_sum):
+        return super().sumcheck_g(d_f, d_h, self.local_domain(codeword_domain), summation_domain, claimed_sum)
+
+    def ldt_combine(self, d_oracles, degrees, random_coefficients, domain):
+        return super().ldt_combine(d_oracles, degrees, random_coefficients, self.local_domain(domain))
+
+    def domain_offsets(self, domain, point):
+        return super().domain_offsets(self.local_domain(domain), point)
+
+    def vanishing_evals(self, vanishing_domain, domain, constant):
+        return super().vanishing_evals(vanishing_domain, self.local_domain(domain), constant)
+
+    def rational_sumcheck_constraint(self, d_p, d_N, d_D, codeword_domain, summation_domain, claimed_sum):
+        return super().rational_sumcheck_constraint(d_p, d_N, d_D, self.local_domain(codeword_domain), summation_domain, claimed_sum)
+
+
+def sharded_ops(lib, torch, device, field, shard):
+    """The sharded operator set of a field: contiguous cosets for affine subspaces, residue classes for multiplicative cosets."""
+    return (ShardedDeviceOps if field.additive else ResidueShardedDeviceOps)(lib, torch, device, field, shard)
+
+
 def sharded_aurora_snark_prover(ops, constraint_system, primary_input, parameters, d_assignment, auxiliary_input=None, round_hook=None):
     """aurora_snark_prover with `ops` a ShardedDeviceOps: every rank calls it with the same (replicated) instance and witness
     and returns the same transcript, byte-identical to the single-GPU prover's."""

@@ -298,6 +298,56 @@ def test_sharded_fractal_prover_equals_oracle(world, log_n):
         assert ret[r][0] == ref, "rank %d" % r
 
 
+# ---- multiplicative cosets: the provers distributed by residue class (libiop_amd/dist.py ResidueShardedDeviceOps) ----
+def _residue_worker(rank, world, port, ret, protocol, log_n, num_inputs):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from emu_lib import emu
+        from libiop_amd import aurora, domains, fractal, r1cs
+        from libiop_amd import dist as idist
+        field = domains.EdwardsFr()
+        ops = idist.sharded_ops(emu(), torch, torch.device("cpu"), field, idist.AuroraShard(dist, rank, world))
+        assert isinstance(ops, idist.ResidueShardedDeviceOps)
+        n = 1 << log_n
+        if protocol == "aurora":
+            cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, n, num_inputs, n - 1, 0x2204)
+            params = aurora.AuroraParameters(field, n, n - 1, num_inputs)
+            d_z = ops.upload(aurora.assignment_vector(field, primary, auxiliary))
+            ret[rank] = (idist.sharded_aurora_snark_prover(ops, cs, primary, params, d_z).serialize(), [])
+        else:
+            cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, n, num_inputs, n - 1, 0x2205)
+            params = fractal.FractalParameters(field, cs)
+            index, (roots, _) = idist.sharded_fractal_snark_indexer(ops, cs, params)
+            d_z = ops.upload(aurora.assignment_vector(field, primary, auxiliary))
+            ret[rank] = (idist.sharded_fractal_snark_prover(ops, index, cs, primary, params, d_z).serialize(), [bytes(r) for r in roots])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("protocol,world,log_n,num_inputs", [("aurora", 2, 8, 15), ("aurora", 4, 9, 15), ("fractal", 2, 7, 0), ("fractal", 4, 9, 0),
+                                                              ("fractal", 2, 8, 15)])
+def test_residue_sharded_provers_equal_oracle(protocol, world, log_n, num_inputs):
+    """Configs 1 and 5's field: every rank returns the transcript (and index root) of the single-process oracle prover, byte for byte."""
+    import oracle
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_residue_worker, args=(world, port, ret, protocol, log_n, num_inputs), nprocs=world, join=True)
+    if protocol == "aurora":
+        ref, ref_roots = oracle.aurora_prove(oracle.FIELD_EDWARDS, log_n, num_inputs, 0x2204), []
+    else:
+        ref, ref_roots = oracle.fractal_prove(oracle.FIELD_EDWARDS, log_n, num_inputs, 0x2205)
+    for r in range(world):
+        assert ret[r][1] == ref_roots, "rank %d index root" % r
+        assert ret[r][0] == ref, "rank %d" % r
+
+
 def test_membership_proof_node_indices_match_oracle():
     import oracle
     from libiop_amd import dist as idist

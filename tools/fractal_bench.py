@@ -20,20 +20,30 @@ def main():
     ap.add_argument("--verify", action="store_true", help="check the last transcript with the oracle verifier (needs oracle/liboracle.so)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
+    # one process per GPU under `python -m torch.distributed.run --nproc-per-node N tools/fractal_bench.py ...` (RCCL); alone otherwise
+    rank, local_rank, world = (int(os.environ.get(v, d)) for v, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
     lib = libiop_amd.lib()
-    lib.init(0)
-    dev = torch.device("cuda:0")
+    lib.init(local_rank)
+    dev = torch.device("cuda", local_rank)
     lib.set_stream(torch.cuda.current_stream().cuda_stream)
     field = domains.GF192() if a.field == "gf192" else domains.EdwardsFr()
     k = a.inputs if a.inputs is not None else (15 if field.additive else 0)            # instrument_fractal_snark.cpp:104-110
-    ops = domains.DeviceOps(lib, torch, dev, field)
+    if world > 1:
+        from libiop_amd import dist as idist
+        ops = idist.sharded_ops(lib, torch, dev, field, idist.AuroraShard(dist, rank, world))   # residue classes for the prime field
+    else:
+        ops = domains.DeviceOps(lib, torch, dev, field)
     n = 1 << a.log_n
     t0 = time.time()
     cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, n, k, n - 1, 0x2205)
     torch.cuda.synchronize()
     print("instance generated in %.2f s" % (time.time() - t0), flush=True)
     params = fractal.FractalParameters(field, cs)
-    res = {"log_n": a.log_n, "field": a.field, "num_inputs": k, "codeword_domain_dim": params.codeword_domain_dim,
+    res = {"log_n": a.log_n, "field": a.field, "num_inputs": k, "n_gpus": world, "codeword_domain_dim": params.codeword_domain_dim,
            "fri_query_repetitions": params.fri_query_repetitions, "localization_parameters": params.localization_parameters, "runs": []}
     for rep in range(2):
         torch.cuda.synchronize()
@@ -41,7 +51,8 @@ def main():
         index, (roots, _) = fractal.fractal_snark_indexer(ops, cs, params)
         torch.cuda.synchronize()
         res.setdefault("indexer_s", []).append(time.time() - t0)
-    print("indexer: %s s" % res["indexer_s"], flush=True)
+    if rank == 0:
+        print("indexer: %s s" % res["indexer_s"], flush=True)
     tr = None
     for rep in range(a.reps):
         marks = []
@@ -60,18 +71,23 @@ def main():
             prof = lib.profile_report()
             run["kernels"] = {kk: {"launches": v[0], "ms": v[1], "bytes": v[2]} for kk, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
         res["runs"].append(run)
-        print(json.dumps(run)[:3000], flush=True)
-    if a.verify:
+        if rank == 0:
+            print(json.dumps(run)[:3000], flush=True)
+    if a.verify and rank == 0:
         import oracle
         code = oracle.FIELD_GF192 if field.additive else oracle.FIELD_EDWARDS
         t0 = time.time()
         ok = oracle.fractal_verify(code, a.log_n, k, 0x2205, tr.serialize(), [bytes(r) for r in roots])
         res["oracle_verifier_accepts"] = bool(ok)
         print("oracle verifier: %s (%.1f s)" % (ok, time.time() - t0), flush=True)
-    if a.out:
+    if a.out and rank == 0:
         os.makedirs(os.path.dirname(a.out), exist_ok=True)
         with open(a.out, "w") as f:
             json.dump(res, f, indent=1)
+
+
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
