@@ -135,6 +135,12 @@ def main():
             traffic = tj["kernels"][dom_name]["traffic_bytes_per_launch"]
     except (OSError, ValueError):
         pass
+    valu = None
+    try:                                        # integer-VALU issue utilisation of that kernel from the committed SQ-counter passes
+        sj = json.load(open(os.path.join(ROOT, "profiles", "r02_sq_aurora.json")))
+        valu = sj["kernels"][dom_name]["valu_issue_utilisation"]
+    except (OSError, ValueError, KeyError):
+        pass
     fft_kernels = ("k_phase1", "k_bfly_upper", "k_bfly_edge", "k_pad_copy", "k_rs_combine", "k_fill")
     fft_ms = sum(v[1] for k, v in prof.items() if k.startswith(fft_kernels))
 
@@ -175,7 +181,9 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
                      "kernel": dom_name, "launches_per_step": dom_cnt, "avg_launch_ms": dom_avg_s * 1e3,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                     "note": "gfx950 has no carry-less multiply: the GF(2^192) butterflies are integer-ALU-bound, see DESIGN.md",
+                     "valu_issue_utilisation": valu,
+                     "note": "gfx950 has no carry-less multiply: the GF(2^192) butterflies are integer-ALU-bound (valu_issue_utilisation = SQ_INSTS_VALU x 4 "
+                             "cycles / (SIMDs x elapsed cycles), profiles/r02_sq_aurora.json), see DESIGN.md",
                      "kernels_ms_per_step": {k: round(v[1], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
                      "kernel_launches_per_step": {k: v[0] for k, v in prof.items()}},
     }
