@@ -245,9 +245,17 @@ class Library:
     def set_stream(self, hip_stream):
         """All later work goes to this hipStream_t, taken as given: 0 is the legacy default stream (torch's default stream)."""
         self._check(self.c.iopx_set_stream(_vp(hip_stream)))
+        self._stream_handle = int(hip_stream or 0)
 
     def use_own_stream(self):
         self._check(self.c.iopx_use_own_stream())
+        self._stream_handle = None
+
+    def shares_stream_with(self, torch, device=None):
+        """True when the library enqueues on torch's current stream (set_stream(torch.cuda.current_stream().cuda_stream)): library
+        calls, torch ops and torch.distributed collectives are then ordered by the stream and need no host synchronisation."""
+        h = getattr(self, "_stream_handle", None)
+        return h is not None and torch.cuda.is_available() and int(torch.cuda.current_stream(device).cuda_stream) == h
 
     def synchronize(self):
         self._check(self.c.iopx_synchronize())

@@ -4,10 +4,10 @@ coefficients is 2^(m-d) independent transforms on contiguous blocks, so rank g o
 [g * 2^m / N, (g+1) * 2^m / N) of every oracle.  FRI cosets (contiguous, subspace.tcc:73-91) and Merkle leaves
 are local to a rank; the only cross-rank data are N sub-tree roots (32 bytes each) per Merkle tree.
 
-Streams: the library enqueues on its own non-blocking HIP stream (or the one given to Library.set_stream).  sharded_lde and
-sharded_fri_fold only enqueue — chain further library calls freely, and call lib.synchronize() before torch (or a
-collective) touches their results; sharded_merkle_root and distributed_fft, which mix library kernels with collectives,
-synchronise both directions themselves."""
+Streams: with Library.set_stream(torch.cuda.current_stream().cuda_stream) — what bench.py and the tools do — library kernels, torch
+ops and torch.distributed collectives are ordered by that one stream (a collective makes the current stream wait for it), so nothing
+here waits on the host: sharded_merkle_root, distributed_fft and the sharded operator sets only enqueue.  When the library runs on
+its own stream instead, the same functions fall back to host synchronisation in both directions (_lib_to_torch / _torch_to_lib)."""
 import hashlib
 
 import numpy as np
@@ -68,7 +68,7 @@ def sharded_merkle_root(lib, torch, dist, d_oracles, n_local, coset_size, rank, 
     dev = d_oracles[0].device
     nodes = torch.empty((2 * leaves - 1, 32), dtype=torch.uint8, device=dev)
     lib.merkle_tree_dev([o.data_ptr() for o in d_oracles], 24, n_local, coset_size, nodes.data_ptr())
-    lib.synchronize()
+    _lib_to_torch(lib, torch)
     sub_root = nodes[0].clone()
     if world == 1:
         return bytes(sub_root.cpu().numpy()), nodes
@@ -155,14 +155,20 @@ class DistributedFFTPlan:
             b = b[: m - 1 - j]
         self.local_basis = np.array([host.gf_to_words(v) for v in b], dtype=np.uint64).reshape(-1, 3)
         self.local_shift = host.gf_to_words(sh)
-        lib.synchronize()
+        _lib_to_torch(lib, torch)
 
 
-def _torch_sync(torch, t):
-    """The library enqueues on its own (non-blocking) stream: before it consumes a buffer that torch ops or collectives
-    produced on torch's streams, those must have completed.  (After library calls the callers use lib.synchronize().)"""
-    if t.device.type != "cpu":
+def _torch_to_lib(lib, torch, t):
+    """Before the library consumes a buffer that torch ops or collectives produced: nothing to do when the library enqueues on
+    torch's current stream (stream order; collectives make the current stream wait for them), a host wait otherwise."""
+    if t.device.type != "cpu" and not lib.shares_stream_with(torch, t.device):
         torch.cuda.current_stream(t.device).synchronize()
+
+
+def _lib_to_torch(lib, torch):
+    """Before torch ops or collectives consume what library calls produced: stream order when the stream is shared."""
+    if not lib.shares_stream_with(torch):
+        lib.synchronize()
 
 
 def _exchange(torch, dist, send_t, peer, recv_like):
@@ -203,9 +209,9 @@ def distributed_fft(lib, torch, dist, plan, d_block):
     peer_of = lambda s2: _rev(s2, r)
     # 2. top r levels
     for j in range(r):
-        _torch_sync(torch, S)
+        _torch_to_lib(lib, torch, S)
         lib.taylor_dev(S.data_ptr(), m - r, plan.twist[j].data_ptr())
-        lib.synchronize()
+        _lib_to_torch(lib, torch)
         # network operations on global index bits (k+1, k), k = r-1 .. j
         for k in range(r - 1, j - 1, -1):
             if k + 1 < r:       # both bits select ranks: whole-shard XORs
@@ -230,9 +236,9 @@ def distributed_fft(lib, torch, dist, plan, d_block):
                     _send(torch, dist, S[1::2].contiguous(), peer)
     # 3. local transform of the sub-polynomial over the recursed domain
     loc = torch.empty_like(S)
-    _torch_sync(torch, S)
+    _torch_to_lib(lib, torch, S)
     lib.additive_FFT_dev(S.data_ptr(), n_loc, plan.local_basis, plan.local_shift, loc.data_ptr())
-    lib.synchronize()
+    _lib_to_torch(lib, torch)
     # 4. the last r butterfly levels across blocks
     cur = loc
     for t in range(r):
@@ -243,10 +249,10 @@ def distributed_fft(lib, torch, dist, plan, d_block):
         lvl = r - 1 - t                                   # recursion level that produced these twiddles
         B = np.array([host.gf_to_words(v) for v in plan.rec[lvl]], dtype=np.uint64).reshape(-1, 3)
         out = torch.empty_like(cur)
-        _torch_sync(torch, other)
+        _torch_to_lib(lib, torch, other)
         lib.combine_dev(a.data_ptr(), bb.data_ptr(), out.data_ptr(), n_loc, (rank & ((1 << t) - 1)) * n_loc, B,
                         host.gf_to_words(plan.rs[lvl]), upper)
-        lib.synchronize()
+        _lib_to_torch(lib, torch)
         cur = out
     return cur
 
@@ -311,7 +317,7 @@ def sharded_mul_merkle_root(lib, torch, dist, la, d_oracles_local, n_local, cose
     # local leaf l' is global leaf rank + N l'
     lib.merkle_leaves_dev([o.data_ptr() for o in d_oracles_local], 24, n_local, coset_size, nodes.data_ptr(),
                           domain_type=la.DOMAIN_MULTIPLICATIVE)
-    lib.synchronize()
+    _lib_to_torch(lib, torch)
     if world > 1:
         if leaves_loc % world:
             raise ValueError("fewer leaves per rank than ranks: gather the oracle first (gather_residues)")
@@ -321,9 +327,9 @@ def sharded_mul_merkle_root(lib, torch, dist, la, d_oracles_local, n_local, cose
         # chunk s, entry u is global leaf rank * L/N + s + N u  ->  position s + N u of the run
         run = got.reshape(world, leaves_loc // world, 32).permute(1, 0, 2).contiguous().reshape(leaves_loc, 32)
         nodes[leaves_loc - 1:] = run
-        _torch_sync(torch, nodes)
+        _torch_to_lib(lib, torch, nodes)
     lib.merkle_inner_dev(nodes.data_ptr(), leaves_loc)
-    lib.synchronize()
+    _lib_to_torch(lib, torch)
     sub_root = nodes[0].clone()
     if world == 1:
         return bytes(sub_root.cpu().numpy()), nodes
@@ -361,11 +367,11 @@ def sharded_fri_commit(lib, torch, dist, d_f_local, basis, shift, localization_p
         b_i, s_i = doms[i]
         cs = 1 << eta
         if w > 1 and f.shape[0] // cs < 2:
-            lib.synchronize()
+            _lib_to_torch(lib, torch)
             parts = [torch.empty_like(f) for _ in range(w)]
             dist.all_gather(parts, f.contiguous())
             f = torch.cat(parts, 0)
-            _torch_sync(torch, f)
+            _torch_to_lib(lib, torch, f)
             w, rk = 1, 0
         root, _ = sharded_merkle_root(lib, torch, dist, [f], f.shape[0], cs, rk, w)
         roots.append(root)
@@ -374,15 +380,15 @@ def sharded_fri_commit(lib, torch, dist, d_f_local, basis, shift, localization_p
         x = hc.squeeze_gf192(1)[0]
         f = sharded_fri_fold(lib, torch, f, b_i, s_i, cs, x, rk, w)
     if w > 1:
-        lib.synchronize()
+        _lib_to_torch(lib, torch)
         parts = [torch.empty_like(f) for _ in range(w)]
         dist.all_gather(parts, f.contiguous())
         f = torch.cat(parts, 0)
-        _torch_sync(torch, f)
+        _torch_to_lib(lib, torch, f)
     b_l, s_l = doms[len(localization_parameters)]
     coeffs = torch.empty_like(f)
     lib.additive_IFFT_dev(f.data_ptr(), b_l, s_l, coeffs.data_ptr())
-    lib.synchronize()
+    _lib_to_torch(lib, torch)
     return roots, coeffs.cpu().numpy().view(np.uint64)[:final_degree_bound].copy()
 
 
@@ -396,9 +402,9 @@ def sharded_mul_fri_commit(lib, torch, dist, la, fri, d_f_local, log_n, gen_int,
     for eta in localization_parameters:
         cs = 1 << eta
         if w > 1 and ((1 << logn) // cs) % (w * w):
-            lib.synchronize()
+            _lib_to_torch(lib, torch)
             f = gather_residues(torch, dist, f, w)
-            _torch_sync(torch, f)
+            _torch_to_lib(lib, torch, f)
             w, rk = 1, 0
         root, _ = sharded_mul_merkle_root(lib, torch, dist, la, [f], f.shape[0], cs, rk, w)
         roots.append(root)
@@ -408,13 +414,13 @@ def sharded_mul_fri_commit(lib, torch, dist, la, fri, d_f_local, log_n, gen_int,
         f = sharded_mul_fri_fold(lib, torch, la, f, logn, gi, sh, cs, x, rk, w)
         logn, sh, gi = logn - eta, pow(sh, cs, P), pow(gi, cs, P)
     if w > 1:
-        lib.synchronize()
+        _lib_to_torch(lib, torch)
         f = gather_residues(torch, dist, f, w)
-        _torch_sync(torch, f)
+        _torch_to_lib(lib, torch, f)
     coeffs = torch.empty_like(f)
     lib._check(lib.c.iopx_mul_ifft_fp3_dev(f.data_ptr(), logn, la._as_u64(_mont(la, gi)).ctypes.data_as(la._u64p),
                                            la._as_u64(_mont(la, sh)).ctypes.data_as(la._u64p), coeffs.data_ptr()))
-    lib.synchronize()
+    _lib_to_torch(lib, torch)
     return roots, coeffs.cpu().numpy().view(np.uint64)[:final_degree_bound].copy()
 
 
@@ -759,12 +765,12 @@ class ResidueShardedDeviceOps(DeviceOps):
         nodes = torch.empty((2 * leaves_loc - 1, 32), dtype=torch.uint8, device=self.device)
         # local leaf l' is global leaf rank + N l' (the sub-coset's own coset structure): digests first, then the exchange
         self.lib.merkle_leaves_dev([t.data_ptr() for t in d_oracles], 24, n_local, coset_size, nodes.data_ptr(), domain_type=domain.domain_type)
-        self.lib.synchronize()
+        _lib_to_torch(self.lib, torch)
         mine = nodes[leaves_loc - 1:].contiguous()              # chunk q holds the leaves that fall into rank q's contiguous run
         got = torch.empty_like(mine)
         sh.dist.all_to_all_single(got.view(-1), mine.view(-1))
         nodes[leaves_loc - 1:] = got.reshape(W, leaves_loc // W, 32).permute(1, 0, 2).contiguous().reshape(leaves_loc, 32)
-        _torch_sync(torch, nodes)
+        _torch_to_lib(self.lib, torch, nodes)
         self.lib.merkle_inner_dev(nodes.data_ptr(), leaves_loc)
         return ShardedMerkleTree(self, MerkleTree(self.lib, nodes, leaves_loc), domain.size // coset_size)
 
