@@ -310,7 +310,7 @@ __device__ __forceinline__ void bf_apply(uint64_t *s, int E, int ia, int ib, con
 }
 
 template<bool INV, bool COMB>
-__global__ void __launch_bounds__(COMB ? 512 : 1024) k_bfly_upper(BfParams p)
+__global__ void __launch_bounds__(COMB ? 512 : 1024, COMB ? 3 : 1) k_bfly_upper(BfParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
     uint64_t *s = iopx_smem;

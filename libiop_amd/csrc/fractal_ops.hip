@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) k_sumcheck_constraint_gf192(ConstraintAdd
             gf_add_to(s, gf_load(a.p, j));
             gf192 t = gf_mul(gf_load(a.D, j), s);
             gf_add_to(t, gf_load(a.N, j));
-            gf_store(a.out, j, gf_mul(t, gf_load(a.zinv, j >> a.k)));
+            gf_store(a.out, j, a.k >= 6 ? gf_mul_uniform(t, gf_load(a.zinv, j >> a.k)) : gf_mul(t, gf_load(a.zinv, j >> a.k)));   // one coset per wavefront
         }
     }
 }

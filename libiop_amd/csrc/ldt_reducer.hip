@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) k_ldt_combine_add_slots(LdtSlotParams q)
                     gf192 v;
 #pragma unroll
                     for (int w = 0; w < 6; ++w) v.w[w] = iopx_ldt_smem[(s * 6 + w) * 256 + lane];
-                    gf_add_to(c, gf_mul(gf_load(p.coef, 2 * o + 1), v));
+                    gf_add_to(c, gf_mul_uniform(v, gf_load(p.coef, 2 * o + 1)));     // the coefficient is the same for every lane: comb product
                 }
                 gf_add_to(acc, gf_mul(c, f));
             }

@@ -24,7 +24,8 @@ __global__ void __launch_bounds__(256) k_rowcheck_add(uint64_t *out, const uint6
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
         gf192 t = gf_mul(gf_load(az, j), gf_load(bz, j));
         gf_add_to(t, gf_load(cz, j));                       // characteristic 2: a b - c = a b + c
-        gf_store(out, j, gf_mul(t, gf_load(zinv, j >> h)));
+        // a wavefront covers 64 consecutive positions: with cosets of at least 64 elements 1 / Z_H is the same for all of them
+        gf_store(out, j, h >= 6 ? gf_mul_uniform(t, gf_load(zinv, j >> h)) : gf_mul(t, gf_load(zinv, j >> h)));
     }
 }
 
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(256) k_lincheck_add(LincheckParams p)
 {
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < p.n; j += (size_t)gridDim.x * blockDim.x) {
         gf192 comb = gf_zero();
-        for (int m = 0; m < p.num_matrices; ++m) gf_add_to(comb, gf_mul(gf_load(p.mz[m], j), gf_load(p.r, m)));
+        for (int m = 0; m < p.num_matrices; ++m) gf_add_to(comb, gf_mul_uniform(gf_load(p.mz[m], j), gf_load(p.r, m)));     // r_m: one constant for the launch
         gf192 acc = gf_mul(comb, gf_load(p.p1, j));
         gf_add_to(acc, gf_mul(gf_load(p.fz, j), gf_load(p.p2, j)));
         gf_store(p.out, j, acc);
