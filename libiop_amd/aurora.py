@@ -522,4 +522,6 @@ def aurora_snark_prover(ops, constraint_system, primary_input, auxiliary_input, 
     full_protocol.register_queries()
     IOP.seal_query_registrations()
     full_protocol.produce_proof(primary_input, auxiliary_input, d_assignment)
-    return IOP.get_transcript()
+    transcript = IOP.get_transcript()
+    IOP.release()
+    return transcript

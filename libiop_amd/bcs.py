@@ -370,6 +370,14 @@ class BCSProver:
             self.virtual_contents_cache[handle.id] = result
         return result
 
+    def release(self):
+        """Drops every device buffer this prover holds (oracles, cached virtual-oracle contents, Merkle trees) and the registered
+        virtual oracles and position calculators, so the memory returns to the allocator when the prover function returns and not
+        when a cyclic garbage collection happens to run.  The prover index is not touched: it belongs to the caller."""
+        self.oracles, self.virtual_contents_cache, self.MT_trees = [], {}, []
+        self.virtual_regs, self.deterministic_positions, self.queries, self.round_hooks = [], [], [], []
+        self.index = None
+
     # ---- transcript (bcs_prover.tcc:136-233) ----
     def _obtain_query_position(self, handle, random_cache, det_cache):
         if handle.random:

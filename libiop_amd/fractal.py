@@ -133,7 +133,9 @@ class RationalLinearCombination:
     def __init__(self, IOP, num_rationals, numerator_handles, denominator_handles):
         if len(numerator_handles) != num_rationals or len(denominator_handles) != num_rationals:
             raise ValueError("Rational Linear Combination: #numerator handles passed in != #denominator handles passed in")
-        self.IOP, self.ops, self.num_rationals, self.coefficients, self._last = IOP, IOP.ops, num_rationals, None, None
+        # no reference back to the round driver: it holds the two virtual oracles below, and a cycle would keep the proof's codewords
+        # alive until the cyclic collector runs instead of until the prover returns
+        self.ops, self.num_rationals, self.coefficients, self._last = IOP.ops, num_rationals, None, None
         domain = IOP.get_oracle_domain(numerator_handles[0])
         denominator_degree = 1 + sum(IOP.get_oracle_degree(h) - 1 for h in denominator_handles)
         self.denominator_handle = IOP.register_virtual_oracle(domain, denominator_degree, denominator_handles, self._Denominator(self))
@@ -510,4 +512,6 @@ def fractal_snark_prover(ops, index, constraint_system, primary_input, auxiliary
     full_protocol.register_queries()
     IOP.seal_query_registrations()
     full_protocol.produce_proof(primary_input, auxiliary_input, index, d_assignment)
-    return IOP.get_transcript()
+    transcript = IOP.get_transcript()
+    IOP.release()
+    return transcript

@@ -120,7 +120,9 @@ def fri_snark_prover(ops, params, d_poly_coeffs=None, d_codeword=None, round_hoo
     if d_codeword is None:
         d_codeword = ops.FFT(d_poly_coeffs, d_poly_coeffs.shape[0], IOP.get_domain(protocol.codeword_domain_handle))
     protocol.produce_proof(d_codeword)
-    return IOP.get_transcript()
+    transcript = IOP.get_transcript()
+    IOP.release()
+    return transcript
 
 
 def squeeze_edwards_fr(hc):
