@@ -313,7 +313,7 @@ class EncodedAuroraProtocol:
         Mz_handles = [self.fAz_handle, self.fBz_handle, self.fCz_handle]
         # the matrices as set_challenge walks them: column c of M lands at summation index reindex(reindex(c)) (:80-84)
         S = self.C if self.C.dim > self.V.dim else self.V
-        col_to_summation = S.reindex_by_subset_array(self.V.dim, self.V.size)[self.V.reindex_by_subset_array(self.I.dim, self.cs.num_variables + 1)]
+        col_to_summation = lambda: S.reindex_by_subset_array(self.V.dim, self.V.size)[self.V.reindex_by_subset_array(self.I.dim, self.cs.num_variables + 1)]
         transposed = self.cs.lincheck_matrices(self.ops, S.size, col_to_summation, (S.kind, S.dim, self.V.dim, self.I.dim))
         self.transposed_matrices, self.Mz_handles = transposed, Mz_handles
         self.multi_lincheck = None if holographic else MultiLincheck(IOP, codeword_domain_handle, constraint_domain_handle, variable_domain_handle,
@@ -345,9 +345,11 @@ class EncodedAuroraProtocol:
         if self.V.additive:
             z_over_variable_domain = d_z
         else:
-            order = np.empty(self.V.size, dtype=np.int64)                                                # create_fw_prime_evals' reindexing (:421-423)
-            order[self.V.reindex_by_subset_array(self.I.dim, self.V.size)] = np.arange(self.V.size)
-            z_over_variable_domain = d_z[ops.upload_raw(order, ops.torch.int64)]
+            def variable_order():                                                                        # create_fw_prime_evals' reindexing (:421-423)
+                order = np.empty(self.V.size, dtype=np.int64)
+                order[self.V.reindex_by_subset_array(self.I.dim, self.V.size)] = np.arange(self.V.size)
+                return ops.upload_raw(order, ops.torch.int64)
+            z_over_variable_domain = d_z[self.cs.cached(("variable order", self.V.dim, self.I.dim), variable_order)]
         fw_prime_evals = ops.sub(z_over_variable_domain, f1v_over_variable_domain)                       # :406-430
         fw_prime = ops.IFFT(fw_prime_evals, self.V)                                                      # :551-555
         nC = self.C.size

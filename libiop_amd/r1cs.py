@@ -47,7 +47,15 @@ class R1CS:
         set_challenge walks (basic_lincheck_aux.tcc:64-88).  Part of the instance's device-resident representation: built on
         first use for a domain layout (`key`) and kept, like the CSR arrays themselves."""
         if key not in self._lincheck_matrices:
+            if callable(col_to_summation):
+                col_to_summation = col_to_summation()
             self._lincheck_matrices[key] = [M.transposed_onto(ops, num_rows_out, col_to_summation) for M in (self.A, self.B, self.C)]
+        return self._lincheck_matrices[key]
+
+    def cached(self, key, build):
+        """Per-instance device-resident helper data that depends on the domain layout only (index permutations): built once."""
+        if key not in self._lincheck_matrices:
+            self._lincheck_matrices[key] = build()
         return self._lincheck_matrices[key]
 
     def num_constraints(self):

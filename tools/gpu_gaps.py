@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""GPU idle gaps inside the last proof of a rocprofv3 --kernel-trace run (rocpd database): every pause longer than --min-us between
+the end of one kernel and the start of the next, with the kernels on both sides — where host work or a host read-back is exposed.
+Usage: gpu_gaps.py <results dir or .db> [--min-us 100] [--last-ms 120]"""
+import argparse, glob, sqlite3
+
+ap = argparse.ArgumentParser()
+ap.add_argument("path")
+ap.add_argument("--min-us", type=float, default=100.0)
+ap.add_argument("--last-ms", type=float, default=120.0, help="look at the kernels of the last this-many milliseconds of the trace")
+a = ap.parse_args()
+path = a.path if a.path.endswith(".db") else glob.glob(a.path + "/**/*.db", recursive=True)[0]
+c = sqlite3.connect(path)
+tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+suf = [t for t in tabs if t.startswith("rocpd_metadata")][0][len("rocpd_metadata"):]
+rows = c.execute("select d.start, d.end, s.kernel_name from rocpd_kernel_dispatch%s d join rocpd_info_kernel_symbol%s s on d.kernel_id = s.id order by d.start" % (suf, suf)).fetchall()
+t_end = rows[-1][1]
+rows = [r for r in rows if r[0] >= t_end - a.last_ms * 1e6]
+busy = sum(r[1] - r[0] for r in rows)
+span = rows[-1][1] - rows[0][0]
+short = lambda n: n.split("iopx")[-1][:40]
+gaps = [(rows[i + 1][0] - rows[i][1], short(rows[i][2]), short(rows[i + 1][2])) for i in range(len(rows) - 1)]
+print("window %.2f ms, kernels busy %.2f ms, idle %.2f ms in %d gaps (%d >= %.0f us)" % (span / 1e6, busy / 1e6, (span - busy) / 1e6, len(gaps),
+      sum(1 for g in gaps if g[0] >= a.min_us * 1e3), a.min_us))
+for g, before, after in sorted(gaps, reverse=True):
+    if g < a.min_us * 1e3:
+        break
+    print("%8.1f us  after %-42s before %s" % (g / 1e3, before, after))
