@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="log2 of the number of R1CS constraints")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the multi-GPU operator set even with one rank (exercises the RCCL calls on a 1-GPU box; run under torch.distributed.run)")
     ap.add_argument("--cpu-log-n", type=int, default=12, help="size of the CPU-baseline sample (oracle prover)")
     args = ap.parse_args()
 
@@ -75,7 +77,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.force_sharded:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -85,7 +87,7 @@ def main():
     lib.set_stream(torch.cuda.current_stream().cuda_stream)
 
     field = domains.GF192()
-    if world > 1:
+    if world > 1 or args.force_sharded:
         from libiop_amd import dist as idist
         ops = idist.ShardedDeviceOps(lib, torch, dev, field, idist.AuroraShard(dist, rank, world))
     else:
@@ -264,7 +266,11 @@ def main():
                                "seconds": cpu_s, "sample_log_n": k}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if args.force_sharded and rank == 0:          # the sharded operator set must produce the single-GPU prover's transcript
+        plain = aurora.aurora_snark_prover(domains.DeviceOps(lib, torch, dev, field), cs, primary, None, params, d_assignment=d_assignment)
+        assert plain.serialize() == transcript.serialize(), "sharded transcript differs from the single-GPU transcript"
+        print("force-sharded: transcript equals the single-GPU prover's", file=sys.stderr)
+    if world > 1 or args.force_sharded:
         dist.destroy_process_group()
 
 

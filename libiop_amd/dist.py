@@ -561,7 +561,9 @@ class ShardedDeviceOps(DeviceOps):
     def mark_fri_domains(self, domains, localization):
         """L^(i+1) stays distributed while it keeps MIN_BLOCK elements per rank (folds are local: cosets are contiguous)."""
         for i in range(1, len(domains)):
-            domains[i].sharded = self._is_sharded(domains[i - 1]) and domains[i].size // self.shard.world >= MIN_BLOCK
+            # the last domain carries no oracle: the final polynomial is interpolated from it on every rank, so it is gathered
+            domains[i].sharded = (self._is_sharded(domains[i - 1]) and i < len(localization)
+                                  and domains[i].size // self.shard.world >= MIN_BLOCK)
         return domains
 
     def _all_gather(self, d_local):

@@ -221,7 +221,7 @@ def test_sharded_fri_commit_equals_single_process(world):
 
 
 # ---- the whole Aurora prover block-distributed over the ranks (libiop_amd/dist.py ShardedDeviceOps) ----
-def _aurora_worker(rank, world, port, ret, log_n, num_inputs):
+def _aurora_worker(rank, world, port, ret, log_n, num_inputs, rs_extra=5):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
@@ -237,7 +237,7 @@ def _aurora_worker(rank, world, port, ret, log_n, num_inputs):
         ops = idist.ShardedDeviceOps(emu(), torch, torch.device("cpu"), field, idist.AuroraShard(dist, rank, world))
         n = 1 << log_n
         cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, n, num_inputs, n - 1, 0x2204)
-        params = aurora.AuroraParameters(field, n, n - 1, num_inputs)
+        params = aurora.AuroraParameters(field, n, n - 1, num_inputs, RS_extra_dimensions=rs_extra)
         d_z = ops.upload(aurora.assignment_vector(field, primary, auxiliary))
         transcript = idist.sharded_aurora_snark_prover(ops, cs, primary, params, d_z)
         ret[rank] = transcript.serialize()
@@ -255,6 +255,19 @@ def test_sharded_aurora_prover_equals_oracle(world, log_n):
     mp.spawn(_aurora_worker, args=(world, port, ret, log_n, 15), nprocs=world, join=True)
     ref = oracle.aurora_prove(oracle.FIELD_GF192, log_n, 15, 0x2204)
     for r in range(world):
+        assert ret[r] == ref, "rank %d" % r
+
+
+def test_sharded_aurora_large_final_domain():
+    """RS_extra_dimensions = 8: the last FRI domain (512 points) is large enough to stay distributed by size alone; it carries no
+    oracle and must be gathered for the final interpolation."""
+    import oracle
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_aurora_worker, args=(2, port, ret, 7, 15, 8), nprocs=2, join=True)
+    ref = oracle.aurora_prove(oracle.FIELD_GF192, 7, 15, 0x2204, rs_extra=8)
+    for r in range(2):
         assert ret[r] == ref, "rank %d" % r
 
 

@@ -18,11 +18,12 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check the last transcript with the oracle verifier (needs oracle/liboracle.so)")
+    ap.add_argument("--force-sharded", action="store_true", help="multi-GPU operator set with one rank (exercises the RCCL calls on a 1-GPU box)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     # one process per GPU under `python -m torch.distributed.run --nproc-per-node N tools/fractal_bench.py ...` (RCCL); alone otherwise
     rank, local_rank, world = (int(os.environ.get(v, d)) for v, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
-    if world > 1:
+    if world > 1 or a.force_sharded:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
@@ -32,7 +33,7 @@ def main():
     lib.set_stream(torch.cuda.current_stream().cuda_stream)
     field = domains.GF192() if a.field == "gf192" else domains.EdwardsFr()
     k = a.inputs if a.inputs is not None else (15 if field.additive else 0)            # instrument_fractal_snark.cpp:104-110
-    if world > 1:
+    if world > 1 or a.force_sharded:
         from libiop_amd import dist as idist
         ops = idist.sharded_ops(lib, torch, dev, field, idist.AuroraShard(dist, rank, world))   # residue classes for the prime field
     else:
@@ -86,7 +87,7 @@ def main():
             json.dump(res, f, indent=1)
 
 
-    if world > 1:
+    if world > 1 or a.force_sharded:
         dist.destroy_process_group()
 
 
