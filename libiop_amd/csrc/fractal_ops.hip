@@ -104,16 +104,7 @@ __global__ void __launch_bounds__(256) k_div_fp3(DivParams p)
 // ---- subset sums over an affine subspace: out[j] = tab[0] + sum_{bit k of j} tab[1 + k] --------------------------------------
 __device__ __forceinline__ gf192 fo_subset_sum(const uint64_t *t, int m, uint32_t jlo, uint32_t jhi_uniform)
 {
-    gf192 v = gf_load(t, 0);
-    const int lo_bits = m < 8 ? m : 8;
-    for (int k = 0; k < lo_bits; ++k) {
-        const uint32_t mask = 0u - ((jlo >> k) & 1u);
-        const gf192 b = gf_load(t, 1 + k);
-#pragma unroll
-        for (int w = 0; w < 6; ++w) v.w[w] = xor_and(v.w[w], mask, b.w[w]);
-    }
-    for (int k = 8; k < m; ++k) if ((jhi_uniform >> (k - 8)) & 1u) gf_add_to(v, gf_load(t, 1 + k));
-    return v;
+    return subset_sum_ext(t, m, jlo, jhi_uniform);
 }
 
 __global__ void __launch_bounds__(256) k_subset_sums_gf192(uint64_t *out, const uint64_t *tab, int m, size_t n)
@@ -258,9 +249,13 @@ static int div_common(const uint64_t *d_num, const uint64_t *d_den, uint64_t *d_
     return IOPX_OK;
 }
 
-static int subset_sums(const std::vector<uint64_t> &tab, size_t m, uint64_t *d_out)
+static int subset_sums(const std::vector<uint64_t> &plain, size_t m, uint64_t *d_out)
 {
     int rc;
+    std::vector<hgf192> entries;
+    for (size_t k = 0; k <= m; ++k) entries.push_back(hgf192::from_words(&plain[3 * k]));
+    std::vector<uint64_t> tab;
+    append_subset_table_with_ext(tab, entries);
     TmpBuf dt;
     if ((rc = dt.alloc(tab.size() * 8)) != IOPX_OK) return rc;
     if ((rc = upload(dt.p, tab.data(), tab.size() * 8)) != IOPX_OK) return rc;
@@ -401,12 +396,14 @@ int iopx_rational_sumcheck_constraint_gf192_dev(const uint64_t *d_p, const uint6
     if (lin.coeff[0].is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the summation domain's basis is linearly dependent");
     const hgf192 c = lin.coeff[0].inverse() * hgf192::from_words(claimed_sum);          // eps^-1 mu (rational_sumcheck.tcc:52-56)
     const hgf192 z_shift = lin.eval(hgf192::from_words(summation_shift));
-    std::vector<uint64_t> ktab(3 * (m + 1)), zinv(3 * cosets);
+    std::vector<uint64_t> ktab, zinv(3 * cosets);
+    std::vector<hgf192> kentries;
     for (size_t i = 0; i <= m; ++i) {
         hgf192 v = hgf192::from_words(i == 0 ? shift : basis + 3 * (i - 1));
         for (size_t s = 0; s < k; ++s) v = v.squared();                                // v^|K|
-        memcpy(&ktab[3 * i], v.w, 24);
+        kentries.push_back(v);
     }
+    append_subset_table_with_ext(ktab, kentries);
     for (size_t cidx = 0; cidx < cosets; ++cidx) {
         hgf192 x = hgf192::from_words(shift);
         for (size_t b = k; b < m; ++b) if ((cidx >> (b - k)) & 1) x += hgf192::from_words(basis + 3 * b);

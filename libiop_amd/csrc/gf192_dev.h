@@ -199,6 +199,30 @@ __device__ __forceinline__ gf192 gf_mul_uniform(const gf192 &a, const gf192 &c_u
     return gf_reduce(r);
 }
 
+// ---- subset sums over an affine subspace --------------------------------------------------------------------------------
+// v_j = t[0] + sum_{bit k of j} t[1 + k] for the j-th element of a 2^m-point subspace (t[0] the shift term, t[1 + k] the image of
+// basis vector k).  A workgroup sweeps 256 consecutive positions, so index bits 0..7 vary across lanes (masked XORs) and the rest
+// are uniform: their contribution is looked up in two 512-entry tables of pre-summed entries (bits 8..16 and 17..25) that the
+// host appends to the table (gf192_host.h subset_table_with_ext) — two loads from a wave-uniform address instead of up to 18
+// dependent conditional ones, which left these kernels waiting on memory (65 % of wave cycles parked in k_fz_add).
+#define SUBSET_EXT_ENTRIES 1024
+__device__ __forceinline__ gf192 subset_sum_ext(const uint64_t *__restrict__ t, int m, uint32_t jlo, uint32_t jhi_uniform)
+{
+    gf192 v = gf_load(t, 0);
+    const int lo_bits = m < 8 ? m : 8;
+    for (int k = 0; k < lo_bits; ++k) {
+        const uint32_t mask = 0u - ((jlo >> k) & 1u);
+        const gf192 b = gf_load(t, 1 + k);
+#pragma unroll
+        for (int w = 0; w < 6; ++w) v.w[w] = xor_and(v.w[w], mask, b.w[w]);
+    }
+    const uint64_t *ext = t + 3 * (size_t)(m + 1);
+    if (m > 8) gf_add_to(v, gf_load(ext, jhi_uniform & 511u));
+    if (m > 17) gf_add_to(v, gf_load(ext, 512u + ((jhi_uniform >> 9) & 511u)));
+    for (int k = 26; k < m; ++k) if ((jhi_uniform >> (k - 8)) & 1u) gf_add_to(v, gf_load(t, 1 + k));
+    return v;
+}
+
 // ---- squaring and inversion -------------------------------------------------------------------------------------------
 // Squaring is GF(2)-linear: bit i moves to bit 2i (four shift-and-mask steps per 16 bits), then the usual reduction: about a
 // sixth of a product.  Inversion is a^(2^192 - 2) by the Itoh-Tsujii chain on 191 = 0b10111111: 191 squarings + 10 products.

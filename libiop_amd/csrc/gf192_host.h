@@ -126,4 +126,22 @@ struct SubspacePoly {
     }
 };
 
+
+// Device layout of a subset-sum table (gf192_dev.h subset_sum_ext): the m + 1 entries, then 512 pre-summed entries for index bits
+// 8..16 and 512 for bits 17..25.
+inline void append_subset_table_with_ext(std::vector<uint64_t> &out, const std::vector<hgf192> &entries)
+{
+    const size_t m = entries.size() - 1;
+    for (const hgf192 &e : entries) out.insert(out.end(), e.w, e.w + 3);
+    for (int level = 0; level < 2; ++level) {
+        const size_t first = 8 + 9 * (size_t)level;
+        for (size_t q = 0; q < 512; ++q) {
+            hgf192 acc = hgf192::zero();
+            for (size_t k = 0; k < 9 && first + k < m; ++k) if ((q >> k) & 1) acc += entries[1 + first + k];
+            out.insert(out.end(), acc.w, acc.w + 3);
+        }
+    }
+}
+static const size_t SUBSET_TABLE_WORDS_EXTRA = 3 * 1024;
+
 } // namespace iopx

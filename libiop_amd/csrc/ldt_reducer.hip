@@ -37,18 +37,7 @@ struct LdtAddParams {
 // rest are uniform.
 __device__ __forceinline__ gf192 ldt_subset_sum(const uint64_t *t, int m, uint32_t jlo, uint32_t jhi_uniform)
 {
-    gf192 v = gf_load(t, 0);
-    const int lo_bits = m < 8 ? m : 8;
-    for (int k = 0; k < lo_bits; ++k) {
-        const uint32_t mask = 0u - ((jlo >> k) & 1u);
-        const gf192 b = gf_load(t, 1 + k);
-#pragma unroll
-        for (int w = 0; w < 6; ++w) v.w[w] = xor_and(v.w[w], mask, b.w[w]);
-    }
-    for (int k = 8; k < m; ++k) {
-        if ((jhi_uniform >> (k - 8)) & 1u) gf_add_to(v, gf_load(t, 1 + k));
-    }
-    return v;
+    return subset_sum_ext(t, m, jlo, jhi_uniform);
 }
 
 __global__ void __launch_bounds__(256) k_ldt_combine_add(LdtAddParams p)
@@ -66,7 +55,7 @@ __global__ void __launch_bounds__(256) k_ldt_combine_add(LdtAddParams p)
                 if (e) {
                     gf192 bump = gf_load(p.coef, 2 * o + 1);
                     for (int i = 0; e; ++i, e >>= 1) {
-                        if (e & 1) bump = gf_mul(bump, ldt_subset_sum(p.tab + 3 * (size_t)i * (p.m + 1), p.m, (uint32_t)(j & 255), jhi));
+                        if (e & 1) bump = gf_mul(bump, ldt_subset_sum(p.tab + 3 * (size_t)i * (p.m + 1 + SUBSET_EXT_ENTRIES), p.m, (uint32_t)(j & 255), jhi));
                     }
                     gf_add_to(c, bump);
                 }
@@ -110,7 +99,7 @@ __global__ void __launch_bounds__(256) k_ldt_combine_add_slots(LdtSlotParams q)
                 }
                 for (int i = 0; e; ++i, e >>= 1) {
                     if (!(e & 1)) continue;
-                    const gf192 t = ldt_subset_sum(p.tab + 3 * (size_t)i * (p.m + 1), p.m, lane, jhi);
+                    const gf192 t = ldt_subset_sum(p.tab + 3 * (size_t)i * (p.m + 1 + SUBSET_EXT_ENTRIES), p.m, lane, jhi);
                     v = have ? gf_mul(v, t) : t;
                     have = true;
                 }
@@ -218,15 +207,14 @@ int iopx_ldt_combine_gf192_dev(const void *const *d_oracles, size_t num_oracles,
     int nbits = 0;
     while (nbits < 64 && (all >> nbits)) ++nbits;
     // basis[k]^(2^i), shift^(2^i) by repeated squaring (exponentiation.tcc:10-18)
-    std::vector<uint64_t> htab((size_t)(nbits ? nbits : 1) * (m + 1) * 3, 0);
+    std::vector<uint64_t> htab;                    // table i: x^(2^i) over the domain, in the subset-sum layout (entries + pre-summed levels)
     std::vector<hgf192> cur;
     cur.push_back(hgf192::from_words(shift));
     for (size_t k = 0; k < m; ++k) cur.push_back(hgf192::from_words(basis + 3 * k));
-    for (int i = 0; i < nbits; ++i) {
-        for (size_t k = 0; k <= m; ++k) {
-            memcpy(&htab[((size_t)i * (m + 1) + k) * 3], cur[k].w, 24);
-            cur[k] = cur[k].squared();
-        }
+    for (int i = 0; i < (nbits ? nbits : 1); ++i) {
+        if ((all >> i) & 1) append_subset_table_with_ext(htab, cur);
+        else htab.resize(htab.size() + 3 * (m + 1) + SUBSET_TABLE_WORDS_EXTRA, 0);          // never read: no exponent has this bit
+        for (size_t k = 0; k <= m; ++k) cur[k] = cur[k].squared();
     }
     TmpBuf dptrs, dtab, dcoef, dexpo;
     if ((rc = dptrs.alloc(num_oracles * sizeof(void *))) != IOPX_OK) return rc;
@@ -245,9 +233,15 @@ int iopx_ldt_combine_gf192_dev(const void *const *d_oracles, size_t num_oracles,
     // slots: distinct exponents; those with >= 3 bits that all contain a common bit set hang off one slot holding that set
     std::vector<uint64_t> distinct;
     for (uint64_t e : pl.expo) if (e && std::find(distinct.begin(), distinct.end(), e) == distinct.end()) distinct.push_back(e);
+    // x^e costs popcount(e) - 1 products per element.  The heavy exponents (at least half as many bits as the heaviest: gaps of the
+    // form 2^k - small, e.g. 2^21 - 3 and 2^21 - 2 in a Fractal proof) share most of their bits: that common part is one parent
+    // slot computed once; light exponents stand alone.
+    int max_pop = 0;
+    for (uint64_t e : distinct) max_pop = std::max(max_pop, __builtin_popcountll(e));
+    const int heavy_pop = std::max(3, (max_pop + 1) / 2);
     uint64_t common = ~(uint64_t)0;
     size_t multi = 0;
-    for (uint64_t e : distinct) if (__builtin_popcountll(e) >= 3) { common &= e; ++multi; }
+    for (uint64_t e : distinct) if (__builtin_popcountll(e) >= heavy_pop) { common &= e; ++multi; }
     if (multi < 2 || __builtin_popcountll(common) < 2) common = 0;
     std::vector<uint64_t> slot_bits;
     std::vector<int> slot_parent, oracle_slot(num_oracles, -1);
@@ -256,7 +250,7 @@ int iopx_ldt_combine_gf192_dev(const void *const *d_oracles, size_t num_oracles,
         int slot;
         if (common && e == common) slot = 0;
         else {
-            const bool on_common = common && __builtin_popcountll(e) >= 3;
+            const bool on_common = common && __builtin_popcountll(e) >= heavy_pop;
             slot_bits.push_back(on_common ? e & ~common : e);
             slot_parent.push_back(on_common ? 0 : -1);
             slot = (int)slot_bits.size() - 1;

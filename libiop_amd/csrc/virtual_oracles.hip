@@ -53,16 +53,7 @@ __global__ void __launch_bounds__(256) k_fz_add(uint64_t *out, const uint64_t *f
         const uint32_t jhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 8));
         const size_t end = base + 256 < n ? base + 256 : n;
         for (size_t j = base + threadIdx.x; j < end; j += blockDim.x) {
-            gf192 z = gf_load(tab, 0);
-            const uint32_t jlo = (uint32_t)(j & 255);
-            const int lo_bits = m < 8 ? m : 8;
-            for (int k = 0; k < lo_bits; ++k) {
-                const uint32_t mask = 0u - ((jlo >> k) & 1u);
-                const gf192 b = gf_load(tab, 1 + k);
-#pragma unroll
-                for (int w = 0; w < 6; ++w) z.w[w] = xor_and(z.w[w], mask, b.w[w]);
-            }
-            for (int k = 8; k < m; ++k) if ((jhi >> (k - 8)) & 1u) gf_add_to(z, gf_load(tab, 1 + k));
+            const gf192 z = subset_sum_ext(tab, m, (uint32_t)(j & 255), jhi);
             gf192 r = gf_mul(gf_load(fw, j), z);
             gf_add_to(r, gf_load(f1v, j));
             gf_store(out, j, r);
@@ -97,16 +88,7 @@ struct SumcheckAddParams {
 
 __device__ __forceinline__ gf192 vo_subset_sum(const uint64_t *t, int m, uint32_t jlo, uint32_t jhi_uniform)
 {
-    gf192 v = gf_load(t, 0);
-    const int lo_bits = m < 8 ? m : 8;
-    for (int k = 0; k < lo_bits; ++k) {
-        const uint32_t mask = 0u - ((jlo >> k) & 1u);
-        const gf192 b = gf_load(t, 1 + k);
-#pragma unroll
-        for (int w = 0; w < 6; ++w) v.w[w] = xor_and(v.w[w], mask, b.w[w]);
-    }
-    for (int k = 8; k < m; ++k) if ((jhi_uniform >> (k - 8)) & 1u) gf_add_to(v, gf_load(t, 1 + k));
-    return v;
+    return subset_sum_ext(t, m, jlo, jhi_uniform);
 }
 
 #define SUMCHECK_BATCH 8
@@ -308,10 +290,11 @@ int iopx_fz_gf192_dev(const uint64_t *d_fw, const uint64_t *d_f1v, const uint64_
     if (input_dim > m || m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "Codeword domain must be bigger than the input variable domain.");
     const SubspacePoly lin(input_basis, input_dim);       // Z_I's linear part
     auto eval = [&](const hgf192 &x) { return lin.eval(x); };
-    std::vector<uint64_t> tab(3 * (m + 1));
-    const hgf192 t0 = eval(hgf192::from_words(shift)) + eval(hgf192::from_words(input_shift));      // Z_I(shift) = lin(shift) + lin(shift_I)
-    memcpy(&tab[0], t0.w, 24);
-    for (size_t k = 0; k < m; ++k) { const hgf192 t = eval(hgf192::from_words(basis + 3 * k)); memcpy(&tab[3 * (k + 1)], t.w, 24); }
+    std::vector<hgf192> entries;
+    entries.push_back(eval(hgf192::from_words(shift)) + eval(hgf192::from_words(input_shift)));    // Z_I(shift) = lin(shift) + lin(shift_I)
+    for (size_t k = 0; k < m; ++k) entries.push_back(eval(hgf192::from_words(basis + 3 * k)));
+    std::vector<uint64_t> tab;
+    append_subset_table_with_ext(tab, entries);
     TmpBuf dt;
     if ((rc = dt.alloc(tab.size() * 8)) != IOPX_OK) return rc;
     if ((rc = upload(dt.p, tab.data(), tab.size() * 8)) != IOPX_OK) return rc;
@@ -356,15 +339,19 @@ int iopx_sumcheck_g_gf192_dev(const uint64_t *d_f, const uint64_t *d_h, const ui
     auto eval = [&](const hgf192 &x) { return lin.eval(x); };
     if (lin.coeff[0].is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the summation domain's basis is linearly dependent");
     const hgf192 c = lin.coeff[0].inverse() * hgf192::from_words(claimed_sum);   // eps^-1 mu (sumcheck.tcc:52-54)
-    std::vector<uint64_t> xtab(3 * (m + 1)), htab(3 * (m + 1)), ztab(3 * (m + 1));
+    std::vector<hgf192> xe, he, ze;
     for (size_t k = 0; k <= m; ++k) {
         const hgf192 v = hgf192::from_words(k == 0 ? shift : basis + 3 * (k - 1));
         hgf192 vh = v;
         for (size_t i = 0; i < summation_dim; ++i) vh = vh.squared();             // v^|H|
         hgf192 vz = eval(v);
         if (k == 0) vz += eval(hgf192::from_words(summation_shift));             // Z_H(shift) = lin(shift) + lin(shift_H)
-        memcpy(&xtab[3 * k], v.w, 24); memcpy(&htab[3 * k], vh.w, 24); memcpy(&ztab[3 * k], vz.w, 24);
+        xe.push_back(v); he.push_back(vh); ze.push_back(vz);
     }
+    std::vector<uint64_t> xtab, htab, ztab;
+    append_subset_table_with_ext(xtab, xe);
+    append_subset_table_with_ext(htab, he);
+    append_subset_table_with_ext(ztab, ze);
     TmpBuf dx, dh, dz, dc;
     if ((rc = dx.alloc(xtab.size() * 8)) != IOPX_OK) return rc;
     if ((rc = dh.alloc(htab.size() * 8)) != IOPX_OK) return rc;

@@ -118,3 +118,8 @@ def test_div_kernel(field_name, n):
 @pytest.mark.parametrize("field_name", ["gf192", "edwards_Fr"])
 def test_domain_kernels(field_name):
     fc.check_domain_kernels(emu_lib.emu(), torch, CPU, field_name, 9, 4)
+
+
+def test_domain_kernels_three_table_levels():
+    """2^19 points: index bits 8..16 and 17..18 go through the two pre-summed table levels of the subset-sum kernels."""
+    fc.check_domain_kernels(emu_lib.emu(), torch, CPU, "gf192", 19, 5, samples=(0, 255, 256, 65535, 65536, 131071, 131072, 300000))
