@@ -54,3 +54,62 @@ def test_merkle_degenerate_shapes():
 
 def test_proof_of_work_without_difficulty():
     assert emu().solve_pow(bytes(32), 0) == bytes(32)       # the challenge itself passes (pow.tcc:92-96)
+
+
+# ---- the holographic prover's entry points: argument checks and degenerate sizes ----
+def _ops(field_cls):
+    import torch
+    from libiop_amd import domains
+    return domains.DeviceOps(emu(), torch, torch.device("cpu"), field_cls())
+
+
+def test_div_argument_checks_and_empty_input():
+    from libiop_amd import domains
+    for cls in (domains.GF192, domains.EdwardsFr):
+        ops = _ops(cls)
+        a = ops.upload(rand_elems(3, 4, W) if cls is domains.GF192 else np.stack([cls().from_int(v) for v in (3, 5, 7, 11)]))
+        with pytest.raises(ValueError):                     # the quotient buffer holds the running products: it cannot alias an input
+            ops.lib.field_div_dev(a.data_ptr(), a.data_ptr(), a.data_ptr(), 4, prime_field=not cls().additive)
+        ops.lib.field_div_dev(None, a.data_ptr(), a.data_ptr(), 0, prime_field=not cls().additive)          # nothing to do, nothing checked
+        inv = ops.div(None, a)
+        assert np.array_equal(ops.download(ops.mul(inv, a)), np.broadcast_to(cls().one(), (4, 3)))
+
+
+def test_rational_combine_limits():
+    from libiop_amd import domains
+    ops = _ops(domains.GF192)
+    v = [ops.upload(rand_elems(10 + i, 8, W)) for i in range(10)]
+    with pytest.raises(ValueError):                         # at most four rationals (the shipped protocols combine three matrices)
+        ops.rational_combine(v[:5], v[5:], rand_elems(1, 5, W), 8)
+    with pytest.raises(ValueError):                         # one coefficient per rational
+        ops.rational_combine(v[:3], v[3:6], rand_elems(1, 2, W), 8)
+    N, D = ops.rational_combine(v[:1], v[1:2], rand_elems(2, 1, W), 8)                                     # one rational: N = c N_0, D = D_0
+    assert np.array_equal(ops.download(D), ops.download(v[1]))
+
+
+def test_sumcheck_constraint_needs_a_sub_domain():
+    from libiop_amd import domains
+    f = domains.GF192()
+    ops = _ops(domains.GF192)
+    L = f.domain(1 << 6, f.domain(1 << 6).element_outside_of_subset())
+    other = domains.Domain(f, domains.ADDITIVE, basis=rand_elems(5, 3, W), shift=np.zeros(3, dtype=np.uint64))   # not a prefix of L's basis
+    x = ops.upload(rand_elems(7, 64, W))
+    with pytest.raises(ValueError):
+        ops.rational_sumcheck_constraint(x, x, x, L, other, f.zero())
+    fe = domains.EdwardsFr()
+    opse = _ops(domains.EdwardsFr)
+    small, big = fe.domain(1 << 4, 19), fe.domain(1 << 6)
+    y = opse.upload(np.stack([fe.from_int(i + 1) for i in range(16)]))
+    with pytest.raises(ValueError):                         # summation domain larger than the codeword domain
+        opse.rational_sumcheck_constraint(y, y, y, small, big, fe.zero())
+
+
+def test_codeword_domain_meeting_the_summation_domain_is_refused():
+    """Z_K vanishes on the codeword domain when it is not shifted off K: the reference divides by zero there; refused here."""
+    from libiop_amd import domains
+    fe = domains.EdwardsFr()
+    ops = _ops(domains.EdwardsFr)
+    L, K = fe.domain(1 << 6), fe.domain(1 << 3)            # both unshifted: K is a subset of L
+    y = ops.upload(np.stack([fe.from_int(i + 1) for i in range(64)]))
+    with pytest.raises(ValueError):
+        ops.rational_sumcheck_constraint(y, y, y, L, K, fe.zero())
