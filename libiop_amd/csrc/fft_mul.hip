@@ -250,10 +250,15 @@ struct MulPlan {
 static std::mutex g_mplan_mu;
 static std::map<std::vector<uint64_t>, std::unique_ptr<MulPlan>> g_mplans;
 
+static void clear_pow_tables();
+
 void clear_mul_plans()
 {
-    std::lock_guard<std::mutex> lk(g_mplan_mu);
-    g_mplans.clear();
+    {
+        std::lock_guard<std::mutex> lk(g_mplan_mu);
+        g_mplans.clear();
+    }
+    clear_pow_tables();
 }
 
 static int mgrid(size_t work, int threads)
@@ -278,7 +283,7 @@ static int fp_build_pow(uint64_t *out, const hfp3 &base, const hfp3 &init, int n
     if (!sq.empty()) { int urc_ = upload(dsq.p, sq.data(), sq.size() * 8); if (urc_ != IOPX_OK) return urc_; }
     { int urc_ = upload(dinit.p, init_t.w, 24); if (urc_ != IOPX_OK) return urc_; }
     const size_t count = (size_t)1 << nb;
-    if (nb <= 8) {
+    if (nb <= 14) {         // up to 14 products per entry: one launch beats the three of the expansion scheme for the small per-call tables
         { ProfScope ps_("k_fp_pow_direct"); hipLaunchKernelGGL(k_fp_pow_direct, dim3(mgrid(count, 256)), dim3(256), 0, stream(), out, (const uint64_t *)dsq.u64(), (const uint64_t *)dinit.u64(), nb, count); }
     } else {
         // out[0..256) = init * base^q ; hi[r] = (base^256)^r ; out[q] = out[q & 255] * hi[q >> 8]
@@ -335,17 +340,51 @@ static int get_mplan(int logn, const uint64_t *gen, MulPlan **out)
 }
 
 // two-level power tables: hi[q] = init * base^(4096 q) (q < 2^max(logc-12,0)), lo[r] = base^r (r < 4096)
-int build_two_level(const hfp3 &base, const hfp3 &init, int logc, TmpBuf &hi, TmpBuf &lo)
+struct TableKey {
+    uint64_t w[7];
+    bool operator<(const TableKey &o) const { return memcmp(w, o.w, sizeof(w)) < 0; }
+};
+static std::map<TableKey, std::unique_ptr<DevBuf>> g_pow_tables;        // device tables of build_two_level, dropped by clear_mul_plans()
+static std::mutex g_pow_tables_mu;
+
+static int cached_pow_table(const hfp3 &base, const hfp3 &init, int bits, bool use_cache, TmpBuf &out)
+{
+    const size_t bytes = (((size_t)1) << bits) * 24;
+    int rc;
+    if (!use_cache) {
+        if ((rc = out.alloc(bytes)) != IOPX_OK) return rc;
+        return fp_build_pow(out.u64(), base, init, bits);
+    }
+    TableKey key;
+    memcpy(key.w, base.w, 24); memcpy(key.w + 3, init.w, 24); key.w[6] = (uint64_t)bits;
+    std::lock_guard<std::mutex> lk(g_pow_tables_mu);
+    auto it = g_pow_tables.find(key);
+    if (it == g_pow_tables.end()) {
+        if (g_pow_tables.size() >= 256) g_pow_tables.clear();            // stream-ordered frees: kernels already enqueued keep their data
+        std::unique_ptr<DevBuf> buf(new DevBuf());
+        if ((rc = buf->alloc(bytes)) != IOPX_OK) return rc;
+        if ((rc = fp_build_pow(buf->u64(), base, init, bits)) != IOPX_OK) return rc;
+        it = g_pow_tables.emplace(key, std::move(buf)).first;
+    }
+    out.borrow(it->second->p, bytes);
+    return IOPX_OK;
+}
+
+static void clear_pow_tables()
+{
+    std::lock_guard<std::mutex> lk(g_pow_tables_mu);
+    g_pow_tables.clear();
+}
+
+int build_two_level(const hfp3 &base, const hfp3 &init, int logc, TmpBuf &hi, TmpBuf &lo, bool cache_hi)
 {
     const int lo_bits = logc < 12 ? logc : 12, hi_bits = logc > 12 ? logc - 12 : 0;
-    int rc;
-    if ((rc = lo.alloc(((size_t)4096) * 24)) != IOPX_OK) return rc;
-    if ((rc = hi.alloc((((size_t)1) << hi_bits) * 24)) != IOPX_OK) return rc;
-    rc = fp_build_pow(lo.u64(), base, hfp3::one(), lo_bits);
+    // lo[r] = base^r for r < 2^lo_bits (the kernels index it with j & 4095: entries past 2^lo_bits are never read when logc < 12)
+    int rc = cached_pow_table(base, hfp3::one(), lo_bits, true, lo);
     if (rc != IOPX_OK) return rc;
     hfp3 b4096 = base;
     for (int k = 0; k < 12; ++k) b4096 = b4096.squared();
-    return fp_build_pow(hi.u64(), b4096, init, hi_bits);
+    return cached_pow_table(b4096, init, hi_bits, cache_hi, hi);
 }
 
 // runs the radix-2 levels on index bits [logrho, logn) (first pass gathers src bit-reversed), natural-order dst

@@ -310,7 +310,8 @@ int iopx_ldt_combine_fp3_dev(const void *const *d_oracles, size_t num_oracles, c
         tabs.emplace_back(new TmpBuf());
         tabs.emplace_back(new TmpBuf());
         TmpBuf &hi = *tabs[tabs.size() - 2], &lo = *tabs[tabs.size() - 1];
-        if ((rc = build_two_level(g.pow(pl.expo[k]), coef(pl.shifted[k]) * s.pow(pl.expo[k]), (int)log_n, hi, lo)) != IOPX_OK) return rc;
+        // the random coefficient rides on the hi half (rebuilt per call); the lo half depends on the degree gap and the domain only
+        if ((rc = build_two_level(g.pow(pl.expo[k]), coef(pl.shifted[k]) * s.pow(pl.expo[k]), (int)log_n, hi, lo, false)) != IOPX_OK) return rc;
         hhi[k] = hi.u64();
         hlo[k] = lo.u64();
     }

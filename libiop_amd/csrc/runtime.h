@@ -81,9 +81,16 @@ struct TmpBuf {
     void release()
     {
         if (!p) return;
-        tmp_free(p, cap);
-        p = nullptr; bytes = 0; cap = 0;
+        if (!borrowed) tmp_free(p, cap);
+        p = nullptr; bytes = 0; cap = 0; borrowed = false;
     }
+    // points at device memory owned elsewhere (a cached table): released without being returned to the pool
+    void borrow(void *q, size_t n)
+    {
+        release();
+        p = q; bytes = n; cap = 0; borrowed = true;
+    }
+    bool borrowed = false;
     uint64_t *u64() const { return (uint64_t *)p; }
 };
 
@@ -99,7 +106,9 @@ struct ProfScope {
 // fft_mul.hip: two-level power tables of the 181-bit prime field on the device,
 // hi[q] = init * base^(4096 q) (q < 2^max(logc-12,0)), lo[r] = base^r (r < 4096), so init * base^j = hi[j >> 12] * lo[j & 4095]
 struct hfp3;
-int build_two_level(const hfp3 &base, const hfp3 &init, int logc, TmpBuf &hi, TmpBuf &lo);
+// Tables are kept by (base, init, logc) — most of them depend on the domain only and recur in every proof; cache_hi = false for a
+// table whose init carries a per-proof value (the LDT coefficients): its lo half is still shared by base.
+int build_two_level(const hfp3 &base, const hfp3 &init, int logc, TmpBuf &hi, TmpBuf &lo, bool cache_hi = true);
 
 // Per-module plan caches dropped by iopx_clear_plans() (the caller has synchronised the device).
 void clear_mul_plans();
