@@ -105,7 +105,13 @@ __global__ void __launch_bounds__(256) k_lincomb_fp3(LincombParams p)
     const fp3 c0 = p.has_constant ? fp_load(p.c, p.num) : fp_zero();
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < p.n; j += (size_t)gridDim.x * blockDim.x) {
         fp3 acc = c0;
-        for (int i = 0; i < p.num; ++i) acc = fp_add(acc, fp_mul(fp_load(p.o[i], j), fp_load(p.c, i)));
+        for (int g = 0; g < p.num; g += 8) {                 // up to 8 products per reduction (fp3_dev.h)
+            fp7w w;
+            fp7w_zero(w);
+            const int e = g + 8 < p.num ? g + 8 : p.num;
+            for (int i = g; i < e; ++i) fp_mac(w, fp_load(p.o[i], j), fp_load(p.c, i));
+            acc = fp_add(acc, fp_redc(w));
+        }
         fp_store(p.out, j, acc);
     }
 }

@@ -171,6 +171,74 @@ __device__ __forceinline__ fp7 fp7_mul(const fp7 &a, const fp7 &b)
     return r;
 }
 
+// ---- sums of products with ONE Montgomery reduction ------------------------------------------------------------------------
+// A product's 13 column sums are each below 7 * 2^58; up to 8 products can share the 64-bit column accumulators (8 * 7 * 2^58, plus
+// the reduction's own 7 * 2^58 per column and a 35-bit carry, stays below 2^64), so sum_i a_i b_i costs 49 multiply-adds per term
+// and 42 once, instead of 91 per term.  Operand limbs must be normalised (< 2^29): fp7_unpack of stored values, table constants.
+struct fp7w {
+    uint64_t c[13];
+};
+
+__device__ __forceinline__ void fp7w_zero(fp7w &w)
+{
+#pragma unroll
+    for (int k = 0; k < 13; ++k) w.c[k] = 0;
+}
+
+__device__ __forceinline__ void fp7w_mac(fp7w &w, const fp7 &a, const fp7 &b)
+{
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) w.c[i + j] += (uint64_t)a.l[i] * b.l[j];
+}
+
+// (the accumulated sum) * 2^-203 mod p, below 2p with normalised limbs when at most 8 products of values below 2^192 and p were summed
+__device__ __forceinline__ fp7 fp7w_redc(const fp7w &w)
+{
+    uint32_t m[7];
+    fp7 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        acc += w.c[k];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * FP7_P[k - i];
+        m[k] = ((uint32_t)acc * FP7_INV) & FP7_MASK;
+        acc += (uint64_t)m[k] * FP7_P[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 7; k < 13; ++k) {
+        acc += w.c[k];
+#pragma unroll
+        for (int i = k - 6; i < 7; ++i) acc += (uint64_t)m[i] * FP7_P[k - i];
+        r.l[k - 7] = (uint32_t)acc & FP7_MASK;
+        acc >>= 29;
+    }
+    r.l[6] = (uint32_t)acc;
+    return r;
+}
+
+__device__ __forceinline__ void fp_mac(fp7w &w, const fp3 &a, const fp3 &b)
+{
+    fp7w_mac(w, fp7_unpack(a), fp7_unpack(b));
+}
+
+// canonical stored form of the accumulated sum * 2^-203
+__device__ __forceinline__ fp3 fp_redc(const fp7w &w)
+{
+    fp3 r = fp7_pack(fp7w_redc(w));
+    fp_cond_sub_p(r.w);
+    return r;
+}
+
+// p - a for a canonical a != 0, 0 for 0
+__device__ __forceinline__ fp3 fp_neg(const fp3 &a)
+{
+    return fp_sub(fp_zero(), a);
+}
+
 // ---- lazily reduced butterflies ---------------------------------------------------------------------------------------
 // A radix-2 butterfly (x, y) -> (x + w y, x - w y) on limb vectors with NO carry handling: t = w y is below 2p with 29-bit
 // limbs; the difference is formed as x + (8p - t) with 8p written so that each of its lower six limbs is at least 2^29 - 1

@@ -157,13 +157,19 @@ __global__ void __launch_bounds__(256) k_rational_combine_fp3(RationalParams p)
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < p.n; j += (size_t)gridDim.x * blockDim.x) {
         fp3 t[RATIONAL_MAX];                                // the denominators in the 2^203 form
         for (int k = 0; k < p.num; ++k) t[k] = fp_mul(fp_load(p.D[k], j), k214);
-        fp3 numer = fp_zero(), denom = fp_load(p.D[0], j);
+        fp3 denom = fp_load(p.D[0], j);
         for (int k = 1; k < p.num; ++k) denom = fp_mul(denom, t[k]);
+        fp7w w;                                               // the last factor of each term is accumulated: one reduction for the sum
+        fp7w_zero(w);
         for (int i = 0; i < p.num; ++i) {
             fp3 cur = fp_mul(fp_load(p.N[i], j), fp_load(p.c, i));
-            for (int k = 0; k < p.num; ++k) if (k != i) cur = fp_mul(cur, t[k]);
-            numer = fp_add(numer, cur);
+            int last = -1;
+            for (int k = 0; k < p.num; ++k) if (k != i) last = k;
+            for (int k = 0; k < p.num; ++k) if (k != i && k != last) cur = fp_mul(cur, t[k]);
+            if (last >= 0) fp_mac(w, cur, t[last]);
+            else fp_mac(w, cur, fp_load(p.c, p.num + 1));     // a single rational: times the 2^203 form of 1
         }
+        const fp3 numer = fp_redc(w);
         fp_store(p.outN, j, numer);
         fp_store(p.outD, j, denom);
     }
@@ -211,8 +217,11 @@ __global__ void __launch_bounds__(256) k_sumcheck_constraint_fp3(uint64_t *out, 
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
         const fp3 x = fp_mul(fp_load(xhi, j >> 12), fp_load(xlo, j & 4095));         // 2^203 form
         const fp3 s = fp_add(fp_mul(fp_load(pp, j), x), c);
-        const fp3 t = fp_sub(fp_mul(fp_load(D, j), s), fp_mul(fp_load(N, j), one));
-        fp_store(out, j, fp_mul(t, fp_load(zinv_scaled, j & (num_cosets - 1))));
+        fp7w w;                                               // D s - N 1 = D s + (p - N) 1 with one reduction
+        fp7w_zero(w);
+        fp_mac(w, fp_load(D, j), s);
+        fp_mac(w, fp_neg(fp_load(N, j)), one);
+        fp_store(out, j, fp_mul(fp_redc(w), fp_load(zinv_scaled, j & (num_cosets - 1))));
     }
 }
 
@@ -290,8 +299,9 @@ static int rational_common(const void *const *d_N, const void *const *d_D, size_
     std::vector<uint64_t> hc(coeffs, coeffs + 3 * num);
     if (prime_field) {
         for (size_t i = 0; i < num; ++i) { const hfp3 t = hfp3::from_words(coeffs + 3 * i).table_form(); memcpy(&hc[3 * i], t.w, 24); }
-        const hfp3 k214 = hfp3::one().table_form().table_form();
+        const hfp3 k203 = hfp3::one().table_form(), k214 = k203.table_form();
         hc.insert(hc.end(), k214.w, k214.w + 3);
+        hc.insert(hc.end(), k203.w, k203.w + 3);
     }
     TmpBuf dc;
     if ((rc = dc.alloc(hc.size() * 8)) != IOPX_OK) return rc;

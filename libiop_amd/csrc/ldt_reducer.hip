@@ -138,12 +138,17 @@ __global__ void __launch_bounds__(256) k_ldt_combine_fp(LdtFpParams p)
 {
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < p.n; j += (size_t)gridDim.x * blockDim.x) {
         fp3 acc = fp_zero();
-        for (int o = 0; o < p.num_oracles; ++o) {
-            const fp3 f = fp_load(p.oracles[o], j);
-            fp3 c = fp_load(p.coef, o);
-            const uint64_t *hi = p.hi[o];
-            if (hi) c = fp_add(c, fp_mul(fp_load(hi, j >> 12), fp_load(p.lo[o], j & 4095)));
-            acc = fp_add(acc, fp_mul(c, f));
+        for (int g = 0; g < p.num_oracles; g += 8) {          // sum_o c_o(x) f_o(x): up to 8 products per reduction (fp3_dev.h)
+            fp7w w;
+            fp7w_zero(w);
+            const int e = g + 8 < p.num_oracles ? g + 8 : p.num_oracles;
+            for (int o = g; o < e; ++o) {
+                fp3 c = fp_load(p.coef, o);
+                const uint64_t *hi = p.hi[o];
+                if (hi) c = fp_add(c, fp_mul(fp_load(hi, j >> 12), fp_load(p.lo[o], j & 4095)));
+                fp_mac(w, c, fp_load(p.oracles[o], j));
+            }
+            acc = fp_add(acc, fp_redc(w));
         }
         fp_store(p.out, j, acc);
     }

@@ -36,9 +36,11 @@ __global__ void __launch_bounds__(256) k_rowcheck_fp(uint64_t *out, const uint64
 {
     const fp3 one = fp_load(one_stored, 0);
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
-        const fp3 ab = fp_mul(fp_load(az, j), fp_load(bz, j));
-        const fp3 c = fp_mul(fp_load(cz, j), one);
-        fp_store(out, j, fp_mul(fp_sub(ab, c), fp_load(zinv_scaled, j & (num_cosets - 1))));
+        fp7w w;                                               // Az Bz - Cz 1 = Az Bz + (p - Cz) 1 with one reduction
+        fp7w_zero(w);
+        fp_mac(w, fp_load(az, j), fp_load(bz, j));
+        fp_mac(w, fp_neg(fp_load(cz, j)), one);
+        fp_store(out, j, fp_mul(fp_redc(w), fp_load(zinv_scaled, j & (num_cosets - 1))));
     }
 }
 
@@ -195,10 +197,14 @@ __global__ void __launch_bounds__(256) k_lincheck_fp(LincheckParams p)
 {
     const fp3 rescale = fp_load(p.r, p.num_matrices);
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < p.n; j += (size_t)gridDim.x * blockDim.x) {
-        fp3 comb = fp_zero();
-        for (int m = 0; m < p.num_matrices; ++m) comb = fp_add(comb, fp_mul(fp_load(p.mz[m], j), fp_load(p.r, m)));
-        const fp3 t = fp_sub(fp_mul(comb, fp_load(p.p1, j)), fp_mul(fp_load(p.fz, j), fp_load(p.p2, j)));
-        fp_store(p.out, j, fp_mul(t, rescale));
+        fp7w w;                                               // sum_m r_m Mz_m: one reduction (at most 8 matrices)
+        fp7w_zero(w);
+        for (int m = 0; m < p.num_matrices; ++m) fp_mac(w, fp_load(p.mz[m], j), fp_load(p.r, m));
+        const fp3 comb = fp_redc(w);
+        fp7w_zero(w);                                         // comb p1 - fz p2 = comb p1 + (p - fz) p2: one reduction
+        fp_mac(w, comb, fp_load(p.p1, j));
+        fp_mac(w, fp_neg(fp_load(p.fz, j)), fp_load(p.p2, j));
+        fp_store(p.out, j, fp_mul(fp_redc(w), rescale));
     }
 }
 

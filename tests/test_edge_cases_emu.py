@@ -113,3 +113,22 @@ def test_codeword_domain_meeting_the_summation_domain_is_refused():
     y = ops.upload(np.stack([fe.from_int(i + 1) for i in range(64)]))
     with pytest.raises(ValueError):
         ops.rational_sumcheck_constraint(y, y, y, L, K, fe.zero())
+
+
+def test_sums_of_products_at_the_limb_bounds():
+    """The prime-field kernels add up to 8 products per Montgomery reduction in 64-bit column accumulators: the largest operands
+    (p - 1 everywhere, and the all-ones limb pattern just below p) must not overflow them, for 8, 9 and 16 terms."""
+    from libiop_amd import domains
+    fe = domains.EdwardsFr()
+    ops = _ops(domains.EdwardsFr)
+    P = fe.P
+    for value in (P - 1, P - 2, (1 << 180) - 1, P // 3):
+        for terms in (1, 7, 8, 9, 16):
+            vecs = [ops.upload(np.stack([fe.from_int(value)] * 5)) for _ in range(terms)]
+            coeffs = np.stack([fe.from_int(value - i) for i in range(terms)])
+            got = ops.download(ops.lincomb(vecs, coeffs, 5))
+            expect = fe.from_int(sum(value * (value - i) for i in range(terms)))
+            assert all(np.array_equal(row, expect) for row in got), (value, terms)
+            got = ops.download(ops.lincomb_affine(vecs, coeffs, fe.from_int(P - 5), 5))
+            expect = fe.from_int(sum(value * (value - i) for i in range(terms)) + P - 5)
+            assert all(np.array_equal(row, expect) for row in got), (value, terms)
