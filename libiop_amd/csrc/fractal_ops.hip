@@ -36,7 +36,7 @@ struct DivParams {
     const uint64_t *num;        // nullable: plain inverses
     const uint64_t *den;
     uint64_t *out;              // distinct from num and den
-    const uint64_t *consts;     // fp3: 2^214, 2^192 (raw), p - 2, 2^203
+    const uint64_t *consts;     // fp3: see fo_fp_consts
     size_t n;
 };
 
@@ -68,19 +68,21 @@ __global__ void __launch_bounds__(256) k_div_gf192(DivParams p)
     }
 }
 
-// F_p: denominators are brought to the 2^203 form (closed under fp_mul, fp3_dev.h), the lane's product is inverted there by
-// x^(p-2), and the last product with a numerator in libff's form (or with the raw 2^192) lands in libff's form.
+// F_p.  The device product is a b 2^-203 and stored values carry 2^192 (fp3_dev.h), so each product with a stored denominator
+// multiplies the running value by d 2^-11: starting from the 2^203 form of 1, run_i = 2^203 (prod_{j<=i} d_j) 2^(-11 i).  Its inverse
+// (x^(p-2), closed under the device product) times 2^-11 once per lane makes before * inv = 2^203 / d_i exactly, at every i — the
+// powers of 2^11 cancel step by step — so the denominators are never converted: 4 products per element plus the amortised inversion.
 __global__ void __launch_bounds__(256) k_div_fp3(DivParams p)
 {
     const size_t T = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const fp3 k214 = fp_load(p.consts, 0), k192 = fp_load(p.consts, 1), one_t = fp_load(p.consts, 3);
+    const fp3 k192 = fp_load(p.consts, 1), one_t = fp_load(p.consts, 3), unscale_t = fp_load(p.consts, 4);
     const uint64_t e0 = p.consts[6], e1 = p.consts[7], e2 = p.consts[8];
     fp3 run = one_t;
     size_t count = 0;
     for (size_t j = tid; j < p.n; j += T, ++count) {
         const fp3 d = fp_load(p.den, j);
         const bool zero = (d.w[0] | d.w[1] | d.w[2] | d.w[3] | d.w[4] | d.w[5]) == 0;
-        run = fp_mul(run, zero ? one_t : fp_mul(d, k214));
+        run = fp_mul(run, zero ? k192 : d);                 // a zero denominator is stepped over as a stored 1
         fp_store(p.out, j, run);
     }
     if (count == 0) return;
@@ -90,13 +92,14 @@ __global__ void __launch_bounds__(256) k_div_fp3(DivParams p)
         const uint64_t w = bit >= 128 ? e2 : (bit >= 64 ? e1 : e0);
         if ((w >> (bit & 63)) & 1) inv = fp_mul(inv, run);
     }
+    inv = fp_mul(inv, unscale_t);
     for (size_t i = count; i-- > 0; ) {
         const size_t j = tid + i * T;
         const fp3 d = fp_load(p.den, j);
         const bool zero = (d.w[0] | d.w[1] | d.w[2] | d.w[3] | d.w[4] | d.w[5]) == 0;
         const fp3 before = i ? fp_load(p.out, j - T) : one_t;
         const fp3 q = fp_mul(before, inv);                  // (1 / d) 2^203
-        inv = fp_mul(inv, zero ? one_t : fp_mul(d, k214));
+        inv = fp_mul(inv, zero ? k192 : d);
         fp_store(p.out, j, zero ? fp_zero() : fp_mul(p.num ? fp_load(p.num, j) : k192, q));
     }
 }
@@ -225,12 +228,15 @@ __global__ void __launch_bounds__(256) k_sumcheck_constraint_fp3(uint64_t *out, 
     }
 }
 
-static void fo_fp_consts(uint64_t (&c)[12])
+// slots of three words: 0: 2^214 (raw), 1: 2^192 = the stored 1, 2: p - 2, 3: 2^203 = the device form of 1, 4: the device form of 2^-11
+static void fo_fp_consts(uint64_t (&c)[15])
 {
     const hfp3 k192 = hfp3::one(), k203 = k192.table_form(), k214 = k203.table_form();
+    const hfp3 unscale_t = hfp3::from_uint(2048).inverse().table_form();
     memcpy(c, k214.w, 24); memcpy(c + 3, k192.w, 24);
     c[6] = hfp3::P[0] - 2; c[7] = hfp3::P[1]; c[8] = hfp3::P[2];
     memcpy(c + 9, k203.w, 24);
+    memcpy(c + 12, unscale_t.w, 24);
 }
 
 static int div_common(const uint64_t *d_num, const uint64_t *d_den, uint64_t *d_out, size_t n, bool prime_field)
@@ -244,7 +250,7 @@ static int div_common(const uint64_t *d_num, const uint64_t *d_den, uint64_t *d_
     p.num = d_num; p.den = d_den; p.out = d_out; p.consts = nullptr; p.n = n;
     TmpBuf dc;
     if (prime_field) {
-        uint64_t c[12];
+        uint64_t c[15];
         fo_fp_consts(c);
         if ((rc = dc.alloc(sizeof(c))) != IOPX_OK) return rc;
         if ((rc = upload(dc.p, c, sizeof(c))) != IOPX_OK) return rc;
