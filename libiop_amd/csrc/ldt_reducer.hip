@@ -111,12 +111,14 @@ __global__ void __launch_bounds__(256) k_ldt_combine_add_slots(LdtSlotParams q)
                 const gf192 f = gf_load(p.oracles[o], j);
                 gf192 c = gf_load(p.coef, 2 * o);
                 const int s = q.oracle_slot[o];
-                if (s >= 0) {
-                    gf192 v;
-#pragma unroll
-                    for (int w = 0; w < 6; ++w) v.w[w] = iopx_ldt_smem[(s * 6 + w) * 256 + lane];
-                    gf_add_to(c, gf_mul_uniform(v, gf_load(p.coef, 2 * o + 1)));     // the coefficient is the same for every lane: comb product
+                if (s < 0) {                                 // an oracle of maximal degree: its multiplier is one constant — comb product
+                    gf_add_to(acc, gf_mul_uniform(f, c));
+                    continue;
                 }
+                gf192 v;
+#pragma unroll
+                for (int w = 0; w < 6; ++w) v.w[w] = iopx_ldt_smem[(s * 6 + w) * 256 + lane];
+                gf_add_to(c, gf_mul_uniform(v, gf_load(p.coef, 2 * o + 1)));         // the coefficient is the same for every lane: comb product
                 gf_add_to(acc, gf_mul(c, f));
             }
             gf_store(p.out, j, acc);
