@@ -360,7 +360,10 @@ static int cached_pow_table(const hfp3 &base, const hfp3 &init, int bits, bool u
     std::lock_guard<std::mutex> lk(g_pow_tables_mu);
     auto it = g_pow_tables.find(key);
     if (it == g_pow_tables.end()) {
-        if (g_pow_tables.size() >= 256) g_pow_tables.clear();            // stream-ordered frees: kernels already enqueued keep their data
+        if (g_pow_tables.size() >= 256) {                                // rare: drain the stream, then drop everything (kernels in flight read these tables)
+            (void)hipStreamSynchronize(stream());
+            g_pow_tables.clear();
+        }
         std::unique_ptr<DevBuf> buf(new DevBuf());
         if ((rc = buf->alloc(bytes)) != IOPX_OK) return rc;
         if ((rc = fp_build_pow(buf->u64(), base, init, bits)) != IOPX_OK) return rc;
