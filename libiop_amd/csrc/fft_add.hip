@@ -52,7 +52,10 @@ static const Tuning &tuning()
         // the last phase-1 pass runs every remaining level inside its tile (multiplier-bound): it may use a larger, narrower tile
         u.p1_fin_tile_bits = env_int("IOPX_P1_FIN_TILE_BITS", u.p1_tile_bits, u.p1_tile_bits, u.tile_bits > u.p1_tile_bits ? u.tile_bits : u.p1_tile_bits);
         u.p1_fin_cols = env_int("IOPX_P1_FIN_COLS", 0, 0, u.p1_fin_tile_bits - 3);   // measured: 4.74 -> 4.59 ms at 2^22 with single-element columns
-        u.p2_cols = env_int("IOPX_P2_COLS", 4, 0, u.tile_bits - 2);     // phase-2 upper passes: 2^c contiguous columns
+        // phase-2 upper passes: 2^c contiguous columns.  With c = 6 every row bit of a tile sits at local bit >= 6, so all of a pass's
+        // butterflies have wave-uniform twiddles (comb product); c = 4 left the two lowest row bits of each pass on the general product
+        // (k_bfly_upper 36.2 -> 33.0 ms per Aurora 2^20 proof, with 96 instead of 65 launches)
+        u.p2_cols = env_int("IOPX_P2_COLS", u.tile_bits - 2 < 6 ? u.tile_bits - 2 : 6, 0, u.tile_bits - 2);
         // the edge pass holds the levels whose twiddles are not wave-uniform (pair bits < 6): general multiplier,
         // small tiles for occupancy; 2^p2_top natural-order runs
         u.edge_tile_bits = env_int("IOPX_EDGE_TILE_BITS", u.tile_bits < 10 ? u.tile_bits : 10, 4, u.tile_bits);
