@@ -61,7 +61,7 @@ static const Tuning &tuning()
         u.edge_tile_bits = env_int("IOPX_EDGE_TILE_BITS", u.tile_bits < 10 ? u.tile_bits : 10, 4, u.tile_bits);
         u.p2_top = env_int("IOPX_P2_TOP", 4, 0, u.edge_tile_bits - 2);
         u.comb = env_int("IOPX_COMB", 1, 0, 1);                         // 1: asm comb multiplier where the twiddle is wave-uniform
-        u.p2_threads = env_int("IOPX_P2_THREADS", u.comb ? (u.tile_bits >= 12 ? 512 : 256) : 1024, 64, u.comb ? 512 : 1024);
+        u.p2_threads = env_int("IOPX_P2_THREADS", u.comb ? 512 : 1024, 64, u.comb ? 512 : 1024);
         return u;
     }();
     return t;
@@ -313,7 +313,7 @@ __device__ __forceinline__ void bf_apply(uint64_t *s, int E, int ia, int ib, con
 }
 
 template<bool INV, bool COMB>
-__global__ void __launch_bounds__(COMB ? 512 : 1024, COMB ? 3 : 1) k_bfly_upper(BfParams p)
+__global__ void __launch_bounds__(COMB ? 512 : 1024, COMB ? 6 : 1) k_bfly_upper(BfParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
     uint64_t *s = iopx_smem;
@@ -339,17 +339,23 @@ __global__ void __launch_bounds__(COMB ? 512 : 1024, COMB ? 3 : 1) k_bfly_upper(
     for (int t = 0; t < nlev; ++t) {
         const int pbit = INV ? p.p_lo + t : p.p_hi - t;
         const int pl = pbit - p.h + p.c;
-        // two butterflies per trip: both twiddle loads are issued ahead of the multiplies
-        for (int bf0 = tid; bf0 < (E >> 1); bf0 += 2 * nt) {
-            const int bf1 = bf0 + nt;
-            const bool ok1 = bf1 < (E >> 1);
-            const int ia0 = ((bf0 >> pl) << (pl + 1)) | (bf0 & ((1 << pl) - 1));
-            const int ia1 = ((bf1 >> pl) << (pl + 1)) | (bf1 & ((1 << pl) - 1));
-            const gf192 tw0 = bf_twiddle(p, coset, base | ((size_t)(ia0 >> p.c) << p.h) | (size_t)(ia0 & cmask), pbit);
-            gf192 tw1 = tw0;
-            if (ok1) tw1 = bf_twiddle(p, coset, base | ((size_t)(ia1 >> p.c) << p.h) | (size_t)(ia1 & cmask), pbit);
-            bf_apply<INV, COMB>(s, E, ia0, ia0 | (1 << pl), tw0, pl >= 6);
-            if (ok1) bf_apply<INV, COMB>(s, E, ia1, ia1 | (1 << pl), tw1, pl >= 6);
+        if (COMB) {
+            // launched only for tiles with >= 64 columns (p.c >= 6), so pl >= 6 at every level: 64 consecutive butterflies share a block and the
+            // twiddle is wave-uniform.  One butterfly per trip, nothing hoisted: the kernel must fit 80 VGPRs (6 waves per SIMD hide the comb
+            // product's branch latency); the twiddle is fetched through a uniform index
+#pragma unroll 1
+            for (int bf = tid; bf < (E >> 1); bf += nt) {
+                const int ia = ((bf >> pl) << (pl + 1)) | (bf & ((1 << pl) - 1));
+                const uint32_t ia_u = __builtin_amdgcn_readfirstlane((uint32_t)(ia & ~63));
+                const gf192 tw = bf_twiddle(p, coset, base | ((size_t)(ia_u >> p.c) << p.h) | (size_t)(ia_u & cmask), pbit);
+                bf_apply<INV, true>(s, E, ia, ia | (1 << pl), tw, true);
+            }
+        } else {
+            for (int bf = tid; bf < (E >> 1); bf += nt) {
+                const int ia = ((bf >> pl) << (pl + 1)) | (bf & ((1 << pl) - 1));
+                const gf192 tw = bf_twiddle(p, coset, base | ((size_t)(ia >> p.c) << p.h) | (size_t)(ia & cmask), pbit);
+                bf_apply<INV, false>(s, E, ia, ia | (1 << pl), tw, false);
+            }
         }
         __syncthreads();
     }
@@ -736,10 +742,10 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         const size_t blocks = ncos << (d - tbits);
         p.total_units = blocks; p.coset_base = cbase;
         p.rs_comb = comb_count ? rs_comb.u64() + 3 * (cbase - comb_base) * d : nullptr;
-        const int maxt = tuning().p2_threads;
+        const int maxt = (tuning().comb && u.c < 6) ? 1024 : tuning().p2_threads;
         const int threads = (1 << tbits) >= 2 * maxt ? maxt : ((1 << tbits) >= 128 ? (1 << tbits) / 2 : 64);
         int rc;
-        if (tuning().comb) {
+        if (tuning().comb && u.c >= 6) {
             if ((rc = set_lds(k_bfly_upper<INV, true>, lds)) != IOPX_OK) return rc;
             { ProfScope ps_("k_bfly_upper", (ncos << d) * 48); hipLaunchKernelGGL((k_bfly_upper<INV, true>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         } else {

@@ -1,93 +1,136 @@
 #!/usr/bin/env python3
 """Generates libiop_amd/csrc/include/iopx/gfx950_comb.h: the GF(2)[x] 192x192 -> 383-bit carry-less product by a
-wave-uniform multiplier as ONE hand-scheduled gfx950 inline-asm block (4-bit-window comb; the per-lane table of
-a*u lives in a fixed VGPR window and is selected with S_SET_GPR_IDX relative addressing, so a window costs 7
-v_xor with no branch and no register copies)."""
+wave-uniform multiplier as ONE hand-scheduled gfx950 inline-asm block.
+
+Round 3 schedule ("uniform-branch comb").  Left-to-right comb with 4-bit windows as before, but the window value — a nibble
+of the wave-uniform c — no longer selects its table entry through S_SET_GPR_IDX relative addressing: the micro-benchmark
+(tools/ubench/comb_rates.hip, profiles/r03_comb_rates.txt) showed that EVERY VALU op with a relative operand issues at the slow
+4.16-cycle rate of shifts / multiplies instead of the 2.5 cycles of a plain v_xor, whatever the scalar work around it.  Instead the
+wave JUMPS (s_setpc_b64 into a 16 x 128-byte block table per word offset) to code with hard-coded registers:
+  * all 336 window XORs are plain fast-class ops;
+  * an entry that is the XOR of two materialised entries is applied with one three-input XOR per word, so only
+    2a, 4a, 8a, 3a, 12a are materialised next to a itself: 35 table VGPRs instead of 112, 35 build ops instead of 124;
+  * each block ends with the dispatch of the next window (one taken branch per window, 56 per product); the branch latency
+    (~58 cycles) is hidden by the other wavefronts of the SIMD: the callers run 5-6 waves per SIMD, which the small table permits.
+Measured (uniform products/s, chip-wide): 5.9e10 (round 2 schedule, 3 waves/SIMD) -> 8.8e10 at 6 waves/SIMD, 9.2e10 at 8.
+"""
 import os
 
-TB = int(os.environ.get("IOPX_COMB_TB", "56"))     # first table VGPR; entries u = 0..15, 7 words each -> v[TB:TB+111].  56: a kernel that keeps its other live values in v0..55 fits 168 VGPRs = 3 waves per SIMD (144, the first choice, pinned every user to 256 VGPRs = 2 waves)
+TB = int(os.environ.get("IOPX_COMB_TB", "40"))     # first table VGPR: v[TB:TB+34]
+SB = int(os.environ.get("IOPX_COMB_SB", "36"))     # scalar scratch: s[SB:SB+17]
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "libiop_amd", "csrc", "include", "iopx", "gfx950_comb.h")
+
+BASIS = {1: None, 2: 0, 4: 1, 8: 2, 3: 3, 12: 4}      # entry -> slot in the VGPR window (a itself is the input operand)
+SPLIT = {5: (4, 1), 6: (4, 2), 7: (4, 3), 9: (8, 1), 10: (8, 2), 11: (8, 3), 13: (12, 1), 14: (12, 2), 15: (12, 3)}
+
+lines = []
+A = lines.append
+L = ".Lcj%=_"
 
 
 def E(u, i):
-    return "v%d" % (TB + 7 * u + i)
-
-
-lines = []
-A = lambda s: lines.append(s)
-A("s_mov_b32 %[sm0], m0")
-# table: E0 = 0, E1 = a
-for i in range(7):
-    A("v_mov_b32 %s, 0" % E(0, i))
-for i in range(6):
-    A("v_mov_b32 %s, %%[a%d]" % (E(1, i), i))
-A("v_mov_b32 %s, 0" % E(1, 6))
+    """register (or operand) of word i of materialised entry u; None when that word is identically zero"""
+    if u == 1:
+        return None if i == 6 else "%%[a%d]" % i
+    return "v%d" % (TB + 7 * BASIS[u] + i)
 
 
 def shl1(dst, src):
     for i in range(6, 0, -1):
-        A("v_alignbit_b32 %s, %s, %s, 31" % (E(dst, i), E(src, i), E(src, i - 1)))
+        if i == 6 and src == 1:
+            A("v_lshrrev_b32 %s, 31, %s" % (E(dst, 6), E(src, 5)))
+        else:
+            A("v_alignbit_b32 %s, %s, %s, 31" % (E(dst, i), E(src, i), E(src, i - 1)))
     A("v_lshlrev_b32 %s, 1, %s" % (E(dst, 0), E(src, 0)))
 
 
-def xor(dst, x, y):
-    for i in range(7):
-        A("v_xor_b32 %s, %s, %s" % (E(dst, i), E(x, i), E(y, i)))
+def dispatch(k):
+    """jump to block (nibble of c[k] selected by the field descriptor in s[SB+16]) of table k"""
+    A("s_bfe_u32 s%d, %%[c%d], s%d" % (SB + 17, k, SB + 16))
+    A("s_lshl_b32 s%d, s%d, 7" % (SB + 17, SB + 17))
+    A("s_add_u32 s%d, s%d, s%d" % (SB, SB + 2 + 2 * k, SB + 17))
+    A("s_addc_u32 s%d, s%d, 0" % (SB + 1, SB + 3 + 2 * k))
+    A("s_setpc_b64 s[%d:%d]" % (SB, SB + 1))
 
 
-shl1(2, 1); xor(3, 2, 1)
-shl1(4, 2); xor(5, 4, 1); xor(6, 4, 2); xor(7, 6, 1)
-shl1(8, 4)
-for v in range(1, 8):
-    xor(8 + v, 8, v)
-# accumulator = 0
+shl1(2, 1); shl1(4, 2); shl1(8, 4)
+for i in range(7):
+    if E(1, i):
+        A("v_xor_b32 %s, %s, %s" % (E(3, i), E(2, i), E(1, i)))
+    else:
+        A("v_mov_b32 %s, %s" % (E(3, i), E(2, i)))
+for i in range(7):
+    A("v_xor_b32 %s, %s, %s" % (E(12, i), E(8, i), E(4, i)))
 for i in range(12):
     A("v_mov_b32 %%[r%d], 0" % i)
-# GPR-index mode stays on for the whole main loop (SRC1-relative); the shifts run with index 0
-A("s_mov_b32 %[st], 0")
-A("s_set_gpr_idx_on %[st], 2")
-for o in range(7, -1, -1):
-    if o != 7:
-        A("s_set_gpr_idx_idx 0")
-        for i in range(11, 0, -1):
-            A("v_alignbit_b32 %%[r%d], %%[r%d], %%[r%d], 28" % (i, i, i - 1))
-        A("v_lshlrev_b32 %[r0], 4, %[r0]")
-    for k in range(6):
-        A("s_bfe_u32 %%[st], %%[c%d], 0x%x" % (k, (4 * o) | (4 << 16)))
-        A("s_mul_i32 %[st], %[st], 7")
-        A("s_set_gpr_idx_idx %[st]")             # SRC1 relative: v[TB + i + 7 * nibble]
-        for i in range(7):
-            A("v_xor_b32 %%[r%d], %%[r%d], %s" % (k + i, k + i, E(0, i)))
-A("s_set_gpr_idx_off")
-A("s_mov_b32 m0, %[sm0]")
+# absolute addresses of the six block tables
+A("s_getpc_b64 s[%d:%d]" % (SB + 14, SB + 15))
+A(L + "anchor:")
+for k in range(6):
+    A("s_add_u32 s%d, s%d, %st%d-%sanchor" % (SB + 2 + 2 * k, SB + 14, L, k, L))
+    A("s_addc_u32 s%d, s%d, 0" % (SB + 3 + 2 * k, SB + 15))
+A("s_mov_b32 s%d, 0x4001c" % (SB + 16))              # s_bfe field descriptor: offset 28, width 4 (the top nibbles first)
+dispatch(0)
+for k in range(6):
+    A(".p2align 7")
+    A(L + "t%d:" % k)
+    for u in range(16):
+        A(".p2align 7")
+        if u:
+            if u in BASIS:
+                for i in range(7):
+                    if E(u, i):
+                        A("v_xor_b32 %%[r%d], %%[r%d], %s" % (k + i, k + i, E(u, i)))
+            else:
+                x, y = SPLIT[u]
+                for i in range(7):
+                    if E(y, i):
+                        A("v_bitop3_b32 %%[r%d], %%[r%d], %s, %s bitop3:0x96" % (k + i, k + i, E(x, i), E(y, i)))
+                    else:
+                        A("v_xor_b32 %%[r%d], %%[r%d], %s" % (k + i, k + i, E(x, i)))
+        if k < 5:
+            dispatch(k + 1)
+        else:
+            A("s_branch %srend" % L)
+A(".p2align 7")
+A(L + "rend:")
+A("s_cmp_eq_u32 s%d, 0x40000" % (SB + 16))
+A("s_cbranch_scc1 %sexit" % L)
+A("s_sub_u32 s%d, s%d, 4" % (SB + 16, SB + 16))
+for i in range(11, 0, -1):
+    A("v_alignbit_b32 %%[r%d], %%[r%d], %%[r%d], 28" % (i, i, i - 1))
+A("v_lshlrev_b32 %[r0], 4, %[r0]")
+dispatch(0)
+A(L + "exit:")
 
 body = "\n".join('        "%s\\n\\t"' % l for l in lines)
-outs = ", ".join('[r%d] "=&v"(r[%d])' % (i, i) for i in range(12)) + ', [st] "=&s"(st), [sm0] "=&s"(sm0)'
+outs = ", ".join('[r%d] "=&v"(r[%d])' % (i, i) for i in range(12))
 ins = ", ".join('[a%d] "v"(a[%d])' % (i, i) for i in range(6)) + ", " + ", ".join('[c%d] "s"(c[%d])' % (i, i) for i in range(6))
-clob = ", ".join('"v%d"' % v for v in range(TB, TB + 112)) + ', "scc"'
+clob = ", ".join(['"v%d"' % v for v in range(TB, TB + 35)] + ['"s%d"' % s for s in range(SB, SB + 18)] + ['"scc"'])
 
 hdr = '''// GENERATED by tools/gen_comb_asm.py — do not edit.
 //
 // r[0..11] = a[0..5] (x) c[0..5]: the 383-bit carry-less product of a per-lane 192-bit a and a WAVE-UNIFORM
-// 192-bit c (c in SGPRs), as one gfx950 inline-asm block.  Left-to-right comb with 4-bit windows
-// (Lopez-Dahab): the per-lane table a*u, u < 16, is built in the fixed VGPR window v[%d:%d]; each of the
-// 48 nibbles of c is extracted on the scalar unit and selects its table entry through S_SET_GPR_IDX
-// (SRC1-relative VGPR addressing), so a window costs exactly 7 v_xor_b32 — no branch, no copies.
-// %d VALU instructions in total.  tests/emu models this function in plain C++.
+// 192-bit c (c in SGPRs), as one gfx950 inline-asm block.  Left-to-right comb with 4-bit windows (Lopez-Dahab).
+// The window value is wave-uniform, so the wave BRANCHES (s_setpc_b64 into a table of 16 x 128-byte code blocks per
+// word offset) to the XORs of that table entry with hard-coded registers: GPR-index relative addressing, which the
+// round-2 schedule used, makes every VALU op that has a relative operand issue at the slow (shift-class) rate on gfx950.
+// Table: a (the input operand), 2a, 4a, 8a, 3a, 12a in v[%d:%d]; the other entries are applied as one three-input XOR per
+// word.  Scalar scratch s[%d:%d].  One taken branch per window: run it at >= 5 waves per SIMD.
+// The caller guarantees that c is identical in every lane (the branches are taken on c alone; EXEC is untouched).
+// tests/emu models this function in plain C++.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 __device__ __forceinline__ void comb_clmul_192_uniform(uint32_t (&r)[12], const uint32_t (&a)[6], const uint32_t (&c)[6])
 {
-    uint32_t st, sm0;
     asm volatile(
 %s
         : %s
         : %s
         : %s);
-    (void)st; (void)sm0;
 }
-''' % (TB, TB + 111, sum(1 for l in lines if l.startswith("v_")), body, outs, ins, clob)
+''' % (TB, TB + 34, SB, SB + 17, body, outs, ins, clob)
 open(OUT, "w").write(hdr)
-print("wrote", OUT, "VALU:", sum(1 for l in lines if l.startswith("v_")), "SALU:", sum(1 for l in lines if l.startswith("s_")))
+print("wrote", OUT)
