@@ -344,8 +344,13 @@ struct TableKey {
     uint64_t w[7];
     bool operator<(const TableKey &o) const { return memcmp(w, o.w, sizeof(w)) < 0; }
 };
-static std::map<TableKey, std::unique_ptr<DevBuf>> g_pow_tables;        // device tables of build_two_level, dropped by clear_mul_plans()
+static std::map<TableKey, std::shared_ptr<DevBuf>> g_pow_tables;        // device tables of build_two_level, dropped by clear_mul_plans()
 static std::mutex g_pow_tables_mu;
+static size_t pow_table_cap()
+{
+    static const size_t cap = [] { const char *v = getenv("IOPX_POW_TABLE_CAP"); const long x = v ? atol(v) : 0; return (size_t)(x >= 1 ? x : 256); }();   // the env override exists for the eviction test
+    return cap;
+}
 
 static int cached_pow_table(const hfp3 &base, const hfp3 &init, int bits, bool use_cache, TmpBuf &out)
 {
@@ -360,16 +365,15 @@ static int cached_pow_table(const hfp3 &base, const hfp3 &init, int bits, bool u
     std::lock_guard<std::mutex> lk(g_pow_tables_mu);
     auto it = g_pow_tables.find(key);
     if (it == g_pow_tables.end()) {
-        if (g_pow_tables.size() >= 256) {                                // rare: drain the stream, then drop everything (kernels in flight read these tables)
-            (void)hipStreamSynchronize(stream());
-            g_pow_tables.clear();
-        }
-        std::unique_ptr<DevBuf> buf(new DevBuf());
+        // rare: drop the cache.  Tables borrowed by a call in progress stay alive through that call's TmpBuf (shared ownership); the
+        // others are freed here — hipFree waits for the device, so kernels in flight that read them have finished by then
+        if (g_pow_tables.size() >= pow_table_cap()) g_pow_tables.clear();
+        std::shared_ptr<DevBuf> buf(new DevBuf());
         if ((rc = buf->alloc(bytes)) != IOPX_OK) return rc;
         if ((rc = fp_build_pow(buf->u64(), base, init, bits)) != IOPX_OK) return rc;
         it = g_pow_tables.emplace(key, std::move(buf)).first;
     }
-    out.borrow(it->second->p, bytes);
+    out.borrow(it->second->p, bytes, it->second);
     return IOPX_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <string>
 #include "../../include/libiop_amd.h"
 
@@ -83,14 +84,19 @@ struct TmpBuf {
         if (!p) return;
         if (!borrowed) tmp_free(p, cap);
         p = nullptr; bytes = 0; cap = 0; borrowed = false;
+        keep.reset();
     }
-    // points at device memory owned elsewhere (a cached table): released without being returned to the pool
-    void borrow(void *q, size_t n)
+    // points at device memory owned elsewhere (a cached table): released without being returned to the pool.  `owner` keeps the
+    // table alive for as long as this call holds it, so a cache eviction between the borrow and the kernel launch cannot free it
+    // (hipFree in the last owner's destructor waits for the device, so kernels in flight are safe as well)
+    void borrow(void *q, size_t n, std::shared_ptr<DevBuf> owner = nullptr)
     {
         release();
         p = q; bytes = n; cap = 0; borrowed = true;
+        keep = std::move(owner);
     }
     bool borrowed = false;
+    std::shared_ptr<DevBuf> keep;
     uint64_t *u64() const { return (uint64_t *)p; }
 };
 

@@ -35,7 +35,7 @@ int fail(int code, const char *fmt, ...)
 
 const char *last_error() { return g_err; }
 
-hipStream_t stream() { return g_stream; }
+hipStream_t stream() { std::lock_guard<std::mutex> lk(g_mu); return g_stream; }
 int bound_device();
 
 int ensure_device()
@@ -75,9 +75,11 @@ int set_stream(void *s, bool own)
 {
     int rc = ensure_device();
     if (rc != IOPX_OK) return rc;
-    // temporaries are recycled in stream order: drain the old stream before work moves to another one
-    (void)hipStreamSynchronize(g_stream);
+    // temporaries are recycled in stream order: drain the old stream before work moves to another one.  Read, drain and
+    // switch under the lock, so a concurrent iopx_set_stream / iopx_use_own_stream from another host thread cannot make this
+    // call drain a stream that is no longer (or not yet) the current one
     std::lock_guard<std::mutex> lk(g_mu);
+    (void)hipStreamSynchronize(g_stream);
     g_caller_stream = !own;
     g_stream = own ? g_own_stream : (hipStream_t)s;
     return IOPX_OK;
@@ -109,7 +111,7 @@ void *tmp_alloc(size_t bytes, size_t *cap)
     if (hipMalloc(&p, c) != hipSuccess) {
         // out of memory: drop the cache (after draining the stream) and retry once
         (void)hipGetLastError();
-        (void)hipStreamSynchronize(g_stream);
+        (void)hipStreamSynchronize(stream());
         std::lock_guard<std::mutex> lk(g_tmp_mu);
         for (auto &b : g_tmp_free) (void)hipFree(b.p);
         g_tmp_free.clear();

@@ -248,6 +248,13 @@ class DeviceOps:
 
     def __init__(self, lib, torch, device, field):
         self.lib, self.torch, self.device, self.field = lib, torch, device, field
+        # The provers interleave torch ops (copies, index assignments, torch.cat, buffers recycled by the caching allocator) with
+        # library kernels WITHOUT host synchronisation: that is only ordered when both enqueue on the same stream.  Refuse the
+        # unshared configuration instead of racing (libiop_amd/dist.py's collectives have their own host-synchronised fallback).
+        dev = torch.device(device) if not isinstance(device, torch.device) else device
+        if dev.type == "cuda" and not lib.shares_stream_with(torch, dev):
+            raise RuntimeError("DeviceOps: the library must enqueue on torch's current stream — call "
+                               "lib.set_stream(torch.cuda.current_stream().cuda_stream) before constructing the operators")
 
     # ---- layout: one GPU holds every vector whole (libiop_amd/dist.py overrides these for contiguous-coset sharding) ----
     def local_size(self, domain):

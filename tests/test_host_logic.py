@@ -97,3 +97,12 @@ def test_fri_commit_multiplicative_matches_oracle_composition():
     final = oracle.multiplicative_ifft(f, oracle.fp_from_ints([sh_int])[0])
     assert not final[1 << (d - sum(loc)):].any()
     assert np.array_equal(res.final_polynomial, final[: 1 << (d - sum(loc))])
+
+
+def test_device_operators_refuse_an_unshared_stream():
+    """the provers interleave torch ops with library kernels without host synchronisation, which is only ordered when
+    the library enqueues on torch's current stream; constructing the operators on a cuda device without that must fail loudly."""
+    from libiop_amd import domains
+    with pytest.raises(RuntimeError, match="set_stream"):
+        domains.DeviceOps(emu(), torch, torch.device("cuda:0"), domains.GF192())
+    domains.DeviceOps(emu(), torch, torch.device("cpu"), domains.GF192())         # the CPU emulation has no streams

@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(256) k_mul(const uint64_t *in, uint64_t *out, 
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     gf192 x = gf_load(in, i & 0xffff);
     gf192 u = gf_load(in, 5 + (blockIdx.x & 7));
+    if (V == -2) u = gf_load(in, (i * 7 + 3) & 0xffff);       // both operands per lane
     if (check) {
         // one product, compared with the general multiplier (top bits of x set on some lanes to exercise the a_hi split)
         if (threadIdx.x & 1) x.w[5] |= 0xe0000000u;
@@ -207,7 +208,8 @@ int main()
     run_issue<12>("round: 6x(7 + bfe,set_idx) + shift12", d, 54);
     run_issue<13>("round: 6x(7 + bfe,mul,set_idx) + shift12", d, 54);
     printf("== whole products (uniform-multiplier products per second, chip-wide) ==\n");
-    run_mul<-1>("general", in, out, h, 4);
+    run_mul<-1>("general(u unif)", in, out, h, 4);
+    run_mul<-2>("general", in, out, h, 4);
     run_mul<0>("v0", in, out, h, 3);
     run_mul<1>("v1", in, out, h, 3);
     run_mul<2>("v2", in, out, h, 3);
