@@ -399,6 +399,37 @@ int iopx_gf192_mul_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out
 /* d_out[i] = d_a[i] * d_c[0]: the wave-uniform-multiplier path the butterfly kernels use. */
 int iopx_gf192_mul_uniform_dev(const uint64_t *d_a, const uint64_t *d_c, uint64_t *d_out, size_t count);
 
+/* ---- support for a native prover built on this ABI (libiop_amd/cpp/{iop,aurora}.hpp; libiop_amd/csrc/prover_support.hip) ---- */
+/* Pooled device allocations for oracles, trees and scratch vectors: blocks are recycled in the order of the library's stream (all
+ * work of the library is enqueued on one stream), so freeing and re-allocating a codeword costs no hipMalloc / hipFree and needs no
+ * synchronisation.  The reference's counterpart is the heap behind std::vector<FieldT> in oracle<FieldT> (libiop/iop/oracles.hpp:22-52). */
+int iopx_pool_alloc(void **dptr, size_t bytes);
+int iopx_pool_free(void *dptr);
+/* Stream-ordered device-to-device copy / byte fill; small host-to-device upload through the library's pinned staging (returns
+ * without synchronising; the host buffer may be released on return). */
+int iopx_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes);
+int iopx_memset_dev(void *dst_dev, int value, size_t bytes);
+int iopx_upload_small(void *dst_dev, const void *src_host, size_t bytes);
+/* d_dst[i] = d_src[d_index[i]] / d_dst[d_index[i]] = d_src[i] for elements of elem_bytes (a multiple of 8) bytes: a whole vector
+ * moved through field_subset::reindex_by_subset (libiop/algebra/field_subset/field_subset.tcc:130-142) — basic_lincheck_aux.tcc:50-58,
+ * r1cs_rs_iop.tcc:406-430 on multiplicative domains. */
+int iopx_gather_dev(const void *d_src, const uint64_t *d_index, size_t count, size_t elem_bytes, void *d_dst);
+int iopx_scatter_dev(const void *d_src, const uint64_t *d_index, size_t count, size_t elem_bytes, void *d_dst);
+/* Bytes moved by every host<->device copy the library has made (optionally reset): what a caller checks to assert that no
+ * codeword-sized vector crossed PCIe during a proof. */
+int iopx_transfer_stats(uint64_t *h2d_bytes, uint64_t *d2h_bytes, int reset);
+/* BLAKE2b (RFC 7693; libsodium's crypto_generichash_blake2b in the reference) on the host, for the Fiat-Shamir hashchain
+ * (libiop/bcs/hashing/blake2b.tcc:10-110, blake2b.cpp:50-74): outlen 1..64, optional key (<= 64 bytes). */
+int iopx_blake2b_host(uint8_t *out, size_t outlen, const void *msg, size_t msglen, const void *key, size_t keylen);
+/* Host scalar arithmetic for per-proof constants (never codeword-sized data): GF(2^192) product; edwards_Fr sum, difference,
+ * inverse, FieldT(uint64) (Montgomery form) and the modulus words (the rejection bound of blake2b.tcc:197-227). */
+int iopx_gf192_host_mul(const uint64_t *a, const uint64_t *b, uint64_t *out);
+int iopx_fp3_host_add(const uint64_t *a, const uint64_t *b, uint64_t *out);
+int iopx_fp3_host_sub(const uint64_t *a, const uint64_t *b, uint64_t *out);
+int iopx_fp3_host_inverse(const uint64_t *a, uint64_t *out);
+int iopx_fp3_from_uint(uint64_t value, uint64_t *out);
+int iopx_fp3_modulus(uint64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

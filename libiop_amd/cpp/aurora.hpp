@@ -1,0 +1,805 @@
+// Aurora SNARK prover (non-zk, BLAKE2b) for C++ callers: the reference's composition, every vector in HBM.
+//
+//   aurora_snark_parameters / aurora_snark_prover        libiop/snark/aurora_snark.tcc:38-146
+//   aurora_iop_parameters, aurora_iop                    libiop/protocols/aurora_iop.tcc:3-186, 262-344
+//   encoded_aurora_protocol, fz_virtual_oracle           libiop/protocols/encoded/r1cs_rs_iop/r1cs_rs_iop.tcc
+//   multi_lincheck, multi_lincheck_virtual_oracle        libiop/protocols/encoded/lincheck/basic_lincheck{,_aux}.tcc
+//   batch_sumcheck_protocol, sumcheck_g_oracle           libiop/protocols/encoded/sumcheck/sumcheck.tcc
+//   rowcheck_ABC_virtual_oracle,
+//   random_linear_combination_oracle                     libiop/protocols/encoded/common/{rowcheck,random_linear_combination}.tcc
+//   LDT_instance_reducer, combined_LDT_virtual_oracle    libiop/protocols/ldt/ldt_reducer{,_aux}.tcc
+//   FRI_protocol                                         libiop/protocols/ldt/fri/fri_ldt.tcc:260-548
+//
+// Registration order — which fixes rounds, Merkle trees and the hashchain's squeeze order — is the reference's.  The bodies call
+// the device operators of include/libiop_amd.h; nothing codeword-sized is ever in a std::vector.  Zero knowledge is out of scope
+// (masks and salts come from libsodium randomness: not reproducible).  Citations are relative to the reference tree.
+#pragma once
+#include <cmath>
+
+#include "r1cs.hpp"
+
+namespace libiop_amd {
+
+// ---- device operators, dispatched on the domain type (FFT_over_field_subset and friends dispatch the same way, fft.tcc:407-475) ----
+namespace dev {
+
+template<typename FieldT> inline const uint64_t *basis_words(const field_subset<FieldT> &D) { return detail::words(D.basis().data()); }
+template<typename FieldT> inline const uint64_t *shift_words(const field_subset<FieldT> &D) { return detail::words(&D.shift()); }
+template<typename FieldT> inline const uint64_t *gen_words(const field_subset<FieldT> &D) { return detail::words(&D.generator()); }
+template<typename FieldT> inline bool additive(const field_subset<FieldT> &D) { return D.type() == affine_subspace_type; }
+
+template<typename FieldT>
+device_vector<FieldT> FFT(const device_vector<FieldT> &coeffs, std::size_t n_coeffs, const field_subset<FieldT> &D)            // fft.tcc:407-419
+{
+    device_vector<FieldT> out(D.num_elements());
+    if (additive(D)) check(iopx_add_fft_gf192_dev(coeffs.words(), n_coeffs, basis_words(D), D.dimension(), shift_words(D), out.words()));
+    else check(iopx_mul_fft_fp3_dev(coeffs.words(), n_coeffs, D.dimension(), gen_words(D), shift_words(D), out.words()));
+    return out;
+}
+
+template<typename FieldT>
+device_vector<FieldT> IFFT(const device_vector<FieldT> &evals, const field_subset<FieldT> &D)                                   // fft.tcc:421-433
+{
+    if (evals.size() != D.num_elements()) throw std::invalid_argument("IFFT: evaluation count != domain size");
+    device_vector<FieldT> out(D.num_elements());
+    if (additive(D)) check(iopx_add_ifft_gf192_dev(evals.words(), basis_words(D), D.dimension(), shift_words(D), out.words()));
+    else check(iopx_mul_ifft_fp3_dev(evals.words(), D.dimension(), gen_words(D), shift_words(D), out.words()));
+    return out;
+}
+
+// FFT_over_field_subset(IFFT_over_field_subset(v, H), L) for `batch` vectors stored back to back.  When H is spanned by the first basis
+// vectors of L the coefficient form is skipped (iopx_add_reextend_gf192_batch_dev); otherwise the two transforms run one after the other.
+template<typename FieldT>
+std::vector<device_vector<FieldT>> reextend_packed(const device_vector<FieldT> &packed, std::size_t batch, const field_subset<FieldT> &H,
+                                                   const field_subset<FieldT> &L)
+{
+    const std::size_t n = H.num_elements();
+    std::vector<device_vector<FieldT>> outs;
+    bool prefix = additive(L) && H.dimension() <= L.dimension();
+    if (prefix) for (std::size_t i = 0; i < H.dimension(); ++i) prefix = prefix && std::memcmp(&H.basis()[i], &L.basis()[i], sizeof(FieldT)) == 0;
+    if (prefix) {
+        std::vector<uint64_t *> ptrs;
+        for (std::size_t k = 0; k < batch; ++k) { outs.emplace_back(L.num_elements()); ptrs.push_back(outs.back().words()); }
+        check(iopx_add_reextend_gf192_batch_dev(packed.words(), batch, basis_words(L), L.dimension(), H.dimension(), shift_words(H), shift_words(L), 0,
+                                                (std::size_t)1 << (L.dimension() - H.dimension()), ptrs.data()));
+        return outs;
+    }
+    for (std::size_t k = 0; k < batch; ++k) outs.push_back(FFT<FieldT>(IFFT<FieldT>(packed.slice(k * n, n), H), n, L));
+    return outs;
+}
+
+// IFFT_of_known_degree_over_field_subset (fft.tcc:435-475): 2^ceil(log2 degree) coefficients
+template<typename FieldT>
+device_vector<FieldT> IFFT_of_known_degree(const device_vector<FieldT> &evals, std::size_t degree, const field_subset<FieldT> &D)
+{
+    const std::size_t k = detail::log2_ceil(degree);
+    if (additive(D)) return IFFT<FieldT>(evals.slice(0, (std::size_t)1 << k), D.get_subset_of_order((std::size_t)1 << k));
+    device_vector<FieldT> out((std::size_t)1 << k);
+    check(iopx_mul_ifft_known_degree_fp3_dev(evals.words(), degree, D.dimension(), gen_words(D), shift_words(D), out.words()));
+    return out;
+}
+
+template<typename FieldT>
+device_vector<FieldT> fold(const device_vector<FieldT> &f, const field_subset<FieldT> &D, std::size_t coset_size, const FieldT &x_i)        // fri_aux.tcc:5-34
+{
+    device_vector<FieldT> out(D.num_elements() / coset_size);
+    if (additive(D)) check(iopx_fri_fold_add_gf192_dev(f.words(), basis_words(D), D.dimension(), shift_words(D), coset_size, detail::words(&x_i), out.words()));
+    else check(iopx_fri_fold_mul_fp3_dev(f.words(), D.dimension(), gen_words(D), shift_words(D), coset_size, detail::words(&x_i), out.words()));
+    return out;
+}
+
+template<typename FieldT>
+device_vector<FieldT> sub(const device_vector<FieldT> &a, const device_vector<FieldT> &b)
+{
+    if (a.size() != b.size()) throw std::invalid_argument("sub: size mismatch");
+    device_vector<FieldT> out(a.size());
+    if (field_host<FieldT>::additive()) check(iopx_gf192_add_dev(a.words(), b.words(), out.words(), a.size()));
+    else check(iopx_fp3_sub_dev(a.words(), b.words(), out.words(), a.size()));
+    return out;
+}
+
+template<typename FieldT>
+device_vector<FieldT> pow_table(std::size_t count, const FieldT &base, const FieldT &init)                                      // out[l] = init * base^l
+{
+    device_vector<FieldT> out(count);
+    if (field_host<FieldT>::additive()) check(iopx_gf192_pow_table_dev(out.words(), count, detail::words(&base), detail::words(&init)));
+    else check(iopx_fp3_pow_table_dev(out.words(), count, detail::words(&base), detail::words(&init)));
+    return out;
+}
+
+// polynomial_over_vanishing_polynomial(P, Z_D).first: n_coeffs - |D| coefficients
+template<typename FieldT>
+device_vector<FieldT> poly_div_vanishing(const device_vector<FieldT> &poly, std::size_t n_coeffs, const field_subset<FieldT> &D)
+{
+    device_vector<FieldT> out(n_coeffs > D.num_elements() ? n_coeffs - D.num_elements() : 0);
+    if (n_coeffs > D.num_elements()) {
+        if (additive(D)) check(iopx_poly_div_vanishing_gf192_dev(poly.words(), n_coeffs, basis_words(D), D.dimension(), shift_words(D), out.words()));
+        else check(iopx_poly_div_vanishing_fp3_dev(poly.words(), n_coeffs, D.dimension(), shift_words(D), out.words()));
+    }
+    return out;
+}
+
+template<typename FieldT>
+std::vector<const void *> pointers(const std::vector<device_vector<FieldT>> &v, std::size_t first = 0)
+{
+    std::vector<const void *> p;
+    for (std::size_t i = first; i < v.size(); ++i) p.push_back(v[i].data());
+    return p;
+}
+
+} // namespace dev
+
+// ---- parameters (aurora_snark.tcc:38-101, aurora_iop.tcc:3-186, common_bcs_parameters.tcc:9-27; non-zk, heuristic FRI soundness,
+// optimistic-heuristic LDT-reducer soundness: the settings of profiling/instrument_aurora_snark.cpp:209-217) ----
+inline std::vector<std::size_t> localization_parameter_to_array(std::size_t localization_parameter, std::size_t codeword_domain_dim, std::size_t RS_extra_dimensions)
+{
+    const std::size_t num_reductions = ((codeword_domain_dim - RS_extra_dimensions - 1) / localization_parameter) + 1;      // fri_ldt.tcc:132-146
+    std::vector<std::size_t> out(1, 1);
+    for (std::size_t i = 1; i < num_reductions; ++i) out.push_back(localization_parameter);
+    return out;
+}
+
+template<typename FieldT>
+struct aurora_snark_parameters {
+    std::size_t security_parameter_, RS_extra_dimensions_, num_constraints_, num_variables_, num_inputs_;
+    std::size_t constraint_domain_dim_, variable_domain_dim_, summation_domain_dim_, codeword_domain_dim_;
+    std::size_t pow_bits_, query_soundness_error_bits_, interactive_soundness_error_bits_;
+    std::vector<std::size_t> localization_parameters_;
+    std::size_t max_tested_degree_bound_, max_constraint_degree_bound_, multi_lincheck_repetitions_, absolute_proximity_parameter_;
+    std::size_t num_output_LDT_instances_, fri_query_repetitions_, fri_interactive_repetitions_;
+
+    static bool is_pow2(std::size_t n) { return n > 0 && (n & (n - 1)) == 0; }
+    static std::size_t repetitions(double bits, double per) { const double r = std::ceil(-bits / per); return r < 1 ? 1 : (std::size_t)r; }
+
+    aurora_snark_parameters(std::size_t num_constraints, std::size_t num_variables, std::size_t num_inputs, std::size_t security_parameter = 128,
+                            std::size_t RS_extra_dimensions = 5, std::size_t FRI_localization_parameter = 2)
+        : security_parameter_(security_parameter), RS_extra_dimensions_(RS_extra_dimensions), num_constraints_(num_constraints), num_variables_(num_variables),
+          num_inputs_(num_inputs)
+    {
+        if (!is_pow2(num_constraints)) throw std::invalid_argument("number of constraints in the constraint system must a power of two.");
+        if (!is_pow2(num_variables + 1)) throw std::invalid_argument("number of variables in the constraint system must be one less than a power of two.");
+        if (!is_pow2(num_inputs + 1)) throw std::invalid_argument("number of inputs in the constraint system must be one less than a power of two.");
+        constraint_domain_dim_ = detail::log2_ceil(num_constraints);                          // aurora_iop.tcc:35-36
+        variable_domain_dim_ = detail::log2_ceil(num_variables + 1);
+        summation_domain_dim_ = std::max(constraint_domain_dim_, variable_domain_dim_);
+        codeword_domain_dim_ = summation_domain_dim_ + RS_extra_dimensions;                   // :39-43 (make_zk false)
+        pow_bits_ = constraint_domain_dim_ + 3;                                               // common_bcs_parameters.tcc:23-25
+        query_soundness_error_bits_ = security_parameter + 1 - pow_bits_;                     // aurora_iop.tcc:77
+        interactive_soundness_error_bits_ = security_parameter + 3;                           // :78
+        localization_parameters_ = localization_parameter_to_array(FRI_localization_parameter, codeword_domain_dim_, RS_extra_dimensions);
+        max_tested_degree_bound_ = (std::size_t)1 << summation_domain_dim_;                   // r1cs_rs_iop.tcc:56-63
+        max_constraint_degree_bound_ = std::max(2 * ((std::size_t)1 << summation_domain_dim_) - 1, 2 * ((std::size_t)1 << constraint_domain_dim_) - 1);
+        const double fbits = (double)field_host<FieldT>::soundness_bits();
+        multi_lincheck_repetitions_ = repetitions((double)interactive_soundness_error_bits_, (double)constraint_domain_dim_ - fbits);     // basic_lincheck.tcc:52-56
+        const std::size_t codeword_size = (std::size_t)1 << codeword_domain_dim_;
+        absolute_proximity_parameter_ = std::min(codeword_size - max_constraint_degree_bound_, codeword_size - max_tested_degree_bound_) - 1;   // ldt_reducer.tcc:34-42
+        num_output_LDT_instances_ = repetitions((double)interactive_soundness_error_bits_, (double)codeword_domain_dim_ - fbits);         // :53-56
+        std::size_t total_localization = 0;
+        for (std::size_t l : localization_parameters_) total_localization += l;
+        if (max_tested_degree_bound_ % ((std::size_t)1 << total_localization))
+            throw std::invalid_argument("FRI only supports testing degree bounds that are a multiple of 2^{sum of localization parameters}.");
+        const double delta = (double)absolute_proximity_parameter_ / (double)codeword_size;   // fri_ldt.tcc:83-106 (heuristic)
+        fri_query_repetitions_ = repetitions((double)query_soundness_error_bits_, std::log2(1 - delta));
+        const double per_interaction = std::log2((double)(((std::size_t)1 << localization_parameters_[0]) - 1)) - fbits;
+        fri_interactive_repetitions_ = repetitions((double)interactive_soundness_error_bits_, per_interaction);
+    }
+};
+
+// ---- virtual oracles: evaluated_contents on device vectors ------------------------------------------------------------------------
+template<typename FieldT>
+class fz_virtual_oracle : public virtual_oracle<FieldT> {                                    // r1cs_rs_iop.tcc:141-222: fw * Z_I + f_1v
+    std::size_t primary_input_size_;
+    field_subset<FieldT> input_variable_domain_, codeword_domain_;
+    device_vector<FieldT> f1v_coefficients_;
+    bool primary_input_set_ = false;
+public:
+    fz_virtual_oracle(std::size_t primary_input_size, const field_subset<FieldT> &input_variable_domain, const field_subset<FieldT> &codeword_domain)
+        : primary_input_size_(primary_input_size), input_variable_domain_(input_variable_domain), codeword_domain_(codeword_domain)
+    {
+        if (input_variable_domain.num_elements() > codeword_domain.num_elements()) throw std::invalid_argument("Codeword domain must be bigger than the input variable domain.");
+    }
+    void set_primary_input(const std::vector<FieldT> &primary_input)
+    {
+        if (primary_input.size() != primary_input_size_) throw std::invalid_argument("Primary input size does not match the previously declared size.");
+        std::vector<FieldT> f1v_evals(1, field_host<FieldT>::one());                          // :199-206
+        f1v_evals.insert(f1v_evals.end(), primary_input.begin(), primary_input.end());
+        f1v_coefficients_ = dev::IFFT<FieldT>(device_vector<FieldT>(device_array<FieldT>::from_host(f1v_evals)), input_variable_domain_);   // :207-210
+        primary_input_set_ = true;
+    }
+    const device_vector<FieldT> &f1v_coefficients() const { return f1v_coefficients_; }
+    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &constituents) const override
+    {
+        if (constituents.size() != 1) throw std::invalid_argument("fz_virtual_oracle has one constituent oracle.");
+        if (!primary_input_set_) throw std::logic_error("Evaluation requested before primary_input is set.");
+        const field_subset<FieldT> &L = codeword_domain_, &I = input_variable_domain_;
+        const device_vector<FieldT> f1v = dev::FFT<FieldT>(f1v_coefficients_, I.num_elements(), L);      // :211-212
+        device_vector<FieldT> out(L.num_elements());
+        if (dev::additive(L))
+            check(iopx_fz_gf192_dev(constituents[0].words(), f1v.words(), dev::basis_words(L), L.dimension(), dev::shift_words(L), dev::basis_words(I),
+                                    I.dimension(), dev::shift_words(I), out.words()));
+        else
+            check(iopx_fz_fp3_dev(constituents[0].words(), f1v.words(), L.dimension(), dev::gen_words(L), dev::shift_words(L), I.dimension(), dev::shift_words(I),
+                                  out.words()));
+        return out;
+    }
+};
+
+template<typename FieldT>
+class rowcheck_ABC_virtual_oracle : public virtual_oracle<FieldT> {                           // common/rowcheck.tcc:5-88
+    field_subset<FieldT> codeword_domain_, constraint_domain_;
+public:
+    rowcheck_ABC_virtual_oracle(const field_subset<FieldT> &codeword_domain, const field_subset<FieldT> &constraint_domain)
+        : codeword_domain_(codeword_domain), constraint_domain_(constraint_domain) {}
+    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
+    {
+        if (c.size() != 3) throw std::invalid_argument("rowcheck_ABC has three constituent oracles.");
+        const field_subset<FieldT> &L = codeword_domain_, &H = constraint_domain_;
+        device_vector<FieldT> out(L.num_elements());
+        if (dev::additive(L))
+            check(iopx_rowcheck_gf192_dev(c[0].words(), c[1].words(), c[2].words(), dev::basis_words(L), L.dimension(), dev::shift_words(L), H.dimension(),
+                                          dev::shift_words(H), out.words()));
+        else
+            check(iopx_rowcheck_fp3_dev(c[0].words(), c[1].words(), c[2].words(), L.dimension(), dev::gen_words(L), dev::shift_words(L), H.dimension(),
+                                        dev::shift_words(H), out.words()));
+        return out;
+    }
+};
+
+template<typename FieldT>
+class multi_lincheck_virtual_oracle : public virtual_oracle<FieldT> {                         // basic_lincheck_aux.tcc:5-144
+    field_subset<FieldT> codeword_domain_, constraint_domain_, variable_domain_, summation_domain_;
+    const std::vector<sparse_matrix<FieldT>> *matrices_T_;
+    std::vector<FieldT> r_Mz_;
+    device_vector<FieldT> p_alpha_evals_;
+public:
+    multi_lincheck_virtual_oracle(const field_subset<FieldT> &L, const field_subset<FieldT> &C, const field_subset<FieldT> &V, const field_subset<FieldT> &S,
+                                  const std::vector<sparse_matrix<FieldT>> *transposed_matrices)
+        : codeword_domain_(L), constraint_domain_(C), variable_domain_(V), summation_domain_(S), matrices_T_(transposed_matrices) {}
+    // :29-99 — alpha powers, p_alpha_prime (the powers at the constraint positions of the summation domain), p_alpha_ABC
+    // (sum_m r_m M_m^T applied to the powers); the interpolation of :94-98 happens together with the extension of :112-118
+    void set_challenge(const FieldT &alpha, const std::vector<FieldT> &r_Mz)
+    {
+        if (r_Mz.size() != matrices_T_->size()) throw std::invalid_argument("Not enough random linear combination coefficients were provided");
+        r_Mz_ = r_Mz;
+        const field_subset<FieldT> &C = constraint_domain_, &S = summation_domain_;
+        const device_vector<FieldT> alpha_powers = dev::pow_table<FieldT>(C.num_elements(), alpha, field_host<FieldT>::one());      // :37-45
+        p_alpha_evals_ = device_vector<FieldT>(2 * S.num_elements());
+        const device_vector<FieldT> prime = p_alpha_evals_.slice(0, S.num_elements()), abc = p_alpha_evals_.slice(S.num_elements(), S.num_elements());
+        if (C.num_elements() == S.num_elements()) {
+            prime.copy_from(alpha_powers);                                                   // reindex_by_subset is the identity
+        } else {                                                                             // :50-58
+            std::vector<uint64_t> idx(C.num_elements());
+            for (std::size_t i = 0; i < idx.size(); ++i) idx[i] = S.reindex_by_subset(C.dimension(), i);
+            const device_array<uint64_t> d_idx = device_array<uint64_t>::from_host(idx);
+            prime.fill_zero();
+            check(iopx_scatter_dev(alpha_powers.data(), d_idx.data(), idx.size(), sizeof(FieldT), prime.data()));
+        }
+        for (std::size_t m = 0; m < matrices_T_->size(); ++m) (*matrices_T_)[m].times_vector(alpha_powers, abc, &r_Mz_[m], m > 0);     // :64-88
+    }
+    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
+    {
+        if (c.size() != matrices_T_->size() + 1) throw std::invalid_argument("multi_lincheck uses more constituent oracles than what was provided.");
+        const std::vector<device_vector<FieldT>> p = dev::reextend_packed<FieldT>(p_alpha_evals_, 2, summation_domain_, codeword_domain_);     // :94-98 + :112-118
+        const std::vector<const void *> Mz = dev::pointers(c, 1);
+        device_vector<FieldT> out(c[0].size());
+        auto fn = field_host<FieldT>::additive() ? iopx_lincheck_gf192_dev : iopx_lincheck_fp3_dev;
+        check(fn(c[0].words(), Mz.data(), Mz.size(), detail::words(r_Mz_.data()), p[0].words(), p[1].words(), c[0].size(), out.words()));
+        return out;
+    }
+};
+
+template<typename FieldT>
+class random_linear_combination_oracle : public virtual_oracle<FieldT> {                      // common/random_linear_combination.tcc
+    std::size_t num_oracles_;
+    std::vector<FieldT> coefficients_;
+public:
+    explicit random_linear_combination_oracle(std::size_t num_oracles) : num_oracles_(num_oracles) {}
+    void set_random_coefficients(const std::vector<FieldT> &coefficients)
+    {
+        if (coefficients.size() != num_oracles_) throw std::invalid_argument("Random Linear Combination Oracle: Expected same number of random coefficients as oracles.");
+        coefficients_ = coefficients;
+    }
+    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
+    {
+        if (c.size() != num_oracles_) throw std::invalid_argument("Random Linear Combination Oracle: Expected same number of evaluations as in registration.");
+        const std::vector<const void *> ptrs = dev::pointers(c);
+        device_vector<FieldT> out(c[0].size());
+        auto fn = field_host<FieldT>::additive() ? iopx_lincomb_gf192_dev : iopx_lincomb_fp3_dev;
+        check(fn(ptrs.data(), ptrs.size(), detail::words(coefficients_.data()), c[0].size(), out.words()));
+        return out;
+    }
+};
+
+template<typename FieldT>
+class sumcheck_g_oracle : public virtual_oracle<FieldT> {                                     // sumcheck.tcc:11-119
+    field_subset<FieldT> summation_domain_, codeword_domain_;
+    FieldT claimed_sum_;
+public:
+    sumcheck_g_oracle(const field_subset<FieldT> &summation_domain, const field_subset<FieldT> &codeword_domain)
+        : summation_domain_(summation_domain), codeword_domain_(codeword_domain), claimed_sum_(field_host<FieldT>::zero()) {}
+    void set_claimed_sum(const FieldT &claimed_sum) { claimed_sum_ = claimed_sum; }
+    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
+    {
+        if (c.size() != 2) throw std::invalid_argument("sumcheck_g_oracle has two constituent oracles");
+        const field_subset<FieldT> &L = codeword_domain_, &H = summation_domain_;
+        device_vector<FieldT> out(L.num_elements());
+        if (dev::additive(L))
+            check(iopx_sumcheck_g_gf192_dev(c[0].words(), c[1].words(), dev::basis_words(L), L.dimension(), dev::shift_words(L), dev::basis_words(H), H.dimension(),
+                                            dev::shift_words(H), detail::words(&claimed_sum_), out.words()));
+        else
+            check(iopx_sumcheck_g_fp3_dev(c[0].words(), c[1].words(), L.dimension(), dev::gen_words(L), dev::shift_words(L), H.dimension(), dev::shift_words(H),
+                                          detail::words(&claimed_sum_), out.words()));
+        return out;
+    }
+};
+
+// combined_LDT_virtual_oracle on device vectors (ldt_reducer_aux.tcc:3-131); libiop_amd.hpp holds the host-vector form of the same class
+template<typename FieldT>
+class combined_LDT_device_oracle : public virtual_oracle<FieldT> {
+    field_subset<FieldT> codeword_domain_;
+    std::vector<std::size_t> degrees_;
+    std::vector<FieldT> coefficients_;
+public:
+    combined_LDT_device_oracle(const field_subset<FieldT> &codeword_domain, const std::vector<std::size_t> &input_oracle_degrees)
+        : codeword_domain_(codeword_domain), degrees_(input_oracle_degrees) {}
+    void set_random_coefficients(const std::vector<FieldT> &coefficients)
+    {
+        if (coefficients.size() != 2 * degrees_.size()) throw std::invalid_argument("Expected the nunmber of random coefficients to be twice the number of oracles.");
+        coefficients_ = coefficients;
+    }
+    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
+    {
+        if (c.size() != degrees_.size()) throw std::invalid_argument("Expected same number of evaluations as in registration.");
+        const field_subset<FieldT> &L = codeword_domain_;
+        const std::vector<const void *> ptrs = dev::pointers(c);
+        device_vector<FieldT> out(L.num_elements());
+        if (dev::additive(L))
+            check(iopx_ldt_combine_gf192_dev(ptrs.data(), ptrs.size(), degrees_.data(), detail::words(coefficients_.data()), dev::basis_words(L), L.dimension(),
+                                             dev::shift_words(L), out.words()));
+        else
+            check(iopx_ldt_combine_fp3_dev(ptrs.data(), ptrs.size(), degrees_.data(), detail::words(coefficients_.data()), L.dimension(), dev::gen_words(L),
+                                           dev::shift_words(L), out.words()));
+        return out;
+    }
+};
+
+// ---- protocols ------------------------------------------------------------------------------------------------------------------
+template<typename FieldT>
+class batch_sumcheck_protocol {                                                               // sumcheck.tcc:167-430, non-zk
+    bcs_prover<FieldT> &IOP_;
+    domain_handle summation_domain_handle_, codeword_domain_handle_;
+    std::size_t degree_bound_, g_degree_, h_degree_;
+    field_subset<FieldT> H_, L_;
+    std::vector<oracle_handle> oracle_handles_;
+    std::vector<FieldT> claimed_sums_;
+    bool registered_ = false;
+    verifier_random_message_handle challenge_handle_;
+    oracle_handle h_handle_, combined_f_handle_, g_handle_;
+    std::shared_ptr<random_linear_combination_oracle<FieldT>> combined_f_oracle_;
+    std::shared_ptr<sumcheck_g_oracle<FieldT>> g_oracle_;
+public:
+    batch_sumcheck_protocol(bcs_prover<FieldT> &IOP, const domain_handle &summation_domain_handle, const domain_handle &codeword_domain_handle, std::size_t degree_bound)
+        : IOP_(IOP), summation_domain_handle_(summation_domain_handle), codeword_domain_handle_(codeword_domain_handle), degree_bound_(degree_bound),
+          H_(IOP.get_domain(summation_domain_handle)), L_(IOP.get_domain(codeword_domain_handle))
+    {
+        g_degree_ = H_.num_elements() - 1;
+        h_degree_ = degree_bound - H_.num_elements();
+    }
+    void attach_oracle_for_summing(const oracle_handle &handle, const FieldT &claimed_sum = field_host<FieldT>::zero())
+    {
+        if (registered_) throw std::logic_error("Called attach_oracle_for_summing after register_proof.");
+        oracle_handles_.push_back(handle);
+        claimed_sums_.push_back(claimed_sum);
+    }
+    void register_challenge() { challenge_handle_ = IOP_.register_verifier_random_message(oracle_handles_.size()); }       // :199-206
+    void register_proof()                                                                    // :235-273
+    {
+        h_handle_ = IOP_.register_oracle("sumcheck h", codeword_domain_handle_, h_degree_, false);
+        combined_f_oracle_ = std::make_shared<random_linear_combination_oracle<FieldT>>(oracle_handles_.size());
+        combined_f_handle_ = IOP_.register_virtual_oracle(codeword_domain_handle_, degree_bound_, oracle_handles_, combined_f_oracle_, true);
+        g_oracle_ = std::make_shared<sumcheck_g_oracle<FieldT>>(H_, L_);
+        g_handle_ = IOP_.register_virtual_oracle(codeword_domain_handle_, g_degree_, { combined_f_handle_, h_handle_ }, g_oracle_);
+        registered_ = true;
+    }
+    void calculate_and_submit_proof()                                                        // :343-388
+    {
+        const std::vector<FieldT> challenge = IOP_.obtain_verifier_random_message(challenge_handle_);
+        combined_f_oracle_->set_random_coefficients(challenge);
+        const device_vector<FieldT> evals = IOP_.get_oracle_evaluations(combined_f_handle_);
+        const device_vector<FieldT> poly = dev::IFFT_of_known_degree<FieldT>(evals, degree_bound_, L_);                    // :351-354
+        FieldT combined_claimed_sum = field_host<FieldT>::zero();                            // :327-341
+        for (std::size_t i = 0; i < challenge.size(); ++i)
+            combined_claimed_sum = field_host<FieldT>::add(combined_claimed_sum, field_host<FieldT>::mul(challenge[i], claimed_sums_[i]));
+        g_oracle_->set_claimed_sum(combined_claimed_sum);
+        const device_vector<FieldT> h = dev::poly_div_vanishing<FieldT>(poly, degree_bound_, H_);                          // :359-365
+        IOP_.submit_oracle(h_handle_, oracle<FieldT>(dev::FFT<FieldT>(h, h.size(), L_)));                                  // :384-387
+    }
+    std::vector<oracle_handle> get_all_oracle_handles() const { return { h_handle_, g_handle_ }; }
+};
+
+template<typename FieldT>
+class multi_lincheck {                                                                        // basic_lincheck.tcc:113-296, non-zk
+    bcs_prover<FieldT> &IOP_;
+    domain_handle codeword_domain_handle_, summation_domain_handle_;
+    std::size_t repetitions_, num_matrices_, lincheck_degree_;
+    std::vector<oracle_handle> constituent_oracle_handles_;
+    std::vector<std::shared_ptr<batch_sumcheck_protocol<FieldT>>> sumchecks_;
+    std::vector<std::shared_ptr<multi_lincheck_virtual_oracle<FieldT>>> oracles_;
+    std::vector<verifier_random_message_handle> alpha_handles_, random_coefficient_handles_;
+public:
+    multi_lincheck(bcs_prover<FieldT> &IOP, const domain_handle &codeword_domain_handle, const domain_handle &constraint_domain_handle,
+                   const domain_handle &variable_domain_handle, const std::vector<sparse_matrix<FieldT>> *transposed_matrices, const oracle_handle &fz_handle,
+                   const std::vector<oracle_handle> &Mz_handles, std::size_t repetitions)
+        : IOP_(IOP), codeword_domain_handle_(codeword_domain_handle), repetitions_(repetitions), num_matrices_(transposed_matrices->size())
+    {
+        if (num_matrices_ < 1) throw std::invalid_argument("multi_lincheck expects at least one matrix");
+        if (Mz_handles.size() != num_matrices_) throw std::invalid_argument("inconsistent number of Mz_handles and matrices passed into multi lincheck.");
+        const field_subset<FieldT> L = IOP.get_domain(codeword_domain_handle), C = IOP.get_domain(constraint_domain_handle), V = IOP.get_domain(variable_domain_handle);
+        summation_domain_handle_ = C.dimension() > V.dimension() ? constraint_domain_handle : variable_domain_handle;      // :137-143
+        const field_subset<FieldT> S = IOP.get_domain(summation_domain_handle_);
+        constituent_oracle_handles_.push_back(fz_handle);
+        constituent_oracle_handles_.insert(constituent_oracle_handles_.end(), Mz_handles.begin(), Mz_handles.end());
+        lincheck_degree_ = S.num_elements() + std::max(IOP.get_oracle_degree(fz_handle), IOP.get_oracle_degree(Mz_handles[0])) - 1;   // :151-154
+        for (std::size_t i = 0; i < repetitions; ++i) {
+            sumchecks_.push_back(std::make_shared<batch_sumcheck_protocol<FieldT>>(IOP, summation_domain_handle_, codeword_domain_handle, lincheck_degree_));
+            oracles_.push_back(std::make_shared<multi_lincheck_virtual_oracle<FieldT>>(L, C, V, S, transposed_matrices));
+        }
+    }
+    void register_challenge()                                                                // :197-218
+    {
+        for (std::size_t i = 0; i < repetitions_; ++i) alpha_handles_.push_back(IOP_.register_verifier_random_message(1));
+        for (std::size_t i = 0; i < repetitions_; ++i) random_coefficient_handles_.push_back(IOP_.register_verifier_random_message(num_matrices_));
+        for (std::size_t i = 0; i < repetitions_; ++i) {
+            const oracle_handle h = IOP_.register_virtual_oracle(codeword_domain_handle_, lincheck_degree_, constituent_oracle_handles_, oracles_[i]);
+            sumchecks_[i]->attach_oracle_for_summing(h);
+            sumchecks_[i]->register_challenge();
+        }
+    }
+    void register_proof() { for (auto &s : sumchecks_) s->register_proof(); }
+    void calculate_and_submit_proof()                                                        // :241-257
+    {
+        for (std::size_t i = 0; i < repetitions_; ++i) {
+            const FieldT alpha = IOP_.obtain_verifier_random_message(alpha_handles_[i])[0];
+            const std::vector<FieldT> r_Mz = IOP_.obtain_verifier_random_message(random_coefficient_handles_[i]);
+            oracles_[i]->set_challenge(alpha, r_Mz);
+            sumchecks_[i]->calculate_and_submit_proof();
+        }
+    }
+    std::vector<oracle_handle> get_all_oracle_handles() const
+    {
+        std::vector<oracle_handle> out;
+        for (auto &s : sumchecks_) for (auto &h : s->get_all_oracle_handles()) out.push_back(h);
+        return out;
+    }
+};
+
+template<typename FieldT>
+class encoded_aurora_protocol {                                                               // r1cs_rs_iop.tcc:252-693, non-zk
+    bcs_prover<FieldT> &IOP_;
+    const r1cs_constraint_system<FieldT> &cs_;
+    field_subset<FieldT> C_, V_, L_, I_;
+    oracle_handle fw_handle_, fAz_handle_, fBz_handle_, fCz_handle_, fz_handle_, rowcheck_handle_;
+    std::shared_ptr<fz_virtual_oracle<FieldT>> fz_oracle_;
+    std::shared_ptr<rowcheck_ABC_virtual_oracle<FieldT>> rowcheck_oracle_;
+    std::shared_ptr<multi_lincheck<FieldT>> multi_lincheck_;
+public:
+    encoded_aurora_protocol(bcs_prover<FieldT> &IOP, const domain_handle &constraint_domain_handle, const domain_handle &variable_domain_handle,
+                            const domain_handle &codeword_domain_handle, const r1cs_constraint_system<FieldT> &constraint_system, std::size_t lincheck_repetitions)
+        : IOP_(IOP), cs_(constraint_system), C_(IOP.get_domain(constraint_domain_handle)), V_(IOP.get_domain(variable_domain_handle)),
+          L_(IOP.get_domain(codeword_domain_handle))
+    {
+        typedef aurora_snark_parameters<FieldT> P;
+        if (!P::is_pow2(cs_.num_inputs() + 1))
+            throw std::invalid_argument("number of inputs in the constraint system must be one less than a power of two.Perhaps pad your number of inputs");
+        I_ = V_.get_subset_of_order(cs_.num_inputs() + 1);                                   // :279-280
+        // register_witness_oracles (:285-375), query bound 0
+        const std::size_t m = (std::size_t)1 << detail::log2_ceil(cs_.num_constraints()), n = (std::size_t)1 << detail::log2_ceil(cs_.num_variables()), k = cs_.num_inputs();
+        const std::size_t fw_degree = n - (k + 1);
+        fw_handle_ = IOP.register_oracle("fw", codeword_domain_handle, fw_degree, false);
+        fAz_handle_ = IOP.register_oracle("fAz", codeword_domain_handle, m, false);
+        fBz_handle_ = IOP.register_oracle("fBz", codeword_domain_handle, m, false);
+        fCz_handle_ = IOP.register_oracle("fCz", codeword_domain_handle, m, false);
+        fz_oracle_ = std::make_shared<fz_virtual_oracle<FieldT>>(k, I_, L_);
+        fz_handle_ = IOP.register_virtual_oracle(codeword_domain_handle, fw_degree + k + 1, { fw_handle_ }, fz_oracle_);
+        const std::vector<oracle_handle> Mz_handles = { fAz_handle_, fBz_handle_, fCz_handle_ };
+        // the matrices as set_challenge walks them: column c of M lands at summation index reindex(reindex(c)) (basic_lincheck_aux.tcc:80-84)
+        const field_subset<FieldT> &S = C_.dimension() > V_.dimension() ? C_ : V_;
+        const std::string key = std::to_string((int)S.type()) + ":" + std::to_string(S.dimension()) + ":" + std::to_string(V_.dimension()) + ":" + std::to_string(I_.dimension());
+        auto it = cs_.lincheck_matrix_cache_.find(key);
+        if (it == cs_.lincheck_matrix_cache_.end()) {
+            std::vector<std::size_t> col_to_summation(cs_.num_variables() + 1);
+            for (std::size_t c = 0; c < col_to_summation.size(); ++c) col_to_summation[c] = S.reindex_by_subset(V_.dimension(), V_.reindex_by_subset(I_.dimension(), c));
+            std::vector<sparse_matrix<FieldT>> T;
+            T.push_back(cs_.A.transposed_onto(S.num_elements(), col_to_summation));
+            T.push_back(cs_.B.transposed_onto(S.num_elements(), col_to_summation));
+            T.push_back(cs_.C.transposed_onto(S.num_elements(), col_to_summation));
+            it = cs_.lincheck_matrix_cache_.emplace(key, std::move(T)).first;
+        }
+        multi_lincheck_ = std::make_shared<multi_lincheck<FieldT>>(IOP, codeword_domain_handle, constraint_domain_handle, variable_domain_handle, &it->second,
+                                                                   fz_handle_, Mz_handles, lincheck_repetitions);
+        rowcheck_oracle_ = std::make_shared<rowcheck_ABC_virtual_oracle<FieldT>>(L_, C_);
+        rowcheck_handle_ = IOP.register_virtual_oracle(codeword_domain_handle, C_.num_elements() - 1, Mz_handles, rowcheck_oracle_);
+    }
+    void register_challenge() { multi_lincheck_->register_challenge(); }
+    void register_proof() { multi_lincheck_->register_proof(); }
+
+    // :481-615.  f_w' interpolates z - f_1v over the variable domain (zero on the input positions, where f_1v already equals z), is
+    // divided by Z_I and extended together with f_Az, f_Bz, f_Cz.  d_assignment: the variable assignment (1, primary, auxiliary)
+    // already resident in HBM (then auxiliary_input is not read).
+    void submit_witness_oracles(const std::vector<FieldT> &primary_input, const std::vector<FieldT> &auxiliary_input, const device_vector<FieldT> *d_assignment = nullptr)
+    {
+        cs_.prepare_device();
+        fz_oracle_->set_primary_input(primary_input);                                        // :485, :508-516
+        const device_vector<FieldT> f1v_over_variable_domain = dev::FFT<FieldT>(fz_oracle_->f1v_coefficients(), I_.num_elements(), V_);      // :517-518
+        device_vector<FieldT> d_z;
+        if (d_assignment) d_z = *d_assignment;
+        else {                                                                               // :581-585
+            std::vector<FieldT> z(1, field_host<FieldT>::one());
+            z.insert(z.end(), primary_input.begin(), primary_input.end());
+            z.insert(z.end(), auxiliary_input.begin(), auxiliary_input.end());
+            d_z = device_vector<FieldT>(device_array<FieldT>::from_host(z));
+        }
+        if (d_z.size() != cs_.num_variables() + 1) throw std::invalid_argument("variable assignment of the wrong size");
+        device_vector<FieldT> z_over_variable_domain = d_z;
+        if (!dev::additive(V_)) {                                                            // create_fw_prime_evals' reindexing (:421-423)
+            const std::string key = "variable order:" + std::to_string(V_.dimension()) + ":" + std::to_string(I_.dimension());
+            auto it = cs_.index_cache_.find(key);
+            if (it == cs_.index_cache_.end()) {
+                std::vector<uint64_t> order(V_.num_elements());
+                for (std::size_t i = 0; i < order.size(); ++i) order[V_.reindex_by_subset(I_.dimension(), i)] = i;
+                it = cs_.index_cache_.emplace(key, device_array<uint64_t>::from_host(order)).first;
+            }
+            z_over_variable_domain = device_vector<FieldT>(V_.num_elements());
+            check(iopx_gather_dev(d_z.data(), it->second.data(), V_.num_elements(), sizeof(FieldT), z_over_variable_domain.data()));
+        }
+        const device_vector<FieldT> fw_prime_evals = dev::sub<FieldT>(z_over_variable_domain, f1v_over_variable_domain);                     // :406-430
+        const device_vector<FieldT> fw_prime = dev::IFFT<FieldT>(fw_prime_evals, V_);                                                        // :551-555
+        const std::size_t nC = C_.num_elements();
+        const device_vector<FieldT> Mz(3 * nC);
+        if (cs_.num_constraints() != nC) Mz.fill_zero();
+        const sparse_matrix<FieldT> *M[3] = { &cs_.A, &cs_.B, &cs_.C };
+        for (int q = 0; q < 3; ++q) M[q]->times_vector(d_z, Mz.slice(q * nC, cs_.num_constraints()));                                       // :586-592, r1cs.tcc:236-268
+        const device_vector<FieldT> fw = dev::poly_div_vanishing<FieldT>(fw_prime, V_.num_elements(), I_);                                   // :563-565
+        std::vector<device_vector<FieldT>> codewords(1, dev::FFT<FieldT>(fw, fw.size(), L_));                                               // :567-568
+        for (auto &cw : dev::reextend_packed<FieldT>(Mz, 3, C_, L_)) codewords.push_back(cw);                                                // :459-478
+        const oracle_handle handles[4] = { fw_handle_, fAz_handle_, fBz_handle_, fCz_handle_ };
+        for (int q = 0; q < 4; ++q) IOP_.submit_oracle(handles[q], oracle<FieldT>(codewords[q]));                                           // :603-606
+    }
+    void calculate_and_submit_proof() { multi_lincheck_->calculate_and_submit_proof(); }
+    std::vector<oracle_handle> get_all_oracle_handles() const                                // :651-672
+    {
+        std::vector<oracle_handle> out = multi_lincheck_->get_all_oracle_handles();
+        for (const oracle_handle &h : { fw_handle_, fAz_handle_, fBz_handle_, fCz_handle_, rowcheck_handle_ }) out.push_back(h);
+        return out;
+    }
+};
+
+template<typename FieldT>
+class FRI_protocol {                                                                          // fri_ldt.tcc:260-548
+    bcs_prover<FieldT> &IOP_;
+    domain_handle codeword_domain_handle_;
+    std::vector<oracle_handle> poly_handles_;
+    std::vector<std::size_t> localization_;
+    std::size_t poly_degree_bound_, interactive_repetitions_, query_repetitions_, num_reductions_, final_polynomial_degree_bound_ = 0;
+    std::vector<field_subset<FieldT>> domains_;
+    std::vector<domain_handle> domain_handles_;
+    std::vector<std::vector<std::vector<oracle_handle>>> oracle_handles_;                    // [round][interaction][ldt]
+    std::vector<std::vector<verifier_random_message_handle>> verifier_challenge_handles_;
+    std::vector<std::vector<prover_message_handle>> final_polynomial_handles_;
+
+    void compute_domains()                                                                   // :279-340
+    {
+        const field_subset<FieldT> L = IOP_.get_domain(codeword_domain_handle_);
+        domains_.push_back(L);
+        if (dev::additive(L)) {                                                              // :310-338 through the library's host-side helper
+            std::size_t total = 0, d = L.dimension();
+            std::vector<std::size_t> dims;
+            for (std::size_t eta : localization_) { d -= eta; dims.push_back(d); total += d; }
+            std::vector<FieldT> bases(total ? total : 1), shifts(localization_.size());
+            check(iopx_fri_domains_gf192(dev::basis_words(L), L.dimension(), dev::shift_words(L), localization_.data(), localization_.size(),
+                                         detail::words(bases.data()), detail::words(shifts.data())));
+            std::size_t off = 0;
+            for (std::size_t i = 0; i < dims.size(); ++i) {
+                domains_.push_back(field_subset<FieldT>(affine_subspace<FieldT>(std::vector<FieldT>(bases.begin() + off, bases.begin() + off + dims[i]), shifts[i])));
+                off += dims[i];
+            }
+        } else {                                                                             // :292-308: size >>= eta, shift <- shift^(2^eta)
+            FieldT sh = L.shift();
+            std::size_t logn = L.dimension();
+            for (std::size_t eta : localization_) {
+                sh = field_host<FieldT>::pow(sh, (uint64_t)1 << eta);
+                logn -= eta;
+                domains_.push_back(field_subset<FieldT>((std::size_t)1 << logn, sh));
+            }
+        }
+    }
+public:
+    FRI_protocol(bcs_prover<FieldT> &IOP, const domain_handle &codeword_domain_handle, const std::vector<oracle_handle> &poly_handles,
+                 const std::vector<std::size_t> &localization_parameters, std::size_t poly_degree_bound, std::size_t interactive_repetitions, std::size_t query_repetitions)
+        : IOP_(IOP), codeword_domain_handle_(codeword_domain_handle), poly_handles_(poly_handles), localization_(localization_parameters),
+          poly_degree_bound_(poly_degree_bound), interactive_repetitions_(interactive_repetitions), query_repetitions_(query_repetitions),
+          num_reductions_(localization_parameters.size())
+    {
+        compute_domains();
+    }
+    void register_interactions()                                                             // :342-398
+    {
+        std::size_t total = localization_[0];
+        domain_handles_.assign(num_reductions_, codeword_domain_handle_);
+        oracle_handles_.assign(num_reductions_, {});
+        oracle_handles_[0].push_back(poly_handles_);
+        verifier_challenge_handles_.emplace_back();
+        for (std::size_t j = 0; j < interactive_repetitions_; ++j) verifier_challenge_handles_[0].push_back(IOP_.register_verifier_random_message(1));
+        for (std::size_t i = 1; i < num_reductions_; ++i) {
+            total += localization_[i];
+            const domain_handle L_i = IOP_.register_domain(domains_[i]);
+            for (std::size_t j = 0; j < interactive_repetitions_; ++j) {
+                oracle_handles_[i].emplace_back();
+                for (std::size_t l = 0; l < poly_handles_.size(); ++l)
+                    oracle_handles_[i][j].push_back(IOP_.register_oracle("f_" + std::to_string(i), L_i, poly_degree_bound_ >> total, false));
+            }
+            IOP_.set_round_parameters(domains_[i].get_subset_of_order((std::size_t)1 << localization_[i]));
+            verifier_challenge_handles_.emplace_back();
+            for (std::size_t j = 0; j < interactive_repetitions_; ++j) verifier_challenge_handles_[i].push_back(IOP_.register_verifier_random_message(1));
+            domain_handles_[i] = L_i;
+        }
+        final_polynomial_degree_bound_ = poly_degree_bound_ >> total;
+        for (std::size_t j = 0; j < interactive_repetitions_; ++j) {
+            final_polynomial_handles_.emplace_back();
+            for (std::size_t l = 0; l < poly_handles_.size(); ++l) final_polynomial_handles_[j].push_back(IOP_.register_prover_message(final_polynomial_degree_bound_));
+        }
+    }
+    void register_queries()                                                                  // :400-472
+    {
+        for (std::size_t q = 0; q < query_repetitions_; ++q) {
+            const query_position_handle s0 = IOP_.register_random_query_position(domain_handles_[0]);
+            std::vector<std::vector<query_position_handle>> coset_positions(num_reductions_);
+            {
+                const field_subset<FieldT> d0 = domains_[0];
+                const std::size_t cs0 = (std::size_t)1 << localization_[0];
+                for (std::size_t i = 0; i < cs0; ++i)                                          // iop/utilities/query_positions.tcc
+                    coset_positions[0].push_back(IOP_.register_deterministic_query_position(
+                        { s0 }, [d0, cs0, i](const std::vector<std::size_t> &seed) { return d0.position_by_coset_indices(d0.coset_index(seed[0], cs0), i, cs0); }));
+            }
+            for (std::size_t r = 1; r < num_reductions_; ++r) {                               // fri_aux.tcc:351-387
+                const field_subset<FieldT> prev = domains_[r - 1], cur = domains_[r];
+                const std::size_t prev_cs = (std::size_t)1 << localization_[r - 1], cur_cs = (std::size_t)1 << localization_[r];
+                for (std::size_t i = 0; i < cur_cs; ++i)
+                    coset_positions[r].push_back(IOP_.register_deterministic_query_position(
+                        { coset_positions[r - 1][0] }, [prev, cur, prev_cs, cur_cs, i](const std::vector<std::size_t> &seed) {
+                            return cur.position_by_coset_indices(cur.coset_index(prev.coset_index(seed[0], prev_cs), cur_cs), i, cur_cs);
+                        }));
+            }
+            for (std::size_t interaction = 0; interaction < interactive_repetitions_; ++interaction)
+                for (std::size_t ldt = 0; ldt < poly_handles_.size(); ++ldt)
+                    for (std::size_t r = 0; r < num_reductions_; ++r) {
+                        const std::size_t queried_interaction = r == 0 ? 0 : interaction;
+                        for (std::size_t j = 0; j < ((std::size_t)1 << localization_[r]); ++j)
+                            IOP_.register_query(oracle_handles_[r][queried_interaction][ldt], coset_positions[r][j]);
+                    }
+        }
+    }
+    void calculate_and_submit_proof()                                                        // :474-548
+    {
+        std::vector<device_vector<FieldT>> first;
+        for (auto &h : poly_handles_) first.push_back(IOP_.get_oracle_evaluations(h));
+        std::vector<std::vector<device_vector<FieldT>>> by_interaction(interactive_repetitions_, first);
+        for (std::size_t i = 0; i < num_reductions_; ++i) {
+            const std::size_t cs = (std::size_t)1 << localization_[i];
+            if (i > 0) {
+                for (std::size_t j = 0; j < interactive_repetitions_; ++j)
+                    for (std::size_t l = 0; l < poly_handles_.size(); ++l) IOP_.submit_oracle(oracle_handles_[i][j][l], oracle<FieldT>(by_interaction[j][l]));     // device-resident: no copy
+                IOP_.signal_prover_round_done();
+            }
+            for (std::size_t j = 0; j < interactive_repetitions_; ++j) {
+                const FieldT x_i = IOP_.obtain_verifier_random_message(verifier_challenge_handles_[i][j])[0];
+                for (std::size_t l = 0; l < poly_handles_.size(); ++l) by_interaction[j][l] = dev::fold<FieldT>(by_interaction[j][l], domains_[i], cs, x_i);       // :522-526
+            }
+        }
+        for (std::size_t j = 0; j < interactive_repetitions_; ++j)
+            for (std::size_t l = 0; l < poly_handles_.size(); ++l) {
+                const device_vector<FieldT> coeffs = dev::IFFT<FieldT>(by_interaction[j][l], domains_[num_reductions_]);                                     // :538
+                IOP_.submit_prover_message(final_polynomial_handles_[j][l], coeffs.to_host(final_polynomial_degree_bound_));
+            }
+        IOP_.signal_prover_round_done();
+    }
+};
+
+template<typename FieldT>
+class LDT_instance_reducer {                                                                  // ldt_reducer.tcc:134-297, non-zk, multi_LDT = FRI_protocol
+    bcs_prover<FieldT> &IOP_;
+    domain_handle codeword_domain_handle_;
+    std::size_t num_output_LDT_instances_, max_tested_degree_bound_;
+    std::vector<std::shared_ptr<combined_LDT_device_oracle<FieldT>>> combined_oracles_;
+    std::vector<oracle_handle> combined_oracle_handles_;
+    std::vector<verifier_random_message_handle> random_coefficients_handles_;
+    std::shared_ptr<FRI_protocol<FieldT>> multi_LDT_;
+public:
+    LDT_instance_reducer(bcs_prover<FieldT> &IOP, const domain_handle &codeword_domain_handle, std::size_t num_output_LDT_instances, std::size_t max_tested_degree_bound)
+        : IOP_(IOP), codeword_domain_handle_(codeword_domain_handle), num_output_LDT_instances_(num_output_LDT_instances), max_tested_degree_bound_(max_tested_degree_bound) {}
+    void register_interactions(const std::vector<oracle_handle> &oracle_handles, const std::vector<std::size_t> &localization_parameters,
+                               std::size_t fri_interactive_repetitions, std::size_t fri_query_repetitions)
+    {
+        std::vector<std::size_t> degrees;
+        for (auto &h : oracle_handles) {
+            degrees.push_back(IOP_.get_oracle_degree(h));
+            if (degrees.back() > max_tested_degree_bound_)
+                throw std::invalid_argument("One of the oracles is registered with claimed degree " + std::to_string(degrees.back()) +
+                                            ", which is greater than the max tested degree bound");
+        }
+        const field_subset<FieldT> L = IOP_.get_domain(codeword_domain_handle_);
+        for (std::size_t i = 0; i < num_output_LDT_instances_; ++i) combined_oracles_.push_back(std::make_shared<combined_LDT_device_oracle<FieldT>>(L, degrees));
+        for (auto &o : combined_oracles_) combined_oracle_handles_.push_back(IOP_.register_virtual_oracle(codeword_domain_handle_, max_tested_degree_bound_, oracle_handles, o));
+        for (std::size_t i = 0; i < num_output_LDT_instances_; ++i) random_coefficients_handles_.push_back(IOP_.register_verifier_random_message(2 * oracle_handles.size()));
+        multi_LDT_ = std::make_shared<FRI_protocol<FieldT>>(IOP_, codeword_domain_handle_, combined_oracle_handles_, localization_parameters, max_tested_degree_bound_,
+                                                            fri_interactive_repetitions, fri_query_repetitions);
+        multi_LDT_->register_interactions();
+    }
+    void register_queries() { multi_LDT_->register_queries(); }
+    void calculate_and_submit_proof()                                                        // :259-272
+    {
+        for (std::size_t i = 0; i < combined_oracles_.size(); ++i)
+            combined_oracles_[i]->set_random_coefficients(IOP_.obtain_verifier_random_message(random_coefficients_handles_[i]));
+        multi_LDT_->calculate_and_submit_proof();
+    }
+};
+
+template<typename FieldT>
+class aurora_iop {                                                                            // aurora_iop.tcc:262-344
+    bcs_prover<FieldT> &IOP_;
+    const aurora_snark_parameters<FieldT> &params_;
+    domain_handle codeword_domain_handle_;
+    std::shared_ptr<encoded_aurora_protocol<FieldT>> protocol_;
+    std::shared_ptr<LDT_instance_reducer<FieldT>> LDT_reducer_;
+    field_subset<FieldT> quotient_map_domain_;
+public:
+    aurora_iop(bcs_prover<FieldT> &IOP, const r1cs_constraint_system<FieldT> &constraint_system, const aurora_snark_parameters<FieldT> &params)
+        : IOP_(IOP), params_(params)
+    {
+        const FieldT codeword_domain_shift = field_subset<FieldT>((std::size_t)1 << params.codeword_domain_dim_).element_outside_of_subset();   // :282-283
+        const domain_handle constraint_h = IOP.register_domain(field_subset<FieldT>((std::size_t)1 << params.constraint_domain_dim_));
+        const domain_handle variable_h = IOP.register_domain(field_subset<FieldT>((std::size_t)1 << params.variable_domain_dim_));
+        codeword_domain_handle_ = IOP.register_domain(field_subset<FieldT>((std::size_t)1 << params.codeword_domain_dim_, codeword_domain_shift));
+        protocol_ = std::make_shared<encoded_aurora_protocol<FieldT>>(IOP, constraint_h, variable_h, codeword_domain_handle_, constraint_system,
+                                                                      params.multi_lincheck_repetitions_);
+        LDT_reducer_ = std::make_shared<LDT_instance_reducer<FieldT>>(IOP, codeword_domain_handle_, params.num_output_LDT_instances_, params.max_tested_degree_bound_);
+        quotient_map_domain_ = IOP.get_domain(codeword_domain_handle_).get_subset_of_order((std::size_t)1 << params.localization_parameters_[0]);
+        IOP.set_round_parameters(quotient_map_domain_);                                      // :307-308
+    }
+    void register_interactions()                                                             // :311-326
+    {
+        protocol_->register_challenge();
+        protocol_->register_proof();
+        IOP_.set_round_parameters(quotient_map_domain_);
+        LDT_reducer_->register_interactions(protocol_->get_all_oracle_handles(), params_.localization_parameters_, params_.fri_interactive_repetitions_,
+                                            params_.fri_query_repetitions_);
+    }
+    void register_queries() { LDT_reducer_->register_queries(); }
+    void produce_proof(const std::vector<FieldT> &primary_input, const std::vector<FieldT> &auxiliary_input, const device_vector<FieldT> *d_assignment = nullptr)   // :334-344
+    {
+        protocol_->submit_witness_oracles(primary_input, auxiliary_input, d_assignment);
+        IOP_.signal_prover_round_done();
+        protocol_->calculate_and_submit_proof();
+        IOP_.signal_prover_round_done();
+        LDT_reducer_->calculate_and_submit_proof();
+    }
+};
+
+// aurora_snark_prover (aurora_snark.tcc:119-146).  With d_assignment — the (1, primary, auxiliary) vector already in HBM — the
+// witness never crosses PCIe inside the call.
+template<typename FieldT>
+bcs_transformation_transcript<FieldT> aurora_snark_prover(const r1cs_constraint_system<FieldT> &constraint_system, const r1cs_primary_input<FieldT> &primary_input,
+                                                          const r1cs_auxiliary_input<FieldT> &auxiliary_input, const aurora_snark_parameters<FieldT> &parameters,
+                                                          const device_vector<FieldT> *d_assignment = nullptr)
+{
+    bcs_prover<FieldT> IOP(parameters.pow_bits_);
+    aurora_iop<FieldT> full_protocol(IOP, constraint_system, parameters);
+    full_protocol.register_interactions();
+    IOP.seal_interaction_registrations();
+    full_protocol.register_queries();
+    IOP.seal_query_registrations();
+    full_protocol.produce_proof(primary_input, auxiliary_input, d_assignment);
+    return IOP.get_transcript();
+}
+
+} // namespace libiop_amd

@@ -1,0 +1,597 @@
+// Device-resident IOP bookkeeping + BCS transformation, prover side, for C++ callers of the C ABI.
+//
+// The reference's provers (libiop/snark/*.tcc) drive  iop_protocol<FieldT>  (libiop/iop/iop.{hpp,tcc})  through its subclass
+// bcs_prover<FieldT, hash>  (libiop/bcs/bcs_prover.{hpp,tcc}, bcs_common.{hpp,tcc}); oracles are std::vector<FieldT> on the heap
+// (libiop/iop/oracles.hpp:22-52).  Here the same registration / round / transcript interface runs with every oracle in HBM:
+//
+//   device_vector<FieldT>                       the storage behind oracle<FieldT> (pooled device memory, iopx_pool_alloc)
+//   oracle<FieldT>, virtual_oracle<FieldT>      iop/oracles.hpp:22-95 (evaluated_contents() downloads lazily)
+//   blake2b_hashchain<FieldT>                   bcs/hashing/blake2b.tcc:10-110, 162-257, blake2b.cpp:50-74 (host, 32-byte state)
+//   bcs_prover<FieldT>                          iop.tcc:22-433 registration + rounds, bcs_common.tcc:399-696 one tree per
+//                                               (round, domain), bcs_prover.tcc:23-98 round end + proof of work, :136-233 transcript
+//   bcs_transformation_transcript<FieldT>       bcs/bcs_common.hpp:36-106
+//
+// Only 32-byte roots, O(log n) challenges and, at the end, the queried values and authentication paths cross PCIe
+// (iopx_transfer_stats counts them).  Non-zk, BLAKE2b digests (what default_bcs_params wires for both accelerated fields).
+// FieldT is any 24-byte type with libff::gf192's or libff::edwards_Fr's layout; field_kind<FieldT> says which.
+#pragma once
+#include <functional>
+#include <map>
+#include <set>
+
+#include "libiop_amd.hpp"
+
+namespace libiop_amd {
+
+// ---- host scalars of FieldT (per-proof constants only) --------------------------------------------------------------------------
+template<typename FieldT>
+struct field_host {
+    static_assert(sizeof(FieldT) == 24, "libiop_amd accelerates 24-byte field elements (libff::gf192 / libff::edwards_Fr layout)");
+    static bool additive() { return field_kind<FieldT>::type == affine_subspace_type; }
+    static FieldT from_words(const uint64_t *w) { FieldT r; std::memcpy((void *)&r, w, 24); return r; }
+    static FieldT zero() { const uint64_t w[3] = { 0, 0, 0 }; return from_words(w); }
+    static FieldT from_uint(uint64_t v)
+    {
+        uint64_t w[3] = { v, 0, 0 };
+        if (!additive()) check(iopx_fp3_from_uint(v, w));
+        return from_words(w);
+    }
+    static FieldT one() { return from_uint(1); }
+    static bool is_zero(const FieldT &a) { const uint64_t *w = detail::words(&a); return (w[0] | w[1] | w[2]) == 0; }
+    static FieldT add(const FieldT &a, const FieldT &b)
+    {
+        uint64_t w[3];
+        if (additive()) for (int i = 0; i < 3; ++i) w[i] = detail::words(&a)[i] ^ detail::words(&b)[i];
+        else check(iopx_fp3_host_add(detail::words(&a), detail::words(&b), w));
+        return from_words(w);
+    }
+    static FieldT mul(const FieldT &a, const FieldT &b)
+    {
+        uint64_t w[3];
+        if (additive()) check(iopx_gf192_host_mul(detail::words(&a), detail::words(&b), w));
+        else check(iopx_fp3_host_mul(detail::words(&a), detail::words(&b), w));
+        return from_words(w);
+    }
+    static FieldT pow(const FieldT &a, uint64_t e)
+    {
+        if (!additive()) { uint64_t w[3]; check(iopx_fp3_host_pow(detail::words(&a), e, w)); return from_words(w); }
+        FieldT r = one(), b = a;
+        for (; e; e >>= 1) { if (e & 1) r = mul(r, b); b = mul(b, b); }
+        return r;
+    }
+    // libff::soundness_log_of_field_size_helper: the extension degree for binary fields, floor(log2 p) for prime fields
+    static std::size_t soundness_bits() { return additive() ? 192 : 180; }
+};
+
+// ---- device memory -----------------------------------------------------------------------------------------------------------------
+namespace detail {
+struct pooled_block {
+    void *p = nullptr;
+    explicit pooled_block(std::size_t bytes) { check(iopx_pool_alloc(&p, bytes)); }
+    pooled_block(const pooled_block &) = delete;
+    pooled_block &operator=(const pooled_block &) = delete;
+    ~pooled_block() { if (p) iopx_pool_free(p); }
+};
+} // namespace detail
+
+// `count` elements of elem_bytes in HBM; copies share the block, slice() is a view
+template<typename T>
+class device_array {
+    std::shared_ptr<detail::pooled_block> block_;
+    std::size_t offset_ = 0, size_ = 0;
+public:
+    device_array() {}
+    explicit device_array(std::size_t count) : block_(std::make_shared<detail::pooled_block>((count ? count : 1) * sizeof(T))), size_(count) {}
+    std::size_t size() const { return size_; }
+    bool empty() const { return size_ == 0; }
+    T *data() const { return block_ ? reinterpret_cast<T *>(block_->p) + offset_ : nullptr; }
+    device_array slice(std::size_t begin, std::size_t count) const
+    {
+        if (begin + count > size_) throw std::invalid_argument("device_array::slice out of range");
+        device_array r;
+        r.block_ = block_; r.offset_ = offset_ + begin; r.size_ = count;
+        return r;
+    }
+    static device_array from_host(const T *src, std::size_t count)
+    {
+        device_array r(count);
+        if (count) check(iopx_memcpy_h2d(r.data(), src, count * sizeof(T)));
+        return r;
+    }
+    static device_array from_host(const std::vector<T> &v) { return from_host(v.data(), v.size()); }
+    std::vector<T> to_host(std::size_t count = (std::size_t)-1) const
+    {
+        if (count == (std::size_t)-1) count = size_;
+        if (count > size_) throw std::invalid_argument("device_array::to_host out of range");
+        std::vector<T> out(count);
+        if (count) check(iopx_memcpy_d2h(out.data(), data(), count * sizeof(T)));
+        return out;
+    }
+    void fill_zero() const { if (size_) check(iopx_memset_dev(data(), 0, size_ * sizeof(T))); }
+    void copy_from(const device_array &src) const
+    {
+        if (src.size() != size_) throw std::invalid_argument("device_array::copy_from: size mismatch");
+        if (size_) check(iopx_memcpy_d2d(data(), src.data(), size_ * sizeof(T)));
+    }
+};
+
+template<typename FieldT>
+class device_vector : public device_array<FieldT> {
+public:
+    device_vector() {}
+    explicit device_vector(std::size_t count) : device_array<FieldT>(count) {}
+    device_vector(const device_array<FieldT> &a) : device_array<FieldT>(a) {}
+    uint64_t *words() const { return reinterpret_cast<uint64_t *>(this->data()); }
+    device_vector slice(std::size_t begin, std::size_t count) const { return device_vector(device_array<FieldT>::slice(begin, count)); }
+};
+
+// ---- oracles (libiop/iop/oracles.hpp) -------------------------------------------------------------------------------------------
+template<typename FieldT>
+class oracle {
+    device_vector<FieldT> device_contents_;
+    mutable std::shared_ptr<std::vector<FieldT>> host_contents_;
+public:
+    oracle() {}
+    oracle(const device_vector<FieldT> &contents) : device_contents_(contents) {}
+    oracle(const std::vector<FieldT> &evaluated_contents) : device_contents_(device_vector<FieldT>::from_host(evaluated_contents)) {}
+    const device_vector<FieldT> &device_contents() const { return device_contents_; }
+    // oracles.hpp:41-44; the one place a whole oracle crosses PCIe, and only when a caller asks for host data
+    const std::shared_ptr<std::vector<FieldT>> &evaluated_contents() const
+    {
+        if (!host_contents_) host_contents_ = std::make_shared<std::vector<FieldT>>(device_contents_.to_host());
+        return host_contents_;
+    }
+    std::size_t size() const { return device_contents_.size(); }
+};
+
+template<typename FieldT>
+class virtual_oracle {
+public:
+    virtual ~virtual_oracle() {}
+    // oracles.hpp:56-95: the prover side needs the whole-domain evaluation only
+    virtual device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &constituent_oracle_evaluations) const = 0;
+};
+
+// ---- handles (libiop/iop/iop.hpp:27-196) ----------------------------------------------------------------------------------------
+struct domain_handle { std::size_t id; };
+struct oracle_handle { std::size_t id; bool is_virtual; };
+typedef oracle_handle oracle_handle_ptr;
+struct prover_message_handle { std::size_t id; };
+struct verifier_random_message_handle { std::size_t id; };
+struct query_position_handle { std::size_t id; bool random; };
+struct query_handle { std::size_t id; };
+
+// ---- Fiat-Shamir hashchain (bcs/hashing/blake2b.tcc) ----------------------------------------------------------------------------
+typedef std::string hash_digest;        // 32 raw bytes (binary_hash_digest)
+
+template<typename FieldT>
+class blake2b_hashchain {
+    uint8_t state_[32];
+    uint64_t squeeze_index_ = 0;
+public:
+    blake2b_hashchain() { std::memset(state_, ' ', 32); }                                     // blake2b.tcc:17
+    // :50-61 — hashes the first digest_len bytes of state || input: the state advances to BLAKE2b-256(state) whatever is absorbed
+    // (reference behaviour F8 of SURVEY.md, reproduced because the verifier does the same)
+    void absorb() { uint8_t next[32]; check(iopx_blake2b_host(next, 32, state_, 32, nullptr, 0)); std::memcpy(state_, next, 32); }
+    // :76-86, :162-257 — element i of squeeze number q = keyed BLAKE2b(state || q, key = i), written raw into the element; prime
+    // field: bits above the modulus MSB cleared, retried with key += num_elements until below p (the bytes ARE mont_repr)
+    std::vector<FieldT> squeeze(std::size_t num_elements)
+    {
+        ++squeeze_index_;
+        uint8_t msg[40];
+        std::memcpy(msg, state_, 32);
+        std::memcpy(msg + 32, &squeeze_index_, 8);
+        std::vector<FieldT> out(num_elements);
+        uint64_t modulus[3] = { 0, 0, 0 };
+        const bool additive = field_host<FieldT>::additive();
+        if (!additive) check(iopx_fp3_modulus(modulus));
+        for (std::size_t i = 0; i < num_elements; ++i) {
+            uint64_t key = i, w[3];
+            for (;;) {
+                check(iopx_blake2b_host(reinterpret_cast<uint8_t *>(w), 24, msg, 40, &key, 8));
+                if (additive) break;
+                key += num_elements;
+                int top = 63;
+                while (top > 0 && !((modulus[2] >> top) & 1)) --top;                         // modulus MSB within the top limb
+                w[2] &= (top == 63) ? ~0ull : ((1ull << (top + 1)) - 1);
+                bool below = false;
+                for (int k = 2; k >= 0; --k) if (w[k] != modulus[k]) { below = w[k] < modulus[k]; break; }
+                if (below) break;
+            }
+            out[i] = field_host<FieldT>::from_words(w);
+        }
+        return out;
+    }
+    // :105-110 — one squeezed element hashed to a digest (blake2b_field_element_hash, :140-160)
+    hash_digest squeeze_root_type()
+    {
+        const std::vector<FieldT> x = squeeze(1);
+        uint8_t d[32];
+        check(iopx_blake2b_host(d, 32, &x[0], 24, nullptr, 0));
+        return hash_digest(reinterpret_cast<const char *>(d), 32);
+    }
+    // :88-105 + blake2b.cpp:50-74
+    std::vector<std::size_t> squeeze_query_positions(std::size_t num_positions, std::size_t range_of_positions)
+    {
+        if (range_of_positions & (range_of_positions - 1)) throw std::invalid_argument("upper_bound must be a power of two.");
+        std::vector<std::size_t> out;
+        for (std::size_t i = 0; i < num_positions; ++i) {
+            ++squeeze_index_;
+            uint64_t v = 0;
+            check(iopx_blake2b_host(reinterpret_cast<uint8_t *>(&v), 8, state_, 32, &squeeze_index_, 8));
+            out.push_back((std::size_t)(v % range_of_positions));
+        }
+        return out;
+    }
+};
+
+// ---- a BCS Merkle tree resident in HBM (bcs/merkle_tree.tcc:92-229) -------------------------------------------------------------
+class device_merkle_tree {
+    device_array<uint8_t> nodes_;
+    std::size_t num_leaves_ = 0;
+public:
+    device_merkle_tree() {}
+    template<typename FieldT>
+    device_merkle_tree(const std::vector<device_vector<FieldT>> &oracles, const field_subset<FieldT> &domain, std::size_t coset_size)
+        : nodes_((2 * (domain.num_elements() / coset_size) - 1) * 32), num_leaves_(domain.num_elements() / coset_size)
+    {
+        std::vector<const void *> ptrs;
+        for (auto &o : oracles) ptrs.push_back(o.data());
+        check(iopx_merkle_blake2b_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), domain.num_elements(), coset_size,
+                                      domain.type() == affine_subspace_type ? IOPX_DOMAIN_ADDITIVE : IOPX_DOMAIN_MULTIPLICATIVE, nullptr, 0, nodes_.data()));
+    }
+    std::size_t num_leaves() const { return num_leaves_; }
+    hash_digest get_root() const                                                              // merkle_tree.tcc:231-240
+    {
+        uint8_t d[32];
+        check(iopx_memcpy_d2h(d, nodes_.data(), 32));
+        return hash_digest(reinterpret_cast<const char *>(d), 32);
+    }
+    std::vector<hash_digest> get_set_membership_proof(const std::vector<std::size_t> &leaf_positions) const      // :242-336
+    {
+        std::vector<hash_digest> out;
+        if (leaf_positions.empty()) return out;
+        std::size_t depth = 0;
+        while (((std::size_t)1 << depth) < num_leaves_) ++depth;
+        std::vector<uint8_t> aux(32 * leaf_positions.size() * (depth + 1));
+        std::size_t count = 0;
+        check(iopx_merkle_membership_proof_dev(nodes_.data(), num_leaves_, leaf_positions.data(), leaf_positions.size(), aux.data(), aux.size() / 32, &count));
+        for (std::size_t i = 0; i < count; ++i) out.emplace_back(reinterpret_cast<const char *>(aux.data()) + 32 * i, 32);
+        return out;
+    }
+};
+
+// ---- bcs_transformation_transcript (bcs/bcs_common.hpp:36-106) -------------------------------------------------------------------
+template<typename FieldT>
+struct bcs_transformation_transcript {
+    std::vector<std::vector<FieldT>> prover_messages_;
+    std::vector<hash_digest> MT_roots_;
+    std::vector<std::vector<std::size_t>> query_positions_;          // per tree, sorted
+    std::vector<std::vector<std::size_t>> MT_leaf_positions_;        // per tree, sorted
+    std::vector<std::vector<std::vector<FieldT>>> query_responses_;  // per tree: [position][oracle]
+    std::vector<std::vector<hash_digest>> MT_set_membership_proofs_; // per tree: auxiliary hashes
+    hash_digest proof_of_work_;
+
+    // The canonical byte form the parity tests compare (the reference's own serialisation is text, bcs_common.tcc:96-390): counts
+    // and positions as 8-byte little-endian integers, elements and digests raw, in the field order of this struct.
+    std::string serialize() const
+    {
+        std::string out;
+        auto u64 = [&](uint64_t v) { out.append(reinterpret_cast<const char *>(&v), 8); };
+        u64(prover_messages_.size());
+        for (auto &m : prover_messages_) { u64(m.size()); out.append(reinterpret_cast<const char *>(m.data()), m.size() * sizeof(FieldT)); }
+        u64(MT_roots_.size());
+        for (auto &r : MT_roots_) out.append(r);
+        for (std::size_t t = 0; t < query_positions_.size(); ++t) {
+            u64(query_positions_[t].size());
+            for (std::size_t p : query_positions_[t]) u64(p);
+            u64(MT_leaf_positions_[t].size());
+            for (std::size_t p : MT_leaf_positions_[t]) u64(p);
+            const auto &resp = query_responses_[t];
+            u64(resp.empty() ? 0 : resp[0].size());
+            for (auto &row : resp) out.append(reinterpret_cast<const char *>(row.data()), row.size() * sizeof(FieldT));
+            u64(MT_set_membership_proofs_[t].size());
+            for (auto &d : MT_set_membership_proofs_[t]) out.append(d);
+        }
+        out.append(proof_of_work_);
+        return out;
+    }
+};
+
+// ---- the round driver ----------------------------------------------------------------------------------------------------------
+template<typename FieldT>
+class bcs_prover {
+public:
+    typedef std::function<std::size_t(const std::vector<std::size_t> &)> position_calculator;
+private:
+    struct oracle_registration { std::size_t domain, degree; std::string name; };
+    struct virtual_registration {
+        std::size_t domain, degree;
+        std::vector<oracle_handle> constituents;
+        std::shared_ptr<virtual_oracle<FieldT>> contents;
+        bool cache;
+    };
+    struct tree_info { std::size_t round, domain; std::vector<std::size_t> oracle_ids; };
+
+    std::size_t pow_bitlen_;
+    blake2b_hashchain<FieldT> hashchain_;
+    // registrations (iop.tcc:22-263)
+    std::vector<field_subset<FieldT>> domains_;
+    std::vector<oracle_registration> oracle_regs_;
+    std::vector<virtual_registration> virtual_regs_;
+    std::vector<std::size_t> prover_message_sizes_, verifier_message_sizes_;
+    std::vector<std::size_t> num_oracles_at_end_of_round_, num_prover_messages_at_end_of_round_, num_verifier_messages_at_end_of_round_;
+    std::vector<std::size_t> round_params_;
+    bool from_prover_ = false, sealed_ = false;
+    std::size_t num_interaction_rounds_ = 0;
+    std::vector<std::size_t> random_position_domains_;
+    std::vector<std::pair<std::vector<query_position_handle>, position_calculator>> deterministic_positions_;
+    std::vector<std::pair<oracle_handle, query_position_handle>> queries_;
+    // run state
+    std::vector<device_vector<FieldT>> oracles_;
+    std::vector<bool> oracle_submitted_, message_submitted_;
+    std::vector<std::vector<FieldT>> prover_messages_;
+    std::size_t num_prover_rounds_done_ = 0, processed_MTs_ = 0;
+    std::vector<device_merkle_tree> MT_trees_;
+    std::vector<hash_digest> MT_roots_;
+    std::vector<tree_info> MT_info_;
+    std::map<std::size_t, std::vector<FieldT>> verifier_random_messages_;
+    std::map<std::size_t, device_vector<FieldT>> virtual_contents_cache_;
+    hash_digest pow_answer_;
+
+    void assert_can_register(std::size_t domain, std::size_t degree) const
+    {
+        if (sealed_) throw std::logic_error("attempted to register an oracle after interactive registrations sealed");
+        if (domain >= domains_.size()) throw std::invalid_argument("domain not registered");
+        if (degree >= domains_[domain].num_elements()) throw std::invalid_argument("attempting to register oracle whose degree exceeds domain size");
+    }
+    void update_rounds_and_direction(bool from_prover)                                       // iop.tcc:36-63
+    {
+        if (from_prover_ == from_prover) return;
+        if (from_prover_) {
+            num_oracles_at_end_of_round_.push_back(oracle_regs_.size());
+            num_prover_messages_at_end_of_round_.push_back(prover_message_sizes_.size());
+            ++num_interaction_rounds_;
+        } else {
+            num_verifier_messages_at_end_of_round_.push_back(verifier_message_sizes_.size());
+        }
+        from_prover_ = from_prover;
+    }
+    // iop.tcc:801-820: domain -> oracle ids of the round, domains in handle order (std::map)
+    std::map<std::size_t, std::vector<std::size_t>> oracles_in_round_by_domain(std::size_t round) const
+    {
+        const std::size_t begin = round == 0 ? 0 : num_oracles_at_end_of_round_[round - 1];
+        std::map<std::size_t, std::vector<std::size_t>> mapping;
+        for (std::size_t oid = begin; oid < num_oracles_at_end_of_round_[round]; ++oid) mapping[oracle_regs_[oid].domain].push_back(oid);
+        return mapping;
+    }
+    std::size_t get_round_parameters(std::size_t round) const { return round < round_params_.size() ? round_params_[round] : 1; }
+
+    void run_hashchain_for_round(std::size_t round, std::size_t num_roots)                   // bcs_common.tcc:550-614
+    {
+        for (std::size_t i = 0; i < num_roots; ++i) hashchain_.absorb();
+        hashchain_.absorb();                                                                 // the round's prover messages
+        const std::size_t start = num_verifier_messages_at_end_of_round_[round];
+        const std::size_t end = round == num_interaction_rounds_ - 1 ? 0 : num_verifier_messages_at_end_of_round_[round + 1];
+        for (std::size_t i = start; i < end; ++i) verifier_random_messages_[i] = hashchain_.squeeze(verifier_message_sizes_[i]);
+    }
+
+    std::size_t obtain_query_position(const query_position_handle &h, std::map<std::size_t, std::size_t> &random_cache, std::map<std::size_t, std::size_t> &det_cache)
+    {
+        if (h.random) {
+            auto it = random_cache.find(h.id);
+            if (it != random_cache.end()) return it->second;
+            const std::size_t n = domains_[random_position_domains_[h.id]].num_elements();
+            return random_cache[h.id] = hashchain_.squeeze_query_positions(1, n)[0];         // bcs_common.tcc:536-548
+        }
+        auto it = det_cache.find(h.id);
+        if (it != det_cache.end()) return it->second;
+        std::vector<std::size_t> seeds;
+        for (auto &s : deterministic_positions_[h.id].first) seeds.push_back(obtain_query_position(s, random_cache, det_cache));
+        return det_cache[h.id] = deterministic_positions_[h.id].second(seeds);
+    }
+    // get_oracle_evaluation_at_point with record = true (iop.tcc:669-714): a query to a virtual oracle touches its constituents
+    void record(const oracle_handle &h, std::size_t position, std::map<std::size_t, std::set<std::size_t>> &positions_by_oracle) const
+    {
+        if (!h.is_virtual) { positions_by_oracle[h.id].insert(position); return; }
+        for (auto &c : virtual_regs_[h.id].constituents) record(c, position, positions_by_oracle);
+    }
+
+public:
+    explicit bcs_prover(std::size_t pow_work_parameter) : pow_bitlen_(pow_work_parameter) {}
+
+    // ---- registration ----
+    domain_handle register_domain(const field_subset<FieldT> &S) { domains_.push_back(S); return domain_handle{ domains_.size() - 1 }; }
+    field_subset<FieldT> get_domain(const domain_handle &h) const { return domains_[h.id]; }      // by value: later registrations may move the table
+    oracle_handle register_oracle(const std::string &name, const domain_handle &domain, std::size_t degree, bool make_zk)
+    {
+        assert_can_register(domain.id, degree);
+        if (make_zk) throw std::invalid_argument("zero-knowledge oracles are out of scope (salts and masks are not reproducible)");
+        update_rounds_and_direction(true);
+        oracle_regs_.push_back({ domain.id, degree, name });
+        oracles_.emplace_back();
+        oracle_submitted_.push_back(false);
+        return oracle_handle{ oracle_regs_.size() - 1, false };
+    }
+    oracle_handle register_virtual_oracle(const domain_handle &domain, std::size_t degree, const std::vector<oracle_handle> &constituents,
+                                          const std::shared_ptr<virtual_oracle<FieldT>> &contents, bool cache_evaluated_contents = false)
+    {
+        assert_can_register(domain.id, degree);
+        virtual_regs_.push_back({ domain.id, degree, constituents, contents, cache_evaluated_contents });
+        return oracle_handle{ virtual_regs_.size() - 1, true };
+    }
+    prover_message_handle register_prover_message(std::size_t size)
+    {
+        update_rounds_and_direction(true);
+        prover_message_sizes_.push_back(size);
+        prover_messages_.emplace_back();
+        message_submitted_.push_back(false);
+        return prover_message_handle{ prover_message_sizes_.size() - 1 };
+    }
+    verifier_random_message_handle register_verifier_random_message(std::size_t size)
+    {
+        update_rounds_and_direction(false);
+        verifier_message_sizes_.push_back(size);
+        return verifier_random_message_handle{ verifier_message_sizes_.size() - 1 };
+    }
+    // bcs_common.tcc:482-495 with round_parameters(domain): the Merkle leaves of the current round hold cosets of |domain|
+    void set_round_parameters(const field_subset<FieldT> &quotient_map_domain)
+    {
+        const std::size_t cur_round = num_interaction_rounds_;
+        if (!round_params_.empty() && cur_round == round_params_.size() - 1) throw std::logic_error("Already set round parameters for this round");
+        while (round_params_.size() < cur_round) round_params_.push_back(1);
+        round_params_.push_back(quotient_map_domain.num_elements());
+    }
+    domain_handle get_oracle_domain(const oracle_handle &h) const { return domain_handle{ h.is_virtual ? virtual_regs_[h.id].domain : oracle_regs_[h.id].domain }; }
+    std::size_t get_oracle_degree(const oracle_handle &h) const { return h.is_virtual ? virtual_regs_[h.id].degree : oracle_regs_[h.id].degree; }
+
+    void seal_interaction_registrations()                                                    // iop.tcc:227-251, bcs_common.tcc:423-480
+    {
+        if (!from_prover_) throw std::logic_error("attempted to seal interaction registrations where verifier sends the last interactive message");
+        num_oracles_at_end_of_round_.push_back(oracle_regs_.size());
+        num_prover_messages_at_end_of_round_.push_back(prover_message_sizes_.size());
+        ++num_interaction_rounds_;
+        sealed_ = true;
+        for (std::size_t round = 0; round < num_interaction_rounds_; ++round)
+            for (auto &kv : oracles_in_round_by_domain(round)) {
+                MT_info_.push_back({ round, kv.first, kv.second });
+                MT_trees_.emplace_back();
+                MT_roots_.emplace_back();
+            }
+    }
+    query_position_handle register_random_query_position(const domain_handle &domain)
+    {
+        random_position_domains_.push_back(domain.id);
+        return query_position_handle{ random_position_domains_.size() - 1, true };
+    }
+    query_position_handle register_deterministic_query_position(const std::vector<query_position_handle> &seeds, const position_calculator &calculator)
+    {
+        deterministic_positions_.emplace_back(seeds, calculator);
+        return query_position_handle{ deterministic_positions_.size() - 1, false };
+    }
+    query_handle register_query(const oracle_handle &oracle, const query_position_handle &position)
+    {
+        queries_.emplace_back(oracle, position);
+        return query_handle{ queries_.size() - 1 };
+    }
+    void seal_query_registrations() {}
+
+    // ---- proving (iop.tcc:265-433, bcs_prover.tcc:23-98) ----
+    void submit_oracle(const oracle_handle &handle, const oracle<FieldT> &contents)
+    {
+        const std::size_t oid = handle.id;
+        if (handle.is_virtual) throw std::invalid_argument("cannot submit a virtual oracle");
+        if (oracle_submitted_[oid]) throw std::invalid_argument("attempted to submit already submitted oracle");
+        const std::size_t begin = num_prover_rounds_done_ == 0 ? 0 : num_oracles_at_end_of_round_[num_prover_rounds_done_ - 1];
+        if (oid < begin) throw std::invalid_argument("submitting an oracle for a previous round");
+        if (oid >= num_oracles_at_end_of_round_[num_prover_rounds_done_])
+            throw std::invalid_argument("submitting an oracle for a future round (did you forget to call signal_prover_round_done?)");
+        if (domains_[oracle_regs_[oid].domain].num_elements() != contents.size()) throw std::invalid_argument("oracle evaluations don't match the domain size");
+        oracles_[oid] = contents.device_contents();
+        oracle_submitted_[oid] = true;
+    }
+    void submit_prover_message(const prover_message_handle &handle, const std::vector<FieldT> &contents)
+    {
+        if (message_submitted_[handle.id]) throw std::invalid_argument("attempted to submit already submitted prover message");
+        if (prover_message_sizes_[handle.id] != contents.size()) throw std::invalid_argument("prover message submission does not match its registered size");
+        prover_messages_[handle.id] = contents;
+        message_submitted_[handle.id] = true;
+    }
+    void signal_prover_round_done()
+    {
+        if (num_prover_rounds_done_ >= num_interaction_rounds_) throw std::logic_error("attempting to signal end of a round after protocol already finished");
+        const std::size_t ended = num_prover_rounds_done_;
+        const std::size_t begin = ended == 0 ? 0 : num_oracles_at_end_of_round_[ended - 1];
+        for (std::size_t oid = begin; oid < num_oracles_at_end_of_round_[ended]; ++oid)
+            if (!oracle_submitted_[oid]) throw std::logic_error("signaling end of round without submitting all oracles in the round");
+        const std::size_t mbegin = ended == 0 ? 0 : num_prover_messages_at_end_of_round_[ended - 1];
+        for (std::size_t mid = mbegin; mid < num_prover_messages_at_end_of_round_[ended]; ++mid)
+            if (!message_submitted_[mid]) throw std::logic_error("signaling end of round without submitting all prover messages in the round");
+        ++num_prover_rounds_done_;
+        // one tree per (round, domain) over every oracle of that domain, leaves serialised by cosets (bcs_prover.tcc:36-47); the
+        // reference indexes Merkle_trees_[processed_MTs_] for each domain of the round: every shipped protocol has one
+        const auto mapping = oracles_in_round_by_domain(ended);
+        if (mapping.size() > 1) throw std::logic_error("more than one oracle domain in a round (bcs_prover.tcc:36-47)");
+        const std::size_t cs = get_round_parameters(ended);
+        std::size_t num_roots = 0;
+        for (auto &kv : mapping) {
+            std::vector<device_vector<FieldT>> round_oracles;
+            for (std::size_t oid : kv.second) round_oracles.push_back(oracles_[oid]);
+            MT_trees_[processed_MTs_] = device_merkle_tree(round_oracles, domains_[kv.first], cs);
+            MT_roots_[processed_MTs_] = MT_trees_[processed_MTs_].get_root();
+            ++processed_MTs_;
+            ++num_roots;
+        }
+        run_hashchain_for_round(ended, num_roots);
+        if (num_prover_rounds_done_ == num_interaction_rounds_) {                            // bcs_prover.tcc:52-59
+            const hash_digest challenge = hashchain_.squeeze_root_type();
+            uint8_t answer[32];
+            check(iopx_pow_solve_blake2b(reinterpret_cast<const uint8_t *>(challenge.data()), pow_bitlen_, answer));
+            pow_answer_ = hash_digest(reinterpret_cast<const char *>(answer), 32);
+        }
+    }
+    std::vector<FieldT> obtain_verifier_random_message(const verifier_random_message_handle &h) const
+    {
+        auto it = verifier_random_messages_.find(h.id);
+        if (it == verifier_random_messages_.end())
+            throw std::logic_error("verifier random message not available yet (did you forget to call signal_prover_round_done?)");
+        return it->second;
+    }
+    // iop.tcc:630-667: the oracle's evaluations in HBM; virtual oracles are evaluated from their constituents
+    device_vector<FieldT> get_oracle_evaluations(const oracle_handle &h)
+    {
+        if (!h.is_virtual) return oracles_[h.id];
+        auto it = virtual_contents_cache_.find(h.id);
+        if (it != virtual_contents_cache_.end()) return it->second;
+        const virtual_registration &reg = virtual_regs_[h.id];
+        std::vector<device_vector<FieldT>> constituents;
+        for (auto &c : reg.constituents) constituents.push_back(get_oracle_evaluations(c));
+        device_vector<FieldT> result = reg.contents->evaluated_contents(constituents);
+        if (reg.cache) virtual_contents_cache_[h.id] = result;
+        return result;
+    }
+
+    // ---- transcript (bcs_prover.tcc:136-233) ----
+    bcs_transformation_transcript<FieldT> get_transcript()
+    {
+        bcs_transformation_transcript<FieldT> t;
+        t.prover_messages_ = prover_messages_;
+        t.MT_roots_ = MT_roots_;
+        std::map<std::size_t, std::size_t> random_cache, det_cache;
+        std::map<std::size_t, std::set<std::size_t>> positions_by_oracle;
+        for (auto &q : queries_) record(q.first, obtain_query_position(q.second, random_cache, det_cache), positions_by_oracle);   // registration order
+        for (std::size_t mt = 0; mt < MT_info_.size(); ++mt) {
+            const tree_info &info = MT_info_[mt];
+            const std::size_t cs = get_round_parameters(info.round);
+            const field_subset<FieldT> &domain = domains_[info.domain];
+            const std::size_t num_leaves = domain.num_elements() / cs;
+            std::set<std::size_t> qset, lset;
+            for (std::size_t oid : info.oracle_ids) {
+                auto it = positions_by_oracle.find(oid);
+                if (it == positions_by_oracle.end()) continue;
+                for (std::size_t pos : it->second) {
+                    qset.insert(pos);
+                    lset.insert(cs == 1 ? pos : (domain.type() == affine_subspace_type ? pos / cs : pos % num_leaves));      // bcs_common.tcc:682-696
+                }
+            }
+            const std::vector<std::size_t> qpos(qset.begin(), qset.end()), lpos(lset.begin(), lset.end());
+            t.query_positions_.push_back(qpos);
+            t.MT_leaf_positions_.push_back(lpos);
+            std::vector<std::vector<FieldT>> responses(qpos.size(), std::vector<FieldT>(info.oracle_ids.size()));
+            if (!qpos.empty()) {                                                             // bcs_prover.tcc:187-197
+                std::vector<const void *> ptrs;
+                for (std::size_t oid : info.oracle_ids) ptrs.push_back(oracles_[oid].data());
+                std::vector<FieldT> flat(qpos.size() * info.oracle_ids.size());
+                check(iopx_query_responses_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), domain.num_elements(), qpos.data(), qpos.size(), flat.data()));
+                for (std::size_t p = 0; p < qpos.size(); ++p)
+                    for (std::size_t k = 0; k < info.oracle_ids.size(); ++k) responses[p][k] = flat[p * info.oracle_ids.size() + k];
+            }
+            t.query_responses_.push_back(responses);
+            t.MT_set_membership_proofs_.push_back(MT_trees_[mt].get_set_membership_proof(lpos));
+        }
+        t.proof_of_work_ = pow_answer_;
+        return t;
+    }
+};
+
+} // namespace libiop_amd

@@ -1044,10 +1044,10 @@ int iopx_add_fft_gf192(const uint64_t *coeffs, size_t n_coeffs, const uint64_t *
     DevBuf din, dout;
     if ((rc = din.alloc(n_coeffs * 24)) != IOPX_OK) return rc;
     if ((rc = dout.alloc(n * 24)) != IOPX_OK) return rc;
-    if (n_coeffs) IOPX_HIP(hipMemcpyAsync(din.p, coeffs, n_coeffs * 24, hipMemcpyHostToDevice, stream()));
+    if (n_coeffs) IOPX_HIP(copy_h2d(din.p, coeffs, n_coeffs * 24, stream()));
     rc = iopx_add_fft_gf192_dev(din.u64(), n_coeffs, basis, m, shift, dout.u64());
     if (rc != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(out, dout.p, n * 24, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(copy_d2h(out, dout.p, n * 24, stream()));
     IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }
@@ -1062,10 +1062,10 @@ int iopx_add_ifft_gf192(const uint64_t *evals, const uint64_t *basis, size_t m, 
     DevBuf din, dout;
     if ((rc = din.alloc(n * 24)) != IOPX_OK) return rc;
     if ((rc = dout.alloc(n * 24)) != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(din.p, evals, n * 24, hipMemcpyHostToDevice, stream()));
+    IOPX_HIP(copy_h2d(din.p, evals, n * 24, stream()));
     rc = iopx_add_ifft_gf192_dev(din.u64(), basis, m, shift, dout.u64());
     if (rc != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(out, dout.p, n * 24, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(copy_d2h(out, dout.p, n * 24, stream()));
     IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }

@@ -669,9 +669,9 @@ int iopx_mul_fft_fp3(const uint64_t *coeffs, size_t n_coeffs, size_t log_n, cons
     DevBuf din, dout;
     if ((rc = din.alloc(n_coeffs * 24)) != IOPX_OK) return rc;
     if ((rc = dout.alloc(n * 24)) != IOPX_OK) return rc;
-    if (n_coeffs) IOPX_HIP(hipMemcpyAsync(din.p, coeffs, n_coeffs * 24, hipMemcpyHostToDevice, stream()));
+    if (n_coeffs) IOPX_HIP(copy_h2d(din.p, coeffs, n_coeffs * 24, stream()));
     if ((rc = iopx_mul_fft_fp3_dev(din.u64(), n_coeffs, log_n, gen, shift, dout.u64())) != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(out, dout.p, n * 24, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(copy_d2h(out, dout.p, n * 24, stream()));
     IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }
@@ -685,9 +685,9 @@ int iopx_mul_ifft_fp3(const uint64_t *evals, size_t log_n, const uint64_t *gen, 
     DevBuf din, dout;
     if ((rc = din.alloc(n * 24)) != IOPX_OK) return rc;
     if ((rc = dout.alloc(n * 24)) != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(din.p, evals, n * 24, hipMemcpyHostToDevice, stream()));
+    IOPX_HIP(copy_h2d(din.p, evals, n * 24, stream()));
     if ((rc = iopx_mul_ifft_fp3_dev(din.u64(), log_n, gen, shift, dout.u64())) != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(out, dout.p, n * 24, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(copy_d2h(out, dout.p, n * 24, stream()));
     IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }
@@ -704,9 +704,9 @@ int iopx_fri_fold_mul_fp3(const uint64_t *f_i, size_t log_n, const uint64_t *gen
     DevBuf din, dout;
     if ((rc = din.alloc(n * 24)) != IOPX_OK) return rc;
     if ((rc = dout.alloc(n_out * 24)) != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(din.p, f_i, n * 24, hipMemcpyHostToDevice, stream()));
+    IOPX_HIP(copy_h2d(din.p, f_i, n * 24, stream()));
     if ((rc = iopx_fri_fold_mul_fp3_dev(din.u64(), log_n, gen, shift, coset_size, x_i, dout.u64())) != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(next, dout.p, n_out * 24, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(copy_d2h(next, dout.p, n_out * 24, stream()));
     IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }

@@ -206,10 +206,10 @@ int iopx_fri_fold_add_gf192(const uint64_t *f_i, const uint64_t *basis, size_t m
     DevBuf din, dout;
     if ((rc = din.alloc(n * 24)) != IOPX_OK) return rc;
     if ((rc = dout.alloc(n_out * 24)) != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(din.p, f_i, n * 24, hipMemcpyHostToDevice, stream()));
+    IOPX_HIP(copy_h2d(din.p, f_i, n * 24, stream()));
     rc = iopx_fri_fold_add_gf192_dev(din.u64(), basis, m, shift, coset_size, x_i, dout.u64());
     if (rc != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(next, dout.p, n_out * 24, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(copy_d2h(next, dout.p, n_out * 24, stream()));
     IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }

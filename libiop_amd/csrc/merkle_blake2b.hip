@@ -313,19 +313,19 @@ int iopx_merkle_blake2b(const void *const *oracles, size_t num_oracles, size_t e
     for (size_t k = 0; k < num_oracles; ++k) {
         bufs.emplace_back(new DevBuf());
         if ((rc = bufs.back()->alloc(n * elem_bytes)) != IOPX_OK) return rc;
-        IOPX_HIP(hipMemcpyAsync(bufs.back()->p, oracles[k], n * elem_bytes, hipMemcpyHostToDevice, stream()));
+        IOPX_HIP(copy_h2d(bufs.back()->p, oracles[k], n * elem_bytes, stream()));
         dptrs.push_back(bufs.back()->p);
     }
     DevBuf dsalt, dnodes;
     if (salts) {
         if ((rc = dsalt.alloc(L * salt_bytes)) != IOPX_OK) return rc;
-        IOPX_HIP(hipMemcpyAsync(dsalt.p, salts, L * salt_bytes, hipMemcpyHostToDevice, stream()));
+        IOPX_HIP(copy_h2d(dsalt.p, salts, L * salt_bytes, stream()));
     }
     if ((rc = dnodes.alloc((2 * L - 1) * 32)) != IOPX_OK) return rc;
     rc = iopx_merkle_blake2b_dev(dptrs.data(), num_oracles, elem_bytes, n, coset_size, domain_type,
                                  salts ? (const uint8_t *)dsalt.p : nullptr, salt_bytes, (uint8_t *)dnodes.p);
     if (rc != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(nodes, dnodes.p, (2 * L - 1) * 32, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(copy_d2h(nodes, dnodes.p, (2 * L - 1) * 32, stream()));
     IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }
@@ -349,7 +349,7 @@ int iopx_pow_solve_blake2b(const uint8_t *challenge, size_t pow_bitlen, uint8_t 
         { ProfScope ps_("k_pow_blake2b");
           hipLaunchKernelGGL(k_pow_blake2b, dim3((unsigned)((batch + 255) / 256 > 16384 ? 16384 : (batch + 255) / 256)), dim3(256), 0, stream(),
                              c, first, batch, mask, (unsigned long long *)best.p); }
-        IOPX_HIP(hipMemcpyAsync(&found, best.p, 8, hipMemcpyDeviceToHost, stream()));
+        IOPX_HIP(copy_d2h(&found, best.p, 8, stream()));
         IOPX_HIP(hipStreamSynchronize(stream()));
         first += batch;
         if (batch < ((uint64_t)1 << 24)) batch <<= 2;
@@ -396,7 +396,7 @@ int iopx_merkle_membership_proof_dev(const uint8_t *d_nodes, size_t num_leaves, 
     { ProfScope ps_("k_gather_nodes");
       hipLaunchKernelGGL(k_gather_nodes, dim3((unsigned)((4 * want.size() + 255) / 256)), dim3(256), 0, stream(), dout.u64(), (const uint64_t *)d_nodes,
                          (const uint64_t *)didx.u64(), want.size()); }
-    IOPX_HIP(hipMemcpyAsync(aux_hashes, dout.p, want.size() * 32, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(copy_d2h(aux_hashes, dout.p, want.size() * 32, stream()));
     IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }
@@ -422,7 +422,7 @@ int iopx_query_responses_dev(const void *const *d_oracles, size_t num_oracles, s
     { ProfScope ps_("k_gather_responses");
       hipLaunchKernelGGL(k_gather_responses, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, stream(), dout.u64(),
                          (const uint64_t *const *)dptrs.p, (const uint64_t *)dpos.u64(), num_oracles, words, num_positions); }
-    IOPX_HIP(hipMemcpyAsync(values, dout.p, total * 8, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(copy_d2h(values, dout.p, total * 8, stream()));
     IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }

@@ -746,19 +746,19 @@ int iopx_merkle_poseidon_bn128(const iopx_poseidon_params *params, const void *c
     for (size_t k = 0; k < num_oracles; ++k) {
         bufs.emplace_back(new DevBuf());
         if ((rc = bufs.back()->alloc(n * 32)) != IOPX_OK) return rc;
-        IOPX_HIP(hipMemcpyAsync(bufs.back()->p, oracles[k], n * 32, hipMemcpyHostToDevice, stream()));
+        IOPX_HIP(copy_h2d(bufs.back()->p, oracles[k], n * 32, stream()));
         dptrs.push_back(bufs.back()->p);
     }
     DevBuf dsalt, dnodes;
     if (salts) {
         if ((rc = dsalt.alloc(L * 32)) != IOPX_OK) return rc;
-        IOPX_HIP(hipMemcpyAsync(dsalt.p, salts, L * 32, hipMemcpyHostToDevice, stream()));
+        IOPX_HIP(copy_h2d(dsalt.p, salts, L * 32, stream()));
     }
     if ((rc = dnodes.alloc((2 * L - 1) * 32)) != IOPX_OK) return rc;
     rc = iopx_merkle_poseidon_bn128_dev(params, dptrs.data(), num_oracles, n, coset_size, domain_type,
                                         salts ? (const uint8_t *)dsalt.p : nullptr, dnodes.u64());
     if (rc != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(nodes, dnodes.p, (2 * L - 1) * 32, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(copy_d2h(nodes, dnodes.p, (2 * L - 1) * 32, stream()));
     IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }
@@ -785,7 +785,7 @@ int iopx_pow_solve_poseidon_bn128(const iopx_poseidon_params *params, const uint
         { ProfScope ps_("k_pow_poseidon");
           if (P.t == 3) hipLaunchKernelGGL(k_pow_poseidon<3>, dim3(grid), dim3(64), 0, stream(), P, c, first, batch, mask, (unsigned long long *)best.p);
           else hipLaunchKernelGGL(k_pow_poseidon<4>, dim3(grid), dim3(64), 0, stream(), P, c, first, batch, mask, (unsigned long long *)best.p); }
-        IOPX_HIP(hipMemcpyAsync(&found, best.p, 8, hipMemcpyDeviceToHost, stream()));
+        IOPX_HIP(copy_d2h(&found, best.p, 8, stream()));
         IOPX_HIP(hipStreamSynchronize(stream()));
         first += batch;
         if (batch < ((uint64_t)1 << 22)) batch <<= 2;
@@ -793,7 +793,7 @@ int iopx_pow_solve_poseidon_bn128(const iopx_poseidon_params *params, const uint
     const uint64_t k[4] = { found, 0, 0, 0 };
     if ((rc = upload((uint64_t *)best.p + 1, k, 32)) != IOPX_OK) return rc;
     hipLaunchKernelGGL(k_bn_to_mont, dim3(1), dim3(64), 0, stream(), (uint64_t *)best.p + 1, (const uint64_t *)best.p + 1, (size_t)1);
-    IOPX_HIP(hipMemcpyAsync(pow, (uint64_t *)best.p + 1, 32, hipMemcpyDeviceToHost, stream()));
+    IOPX_HIP(copy_d2h(pow, (uint64_t *)best.p + 1, 32, stream()));
     IOPX_HIP(hipStreamSynchronize(stream()));
     return IOPX_OK;
 }

@@ -1,6 +1,7 @@
 // Internal runtime of libiop_amd: error reporting, the current HIP stream, small helpers.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -26,6 +27,20 @@ int ensure_device();
         if (e_ != hipSuccess)                                                                  \
             return ::iopx::fail(IOPX_ERR_RUNTIME, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
+
+// Every host<->device copy of the library goes through these two, which keep byte counters (iopx_transfer_stats): a prover that
+// claims "no codeword crosses PCIe" can be checked against them.
+extern std::atomic_uint_fast64_t g_bytes_h2d, g_bytes_d2h;
+static inline hipError_t copy_h2d(void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    g_bytes_h2d += bytes;
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+}
+static inline hipError_t copy_d2h(void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    g_bytes_d2h += bytes;
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
+}
 
 // Device buffer owned by a plan / a call (freed in the destructor, stream-ordered use only).
 struct DevBuf {

@@ -161,7 +161,7 @@ int upload(void *dst_dev, const void *src_host, size_t bytes)
         c = &g_stage.back();
     }
     memcpy(c->p, src_host, bytes);
-    IOPX_HIP(hipMemcpyAsync(dst_dev, c->p, bytes, hipMemcpyHostToDevice, g_stream));
+    IOPX_HIP(copy_h2d(dst_dev, c->p, bytes, g_stream));
     IOPX_HIP(hipEventRecord(c->done, g_stream));
     c->busy = true;
     return IOPX_OK;
@@ -295,7 +295,7 @@ int iopx_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes)
 {
     int rc = iopx::ensure_device();
     if (rc != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, iopx::stream()));
+    IOPX_HIP(iopx::copy_h2d(dst_dev, src_host, bytes, iopx::stream()));
     IOPX_HIP(hipStreamSynchronize(iopx::stream()));
     return IOPX_OK;
 }
@@ -304,7 +304,7 @@ int iopx_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes)
 {
     int rc = iopx::ensure_device();
     if (rc != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, iopx::stream()));
+    IOPX_HIP(iopx::copy_d2h(dst_host, src_dev, bytes, iopx::stream()));
     IOPX_HIP(hipStreamSynchronize(iopx::stream()));
     return IOPX_OK;
 }

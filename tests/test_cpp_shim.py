@@ -14,7 +14,8 @@ EXE = os.path.join(ROOT, "tests", "cpp", "test_shim")
 def _build():
     lib = iopx_build.build()
     src = os.path.join(ROOT, "tests", "cpp", "test_shim.cpp")
-    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src), os.path.getmtime(lib)):
+    hdrs = [os.path.join(ROOT, "libiop_amd", "cpp", h) for h in os.listdir(os.path.join(ROOT, "libiop_amd", "cpp"))]
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max([os.path.getmtime(src), os.path.getmtime(lib)] + [os.path.getmtime(h) for h in hdrs]):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-mpclmul", "-msse4.1", src, "-o", EXE,
                                "-L" + os.path.dirname(lib), "-liop_amd", "-Wl,-rpath," + os.path.dirname(lib),
                                "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
@@ -41,6 +42,28 @@ def test_cpp_shim_parity_on_cpu_emulation():
                            "-Wl,-rpath," + emu_dir])
     r = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "gpu ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_cpp_aurora_prover_on_cpu_emulation():
+    """VERDICT r2 row (b'): the C++ prover surface — libiop_amd/cpp/{iop,r1cs,aurora}.hpp, aurora_snark_prover<FieldT>(cs, primary,
+    auxiliary, params) with device-resident oracles — proves 2^7..2^10 instances over both fields; transcript bytes equal the oracle
+    prover's, and the PCIe byte counters stay far below one codeword.  Here against the CPU build of the kernel sources."""
+    from emu_lib import emu
+    emu()
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    exe = os.path.join(ROOT, "tests", "cpp", "test_shim_emu")
+    src = os.path.join(ROOT, "tests", "cpp", "test_shim.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-mpclmul", "-msse4.1", src, "-o", exe, os.path.join(emu_dir, "libiopx_emu.so"),
+                           "-Wl,-rpath," + emu_dir])
+    r = subprocess.run([exe, "aurora", "10"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "aurora ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_aurora_prover_on_gpu():
+    exe = _build()
+    r = subprocess.run([exe, "aurora", "12"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "aurora ok" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.gpu
