@@ -18,6 +18,7 @@ config.secondary_fractal configs[4]'s Fractal prover on this GPU.
 N > 1 (one process per GPU): see libiop_amd/dist.py — the proof is sharded by contiguous cosets; "strong" scaling.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus N ...                      (starts torch.distributed.run itself, as a child process, when RANK is unset)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 import argparse
@@ -32,6 +33,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ELEM = 24
+
+
+def kernel_sources_digest():
+    """sha256 over the kernel sources: profile-derived figures are only quoted when they were collected on these sources."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "libiop_amd", "csrc")
+    for dp, _, fs in sorted(os.walk(csrc)):
+        for f in sorted(fs):
+            if f.endswith((".hip", ".h")):
+                h.update(open(os.path.join(dp, f), "rb").read())
+    return h.hexdigest()
+
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 SEED = 0x2204                  # SURVEY.md §8d
 
@@ -56,6 +71,64 @@ def aurora_transform_inventory(log_n, rs_extra, final_dim):
     return inv
 
 
+def launcher_command(gpus, argv):
+    """The command `python bench.py --gpus N` re-runs itself with: one rank per GPU of this node, rendezvous on 127.0.0.1."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def host_description():
+    """CPU model and core count of the box the baseline runs on (lscpu / nproc)."""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"cpu_model": model, "logical_cores": os.cpu_count()}
+
+
+def _oracle_prove(k):
+    import oracle
+    t0 = time.perf_counter()
+    oracle.aurora_prove(oracle.FIELD_GF192, k, 15, SEED)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_leg(k, all_cores):
+    """Times the oracle prover (test infrastructure: used here as the reported CPU baseline only) on the 2^k-constraint sample."""
+    import oracle
+    t0 = time.perf_counter()
+    ref = oracle.aurora_prove(oracle.FIELD_GF192, k, 15, SEED)
+    cpu_s = time.perf_counter() - t0
+    out = {"transcript": ref, "seconds": cpu_s, "log_n": k, "host": host_description()}
+    if all_cores:
+        # not in the reference (it is single-threaded): one independent proof per logical core, all at once — a throughput figure
+        import multiprocessing as mp
+        cores = os.cpu_count() or 1
+        kk = max(k - 1, 8)
+        t0 = time.perf_counter()
+        with mp.get_context("spawn").Pool(cores) as pool:
+            pool.map(_oracle_prove, [kk] * cores)
+        out["all_cores"] = {"cores": cores, "log_n": kk, "seconds_for_one_proof_per_core": time.perf_counter() - t0}
+    return out
+
+
+def alu_model():
+    """profiles/r03_alu_model.json (tools/alu_model.py): the VALU-issue ceiling of the butterfly kernels from their ISA and the measured
+    per-class instruction costs; None when the file is missing."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r03_alu_model.json")))
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,17 +139,32 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the multi-GPU operator set even with one rank (exercises the RCCL calls on a 1-GPU box; run under torch.distributed.run)")
-    ap.add_argument("--cpu-log-n", type=int, default=12, help="size of the CPU-baseline sample (oracle prover)")
+    ap.add_argument("--cpu-log-n", type=int, default=13, help="size of the CPU-baseline sample (oracle prover); 2^13: about 20 s on one core")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-host-cores variant of the CPU baseline (one independent oracle proof per core)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Started as `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet (torch is not even imported),
+        # the ranks run as CHILD processes of torch.distributed.run and this process only forwards their exit code.
+        import subprocess
+        sys.exit(subprocess.call(launcher_command(args.gpus, sys.argv[1:])))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    # CPU baseline FIRST (rank 0, N = 1 only), before the GPU is busy: the oracle's literal restatement of the reference prover (PCLMUL
+    # gf192, one thread — the reference is single-threaded) on a bounded sample of the same workload; its transcript is compared with the
+    # device prover's for that instance further down, before the number is reported.
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_leg(args.cpu_log_n, not args.no_cpu_all_cores)
 
     import torch
     import torch.distributed as dist
     import libiop_amd
     from libiop_amd import aurora, domains, r1cs
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or args.force_sharded:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
@@ -133,19 +221,27 @@ def main():
     dom_avg_s = dom_ms / dom_cnt / 1e3
     alg_bytes_per_launch = dom_bytes / dom_cnt if dom_bytes else None
     achieved = (dom_bytes / (dom_ms / 1e3) / 1e9) if dom_bytes else None
-    traffic = None
-    try:                                        # HBM bytes per launch of that kernel from the committed PMC run (profiles/)
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic_aurora.json")))
-        if tj.get("log_n") == args.log_n and dom_name in tj.get("kernels", {}):
+    # HBM bytes per launch of that kernel: NOT measured in this run (PMC counters need rocprofv3 passes of their own) — taken from the
+    # committed PMC run of the same kernels and labelled with its file; null when that run covered other kernel sources
+    traffic, traffic_source = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic_aurora.json")))
+        if tj.get("log_n") == args.log_n and dom_name in tj.get("kernels", {}) and tj.get("kernel_sources_sha256") == kernel_sources_digest():
             traffic = tj["kernels"][dom_name]["traffic_bytes_per_launch"]
+            traffic_source = "profiles/r03_traffic_aurora.json (rocprofv3 --pmc passes of this command, collected %s)" % tj.get("collected", "?")
     except (OSError, ValueError):
         pass
-    valu = None
-    try:                                        # integer-VALU issue utilisation of that kernel from the committed SQ-counter passes
-        sj = json.load(open(os.path.join(ROOT, "profiles", "r02_sq_aurora.json")))
-        valu = sj["kernels"][dom_name]["valu_issue_utilisation"]
-    except (OSError, ValueError, KeyError):
-        pass
+    # ALU ceiling: the rate measured live in this run (field products of the launches / their HIP-event time) against the VALU-issue
+    # ceiling of the kernel's instruction mix (tools/alu_model.py: ISA histogram x per-class cycles measured by tools/ubench/valu_rates)
+    products = getattr(lib, "last_profile_products", {})
+    model = alu_model()
+    alu = {}
+    if model:
+        for kname, kmod in model["kernels"].items():
+            if kname in prof and products.get(kname):
+                rate = products[kname] / (prof[kname][1] / 1e3)
+                alu[kname] = {"products_per_s": rate, "ceiling_products_per_s": kmod["alu_ceiling_products_per_s"],
+                              "alu_ceiling_frac": rate / kmod["alu_ceiling_products_per_s"], "cycles_per_wave_product_model": kmod["cycles_per_wave_butterfly"]}
     fft_kernels = ("k_phase1", "k_bfly_upper", "k_bfly_edge", "k_pad_copy", "k_rs_combine", "k_fill")
     fft_ms = sum(v[1] for k, v in prof.items() if k.startswith(fft_kernels))
 
@@ -186,9 +282,13 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
                      "kernel": dom_name, "launches_per_step": dom_cnt, "avg_launch_ms": dom_avg_s * 1e3,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                     "valu_issue_utilisation": valu,
-                     "note": "gfx950 has no carry-less multiply: the GF(2^192) butterflies are integer-ALU-bound (valu_issue_utilisation = SQ_INSTS_VALU x 4 "
-                             "cycles / (SIMDs x elapsed cycles), profiles/r02_sq_aurora.json), see DESIGN.md",
+                     "traffic_source": traffic_source,
+                     "binding": "integer VALU issue (gfx950 has no carry-less multiply: a GF(2^192) product is ~450-1000 VALU ops)",
+                     "alu_ceiling_frac": alu.get(dom_name, {}).get("alu_ceiling_frac"),
+                     "alu": alu,
+                     "note": "frac = algorithmic bytes / HBM peak as the contract asks; the kernel is bound by VALU issue, for which alu_ceiling_frac is the "
+                             "figure: measured products/s over the ceiling of the kernel's instruction mix at the per-class issue costs measured on this GPU "
+                             "(profiles/r03_alu_model.json, profiles/r03_valu_rates.txt)",
                      "kernels_ms_per_step": {k: round(v[1], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
                      "kernel_launches_per_step": {k: v[0] for k, v in prof.items()}},
     }
@@ -242,28 +342,35 @@ def main():
             "prover_ms": sorted(times5[1:])[len(times5[1:]) // 2] * 1e3, "prover_ms_min": min(times5[1:]) * 1e3, "prover_ms_all": [round(t * 1e3, 2) for t in times5], "indexer_ms_first_call": indexer_s * 1e3,
             "argument_bytes": len(tr5.serialize()), "fri_query_repetitions": params5.fri_query_repetitions,
             "kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof5.items(), key=lambda kv: -kv[1][1])[:10]}}
+        d5, (c5, ms5, b5) = max(prof5.items(), key=lambda kv: kv[1][1])
+        out["config"]["secondary_fractal"]["roofline"] = {
+            "bound": "hbm", "kernel": d5, "launches_per_proof": c5, "avg_launch_ms": ms5 / c5, "algorithmic_bytes_per_launch": b5 / c5 if b5 else None,
+            "achieved": (b5 / (ms5 / 1e3) / 1e9) if b5 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (b5 / (ms5 / 1e3) / 1e9 / HBM_PEAK_GBS) if b5 else None,
+            "traffic": None, "binding": "integer VALU issue (29-bit-limb Montgomery products in v_mad_u64_u32 accumulators)"}
         del index5, tr5, cs5, d_z5
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # CPU baseline: the oracle's literal restatement of the reference prover (PCLMUL gf192, one thread) on a bounded sample
-        # of the same workload — the same protocol and rate on a 2^cpu_log_n-constraint instance — checked against the device
-        # prover's transcript for that instance byte for byte before its time is accepted.
-        import oracle
-        k = args.cpu_log_n
+    if cpu is not None:
+        # the sample instance on the device: the transcript must equal the CPU oracle prover's byte for byte before its time is reported
+        k = cpu["log_n"]
         nk = 1 << k
         cs_k, prim_k, aux_k = r1cs.generate_r1cs_example(ops, nk, 15, nk - 1, SEED)
         params_k = aurora.AuroraParameters(field, nk, nk - 1, 15)
         mine = aurora.aurora_snark_prover(ops, cs_k, prim_k, aux_k, params_k).serialize()
-        t0 = time.perf_counter()
-        ref = oracle.aurora_prove(oracle.FIELD_GF192, k, 15, SEED)
-        cpu_s = time.perf_counter() - t0
-        assert mine == ref, "device transcript differs from the CPU oracle prover's"
+        assert mine == cpu["transcript"], "device transcript differs from the CPU oracle prover's"
         inv_k = aurora_transform_inventory(k, params_k.RS_extra_dimensions, params_k.codeword_domain_dim - sum(params_k.localization_parameters))
         ops_k = sum(sum(ref_fft_ops(m)) for _, m in inv_k)
-        out["cpu_baseline"] = {"value": ops_k / cpu_s, "unit": "field-ops/s", "cores": 1, "kind": "port",
-                               "sample": "the same prover on a 2^%d-constraint instance (same protocol, rate 1/32, seed): %.2f s on one core; its "
-                                         "transcript equals the device prover's byte for byte" % (k, cpu_s),
-                               "seconds": cpu_s, "sample_log_n": k}
+        out["cpu_baseline"] = {"value": ops_k / cpu["seconds"], "unit": "field-ops/s", "cores": 1, "kind": "port",
+                               "sample": "the same prover on a 2^%d-constraint instance (same protocol, rate 1/32, seed): %.2f s on one core, run before the "
+                                         "GPU loop; its transcript equals the device prover's byte for byte" % (k, cpu["seconds"]),
+                               "seconds": cpu["seconds"], "sample_log_n": k, "host": cpu["host"]}
+        if "all_cores" in cpu:
+            ac = cpu["all_cores"]
+            inv_a = aurora_transform_inventory(ac["log_n"], params_k.RS_extra_dimensions, ac["log_n"] + params_k.RS_extra_dimensions - sum(
+                aurora.AuroraParameters(field, 1 << ac["log_n"], (1 << ac["log_n"]) - 1, 15).localization_parameters))
+            out["cpu_baseline"]["all_cores_not_in_reference"] = {
+                "value": ac["cores"] * sum(sum(ref_fft_ops(m)) for _, m in inv_a) / ac["seconds_for_one_proof_per_core"], "unit": "field-ops/s", "cores": ac["cores"],
+                "sample": "one independent 2^%d proof per logical core, all at once: %.2f s (the reference prover is single-threaded; this is an upper "
+                          "bound on what a multi-threaded port could reach)" % (ac["log_n"], ac["seconds_for_one_proof_per_core"])}
     if rank == 0:
         print(json.dumps(out))
     if args.force_sharded and rank == 0:          # the sharded operator set must produce the single-GPU prover's transcript

@@ -388,7 +388,7 @@ int iopx_pow_solve_poseidon_bn128(const iopx_poseidon_params *params, const uint
 /* ---- measurement hooks -------------------------------------------------------------------------- */
 /* Per-kernel timing with HIP events recorded on the library's stream around every kernel launch.
  * iopx_profile_begin() starts recording; iopx_profile_report() synchronises, stops recording and writes
- * one text line per kernel: "<kernel> <launches> <total_ms> <algorithmic_bytes>\n" (used by bench.py for the roofline line;
+ * one text line per kernel: "<kernel> <launches> <total_ms> <algorithmic_bytes> <field_products>\n" (used by bench.py for the roofline line;
  * algorithmic_bytes = elements swept x 24 x (read + write) summed over the launches, 0 for kernels that do not report it). */
 int iopx_profile_begin(void);
 int iopx_profile_report(char *buf, size_t cap);

@@ -817,13 +817,16 @@ class Library:
         self._check(self.c.iopx_profile_begin())
 
     def profile_report(self):
-        """Returns {kernel: (launches, total_ms, algorithmic_bytes)} for the launches since profile_begin()."""
+        """Returns {kernel: (launches, total_ms, algorithmic_bytes)} for the launches since profile_begin(); the field products each kernel
+        reported (0 for kernels that do not) are kept in self.last_profile_products."""
         buf = ctypes.create_string_buffer(1 << 16)
         self._check(self.c.iopx_profile_report(buf, len(buf)))
-        out = {}
+        out, products = {}, {}
         for line in buf.value.decode().splitlines():
             f = line.split()
             out[f[0]] = (int(f[1]), float(f[2]), float(f[3]) if len(f) > 3 else 0.0)
+            products[f[0]] = float(f[4]) if len(f) > 4 else 0.0
+        self.last_profile_products = products
         return out
 
     def gf192_mul_dev(self, d_a, d_b, d_out, count):

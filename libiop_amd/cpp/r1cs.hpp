@@ -97,4 +97,79 @@ public:
     void prepare_device() const { A.to_device(); B.to_device(); C.to_device(); }
 };
 
+// ---- the synthetic instance the reference's harnesses prove (libiop/relations/examples/r1cs_examples.tcc:23-78, called as
+// generate_r1cs_example(n, 15, n - 1) by profiling/instrument_aurora_snark.cpp:108-110), seeded with SplitMix64 instead of
+// libsodium randomness so that every implementation derives the same instance from (n, k, seed) ----
+inline uint64_t splitmix64_at(uint64_t seed, uint64_t index)
+{
+    uint64_t z = seed + (index + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// element i takes stream outputs 3 i .. 3 i + 2 as its words: GF(2^192) the raw words; the prime field the 192-bit draw reduced
+// mod p, in Montgomery form (one Montgomery product with R^2 does both)
+template<typename FieldT>
+std::vector<FieldT> seeded_elements(uint64_t seed, std::size_t count)
+{
+    typedef field_host<FieldT> H;
+    std::vector<FieldT> out(count);
+    const FieldT R2 = H::additive() ? H::one() : H::pow(H::from_uint(2), 192);       // the element 2^192: its stored words are R^2 mod p
+    for (std::size_t i = 0; i < count; ++i) {
+        uint64_t w[3];
+        for (int k = 0; k < 3; ++k) w[k] = splitmix64_at(seed, 3 * i + k);
+        out[i] = H::from_words(w);
+        if (!H::additive()) out[i] = H::mul(out[i], R2);
+    }
+    return out;
+}
+
+template<typename FieldT>
+struct r1cs_example {
+    r1cs_constraint_system<FieldT> constraint_system;
+    r1cs_primary_input<FieldT> primary_input;
+    r1cs_auxiliary_input<FieldT> auxiliary_input;
+};
+
+// constraint i is z[i mod m] * z[(i + 7) mod m] = coef_i * z[(2 i + 1) mod m] with coef_i = A B / C (the constant term carries A B
+// when C's variable is zero); the products and inverses run on the device (2^20 field inversions on one host core would take minutes)
+template<typename FieldT>
+r1cs_example<FieldT> generate_r1cs_example(std::size_t num_constraints, std::size_t num_inputs, std::size_t num_variables, uint64_t seed)
+{
+    typedef field_host<FieldT> H;
+    if (num_inputs > num_variables) throw std::invalid_argument("Number of inputs can't exceed number of variables.");
+    r1cs_example<FieldT> ex;
+    const std::vector<FieldT> z = seeded_elements<FieldT>(seed, num_variables);
+    std::vector<uint64_t> a_idx(num_constraints), b_idx(num_constraints), c_idx(num_constraints);
+    for (std::size_t i = 0; i < num_constraints; ++i) { a_idx[i] = i % num_variables; b_idx[i] = (i + 7) % num_variables; c_idx[i] = (2 * i + 1) % num_variables; }
+    const device_vector<FieldT> d_z(device_array<FieldT>::from_host(z));
+    auto gathered = [&](const device_vector<FieldT> &src, const std::vector<uint64_t> &idx) {
+        const device_array<uint64_t> d_idx = device_array<uint64_t>::from_host(idx);
+        device_vector<FieldT> out(idx.size());
+        check(iopx_gather_dev(src.data(), d_idx.data(), idx.size(), sizeof(FieldT), out.data()));
+        return out;
+    };
+    auto product = [&](const device_vector<FieldT> &a, const device_vector<FieldT> &b) {
+        device_vector<FieldT> out(a.size());
+        check((H::additive() ? iopx_gf192_mul_dev : iopx_fp3_mul_dev)(a.words(), b.words(), out.words(), a.size()));
+        return out;
+    };
+    const device_vector<FieldT> ab = product(gathered(d_z, a_idx), gathered(d_z, b_idx));
+    device_vector<FieldT> z_inv(num_variables);
+    check((H::additive() ? iopx_gf192_inv_dev : iopx_fp3_inv_dev)(d_z.words(), z_inv.words(), num_variables));      // zero stays zero
+    const std::vector<FieldT> coef = product(ab, gathered(z_inv, c_idx)).to_host(), ab_host = ab.to_host();
+    r1cs_constraint_system<FieldT> &cs = ex.constraint_system;
+    cs.primary_input_size_ = num_inputs;
+    cs.auxiliary_input_size_ = num_variables - num_inputs;
+    const FieldT one = H::one();
+    for (std::size_t i = 0; i < num_constraints; ++i) {
+        const bool c_zero = H::is_zero(z[c_idx[i]]);
+        cs.add_constraint({ { { a_idx[i] + 1, one } }, { { b_idx[i] + 1, one } }, { c_zero ? linear_term<FieldT>{ 0, ab_host[i] } : linear_term<FieldT>{ c_idx[i] + 1, coef[i] } } });
+    }
+    ex.primary_input.assign(z.begin(), z.begin() + num_inputs);
+    ex.auxiliary_input.assign(z.begin() + num_inputs, z.end());
+    return ex;
+}
+
 } // namespace libiop_amd

@@ -730,7 +730,7 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         p.rs_comb = comb_count ? rs_comb.u64() + 3 * (cbase - comb_base) * d : nullptr;
         int rc;
         if ((rc = set_lds(k_bfly_edge<INV, false>, lds)) != IOPX_OK) return rc;
-        { ProfScope ps_("k_bfly_edge", (ncos << d) * 48); hipLaunchKernelGGL((k_bfly_edge<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        { ProfScope ps_("k_bfly_edge", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)p.a_low); hipLaunchKernelGGL((k_bfly_edge<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         return IOPX_OK;
     };
     auto launch_upper = [&](const Up &u, const uint64_t *s, uint64_t *dd, int shared, size_t ncos, size_t cbase) -> int {
@@ -747,10 +747,10 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         int rc;
         if (tuning().comb && u.c >= 6) {
             if ((rc = set_lds(k_bfly_upper<INV, true>, lds)) != IOPX_OK) return rc;
-            { ProfScope ps_("k_bfly_upper", (ncos << d) * 48); hipLaunchKernelGGL((k_bfly_upper<INV, true>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+            { ProfScope ps_("k_bfly_upper", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, true>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         } else {
             if ((rc = set_lds(k_bfly_upper<INV, false>, lds)) != IOPX_OK) return rc;
-            { ProfScope ps_("k_bfly_upper", (ncos << d) * 48); hipLaunchKernelGGL((k_bfly_upper<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+            { ProfScope ps_("k_bfly_upper", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         }
         return IOPX_OK;
     };

@@ -117,10 +117,11 @@ struct TmpBuf {
 
 // Per-kernel timing with HIP events on the library's stream (iopx_profile_begin / iopx_profile_report).
 // Costs nothing when profiling is off.  Usage: { ProfScope ps("k_name"); hipLaunchKernelGGL(...); }
-// work_bytes: the launch's ALGORITHMIC bytes (elements swept x 24 x (read + write)), summed per kernel in the report.
+// work_bytes: the launch's ALGORITHMIC bytes (elements swept x 24 x (read + write)), summed per kernel in the report;
+// work_products: the field multiplications the launch performs (the unit of the ALU ceiling in bench.py's roofline block).
 struct ProfScope {
     int slot;
-    explicit ProfScope(const char *name, size_t work_bytes = 0);
+    explicit ProfScope(const char *name, size_t work_bytes = 0, size_t work_products = 0);
     ~ProfScope();
 };
 

@@ -168,16 +168,17 @@ int upload(void *dst_dev, const void *src_host, size_t bytes)
 }
 
 // ---- per-kernel profiling -----------------------------------------------------------------------
-struct ProfRec { const char *name; hipEvent_t a, b; size_t bytes; };
+struct ProfRec { const char *name; hipEvent_t a, b; size_t bytes, products; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 
-ProfScope::ProfScope(const char *name, size_t work_bytes) : slot(-1)
+ProfScope::ProfScope(const char *name, size_t work_bytes, size_t work_products) : slot(-1)
 {
     if (!g_prof_on) return;
     ProfRec r;
     r.name = name;
     r.bytes = work_bytes;
+    r.products = work_products;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
     (void)hipEventRecord(r.a, g_stream);
     slot = (int)g_prof.size();
@@ -203,14 +204,14 @@ int iopx_profile_begin(void)
     return IOPX_OK;
 }
 
-// Stops profiling and writes one line per kernel name: "<name> <launches> <total_ms> <algorithmic_bytes>\n".
+// Stops profiling and writes one line per kernel name: "<name> <launches> <total_ms> <algorithmic_bytes> <field_products>\n".
 int iopx_profile_report(char *buf, size_t cap)
 {
     int rc = iopx::ensure_device();
     if (rc != IOPX_OK) return rc;
     iopx::g_prof_on = false;
     IOPX_HIP(hipStreamSynchronize(iopx::stream()));
-    struct Agg { size_t launches = 0; double ms = 0; double bytes = 0; };
+    struct Agg { size_t launches = 0; double ms = 0; double bytes = 0; double products = 0; };
     std::map<std::string, Agg> agg;
     for (auto &r : iopx::g_prof) {
         float ms = 0.f;
@@ -219,6 +220,7 @@ int iopx_profile_report(char *buf, size_t cap)
             e.launches += 1;
             e.ms += ms;
             e.bytes += (double)r.bytes;
+            e.products += (double)r.products;
         }
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -227,7 +229,7 @@ int iopx_profile_report(char *buf, size_t cap)
     std::string out;
     for (auto &kv : agg) {
         char line[256];
-        snprintf(line, sizeof(line), "%s %zu %.6f %.0f\n", kv.first.c_str(), kv.second.launches, kv.second.ms, kv.second.bytes);
+        snprintf(line, sizeof(line), "%s %zu %.6f %.0f %.0f\n", kv.first.c_str(), kv.second.launches, kv.second.ms, kv.second.bytes, kv.second.products);
         out += line;
     }
     if (buf && cap) {

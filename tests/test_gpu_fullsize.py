@@ -238,3 +238,73 @@ def test_fractal_2p20_proof_accepted_by_the_oracle_verifier(env):
     transcript.query_responses[0] = transcript.query_responses[0].copy()
     transcript.query_responses[0][3, 6, 1] ^= np.uint64(4)
     assert not oracle.fractal_verify(oracle.FIELD_EDWARDS, D, 0, 0x2205, transcript.serialize(), roots)
+
+
+def test_fri_snark_cfg3_full_size_accepted_by_the_oracle_verifier(env):
+    """BASELINE config 3 at its own size: the FRI-only SNARK for a degree-2^20 polynomial on the 2^22-point
+    codeword domain (RS_extra_dimensions 2, localization 2 -> [1, 2 x 9], 10 Merkle trees, 1 interactive and 10 query repetitions:
+    profiling/instrument_fri_snark.cpp:84-86,144-148; protocols/fri_iop.tcc:3-101; fri_ldt.tcc:475-548) is proved on the device
+    and accepted by the oracle's verifier; a flipped answer, a flipped final-polynomial coefficient and a wrong root are rejected."""
+    import copy
+    from libiop_amd import fri, r1cs
+    lib, torch, dev, ops, _ = env
+    dim, rs_extra, loc, interactions, queries, seed = 22, 2, 2, 1, 10, 0x2203
+    params = fri.FRISnarkParameters(dim, rs_extra, loc, interactions, queries)
+    assert params.poly_degree_bound == 1 << 20 and params.localization_parameters == [1] + [2] * 9
+    coeffs = r1cs.seeded_elements(ops.field, seed, params.poly_degree_bound)
+    transcript = fri.fri_snark_prover(ops, params, d_poly_coeffs=ops.upload(coeffs))
+    assert len(transcript.MT_roots) == 10
+    args = (oracle.FIELD_GF192, dim, rs_extra, loc, interactions, queries)
+    assert oracle.fri_snark_verify(*args, transcript.serialize())
+    t = copy.deepcopy(transcript)
+    t.query_responses[1] = t.query_responses[1].copy(); t.query_responses[1][0, 0, 1] ^= np.uint64(1)
+    assert not oracle.fri_snark_verify(*args, t.serialize())
+    t = copy.deepcopy(transcript)
+    t.prover_messages[0] = t.prover_messages[0].copy(); t.prover_messages[0][0, 0] ^= np.uint64(1)
+    assert not oracle.fri_snark_verify(*args, t.serialize())
+    t = copy.deepcopy(transcript)
+    r = bytearray(t.MT_roots[0]); r[5] ^= 1; t.MT_roots[0] = bytes(r)
+    assert not oracle.fri_snark_verify(*args, t.serialize())
+
+
+def test_aurora_2p14_transcript_byte_equal_to_the_oracle_prover(env):
+    """the largest byte-equal case (the oracle prover needs about a minute for it on one host core)."""
+    import aurora_cases
+    lib, torch, dev, _, _ = env
+    aurora_cases.check_transcript_equals_oracle(lib, torch, dev, "gf192", 14, 15, 0x2204)
+
+
+def test_fractal_2p14_transcript_byte_equal_to_the_oracle_prover(env):
+    import fractal_cases
+    lib, torch, dev, _, _ = env
+    fractal_cases.check_transcript_equals_oracle(lib, torch, dev, "edwards_Fr", 14, 0, 0x2205)
+
+
+def test_cpp_prover_transcripts_equal_the_python_provers_at_2p20(env):
+    """The C++ prover surface (libiop_amd/cpp/aurora.hpp, tools/cpp/aurora_bench.cpp) derives the same 2^20-constraint instance from
+    the seed and must produce the Python prover's transcript (whose acceptance by the oracle verifier is tested above): compared
+    through BLAKE2b-256 of the canonical transcript bytes, both fields."""
+    import json
+    import os
+    import subprocess
+    from libiop_amd import aurora, build as iopx_build, r1cs
+    lib, torch, dev, ops_gf, ops_fr = env
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "cpp", "aurora_bench")
+    libpath = iopx_build.build()
+    src = os.path.join(root, "tools", "cpp", "aurora_bench.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", src, "-o", exe, "-L" + os.path.dirname(libpath), "-liop_amd", "-Wl,-rpath," + os.path.dirname(libpath),
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    n = 1 << D
+    for ops, flag in ((ops_gf, "gf192"), (ops_fr, "edwards")):
+        cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, n, 15, n - 1, 0x2204)
+        params = aurora.AuroraParameters(ops.field, n, n - 1, 15)
+        mine = aurora.aurora_snark_prover(ops, cs, primary, auxiliary, params).serialize()
+        del cs
+        torch.cuda.synchronize()
+        r = subprocess.run([exe, "--log-n", str(D), "--steps", "1", "--warmup", "1", "--field", flag], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        assert out["argument_bytes"] == len(mine)
+        assert out["transcript_blake2b"] == hashlib.blake2b(mine, digest_size=32).hexdigest(), flag
+        assert out["pcie_h2d_bytes_per_proof"] + out["pcie_d2h_bytes_per_proof"] < (1 << 20)      # a codeword is 768 MiB
