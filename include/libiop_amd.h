@@ -379,6 +379,12 @@ int iopx_gf192_inverse_host(const uint64_t *x, uint64_t *out);
  * 0, 1, 2, ...) for which the last word of H(challenge || candidate) has its low pow_bitlen bits zero
  * (verify_pow_internal, :143-162; pow_bitlen = pow_parameters::pow_bitlen(), :21-32).  challenge, pow: 32 host bytes. */
 int iopx_pow_solve_blake2b(const uint8_t *challenge, size_t pow_bitlen, uint8_t *pow);
+/* The same search over one range of candidates, for a grind split across GPUs by candidate range (libiop_amd/dist.py: the smallest
+ * passing index over all ranks is the reference's first hit).  Candidate index 0 is the challenge itself, index i >= 1 the challenge
+ * with its last word set to i - 1; *found receives the smallest passing index in [first, first + count) or UINT64_MAX.
+ * iopx_pow_candidate_blake2b writes the 32-byte answer of a candidate index (host only). */
+int iopx_pow_search_blake2b(const uint8_t *challenge, size_t pow_bitlen, uint64_t first, uint64_t count, uint64_t *found);
+int iopx_pow_candidate_blake2b(const uint8_t *challenge, uint64_t index, uint8_t *pow);
 /* pow<FieldT, FieldT>::solve_pow (pow.tcc:73-84,129-141) with the Poseidon two-to-one hash over alt_bn128 Fr: the
  * smallest k >= 0 such that word 0 of two_to_one(challenge, FieldT(k)) (canonical integer) has its low pow_bitlen bits
  * zero.  challenge, pow: 4 host words each, Montgomery form. */

@@ -55,7 +55,7 @@ EXPORTED_SYMBOLS = [
     "iopx_fp3_subgroup_generator", "iopx_fp3_multiplicative_generator", "iopx_fp3_host_mul", "iopx_fp3_host_pow", "iopx_poseidon_shipped_params", "iopx_fri_domains_gf192", "iopx_add_reextend_gf192_batch_dev",
     "iopx_pool_alloc", "iopx_pool_free", "iopx_memcpy_d2d", "iopx_memset_dev", "iopx_upload_small", "iopx_gather_dev", "iopx_scatter_dev",
     "iopx_transfer_stats", "iopx_blake2b_host", "iopx_gf192_host_mul", "iopx_fp3_host_add", "iopx_fp3_host_sub", "iopx_fp3_host_inverse",
-    "iopx_fp3_from_uint", "iopx_fp3_modulus",
+    "iopx_fp3_from_uint", "iopx_fp3_modulus", "iopx_pow_search_blake2b", "iopx_pow_candidate_blake2b",
 ]
 
 
@@ -606,6 +606,22 @@ class Library:
         out = np.empty(4, dtype=np.uint64)
         self._check(self.c.iopx_pow_solve_poseidon_bn128(ctypes.byref(poseidon_params.c), _vp(ch.ctypes.data), int(pow_bitlen), _vp(out.ctypes.data)))
         return out
+
+    def pow_search(self, challenge, pow_bitlen, first, count):
+        """The smallest passing proof-of-work candidate index in [first, first + count) or None (candidate 0 = the challenge itself,
+        i >= 1 = the challenge with its last word set to i - 1: the reference's search order, pow.tcc:86-112)."""
+        ch = (ctypes.c_uint8 * 32).from_buffer_copy(bytes(challenge))
+        found = ctypes.c_uint64(0)
+        self.c.iopx_pow_search_blake2b.argtypes = [_vp, _sz, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]
+        self._check(self.c.iopx_pow_search_blake2b(ctypes.addressof(ch), int(pow_bitlen), int(first), int(count), ctypes.byref(found)))
+        return None if found.value == 0xFFFFFFFFFFFFFFFF else int(found.value)
+
+    def pow_candidate(self, challenge, index):
+        ch = (ctypes.c_uint8 * 32).from_buffer_copy(bytes(challenge))
+        out = (ctypes.c_uint8 * 32)()
+        self.c.iopx_pow_candidate_blake2b.argtypes = [_vp, ctypes.c_uint64, _vp]
+        self._check(self.c.iopx_pow_candidate_blake2b(ctypes.addressof(ch), int(index), ctypes.addressof(out)))
+        return bytes(out)
 
     # ---- device-pointer operators (integers are raw device addresses, e.g. torch.Tensor.data_ptr()) ----
     def additive_FFT_dev(self, d_coeffs, n_coeffs, basis, shift, d_out):

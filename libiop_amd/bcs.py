@@ -333,7 +333,7 @@ class BCSProver:
         # bcs_prover.tcc:52-59; the indexer's one-round protocol registers no proof of work (bcs_common.tcc:426-431)
         if self.num_prover_rounds_done == self.num_interaction_rounds and not (self.is_holographic and self.num_interaction_rounds == 1):
             challenge = self._squeeze_root_type()
-            self.pow_answer = self.lib.solve_pow(challenge, self.pow_bitlen)
+            self.pow_answer = self.ops.solve_pow(challenge, self.pow_bitlen)
         for hook in self.round_hooks:
             hook(ended)
 

@@ -434,7 +434,8 @@ static int run_mfft(const uint64_t *cache, const uint64_t *src, size_t n_src, ui
         const size_t blocks = (size_t)1 << (logn - tbits);
         const int threads = (1 << tbits) >= 512 ? (1 << tbits) / 8 : 64;          // one radix-8 group per lane and step
         if (lds > 64 * 1024) IOPX_HIP(hipFuncSetAttribute((const void *)k_mfft_pass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        { ProfScope ps_("k_mfft_pass"); hipLaunchKernelGGL(k_mfft_pass, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        // algorithmic bytes: the pass reads and writes the 2^logn-element vector once; products: one per radix-2 butterfly of its levels
+        { ProfScope ps_("k_mfft_pass", ((size_t)48) << logn, (((size_t)1 << logn) >> 1) * (size_t)(ps.b_hi >= ps.b_lo ? ps.b_hi - ps.b_lo + 1 : 0)); hipLaunchKernelGGL(k_mfft_pass, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
     }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;

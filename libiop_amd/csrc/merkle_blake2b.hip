@@ -330,11 +330,13 @@ int iopx_merkle_blake2b(const void *const *oracles, size_t num_oracles, size_t e
     return IOPX_OK;
 }
 
-int iopx_pow_solve_blake2b(const uint8_t *challenge, size_t pow_bitlen, uint8_t *pow)
+// Candidates in the reference's order (pow.tcc:86-112): index 0 is the challenge itself, index i >= 1 the challenge with its last
+// 8-byte word set to i - 1.  Searches [first, first + count) and reports the smallest passing index, or ~0.
+int iopx_pow_search_blake2b(const uint8_t *challenge, size_t pow_bitlen, uint64_t first, uint64_t count, uint64_t *found)
 {
     int rc = ensure_device();
     if (rc != IOPX_OK) return rc;
-    if (!challenge || !pow) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (!challenge || !found) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
     if (pow_bitlen > 30) return fail(IOPX_ERR_INVALID_ARGUMENT, "pow_bitlen %zu: the reference's `1 << pow_bitlen` is an int shift", pow_bitlen);
     PowChallenge c;
     memcpy(c.w, challenge, 32);
@@ -343,20 +345,38 @@ int iopx_pow_solve_blake2b(const uint8_t *challenge, size_t pow_bitlen, uint8_t 
     if ((rc = best.alloc(8)) != IOPX_OK) return rc;
     const unsigned long long none = ~0ull;
     if ((rc = upload(best.p, &none, 8)) != IOPX_OK) return rc;
-    unsigned long long found = none;
-    uint64_t first = 0, batch = (uint64_t)1 << 16;      // the first batch is small: low difficulties finish in one launch
-    while (found == none) {
+    unsigned long long hit = none;
+    if (count) {
         { ProfScope ps_("k_pow_blake2b");
-          hipLaunchKernelGGL(k_pow_blake2b, dim3((unsigned)((batch + 255) / 256 > 16384 ? 16384 : (batch + 255) / 256)), dim3(256), 0, stream(),
-                             c, first, batch, mask, (unsigned long long *)best.p); }
-        IOPX_HIP(copy_d2h(&found, best.p, 8, stream()));
+          hipLaunchKernelGGL(k_pow_blake2b, dim3((unsigned)((count + 255) / 256 > 16384 ? 16384 : (count + 255) / 256)), dim3(256), 0, stream(),
+                             c, first, count, mask, (unsigned long long *)best.p); }
+        IOPX_HIP(copy_d2h(&hit, best.p, 8, stream()));
         IOPX_HIP(hipStreamSynchronize(stream()));
+    }
+    *found = hit;
+    return IOPX_OK;
+}
+
+// the 32-byte answer of candidate `index` (see iopx_pow_search_blake2b)
+int iopx_pow_candidate_blake2b(const uint8_t *challenge, uint64_t index, uint8_t *pow)
+{
+    if (!challenge || !pow) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    memcpy(pow, challenge, 32);
+    if (index != 0) { const uint64_t v = index - 1; memcpy(pow + 24, &v, 8); }
+    return IOPX_OK;
+}
+
+int iopx_pow_solve_blake2b(const uint8_t *challenge, size_t pow_bitlen, uint8_t *pow)
+{
+    if (!challenge || !pow) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    uint64_t found = ~0ull, first = 0, batch = (uint64_t)1 << 16;      // the first batch is small: low difficulties finish in one launch
+    while (found == ~0ull) {
+        const int rc = iopx_pow_search_blake2b(challenge, pow_bitlen, first, batch, &found);
+        if (rc != IOPX_OK) return rc;
         first += batch;
         if (batch < ((uint64_t)1 << 24)) batch <<= 2;
     }
-    memcpy(pow, challenge, 32);
-    if (found != 0) { const uint64_t v = found - 1; memcpy(pow + 24, &v, 8); }
-    return IOPX_OK;
+    return iopx_pow_candidate_blake2b(challenge, found, pow);
 }
 
 // merkle_tree::get_set_membership_proof (libiop/bcs/merkle_tree.tcc:242-336) on a device-resident node array.

@@ -454,51 +454,70 @@ class AuroraShard:
 
 
 class ShardedMerkleTree:
-    """Global tree = top r levels (host, from the all-gathered sub-roots) over N device-resident sub-trees."""
+    """Global tree = top r levels over N device-resident sub-trees.  The N sub-roots are all-gathered as 32-byte device tensors (one
+    collective on the stream) and the top log2 N levels are hashed on the device (iopx_merkle_inner_blake2b_dev over the N sub-roots
+    as leaves); only the root is read back, as for a single-GPU tree."""
 
     def __init__(self, ops, sub_tree, num_leaves_global):
         self.ops, self.sub, self.L = ops, sub_tree, num_leaves_global
-        sh = ops.shard
-        gathered = [None] * sh.world
-        sh.dist.all_gather_object(gathered, sub_tree.root())
-        # top levels in heap order: level r (sub-roots) up to the root
-        self.top = {}
-        level = gathered
-        for depth in range(sh.r, -1, -1):
-            for j, dg in enumerate(level):
-                self.top[(1 << depth) - 1 + j] = dg
-            level = [hashlib.blake2b(level[2 * i] + level[2 * i + 1], digest_size=32).digest() for i in range(len(level) // 2)]
+        sh, torch, lib = ops.shard, ops.torch, ops.lib
+        W = sh.world
+        _lib_to_torch(lib, torch)
+        sub_root = sub_tree.nodes[0].contiguous()
+        self.top_nodes = torch.zeros((2 * W - 1, 32), dtype=torch.uint8, device=sub_root.device)     # heap order: level r = the sub-roots
+        if W == 1:
+            self.top_nodes[0].copy_(sub_root)
+        else:
+            parts = [torch.empty_like(sub_root) for _ in range(W)]
+            sh.dist.all_gather(parts, sub_root)
+            self.top_nodes[W - 1:].copy_(torch.stack(parts))
+            _torch_to_lib(lib, torch, self.top_nodes)
+            lib.merkle_inner_dev(self.top_nodes.data_ptr(), W)
+        self._top_host = None
 
     def root(self):
-        return self.top[0]
+        return self.ops.lib.read_digest(self.top_nodes.data_ptr())
+
+    def _top_table(self):
+        if self._top_host is None:
+            _lib_to_torch(self.ops.lib, self.ops.torch)
+            self._top_host = self.top_nodes.cpu().numpy()
+        return self._top_host
 
     def membership_proof(self, leaf_positions):
-        """merkle_tree::get_set_membership_proof (merkle_tree.tcc:242-336) over the distributed tree: the index walk on the host,
-        every auxiliary node fetched from the rank that owns it."""
+        """merkle_tree::get_set_membership_proof (merkle_tree.tcc:242-336) over the distributed tree: the index walk on the host (the
+        same on every rank); every rank writes the auxiliary nodes it owns into a zeroed (count, 32) device tensor, one all-reduce
+        (sum: exactly one owner per row) completes it everywhere; the nodes of the top levels come from the replicated top table."""
         sh, torch = self.ops.shard, self.ops.torch
         idx = membership_proof_node_indices(self.L, leaf_positions)
+        if not idx:
+            return np.zeros((0, 32), dtype=np.uint8)
         r = sh.r
-        mine = {}
-        local_req = []
-        for node in idx:
+        rows, local_nodes, top_rows = [], [], []
+        for row, node in enumerate(idx):
             depth = (node + 1).bit_length() - 1
             if depth <= r:
+                top_rows.append((row, node))
                 continue
             j = node - ((1 << depth) - 1)
             owner, loc_depth = j >> (depth - r), depth - r
             if owner == sh.rank:
-                local_req.append((node, (1 << loc_depth) - 1 + (j & ((1 << loc_depth) - 1))))
-        if local_req:
-            sel = self.ops.upload_raw(np.array([l for _, l in local_req], dtype=np.int64), torch.int64)
-            got = self.sub.nodes[sel].cpu().numpy()
-            for (node, _), dg in zip(local_req, got):
-                mine[node] = bytes(dg)
-        everyone = [None] * sh.world
-        sh.dist.all_gather_object(everyone, mine)
-        table = dict(self.top)
-        for d in everyone:
-            table.update(d)
-        return np.frombuffer(b"".join(table[node] for node in idx), dtype=np.uint8).reshape(-1, 32).copy()
+                rows.append(row)
+                local_nodes.append((1 << loc_depth) - 1 + (j & ((1 << loc_depth) - 1)))
+        buf = torch.zeros((len(idx), 32), dtype=torch.uint8, device=self.sub.nodes.device)
+        if rows:
+            sel = self.ops.upload_raw(np.array(local_nodes, dtype=np.int64), torch.int64)
+            dst = self.ops.upload_raw(np.array(rows, dtype=np.int64), torch.int64)
+            _lib_to_torch(self.ops.lib, torch)
+            buf[dst] = self.sub.nodes[sel]
+        if sh.world > 1:
+            sh.dist.all_reduce(buf)
+        out = buf.cpu().numpy()
+        if top_rows:
+            top = self._top_table()
+            for row, node in top_rows:
+                out[row] = top[node]
+        return out
 
 
 def membership_proof_node_indices(num_leaves, positions):
@@ -632,17 +651,11 @@ class ShardedDeviceOps(DeviceOps):
             return super().query_responses(d_oracles, domain, positions)
         block = self.local_size(domain)
         lo = self.shard.rank * block
-        mine_pos = [p for p in positions if lo <= p < lo + block]
-        mine = {}
-        if mine_pos:
-            vals = self.lib.query_responses_dev([t.data_ptr() for t in d_oracles], 24, block, [p - lo for p in mine_pos])
-            mine = {p: vals[i] for i, p in enumerate(mine_pos)}
-        everyone = [None] * self.shard.world
-        self.shard.dist.all_gather_object(everyone, mine)
-        table = {}
-        for d in everyone:
-            table.update(d)
-        return np.stack([table[p] for p in positions]) if positions else np.zeros((0, len(d_oracles), 3), dtype=np.uint64)
+        owned = [(row, p - lo) for row, p in enumerate(positions) if lo <= p < lo + block]
+        return _collect_query_responses(self, d_oracles, positions, owned)
+
+    def solve_pow(self, challenge, pow_bitlen):
+        return _sharded_solve_pow(self, challenge, pow_bitlen)
 
     # ---- pointwise operators: the rank's block is the sub-domain ----
     def rowcheck(self, d_az, d_bz, d_cz, codeword_domain, constraint_domain):
@@ -780,17 +793,11 @@ class ResidueShardedDeviceOps(DeviceOps):
         if not self._is_sharded(domain):
             return super().query_responses(d_oracles, domain, positions)
         W, rank = self.shard.world, self.shard.rank
-        mine_pos = [p for p in positions if p % W == rank]
-        mine = {}
-        if mine_pos:
-            vals = self.lib.query_responses_dev([t.data_ptr() for t in d_oracles], 24, self.local_size(domain), [p // W for p in mine_pos])
-            mine = {p: vals[i] for i, p in enumerate(mine_pos)}
-        everyone = [None] * W
-        self.shard.dist.all_gather_object(everyone, mine)
-        table = {}
-        for d in everyone:
-            table.update(d)
-        return np.stack([table[p] for p in positions]) if positions else np.zeros((0, len(d_oracles), 3), dtype=np.uint64)
+        owned = [(row, p // W) for row, p in enumerate(positions) if p % W == rank]
+        return _collect_query_responses(self, d_oracles, positions, owned)
+
+    def solve_pow(self, challenge, pow_bitlen):
+        return _sharded_solve_pow(self, challenge, pow_bitlen)
 
     # ---- pointwise operators: the rank's residue class is a coset in its own right ----
     def rowcheck(self, d_az, d_bz, d_cz, codeword_domain, constraint_domain):
@@ -813,6 +820,45 @@ class ResidueShardedDeviceOps(DeviceOps):
 
     def rational_sumcheck_constraint(self, d_p, d_N, d_D, codeword_domain, summation_domain, claimed_sum):
         return super().rational_sumcheck_constraint(d_p, d_N, d_D, self.local_domain(codeword_domain), summation_domain, claimed_sum)
+
+
+def _collect_query_responses(ops, d_oracles, positions, owned):
+    """values[p][k] = oracle_k[positions[p]] for oracles distributed over the ranks: every rank writes the rows it owns (row, local
+    index) into a zeroed (positions, oracles, 3) device tensor, one all-reduce (sum: one owner per row) completes it everywhere."""
+    torch = ops.torch
+    if not positions:
+        return np.zeros((0, len(d_oracles), 3), dtype=np.uint64)
+    buf = torch.zeros((len(positions), len(d_oracles), 3), dtype=torch.int64, device=d_oracles[0].device)
+    if owned:
+        rows = ops.upload_raw(np.array([r for r, _ in owned], dtype=np.int64), torch.int64)
+        loc = ops.upload_raw(np.array([l for _, l in owned], dtype=np.int64), torch.int64)
+        _lib_to_torch(ops.lib, torch)
+        buf[rows] = torch.stack([t[loc] for t in d_oracles], dim=1)
+    if ops.shard.world > 1:
+        ops.shard.dist.all_reduce(buf)
+    return buf.cpu().numpy().view(np.uint64)
+
+
+def _sharded_solve_pow(ops, challenge, pow_bitlen):
+    """pow::solve_pow (bcs/pow.tcc:67-103) split by candidate range: in super-batch s rank r searches candidates
+    [(s N + r) B_s, (s N + r + 1) B_s); a min all-reduce of the hits ends the search at the first super-batch that has one, and the
+    minimum is the reference's first hit (the candidates of earlier super-batches all failed)."""
+    sh, torch, lib = ops.shard, ops.torch, ops.lib
+    if sh.world == 1:
+        return lib.solve_pow(challenge, pow_bitlen)
+    none = (1 << 62)
+    first, batch = 0, 1 << 14
+    dev = ops.device
+    while True:
+        hit = lib.pow_search(challenge, pow_bitlen, first + sh.rank * batch, batch)
+        t = torch.tensor([none if hit is None else hit], dtype=torch.int64, device=dev)
+        sh.dist.all_reduce(t, op=sh.dist.ReduceOp.MIN)
+        best = int(t.item())
+        if best != none:
+            return lib.pow_candidate(challenge, best)
+        first += sh.world * batch
+        if batch < (1 << 22):
+            batch <<= 2
 
 
 def sharded_ops(lib, torch, device, field, shard):

@@ -380,6 +380,10 @@ class DeviceOps:
                                                                  _p(x_i), out.data_ptr()))
         return out
 
+    def solve_pow(self, challenge, pow_bitlen):
+        """pow::solve_pow (bcs/pow.tcc:67-103): the first passing candidate in the reference's order."""
+        return self.lib.solve_pow(challenge, pow_bitlen)
+
     def merkle_tree(self, d_oracles, domain, coset_size):
         """construct_with_leaves_serialized_by_cosets + compute_inner_nodes over device-resident oracles."""
         leaves = domain.size // coset_size

@@ -245,7 +245,7 @@ def _aurora_worker(rank, world, port, ret, log_n, num_inputs, rs_extra=5):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,log_n", [(2, 7), (4, 8), (2, 9)])
+@pytest.mark.parametrize("world,log_n", [(2, 7), (4, 8), (2, 9), (8, 7)])       # (8, 7): config 4's own split — 8 ranks x 4 cosets of every codeword
 def test_sharded_aurora_prover_equals_oracle(world, log_n):
     """Every rank returns the transcript of the single-process oracle prover, byte for byte."""
     import oracle
@@ -297,7 +297,7 @@ def _fractal_worker(rank, world, port, ret, log_n, num_inputs):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,log_n", [(2, 6), (4, 7)])
+@pytest.mark.parametrize("world,log_n", [(2, 6), (4, 7), (8, 7)])
 def test_sharded_fractal_prover_equals_oracle(world, log_n):
     """Every rank returns the index root and the transcript of the single-process oracle indexer / prover, byte for byte."""
     import oracle

@@ -11,7 +11,7 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed)
 {
     uint32_t a[8];
     for (int i = 0; i < 8; ++i) a[i] = seed * (threadIdx.x + 1) + i;
-    uint32_t b = seed ^ 0x9e3779b9u, c = seed + 77;
+    uint32_t b = seed ^ 0x9e3779b9u, c = seed + 77, sc = 0;
     for (int r = 0; r < REP; ++r) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -33,6 +33,12 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed)
             if (OP == 15) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
             if (OP == 16) asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(*(uint64_t *)&a[i & 6]));
             if (OP == 17) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if (OP == 18) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xe4" : "+v"(a[i]) : "v"(b), "s"(seed));
+            if (OP == 19) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xe4" : "+v"(a[i]) : "v"(b), "v"(c));
+            if (OP == 20) asm volatile("v_bitop3_b32 %0, %1, %0, %2 bitop3:0xe4" : "+v"(a[i]) : "s"(seed), "v"(c));
+            if (OP == 21) asm volatile("v_readfirstlane_b32 %1, %0\n\tv_xor_b32 %0, %1, %0" : "+v"(a[i]), "=s"(sc) : );
+            if (OP == 22) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a[i]) : "s"(seed));
+            if (OP == 23) asm volatile("v_and_b32 %0, 0x55555555, %0" : "+v"(a[i]));
         }
     }
     uint32_t s = 0;
@@ -75,5 +81,11 @@ int main()
     run<15>("v_add_u32", d);
     run<17>("v_add3_u32", d);
     run<16>("v_lshrrev_b64", d);
+    run<18>("v_bitop3 0xe4 (vgpr, vgpr, sgpr)", d);
+    run<19>("v_bitop3 0xe4 (3 vgpr)", d);
+    run<20>("v_bitop3 0xe4 (sgpr, vgpr, vgpr)", d);
+    run<22>("v_xor_b32 (VOP2, sgpr src0)", d);
+    run<23>("v_and_b32 (VOP2, literal)", d);
+    run<21>("v_readfirstlane + v_xor pair", d);
     return 0;
 }
