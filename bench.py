@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-host-cores variant of the CPU baseline (one independent oracle proof per core)")
     args = ap.parse_args()
 
+    # RCCL prints a version banner on STDOUT at NCCL_DEBUG=VERSION/INFO (seen on the GPU box: five lines ahead of the JSON line);
+    # stdout carries the one JSON line only, so the debug level is pinned to WARN unless IOPX_NCCL_DEBUG says otherwise
+    os.environ["NCCL_DEBUG"] = os.environ.get("IOPX_NCCL_DEBUG", "WARN")
     if args.gpus > 1 and "RANK" not in os.environ:
         # Started as `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet (torch is not even imported),
         # the ranks run as CHILD processes of torch.distributed.run and this process only forwards their exit code.
