@@ -193,7 +193,23 @@ def main():
     d_assignment = ops.upload(aurora.assignment_vector(field, primary, auxiliary))      # resident in HBM before the timed region
     torch.cuda.synchronize()
 
-    def step():          # with ShardedDeviceOps the same prover runs block-distributed (libiop_amd/dist.py)
+    sharded = world > 1 or args.force_sharded
+    native = None
+    if not sharded:
+        # N = 1: the native prover behind the C ABI (iopx_aurora_prove: libiop_amd/cpp/aurora.hpp inside the library) on its own copy of
+        # the same seeded instance; the Python prover (libiop_amd/aurora.py) proves it once below as a cross-check of the transcript bytes
+        native = lib.aurora_example_instance(0, n, 15, n - 1, SEED)
+
+    class _Bytes:
+        def __init__(self, b):
+            self.b = b
+
+        def serialize(self):
+            return self.b
+
+    def step():          # with ShardedDeviceOps the Python prover runs block-distributed (libiop_amd/dist.py)
+        if native is not None:
+            return _Bytes(lib.aurora_prove(native, 128, params.RS_extra_dimensions, 2))
         return aurora.aurora_snark_prover(ops, cs, primary, None, params, d_assignment=d_assignment)
 
     transcript = None
@@ -219,6 +235,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prover_s = dt / args.steps
+
+    if native is not None:
+        check = aurora.aurora_snark_prover(ops, cs, primary, None, params, d_assignment=d_assignment).serialize()
+        assert check == transcript.serialize(), "native prover's transcript differs from the Python prover's"
 
     # per-kernel durations of one more proof, live, with HIP events on the stream the kernels are launched on
     lib.profile_begin()
@@ -276,6 +296,8 @@ def main():
                         "security 128, RS_extra_dimensions 5, FRI localization 2, non-zk, BLAKE2b: one complete proof per step, "
                         "instance and witness resident in HBM" % (args.log_n, SEED),
             "log_n": args.log_n, "field": "gf192", "prover_s": prover_s,
+            "prover": "native: iopx_aurora_prove (libiop_amd/cpp/aurora.hpp behind the C ABI); transcript equal to libiop_amd/aurora.py's" if native is not None
+                      else "libiop_amd/aurora.py over libiop_amd/dist.py's sharded operators",
             "codeword_domain_dim": params.codeword_domain_dim, "localization": params.localization_parameters,
             "fri_query_repetitions": params.fri_query_repetitions, "pow_bits": params.pow_bits,
             "argument_bytes": len(transcript.serialize()) if transcript is not None else None,

@@ -436,6 +436,32 @@ int iopx_fp3_host_inverse(const uint64_t *a, uint64_t *out);
 int iopx_fp3_from_uint(uint64_t value, uint64_t *out);
 int iopx_fp3_modulus(uint64_t *out);
 
+/* ---- the Aurora prover itself (libiop_amd/csrc/prover_capi.hip over libiop_amd/cpp/aurora.hpp) ------------------------------------ */
+/* aurora_snark_prover (libiop/snark/aurora_snark.tcc:119-146; non-zk, BLAKE2b, heuristic FRI / LDT-reducer soundness as in
+ * profiling/instrument_aurora_snark.cpp:209-217) with every oracle resident in HBM.  An instance holds the R1CS (three CSR matrices over
+ * columns 0 = the constant 1, j >= 1 = variable j - 1 of (primary, auxiliary): relations/r1cs.tcc:236-268), its device form, the tables a
+ * proof derives from it, and the variable assignment in HBM; it is created once and proves any number of times.  The transcript is
+ * returned in the canonical byte form of bcs_transformation_transcript (libiop_amd/cpp/iop.hpp serialize()) in a malloc'ed buffer the
+ * caller releases with iopx_host_free. */
+#define IOPX_FIELD_GF192 0
+#define IOPX_FIELD_EDWARDS_FR 1
+typedef struct iopx_r1cs {
+    size_t num_constraints, num_variables, num_inputs;
+    const uint64_t *row_ptr[3];   /* A, B, C: num_constraints + 1 offsets each */
+    const uint32_t *col[3];       /* column of each entry */
+    const uint64_t *coeff[3];     /* 3 words per entry */
+} iopx_r1cs;
+typedef struct iopx_aurora_instance iopx_aurora_instance;
+/* assignment: num_variables elements (primary inputs first), host memory */
+int iopx_aurora_instance_create(const iopx_r1cs *r1cs, const uint64_t *assignment, int field, iopx_aurora_instance **out);
+/* generate_r1cs_example (libiop/relations/examples/r1cs_examples.tcc:23-78) seeded with SplitMix64 */
+int iopx_aurora_example_instance_create(int field, size_t num_constraints, size_t num_inputs, size_t num_variables, uint64_t seed,
+                                        iopx_aurora_instance **out);
+int iopx_aurora_prove(iopx_aurora_instance *instance, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter,
+                      uint8_t **transcript, size_t *transcript_bytes);
+int iopx_aurora_instance_free(iopx_aurora_instance *instance);
+int iopx_host_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

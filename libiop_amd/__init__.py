@@ -56,6 +56,7 @@ EXPORTED_SYMBOLS = [
     "iopx_pool_alloc", "iopx_pool_free", "iopx_memcpy_d2d", "iopx_memset_dev", "iopx_upload_small", "iopx_gather_dev", "iopx_scatter_dev",
     "iopx_transfer_stats", "iopx_blake2b_host", "iopx_gf192_host_mul", "iopx_fp3_host_add", "iopx_fp3_host_sub", "iopx_fp3_host_inverse",
     "iopx_fp3_from_uint", "iopx_fp3_modulus", "iopx_pow_search_blake2b", "iopx_pow_candidate_blake2b",
+    "iopx_aurora_instance_create", "iopx_aurora_example_instance_create", "iopx_aurora_prove", "iopx_aurora_instance_free", "iopx_host_free",
 ]
 
 
@@ -606,6 +607,29 @@ class Library:
         out = np.empty(4, dtype=np.uint64)
         self._check(self.c.iopx_pow_solve_poseidon_bn128(ctypes.byref(poseidon_params.c), _vp(ch.ctypes.data), int(pow_bitlen), _vp(out.ctypes.data)))
         return out
+
+    # ---- the native Aurora prover (libiop_amd/csrc/prover_capi.hip) ----
+    def aurora_example_instance(self, field_code, num_constraints, num_inputs, num_variables, seed):
+        """Opaque handle of generate_r1cs_example(n, k, vars) seeded with `seed`, resident in HBM (release with aurora_instance_free)."""
+        h = ctypes.c_void_p()
+        self.c.iopx_aurora_example_instance_create.argtypes = [ctypes.c_int, _sz, _sz, _sz, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
+        self._check(self.c.iopx_aurora_example_instance_create(int(field_code), int(num_constraints), int(num_inputs), int(num_variables), int(seed), ctypes.byref(h)))
+        return h
+
+    def aurora_prove(self, instance, security_parameter=128, RS_extra_dimensions=5, FRI_localization_parameter=2):
+        """aurora_snark_prover through the C ABI: the canonical transcript bytes."""
+        buf, n = ctypes.c_void_p(), _sz(0)
+        self.c.iopx_aurora_prove.argtypes = [ctypes.c_void_p, _sz, _sz, _sz, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_sz)]
+        self._check(self.c.iopx_aurora_prove(instance, int(security_parameter), int(RS_extra_dimensions), int(FRI_localization_parameter), ctypes.byref(buf), ctypes.byref(n)))
+        try:
+            return ctypes.string_at(buf, n.value)
+        finally:
+            self.c.iopx_host_free.argtypes = [ctypes.c_void_p]
+            self.c.iopx_host_free(buf)
+
+    def aurora_instance_free(self, instance):
+        self.c.iopx_aurora_instance_free.argtypes = [ctypes.c_void_p]
+        self.c.iopx_aurora_instance_free(instance)
 
     def pow_search(self, challenge, pow_bitlen, first, count):
         """The smallest passing proof-of-work candidate index in [first, first + count) or None (candidate 0 = the challenge itself,

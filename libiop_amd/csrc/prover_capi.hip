@@ -1,0 +1,160 @@
+// The Aurora prover behind the C ABI: iopx_aurora_* (include/libiop_amd.h).
+//
+// The orchestration is the C++ surface of libiop_amd/cpp/aurora.hpp — aurora_snark_prover<FieldT>(cs, primary, auxiliary, params),
+// the signature of libiop/snark/aurora_snark.tcc:120-146 — instantiated for the two accelerated fields and wrapped in plain C types, so
+// that a caller without a C++ toolchain (the ctypes binding, bench.py) reaches the native prover too.  Host-only code: no kernels here.
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../cpp/aurora.hpp"
+#include "../cpp/fields.hpp"
+#include "runtime.h"
+
+namespace {
+
+using namespace libiop_amd;
+
+struct InstanceBase {
+    virtual ~InstanceBase() {}
+    virtual std::string prove(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) = 0;
+    virtual size_t num_constraints() const = 0;
+};
+
+template<typename F>
+struct Instance : InstanceBase {
+    r1cs_constraint_system<F> cs;
+    std::vector<F> primary, auxiliary;
+    device_vector<F> d_assignment;          // (1, primary, auxiliary), resident in HBM
+
+    void finish()
+    {
+        cs.prepare_device();
+        std::vector<F> z(1, field_host<F>::one());
+        z.insert(z.end(), primary.begin(), primary.end());
+        z.insert(z.end(), auxiliary.begin(), auxiliary.end());
+        d_assignment = device_vector<F>(device_array<F>::from_host(z));
+    }
+    size_t num_constraints() const override { return cs.num_constraints(); }
+    std::string prove(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) override
+    {
+        const aurora_snark_parameters<F> params(cs.num_constraints(), cs.num_variables(), cs.num_inputs(), security_parameter, RS_extra_dimensions,
+                                                FRI_localization_parameter);
+        return aurora_snark_prover<F>(cs, primary, auxiliary, params, &d_assignment).serialize();
+    }
+};
+
+template<typename F>
+InstanceBase *make_from_csr(const iopx_r1cs *r, const uint64_t *assignment)
+{
+    auto *inst = new Instance<F>();
+    inst->cs.primary_input_size_ = r->num_inputs;
+    inst->cs.auxiliary_input_size_ = r->num_variables - r->num_inputs;
+    sparse_matrix<F> *M[3] = { &inst->cs.A, &inst->cs.B, &inst->cs.C };
+    for (int q = 0; q < 3; ++q) {
+        M[q]->rows = r->num_constraints;
+        M[q]->row_ptr.assign(r->row_ptr[q], r->row_ptr[q] + r->num_constraints + 1);
+        const size_t nnz = (size_t)r->row_ptr[q][r->num_constraints];
+        M[q]->col.assign(r->col[q], r->col[q] + nnz);
+        M[q]->coeff.resize(nnz);
+        if (nnz) std::memcpy((void *)M[q]->coeff.data(), r->coeff[q], nnz * 24);
+        for (uint32_t c : M[q]->col) if (c > r->num_variables) throw std::invalid_argument("iopx_aurora_instance_create: column index exceeds the number of variables");
+    }
+    inst->primary.resize(r->num_inputs);
+    inst->auxiliary.resize(r->num_variables - r->num_inputs);
+    if (r->num_inputs) std::memcpy((void *)inst->primary.data(), assignment, r->num_inputs * 24);
+    if (r->num_variables > r->num_inputs) std::memcpy((void *)inst->auxiliary.data(), assignment + 3 * r->num_inputs, (r->num_variables - r->num_inputs) * 24);
+    inst->finish();
+    return inst;
+}
+
+template<typename F>
+InstanceBase *make_example(size_t num_constraints, size_t num_inputs, size_t num_variables, uint64_t seed)
+{
+    auto *inst = new Instance<F>();
+    r1cs_example<F> ex = generate_r1cs_example<F>(num_constraints, num_inputs, num_variables, seed);
+    inst->cs = std::move(ex.constraint_system);
+    inst->primary = std::move(ex.primary_input);
+    inst->auxiliary = std::move(ex.auxiliary_input);
+    inst->finish();
+    return inst;
+}
+
+template<typename Fn>
+int guarded(Fn fn)
+{
+    try {
+        fn();
+        return IOPX_OK;
+    } catch (const std::invalid_argument &e) {
+        return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "%s", e.what());
+    } catch (const std::logic_error &e) {
+        return iopx::fail(IOPX_ERR_LOGIC, "%s", e.what());
+    } catch (const std::bad_alloc &) {
+        return iopx::fail(IOPX_ERR_RUNTIME, "out of host memory");
+    } catch (const std::exception &e) {
+        // a failure inside a nested C-ABI call has already recorded its message; keep the outer wording when it is more specific
+        return iopx::fail(IOPX_ERR_RUNTIME, "%s", e.what());
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int iopx_aurora_instance_create(const iopx_r1cs *r1cs, const uint64_t *assignment, int field, iopx_aurora_instance **out)
+{
+    int rc = iopx::ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!r1cs || !assignment || !out) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    for (int q = 0; q < 3; ++q) if (!r1cs->row_ptr[q] || (!r1cs->col[q] && r1cs->row_ptr[q][r1cs->num_constraints]) || (!r1cs->coeff[q] && r1cs->row_ptr[q][r1cs->num_constraints]))
+        return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null matrix array");
+    if (r1cs->num_inputs > r1cs->num_variables) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "Number of inputs can't exceed number of variables.");
+    return guarded([&] {
+        if (field == IOPX_FIELD_GF192) *out = reinterpret_cast<iopx_aurora_instance *>(make_from_csr<gf192_element>(r1cs, assignment));
+        else if (field == IOPX_FIELD_EDWARDS_FR) *out = reinterpret_cast<iopx_aurora_instance *>(make_from_csr<edwards_Fr_element>(r1cs, assignment));
+        else throw std::invalid_argument("unknown field");
+    });
+}
+
+int iopx_aurora_example_instance_create(int field, size_t num_constraints, size_t num_inputs, size_t num_variables, uint64_t seed, iopx_aurora_instance **out)
+{
+    int rc = iopx::ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!out) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    return guarded([&] {
+        if (field == IOPX_FIELD_GF192) *out = reinterpret_cast<iopx_aurora_instance *>(make_example<gf192_element>(num_constraints, num_inputs, num_variables, seed));
+        else if (field == IOPX_FIELD_EDWARDS_FR) *out = reinterpret_cast<iopx_aurora_instance *>(make_example<edwards_Fr_element>(num_constraints, num_inputs, num_variables, seed));
+        else throw std::invalid_argument("unknown field");
+    });
+}
+
+int iopx_aurora_prove(iopx_aurora_instance *instance, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter,
+                      uint8_t **transcript, size_t *transcript_bytes)
+{
+    int rc = iopx::ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!instance || !transcript || !transcript_bytes) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    return guarded([&] {
+        const std::string t = reinterpret_cast<InstanceBase *>(instance)->prove(security_parameter, RS_extra_dimensions, FRI_localization_parameter);
+        uint8_t *buf = static_cast<uint8_t *>(std::malloc(t.size() ? t.size() : 1));
+        if (!buf) throw std::bad_alloc();
+        std::memcpy(buf, t.data(), t.size());
+        *transcript = buf;
+        *transcript_bytes = t.size();
+    });
+}
+
+int iopx_aurora_instance_free(iopx_aurora_instance *instance)
+{
+    delete reinterpret_cast<InstanceBase *>(instance);
+    return IOPX_OK;
+}
+
+int iopx_host_free(void *p)
+{
+    std::free(p);
+    return IOPX_OK;
+}
+
+} // extern "C"

@@ -82,3 +82,35 @@ def test_argument_checks():
         aurora.AuroraParameters(domains.GF192(), 128, 126, 15)
     with pytest.raises(ValueError):
         aurora.AuroraParameters(domains.GF192(), 128, 127, 14)
+
+
+@pytest.mark.parametrize("field_name,log_n,num_inputs", [("gf192", 7, 15), ("gf192", 9, 15), ("edwards_Fr", 8, 15), ("edwards_Fr", 7, 0)])
+def test_native_prover_behind_the_c_abi_equals_oracle(field_name, log_n, num_inputs):
+    """iopx_aurora_prove (libiop_amd/csrc/prover_capi.hip: the C++ prover surface inside the library) on the seeded instance: the
+    transcript bytes equal the oracle prover's; instances are reusable."""
+    lib = emu_lib.emu()
+    code = {"gf192": 0, "edwards_Fr": 1}[field_name]
+    n = 1 << log_n
+    inst = lib.aurora_example_instance(code, n, num_inputs, n - 1, 0x2204)
+    try:
+        ref = oracle.aurora_prove(ac.FIELDS[field_name][0], log_n, num_inputs, 0x2204)
+        assert lib.aurora_prove(inst) == ref
+        assert lib.aurora_prove(inst) == ref
+        ref3 = oracle.aurora_prove(ac.FIELDS[field_name][0], log_n, num_inputs, 0x2204, rs_extra=3, localization=1)
+        assert lib.aurora_prove(inst, RS_extra_dimensions=3, FRI_localization_parameter=1) == ref3
+    finally:
+        lib.aurora_instance_free(inst)
+
+
+def test_native_prover_argument_checks():
+    lib = emu_lib.emu()
+    inst = lib.aurora_example_instance(0, 100, 15, 127, 1)
+    try:
+        with pytest.raises(ValueError):
+            lib.aurora_prove(inst)                                   # constraints not a power of two (aurora_iop.tcc:19-33)
+    finally:
+        lib.aurora_instance_free(inst)
+    with pytest.raises(ValueError):
+        lib.aurora_example_instance(0, 128, 200, 127, 1)         # more inputs than variables (r1cs_examples.tcc:29-32)
+    with pytest.raises(ValueError):
+        lib.aurora_example_instance(7, 128, 15, 127, 1)          # unknown field

@@ -472,6 +472,19 @@ def test_aurora_transcript_equals_oracle_prover(gpu, field_name, log_n, num_inpu
             assert not oracle.aurora_verify(code, log_n, num_inputs, 0x2204, data), label
 
 
+@pytest.mark.parametrize("field_name,log_n,num_inputs", [("gf192", 8, 15), ("gf192", 12, 15), ("edwards_Fr", 9, 7), ("edwards_Fr", 12, 15)])
+def test_native_aurora_prover_behind_the_c_abi(gpu, field_name, log_n, num_inputs):
+    """iopx_aurora_prove — the C++ prover surface (libiop_amd/cpp/aurora.hpp) inside the library — against the oracle prover, byte for byte."""
+    n = 1 << log_n
+    inst = gpu.aurora_example_instance({"gf192": 0, "edwards_Fr": 1}[field_name], n, num_inputs, n - 1, 0x2204)
+    try:
+        ref = oracle.aurora_prove(ac.FIELDS[field_name][0], log_n, num_inputs, 0x2204)
+        assert gpu.aurora_prove(inst) == ref
+        assert gpu.aurora_prove(inst) == ref
+    finally:
+        gpu.aurora_instance_free(inst)
+
+
 @pytest.mark.parametrize("field_name", ["gf192", "edwards_Fr"])
 def test_aurora_other_rates(gpu, field_name):
     import torch
