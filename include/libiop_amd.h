@@ -459,6 +459,16 @@ int iopx_aurora_example_instance_create(int field, size_t num_constraints, size_
                                         iopx_aurora_instance **out);
 int iopx_aurora_prove(iopx_aurora_instance *instance, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter,
                       uint8_t **transcript, size_t *transcript_bytes);
+/* fractal_snark_indexer / fractal_snark_prover (libiop/snark/fractal_snark.tcc:114-162; non-zk, BLAKE2b; RS_extra_dimensions 3 and
+ * localization 2 in profiling/instrument_fractal_snark.cpp:93-120) on the same instance handle (square matrices: num_constraints =
+ * num_variables + 1).  iopx_fractal_index builds the prover index — twelve index oracles over the codeword domain, their Merkle tree and
+ * their evaluations over the index domain, kept in HBM inside the instance — and returns the verifier index, the tree's root(s), 32 bytes
+ * each; iopx_fractal_prove proves against that index any number of times (same parameters) and returns the transcript without the
+ * index's roots, as bcs_prover::get_transcript does for a holographic protocol (bcs_prover.tcc:119-134). */
+int iopx_fractal_index(iopx_aurora_instance *instance, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter,
+                       uint8_t *index_roots, size_t root_capacity, size_t *num_roots);
+int iopx_fractal_prove(iopx_aurora_instance *instance, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter,
+                       uint8_t **transcript, size_t *transcript_bytes);
 int iopx_aurora_instance_free(iopx_aurora_instance *instance);
 int iopx_host_free(void *p);
 

@@ -57,6 +57,7 @@ EXPORTED_SYMBOLS = [
     "iopx_transfer_stats", "iopx_blake2b_host", "iopx_gf192_host_mul", "iopx_fp3_host_add", "iopx_fp3_host_sub", "iopx_fp3_host_inverse",
     "iopx_fp3_from_uint", "iopx_fp3_modulus", "iopx_pow_search_blake2b", "iopx_pow_candidate_blake2b",
     "iopx_aurora_instance_create", "iopx_aurora_example_instance_create", "iopx_aurora_prove", "iopx_aurora_instance_free", "iopx_host_free",
+    "iopx_fractal_index", "iopx_fractal_prove",
 ]
 
 
@@ -621,6 +622,25 @@ class Library:
         buf, n = ctypes.c_void_p(), _sz(0)
         self.c.iopx_aurora_prove.argtypes = [ctypes.c_void_p, _sz, _sz, _sz, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_sz)]
         self._check(self.c.iopx_aurora_prove(instance, int(security_parameter), int(RS_extra_dimensions), int(FRI_localization_parameter), ctypes.byref(buf), ctypes.byref(n)))
+        try:
+            return ctypes.string_at(buf, n.value)
+        finally:
+            self.c.iopx_host_free.argtypes = [ctypes.c_void_p]
+            self.c.iopx_host_free(buf)
+
+    def fractal_index(self, instance, security_parameter=128, RS_extra_dimensions=3, FRI_localization_parameter=2):
+        """fractal_snark_indexer on the instance: the prover index stays in HBM inside it; returns the verifier index (the tree roots)."""
+        roots = (ctypes.c_uint8 * (32 * 8))()
+        n = _sz(0)
+        self.c.iopx_fractal_index.argtypes = [ctypes.c_void_p, _sz, _sz, _sz, ctypes.c_void_p, _sz, ctypes.POINTER(_sz)]
+        self._check(self.c.iopx_fractal_index(instance, int(security_parameter), int(RS_extra_dimensions), int(FRI_localization_parameter), ctypes.addressof(roots), 8,
+                                              ctypes.byref(n)))
+        return [bytes(roots[32 * i:32 * (i + 1)]) for i in range(n.value)]
+
+    def fractal_prove(self, instance, security_parameter=128, RS_extra_dimensions=3, FRI_localization_parameter=2):
+        buf, n = ctypes.c_void_p(), _sz(0)
+        self.c.iopx_fractal_prove.argtypes = [ctypes.c_void_p, _sz, _sz, _sz, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_sz)]
+        self._check(self.c.iopx_fractal_prove(instance, int(security_parameter), int(RS_extra_dimensions), int(FRI_localization_parameter), ctypes.byref(buf), ctypes.byref(n)))
         try:
             return ctypes.string_at(buf, n.value)
         finally:

@@ -482,9 +482,11 @@ class encoded_aurora_protocol {                                                 
     std::shared_ptr<fz_virtual_oracle<FieldT>> fz_oracle_;
     std::shared_ptr<rowcheck_ABC_virtual_oracle<FieldT>> rowcheck_oracle_;
     std::shared_ptr<multi_lincheck<FieldT>> multi_lincheck_;
+    const std::vector<sparse_matrix<FieldT>> *transposed_matrices_ = nullptr;
 public:
     encoded_aurora_protocol(bcs_prover<FieldT> &IOP, const domain_handle &constraint_domain_handle, const domain_handle &variable_domain_handle,
-                            const domain_handle &codeword_domain_handle, const r1cs_constraint_system<FieldT> &constraint_system, std::size_t lincheck_repetitions)
+                            const domain_handle &codeword_domain_handle, const r1cs_constraint_system<FieldT> &constraint_system, std::size_t lincheck_repetitions,
+                            bool holographic = false)                                        // holographic: the lincheck is fractal.hpp's (r1cs_rs_iop.tcc:344-357)
         : IOP_(IOP), cs_(constraint_system), C_(IOP.get_domain(constraint_domain_handle)), V_(IOP.get_domain(variable_domain_handle)),
           L_(IOP.get_domain(codeword_domain_handle))
     {
@@ -515,13 +517,20 @@ public:
             T.push_back(cs_.C.transposed_onto(S.num_elements(), col_to_summation));
             it = cs_.lincheck_matrix_cache_.emplace(key, std::move(T)).first;
         }
-        multi_lincheck_ = std::make_shared<multi_lincheck<FieldT>>(IOP, codeword_domain_handle, constraint_domain_handle, variable_domain_handle, &it->second,
-                                                                   fz_handle_, Mz_handles, lincheck_repetitions);
+        transposed_matrices_ = &it->second;
+        if (!holographic)
+            multi_lincheck_ = std::make_shared<multi_lincheck<FieldT>>(IOP, codeword_domain_handle, constraint_domain_handle, variable_domain_handle, &it->second,
+                                                                       fz_handle_, Mz_handles, lincheck_repetitions);
         rowcheck_oracle_ = std::make_shared<rowcheck_ABC_virtual_oracle<FieldT>>(L_, C_);
         rowcheck_handle_ = IOP.register_virtual_oracle(codeword_domain_handle, C_.num_elements() - 1, Mz_handles, rowcheck_oracle_);
     }
     void register_challenge() { multi_lincheck_->register_challenge(); }
     void register_proof() { multi_lincheck_->register_proof(); }
+    const field_subset<FieldT> &input_variable_domain() const { return I_; }
+    const std::vector<sparse_matrix<FieldT>> *transposed_matrices() const { return transposed_matrices_; }
+    oracle_handle fz_handle() const { return fz_handle_; }
+    std::vector<oracle_handle> Mz_handles() const { return { fAz_handle_, fBz_handle_, fCz_handle_ }; }
+    std::vector<oracle_handle> witness_and_rowcheck_handles() const { return { fw_handle_, fAz_handle_, fBz_handle_, fCz_handle_, rowcheck_handle_ }; }
 
     // :481-615.  f_w' interpolates z - f_1v over the variable domain (zero on the input positions, where f_1v already equals z), is
     // divided by Z_I and extended together with f_Az, f_Bz, f_Cz.  d_assignment: the variable assignment (1, primary, auxiliary)

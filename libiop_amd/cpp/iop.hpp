@@ -59,6 +59,55 @@ struct field_host {
         for (; e; e >>= 1) { if (e & 1) r = mul(r, b); b = mul(b, b); }
         return r;
     }
+    static FieldT sub(const FieldT &a, const FieldT &b)
+    {
+        if (additive()) return add(a, b);
+        uint64_t w[3];
+        check(iopx_fp3_host_sub(detail::words(&a), detail::words(&b), w));
+        return from_words(w);
+    }
+    static FieldT neg(const FieldT &a) { return sub(zero(), a); }
+    static FieldT inverse(const FieldT &a)
+    {
+        uint64_t w[3];
+        if (additive()) check(iopx_gf192_inverse_host(detail::words(&a), w));
+        else check(iopx_fp3_host_inverse(detail::words(&a), w));
+        return from_words(w);
+    }
+    // Z_S(x) for the domain S (vanishing_polynomial::evaluation_at_point): the linearized polynomial of the subspace through the
+    // library's host helper / x^|S| - shift^|S| (vanishing_polynomial.tcc:14-25)
+    static FieldT vanishing_eval(const field_subset<FieldT> &S, const FieldT &x)
+    {
+        if (S.type() == affine_subspace_type) {
+            uint64_t w[3];
+            check(iopx_gf192_vanishing_host(detail::words(S.basis().data()), S.dimension(), detail::words(&S.shift()), detail::words(&x), w, nullptr));
+            return from_words(w);
+        }
+        return sub(pow(x, S.num_elements()), pow(S.shift(), S.num_elements()));
+    }
+    // (DZ_S)(x): the linear coefficient for subspaces (vanishing_polynomial.tcc:63-72), |S| x^(|S| - 1) for cosets (:57-62)
+    static FieldT vanishing_derivative(const field_subset<FieldT> &S, const FieldT &x)
+    {
+        if (S.type() == affine_subspace_type) {
+            uint64_t w[3];
+            check(iopx_gf192_vanishing_host(detail::words(S.basis().data()), S.dimension(), detail::words(&S.shift()), detail::words(&x), nullptr, w));
+            return from_words(w);
+        }
+        return mul(from_uint(S.num_elements()), pow(x, S.num_elements() - 1));
+    }
+    // membership of x in S: standard-basis subspaces (x + shift below 2^dim) / (x / shift)^|S| = 1
+    static bool element_in_domain(const field_subset<FieldT> &S, const FieldT &x)
+    {
+        if (S.type() == affine_subspace_type) {
+            if (!S.subspace().is_standard_basis()) throw std::logic_error("membership test for a non-standard basis");
+            const FieldT v = add(x, S.shift());
+            const uint64_t *w = detail::words(&v);
+            return w[1] == 0 && w[2] == 0 && (S.dimension() >= 64 || w[0] < ((uint64_t)1 << S.dimension()));
+        }
+        const FieldT r = pow(mul(x, inverse(S.shift())), S.num_elements());
+        const FieldT o = one();
+        return std::memcmp(&r, &o, sizeof(FieldT)) == 0;
+    }
     // libff::soundness_log_of_field_size_helper: the extension degree for binary fields, floor(log2 p) for prime fields
     static std::size_t soundness_bits() { return additive() ? 192 : 180; }
 };
@@ -298,7 +347,23 @@ struct bcs_transformation_transcript {
     }
 };
 
+// bcs_prover_index (bcs/bcs_common.hpp): the index round's oracles and their Merkle trees, device resident, plus what the protocol's
+// indexer wants the prover to find next to them (iop_prover_index::all_oracle_evals_; here also the index evaluations over K)
+template<typename FieldT>
+struct bcs_prover_index {
+    std::vector<device_vector<FieldT>> oracles;
+    std::vector<device_merkle_tree> trees;
+    std::vector<hash_digest> roots;
+    std::vector<std::vector<FieldT>> prover_messages;
+    std::vector<std::vector<device_vector<FieldT>>> index_evals_over_K;
+};
+struct bcs_verifier_index {                     // bcs_indexer::get_verifier_index (bcs_indexer.tcc:67-77)
+    std::vector<hash_digest> index_MT_roots_;
+};
+
 // ---- the round driver ----------------------------------------------------------------------------------------------------------
+// Without interactions registered after the index round it is the bcs_indexer (bcs/bcs_indexer.tcc): signal_index_submissions_done
+// then Merkleises the submitted index oracles.
 template<typename FieldT>
 class bcs_prover {
 public:
@@ -314,6 +379,8 @@ private:
     struct tree_info { std::size_t round, domain; std::vector<std::size_t> oracle_ids; };
 
     std::size_t pow_bitlen_;
+    const bcs_prover_index<FieldT> *index_ = nullptr;                                        // bcs_prover.tcc:12-21
+    bool is_holographic_ = false;
     blake2b_hashchain<FieldT> hashchain_;
     // registrations (iop.tcc:22-263)
     std::vector<field_subset<FieldT>> domains_;
@@ -398,7 +465,7 @@ private:
     }
 
 public:
-    explicit bcs_prover(std::size_t pow_work_parameter) : pow_bitlen_(pow_work_parameter) {}
+    explicit bcs_prover(std::size_t pow_work_parameter, const bcs_prover_index<FieldT> *index = nullptr) : pow_bitlen_(pow_work_parameter), index_(index) {}
 
     // ---- registration ----
     domain_handle register_domain(const field_subset<FieldT> &S) { domains_.push_back(S); return domain_handle{ domains_.size() - 1 }; }
@@ -408,10 +475,27 @@ public:
         assert_can_register(domain.id, degree);
         if (make_zk) throw std::invalid_argument("zero-knowledge oracles are out of scope (salts and masks are not reproducible)");
         update_rounds_and_direction(true);
+        if (is_holographic_ && num_interaction_rounds_ == 0) throw std::invalid_argument("Cannot register non-index oracles in round 0 of a holographic IOP");
         oracle_regs_.push_back({ domain.id, degree, name });
         oracles_.emplace_back();
         oracle_submitted_.push_back(false);
         return oracle_handle{ oracle_regs_.size() - 1, false };
+    }
+    oracle_handle register_index_oracle(const domain_handle &domain, std::size_t degree)     // iop.tcc:106-125
+    {
+        assert_can_register(domain.id, degree);
+        if (num_prover_rounds_done_ != 0) throw std::invalid_argument("index oracles must be created in the 0th round");
+        update_rounds_and_direction(true);
+        is_holographic_ = true;
+        oracle_regs_.push_back({ domain.id, degree, "index" });
+        oracles_.emplace_back();
+        oracle_submitted_.push_back(false);
+        return oracle_handle{ oracle_regs_.size() - 1, false };
+    }
+    void signal_index_registrations_done()                                                   // iop.tcc:377-386
+    {
+        if (!is_holographic_ || num_interaction_rounds_ != 0) throw std::invalid_argument("Should only be used to end round 0 of a holographic IOP");
+        update_rounds_and_direction(false);
     }
     oracle_handle register_virtual_oracle(const domain_handle &domain, std::size_t degree, const std::vector<oracle_handle> &constituents,
                                           const std::shared_ptr<virtual_oracle<FieldT>> &contents, bool cache_evaluated_contents = false)
@@ -497,7 +581,43 @@ public:
         prover_messages_[handle.id] = contents;
         message_submitted_[handle.id] = true;
     }
-    void signal_prover_round_done()
+    // iop_protocol::submit_prover_index (iop.tcc:309-341) + bcs_prover::signal_index_submissions_done (bcs_prover.tcc:68-80): round 0's
+    // oracles, messages and trees come from the index; only the hashchain runs
+    void submit_prover_index(const bcs_prover_index<FieldT> &index)
+    {
+        if (num_prover_rounds_done_ != 0) throw std::invalid_argument("The IOP prover index should only be for round 0");
+        const std::size_t count = num_oracles_at_end_of_round_[0];
+        if (index.oracles.size() != count) throw std::invalid_argument("The IOP prover index provided the wrong number of evaluations");
+        for (std::size_t oid = 0; oid < count; ++oid) submit_oracle(oracle_handle{ oid, false }, oracle<FieldT>(index.oracles[oid]));
+        for (std::size_t mid = 0; mid < num_prover_messages_at_end_of_round_[0]; ++mid) submit_prover_message(prover_message_handle{ mid }, index.prover_messages[mid]);
+        signal_index_submissions_done();
+    }
+    // bcs_indexer.tcc:17-53 when no index was given (the trees are built here), bcs_prover.tcc:68-80 otherwise
+    void signal_index_submissions_done()
+    {
+        if (num_prover_rounds_done_ != 0) throw std::invalid_argument("Index submissions should be round 0");
+        finish_round(index_ == nullptr);
+    }
+    std::size_t num_index_trees() const { return oracles_in_round_by_domain(0).size(); }
+    bcs_prover_index<FieldT> get_prover_index() const                                        // bcs_indexer::get_bcs_prover_index (bcs_indexer.tcc:80-103)
+    {
+        bcs_prover_index<FieldT> idx;
+        const std::size_t k = num_index_trees(), count = num_oracles_at_end_of_round_[0];
+        idx.oracles.assign(oracles_.begin(), oracles_.begin() + count);
+        idx.trees.assign(MT_trees_.begin(), MT_trees_.begin() + k);
+        idx.roots.assign(MT_roots_.begin(), MT_roots_.begin() + k);
+        idx.prover_messages.assign(prover_messages_.begin(), prover_messages_.begin() + num_prover_messages_at_end_of_round_[0]);
+        return idx;
+    }
+    bcs_verifier_index get_verifier_index() const
+    {
+        bcs_verifier_index v;
+        v.index_MT_roots_.assign(MT_roots_.begin(), MT_roots_.begin() + num_index_trees());
+        return v;
+    }
+    void signal_prover_round_done() { finish_round(true); }
+private:
+    void finish_round(bool build_trees)
     {
         if (num_prover_rounds_done_ >= num_interaction_rounds_) throw std::logic_error("attempting to signal end of a round after protocol already finished");
         const std::size_t ended = num_prover_rounds_done_;
@@ -515,21 +635,28 @@ public:
         const std::size_t cs = get_round_parameters(ended);
         std::size_t num_roots = 0;
         for (auto &kv : mapping) {
-            std::vector<device_vector<FieldT>> round_oracles;
-            for (std::size_t oid : kv.second) round_oracles.push_back(oracles_[oid]);
-            MT_trees_[processed_MTs_] = device_merkle_tree(round_oracles, domains_[kv.first], cs);
-            MT_roots_[processed_MTs_] = MT_trees_[processed_MTs_].get_root();
+            if (build_trees) {
+                std::vector<device_vector<FieldT>> round_oracles;
+                for (std::size_t oid : kv.second) round_oracles.push_back(oracles_[oid]);
+                MT_trees_[processed_MTs_] = device_merkle_tree(round_oracles, domains_[kv.first], cs);
+                MT_roots_[processed_MTs_] = MT_trees_[processed_MTs_].get_root();
+            } else {                                                                         // "The Merkle trees are already filled in by the preprocessor."
+                MT_trees_[processed_MTs_] = index_->trees[processed_MTs_];
+                MT_roots_[processed_MTs_] = index_->roots[processed_MTs_];
+            }
             ++processed_MTs_;
             ++num_roots;
         }
         run_hashchain_for_round(ended, num_roots);
-        if (num_prover_rounds_done_ == num_interaction_rounds_) {                            // bcs_prover.tcc:52-59
+        // bcs_prover.tcc:52-59; the indexer's one-round protocol registers no proof of work (bcs_common.tcc:426-431)
+        if (num_prover_rounds_done_ == num_interaction_rounds_ && !(is_holographic_ && num_interaction_rounds_ == 1)) {
             const hash_digest challenge = hashchain_.squeeze_root_type();
             uint8_t answer[32];
             check(iopx_pow_solve_blake2b(reinterpret_cast<const uint8_t *>(challenge.data()), pow_bitlen_, answer));
             pow_answer_ = hash_digest(reinterpret_cast<const char *>(answer), 32);
         }
     }
+public:
     std::vector<FieldT> obtain_verifier_random_message(const verifier_random_message_handle &h) const
     {
         auto it = verifier_random_messages_.find(h.id);
@@ -588,6 +715,10 @@ public:
             }
             t.query_responses_.push_back(responses);
             t.MT_set_membership_proofs_.push_back(MT_trees_[mt].get_set_membership_proof(lpos));
+        }
+        if (is_holographic_) {                                                               // remove_index_info_from_transcript (bcs_prover.tcc:119-134)
+            t.prover_messages_.erase(t.prover_messages_.begin(), t.prover_messages_.begin() + num_prover_messages_at_end_of_round_[0]);
+            t.MT_roots_.erase(t.MT_roots_.begin(), t.MT_roots_.begin() + num_index_trees());
         }
         t.proof_of_work_ = pow_answer_;
         return t;

@@ -1,13 +1,15 @@
-// The Aurora prover behind the C ABI: iopx_aurora_* (include/libiop_amd.h).
+// The Aurora and Fractal provers behind the C ABI: iopx_aurora_* / iopx_fractal_* (include/libiop_amd.h).
 //
 // The orchestration is the C++ surface of libiop_amd/cpp/aurora.hpp — aurora_snark_prover<FieldT>(cs, primary, auxiliary, params),
 // the signature of libiop/snark/aurora_snark.tcc:120-146 — instantiated for the two accelerated fields and wrapped in plain C types, so
 // that a caller without a C++ toolchain (the ctypes binding, bench.py) reaches the native prover too.  Host-only code: no kernels here.
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 
 #include "../cpp/aurora.hpp"
+#include "../cpp/fractal.hpp"
 #include "../cpp/fields.hpp"
 #include "runtime.h"
 
@@ -19,6 +21,8 @@ struct InstanceBase {
     virtual ~InstanceBase() {}
     virtual std::string prove(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) = 0;
     virtual size_t num_constraints() const = 0;
+    virtual std::vector<std::string> fractal_index(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) = 0;
+    virtual std::string fractal_prove(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) = 0;
 };
 
 template<typename F>
@@ -35,7 +39,26 @@ struct Instance : InstanceBase {
         z.insert(z.end(), auxiliary.begin(), auxiliary.end());
         d_assignment = device_vector<F>(device_array<F>::from_host(z));
     }
+    // the Fractal prover index (twelve index oracles, their tree, their evaluations over the index domain) for one parameter set
+    std::unique_ptr<bcs_prover_index<F>> index;
+    size_t index_params[3] = { 0, 0, 0 };
+
     size_t num_constraints() const override { return cs.num_constraints(); }
+    std::vector<std::string> fractal_index(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) override
+    {
+        const fractal_snark_parameters<F> params(cs, security_parameter, RS_extra_dimensions, FRI_localization_parameter);
+        auto made = fractal_snark_indexer<F>(cs, params);
+        index.reset(new bcs_prover_index<F>(std::move(made.first)));
+        index_params[0] = security_parameter; index_params[1] = RS_extra_dimensions; index_params[2] = FRI_localization_parameter;
+        return made.second.index_MT_roots_;
+    }
+    std::string fractal_prove(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) override
+    {
+        if (!index || index_params[0] != security_parameter || index_params[1] != RS_extra_dimensions || index_params[2] != FRI_localization_parameter)
+            throw std::logic_error("iopx_fractal_prove: no index for these parameters (call iopx_fractal_index first)");
+        const fractal_snark_parameters<F> params(cs, security_parameter, RS_extra_dimensions, FRI_localization_parameter);
+        return fractal_snark_prover<F>(*index, cs, primary, auxiliary, params, &d_assignment).serialize();
+    }
     std::string prove(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) override
     {
         const aurora_snark_parameters<F> params(cs.num_constraints(), cs.num_variables(), cs.num_inputs(), security_parameter, RS_extra_dimensions,
@@ -137,6 +160,38 @@ int iopx_aurora_prove(iopx_aurora_instance *instance, size_t security_parameter,
     if (!instance || !transcript || !transcript_bytes) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
     return guarded([&] {
         const std::string t = reinterpret_cast<InstanceBase *>(instance)->prove(security_parameter, RS_extra_dimensions, FRI_localization_parameter);
+        uint8_t *buf = static_cast<uint8_t *>(std::malloc(t.size() ? t.size() : 1));
+        if (!buf) throw std::bad_alloc();
+        std::memcpy(buf, t.data(), t.size());
+        *transcript = buf;
+        *transcript_bytes = t.size();
+    });
+}
+
+int iopx_fractal_index(iopx_aurora_instance *instance, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter,
+                       uint8_t *index_roots, size_t root_capacity, size_t *num_roots)
+{
+    int rc = iopx::ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!instance || !num_roots) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    return guarded([&] {
+        const std::vector<std::string> roots = reinterpret_cast<InstanceBase *>(instance)->fractal_index(security_parameter, RS_extra_dimensions, FRI_localization_parameter);
+        *num_roots = roots.size();
+        if (index_roots) {
+            if (root_capacity < roots.size()) throw std::invalid_argument("iopx_fractal_index: root buffer too small");
+            for (size_t i = 0; i < roots.size(); ++i) std::memcpy(index_roots + 32 * i, roots[i].data(), 32);
+        }
+    });
+}
+
+int iopx_fractal_prove(iopx_aurora_instance *instance, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter,
+                       uint8_t **transcript, size_t *transcript_bytes)
+{
+    int rc = iopx::ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!instance || !transcript || !transcript_bytes) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    return guarded([&] {
+        const std::string t = reinterpret_cast<InstanceBase *>(instance)->fractal_prove(security_parameter, RS_extra_dimensions, FRI_localization_parameter);
         uint8_t *buf = static_cast<uint8_t *>(std::malloc(t.size() ? t.size() : 1));
         if (!buf) throw std::bad_alloc();
         std::memcpy(buf, t.data(), t.size());

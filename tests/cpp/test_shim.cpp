@@ -11,6 +11,7 @@
 
 #include "../../libiop_amd/cpp/libiop_amd.hpp"
 #include "../../libiop_amd/cpp/aurora.hpp"
+#include "../../libiop_amd/cpp/fractal.hpp"
 #include "../../oracle/field.hpp"
 #include "../../oracle/algebra.hpp"
 #include "../../oracle/fri.hpp"
@@ -21,6 +22,7 @@
 #include "../../oracle/poseidon.hpp"
 #include "../../oracle/domain.hpp"
 #include "../../oracle/aurora.hpp"
+#include "../../oracle/fractal.hpp"
 
 typedef oracle::gf192 FieldT;
 typedef oracle::edwards_Fr Fr;
@@ -347,9 +349,50 @@ static int run_aurora(size_t max_log_n)
     return 0;
 }
 
+// fractal_snark_indexer / fractal_snark_prover of libiop_amd/cpp/fractal.hpp (libiop/snark/fractal_snark.tcc:114-162): the index tree's
+// root and the transcript bytes must equal the oracle indexer's / prover's; one index serves several proofs
+template<typename F>
+static int run_fractal_case(size_t log_n, size_t num_inputs, uint64_t seed)
+{
+    const size_t n = (size_t)1 << log_n;
+    const oracle::r1cs_example<F> ex = oracle::generate_r1cs_example<F>(n, num_inputs, n - 1, seed);
+    libiop_amd::r1cs_constraint_system<F> cs;
+    cs.primary_input_size_ = num_inputs;
+    cs.auxiliary_input_size_ = n - 1 - num_inputs;
+    for (size_t i = 0; i < n; ++i) cs.add_constraint({ to_lc<F>(ex.cs.A[i]), to_lc<F>(ex.cs.B[i]), to_lc<F>(ex.cs.C[i]) });
+    const libiop_amd::fractal_snark_parameters<F> params(cs);
+    const oracle::fractal_parameters<F> oparams(128, 3, 2, ex.cs);
+    const auto index = libiop_amd::fractal_snark_indexer<F>(cs, params);
+    const oracle::fractal_index<F> oindex = oracle::fractal_snark_indexer<F>(ex.cs, oparams);
+    CHECK(index.second.index_MT_roots_.size() == oindex.MT_roots.size());
+    for (size_t i = 0; i < oindex.MT_roots.size(); ++i) CHECK(memcmp(index.second.index_MT_roots_[i].data(), oindex.MT_roots[i].data(), 32) == 0);
+    const std::vector<uint8_t> ref = oracle::fractal_snark_prover<F>(oindex, ex.cs, ex.primary_input, ex.auxiliary_input, oparams).serialize();
+    for (int rep = 0; rep < 2; ++rep) {
+        const std::string mine = libiop_amd::fractal_snark_prover<F>(index.first, cs, ex.primary_input, ex.auxiliary_input, params).serialize();
+        CHECK(mine.size() == ref.size() && memcmp(mine.data(), ref.data(), ref.size()) == 0);
+    }
+    printf("fractal %s 2^%zu (k = %zu): index root and %zu transcript bytes equal the oracle's\n", libiop_amd::field_host<F>::additive() ? "gf192" : "edwards_Fr", log_n,
+           num_inputs, ref.size());
+    return 0;
+}
+
+static int run_fractal(size_t max_log_n)
+{
+    for (size_t log_n = 6; log_n <= max_log_n; ++log_n) {
+        if (run_fractal_case<Fr>(log_n, 0, 0x2205)) return 1;
+        if (run_fractal_case<FieldT>(log_n, 0, 0x2205)) return 1;
+    }
+    if (run_fractal_case<Fr>(7, 15, 0x2205)) return 1;
+    if (run_fractal_case<FieldT>(7, 15, 0x2205)) return 1;
+    if (run_fractal_case<Fr>(6, 1, 91)) return 1;              // reference quirk F15 (num_inputs = 1 over multiplicative domains) is followed
+    printf("fractal ok\n");
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     const std::string mode = argc > 1 ? argv[1] : "nodevice";
+    if (mode == "fractal") return run_fractal(argc > 2 ? (size_t)atoi(argv[2]) : 8);
     if (mode == "aurora") return run_aurora(argc > 2 ? (size_t)atoi(argv[2]) : 10);
     return mode == "gpu" ? run_gpu() : run_nodevice();
 }

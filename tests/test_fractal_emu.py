@@ -123,3 +123,23 @@ def test_domain_kernels(field_name):
 def test_domain_kernels_three_table_levels():
     """2^19 points: index bits 8..16 and 17..18 go through the two pre-summed table levels of the subset-sum kernels."""
     fc.check_domain_kernels(emu_lib.emu(), torch, CPU, "gf192", 19, 5, samples=(0, 255, 256, 65535, 65536, 131071, 131072, 300000))
+
+
+@pytest.mark.parametrize("field_name,log_n,num_inputs", [("edwards_Fr", 7, 0), ("gf192", 6, 0), ("edwards_Fr", 6, 15)])
+def test_native_indexer_and_prover_behind_the_c_abi(field_name, log_n, num_inputs):
+    """iopx_fractal_index / iopx_fractal_prove (libiop_amd/cpp/fractal.hpp inside the library): roots and transcript equal the oracle's."""
+    import oracle
+    lib = emu_lib.emu()
+    n = 1 << log_n
+    inst = lib.aurora_example_instance({"gf192": 0, "edwards_Fr": 1}[field_name], n, num_inputs, n - 1, 0x2205)
+    try:
+        with pytest.raises(AssertionError):
+            lib.fractal_prove(inst)                       # no index yet: std::logic_error
+        roots = lib.fractal_index(inst)
+        code = {"gf192": oracle.FIELD_GF192, "edwards_Fr": oracle.FIELD_EDWARDS}[field_name]
+        ref, ref_roots = oracle.fractal_prove(code, log_n, num_inputs, 0x2205)
+        assert roots == ref_roots
+        assert lib.fractal_prove(inst) == ref
+        assert lib.fractal_prove(inst) == ref
+    finally:
+        lib.aurora_instance_free(inst)
