@@ -3,9 +3,23 @@
 phase-1 kernel with the guide's gfx950 correction (FETCH_SIZE counts half of a coalesced streaming read: doubled; WRITE_SIZE
 exact), both in KiB.  Usage: make_traffic_json.py <fetch_dir> <write_dir> <log_n> <out.json> [kernel substring ...]"""
 import glob
+import hashlib
 import json
+import os
 import sqlite3
 import sys
+import time
+
+
+def kernel_sources_digest():
+    """The same digest bench.py computes: the figures are only quoted for the kernel sources they were collected on."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for dp, _, fs in sorted(os.walk(os.path.join(root, "libiop_amd", "csrc"))):
+        for f in sorted(fs):
+            if f.endswith((".hip", ".h")):
+                h.update(open(os.path.join(dp, f), "rb").read())
+    return h.hexdigest()
 
 
 def avg_counter(d, counter, kernel_like):
@@ -23,6 +37,8 @@ out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over bench.py (summaries next to this file in profiles/)",
     "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE reports 1/2 of the bytes of a coalesced streaming read on gfx950 -> doubled; WRITE_SIZE exact; both KiB",
     "log_n": int(sys.argv[3]),
+    "kernel_sources_sha256": kernel_sources_digest(),
+    "collected": time.strftime("%Y-%m-%d"),
     "kernels": {},
 }
 for k in kernels:
