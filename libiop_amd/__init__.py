@@ -651,6 +651,14 @@ class Library:
         self.c.iopx_aurora_instance_free.argtypes = [ctypes.c_void_p]
         self.c.iopx_aurora_instance_free(instance)
 
+    def blake2b_host(self, msg, digest_size=32, key=b""):
+        """The library's host-side BLAKE2b (the hashchain of the native prover): no device needed."""
+        out = (ctypes.c_uint8 * int(digest_size))()
+        m, k = bytes(msg), bytes(key)
+        self.c.iopx_blake2b_host.argtypes = [ctypes.c_void_p, _sz, ctypes.c_char_p, _sz, ctypes.c_char_p, _sz]
+        self._check(self.c.iopx_blake2b_host(ctypes.addressof(out), int(digest_size), m if m else None, len(m), k if k else None, len(k)))
+        return bytes(out)
+
     def pow_search(self, challenge, pow_bitlen, first, count):
         """The smallest passing proof-of-work candidate index in [first, first + count) or None (candidate 0 = the challenge itself,
         i >= 1 = the challenge with its last word set to i - 1: the reference's search order, pow.tcc:86-112)."""
