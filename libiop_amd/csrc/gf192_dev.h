@@ -59,19 +59,33 @@ __device__ __forceinline__ bool gf_is_zero(const gf192 &a)
     return (a.w[0] | a.w[1] | a.w[2] | a.w[3] | a.w[4] | a.w[5]) == 0;
 }
 
-// Fold a 12-word (383-bit) carry-less product modulo x^192 + x^7 + x^2 + x + 1.
-// x^192 = x^7 + x^2 + x + 1, so word i (i >= 6) folds onto words i-6 and i-5.
+// Fold a 12-word (383-bit) carry-less product modulo x^192 + x^7 + x^2 + x + 1: with H = c[6..11], the result is
+// L + H (1 + x + x^2 + x^7) and a second, 7-bit fold of what that pushes past bit 191.
+//
+// Written as multi-word shifts of H — word j of H << s is one v_alignbit of (H[j], H[j-1]) — so a word of the result costs three
+// shift-class ops and two three-input XORs: 24 slow + 16 fast ops in all.  The word-at-a-time form (for each high word t:
+// c[i-6] ^= t ^ t<<1 ^ t<<2 ^ t<<7, c[i-5] ^= t>>31 ^ t>>30 ^ t>>25) takes 36 + 24; shifts issue at 4.2 cycles against 2.5
+// (profiles/r03_valu_rates.txt), and the reduction follows every product of every kernel.
+__device__ __forceinline__ uint32_t gf_funnel(uint32_t hi, uint32_t lo, int s)          // bits [32 - s, 64 - s) of hi:lo, 0 < s < 32
+{
+    return __builtin_amdgcn_alignbit(hi, lo, 32 - s);
+}
+
 __device__ __forceinline__ gf192 gf_reduce(uint32_t (&c)[12])
 {
-#pragma unroll
-    for (int i = 11; i >= 6; --i) {
-        const uint32_t t = c[i];
-        c[i - 6] ^= t ^ (t << 1) ^ (t << 2) ^ (t << 7);
-        c[i - 5] ^= (t >> 31) ^ (t >> 30) ^ (t >> 25);
-    }
     gf192 r;
+    uint32_t prev = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) r.w[i] = c[i];
+    for (int j = 0; j < 6; ++j) {
+        const uint32_t h = c[6 + j];
+        const uint32_t s1 = gf_funnel(h, prev, 1), s2 = gf_funnel(h, prev, 2), s7 = gf_funnel(h, prev, 7);
+        r.w[j] = __builtin_amdgcn_bitop3_b32(c[j], h, s1, 0x96);
+        r.w[j] = __builtin_amdgcn_bitop3_b32(r.w[j], s2, s7, 0x96);
+        prev = h;
+    }
+    // bits 192..198: the top 1, 2 and 7 bits of H's last word
+    const uint32_t t = (prev >> 31) ^ (prev >> 30) ^ (prev >> 25);
+    r.w[0] ^= t ^ (t << 1) ^ (t << 2) ^ (t << 7);
     return r;
 }
 
