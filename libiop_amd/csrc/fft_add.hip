@@ -283,6 +283,31 @@ __device__ __forceinline__ gf192 bf_twiddle(const BfParams &p, size_t coset, siz
     return tw;
 }
 
+// the same twiddle fetched through the scalar unit: `u_uniform` is wave-uniform (64 consecutive butterflies of one block)
+__device__ __forceinline__ gf192 bf_twiddle_uniform(const BfParams &p, size_t coset, size_t u_uniform, int pbit)
+{
+    const int l = p.d - 1 - pbit;
+    const uint64_t *t = p.ltab + 3 * ((((size_t)1) << l) - 1 + (u_uniform >> (pbit + 1)));
+    uint64_t w0 = uniform_load64(t), w1 = uniform_load64(t + 1), w2 = uniform_load64(t + 2);
+    if (p.rs_comb) {
+        const uint64_t *r = p.rs_comb + 3 * (coset * p.d + l);
+        w0 ^= uniform_load64(r); w1 ^= uniform_load64(r + 1); w2 ^= uniform_load64(r + 2);
+    } else {
+        const uint64_t *r = p.rs + 3 * (size_t)l;
+        w0 ^= uniform_load64(r); w1 ^= uniform_load64(r + 1); w2 ^= uniform_load64(r + 2);
+        const size_t gc = p.coset_base + coset;
+        for (int v = 0; v < p.nhi; ++v) {
+            if ((gc >> v) & 1) {
+                const uint64_t *q = p.rs + 3 * ((size_t)(1 + v) * p.d + l);
+                w0 ^= uniform_load64(q); w1 ^= uniform_load64(q + 1); w2 ^= uniform_load64(q + 2);
+            }
+        }
+    }
+    gf192 tw;
+    tw.w[0] = (uint32_t)w0; tw.w[1] = (uint32_t)(w0 >> 32); tw.w[2] = (uint32_t)w1; tw.w[3] = (uint32_t)(w1 >> 32); tw.w[4] = (uint32_t)w2; tw.w[5] = (uint32_t)(w2 >> 32);
+    return tw;
+}
+
 // `uniform`: every lane of the wavefront has the same twiddle (64 consecutive butterflies of one block)
 // rs_comb[c * d + l] = rs[l] + sum_{bit v of (coset_base + c)} rs[(1 + v) * d + l]
 __global__ void k_rs_combine(uint64_t *out, const uint64_t *rs, int d, int nhi, size_t coset_base, size_t count)
@@ -344,10 +369,10 @@ __global__ void __launch_bounds__(COMB ? 512 : 1024, COMB ? 6 : 1) k_bfly_upper(
             // twiddle is wave-uniform.  One butterfly per trip, nothing hoisted: the kernel must fit 80 VGPRs (6 waves per SIMD hide the comb
             // product's branch latency); the twiddle is fetched through a uniform index
 #pragma unroll 1
-            for (int bf = tid; bf < (E >> 1); bf += nt) {
+            for (int bf = tid; bf < (E >> 1); bf += nt) {          // (requesting the next trip's twiddle ahead of the product changed nothing: 22.0 vs 22.1 ms)
                 const int ia = ((bf >> pl) << (pl + 1)) | (bf & ((1 << pl) - 1));
                 const uint32_t ia_u = __builtin_amdgcn_readfirstlane((uint32_t)(ia & ~63));
-                const gf192 tw = bf_twiddle(p, coset, base | ((size_t)(ia_u >> p.c) << p.h) | (size_t)(ia_u & cmask), pbit);
+                const gf192 tw = bf_twiddle_uniform(p, coset, base | ((size_t)(ia_u >> p.c) << p.h) | (size_t)(ia_u & cmask), pbit);
                 bf_apply<INV, true>(s, E, ia, ia | (1 << pl), tw, true);
             }
         } else {

@@ -25,3 +25,5 @@ static inline void comb_clmul_192_uniform(uint32_t (&r)[12], const uint32_t (&a)
         }
     }
 }
+
+static inline uint64_t uniform_load64(const uint64_t *p) { return *p; }

@@ -131,6 +131,14 @@ __device__ __forceinline__ void comb_clmul_192_uniform(uint32_t (&r)[12], const 
         : %s
         : %s);
 }
+
+// A 64-bit load through the scalar unit: the address must be wave-uniform (the caller passes an index made uniform with
+// readfirstlane).  The constant address space makes the compiler emit s_load instead of a per-lane global_load followed by
+// v_readfirstlane: the twiddle of a comb product is needed in SGPRs anyway.  The data must not be written by the same kernel.
+__device__ __forceinline__ uint64_t uniform_load64(const uint64_t *p)
+{
+    return *(const __attribute__((address_space(4))) uint64_t *)(uintptr_t)p;
+}
 ''' % (TB, TB + 34, SB, SB + 17, body, outs, ins, clob)
 open(OUT, "w").write(hdr)
 print("wrote", OUT)
