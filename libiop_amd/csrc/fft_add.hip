@@ -471,6 +471,99 @@ __global__ void __launch_bounds__(COMB ? 512 : 1024) k_bfly_edge(BfParams p)
     }
 }
 
+
+// Forward last pass for a BATCH of polynomials over the same domain (the prover extends f_Az, f_Bz, f_Cz, then p_alpha' and p_alpha^ABC,
+// together: r1cs_rs_iop.tcc:459-478, basic_lincheck_aux.tcc:94-118).  The twiddle of a butterfly depends on its block and coset, not on
+// the polynomial, so the B * 2^pbit butterflies of one block at pair bit pbit share it: with B >= 2 the two highest edge levels (pbit 5
+// and 4) fill a wavefront with one twiddle — lanes run over (polynomial, butterfly of the block) — and take the comb product instead of
+// the general one (1630 against 3250 cycles per wave-butterfly; 3/4-full waves still win).  The lower levels are k_bfly_edge's.
+struct BfBatchParams {
+    BfParams p;
+    const uint64_t *srcs[4];
+    uint64_t *dsts[4];
+    int batch;
+};
+
+__global__ void __launch_bounds__(512) k_bfly_edge_fwd_batch(BfBatchParams q)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
+    const BfParams &p = q.p;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tb = p.a_low + p.c_top;                   // bits of one tile
+    const int E = 1 << (tb + p.g_bits);                 // elements of ONE polynomial in LDS (2^g_bits tiles)
+    const int midbits = p.d - tb;
+    const size_t unit0 = (size_t)blockIdx.x << p.g_bits;
+    const int lomask = (1 << p.a_low) - 1, tmask = (1 << p.c_top) - 1;
+
+    for (int b = 0; b < q.batch; ++b) {
+        uint64_t *s = iopx_smem + 3 * (size_t)E * b;
+        for (int e = tid; e < E; e += nt) {
+            const size_t unit = unit0 + (size_t)(e >> tb);
+            if (unit >= p.total_units) continue;
+            const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
+            const int li = e & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
+            const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
+            lds_put(s, E, e, gf_load(q.srcs[b] + 3 * (coset << p.d), u));
+        }
+    }
+    __syncthreads();
+
+    for (int t = 0; t < p.a_low; ++t) {
+        const int pbit = p.a_low - 1 - t;
+        const int G = 1 << pbit;                        // butterflies that share a twiddle, per polynomial
+        if (pbit >= 4 && q.batch * G >= 48) {
+            const int groups = (E >> 1) >> pbit, chunks = (q.batch * G + 63) >> 6;
+            // a strided loop over (work item, lane) like every other loop here; the block size is a multiple of 64, so x >> 6 is the
+            // same in all lanes of a wavefront
+            for (int x = tid; x < groups * chunks * 64; x += nt) {
+                const int w = __builtin_amdgcn_readfirstlane(x >> 6), lane = x & 63;
+                const int g = w / chunks, ch = w - g * chunks;
+                const int ia0 = g << (pbit + 1);
+                const size_t unit = unit0 + (size_t)(ia0 >> tb);
+                if (unit >= p.total_units) continue;
+                const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
+                const int li = ia0 & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
+                const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
+                const gf192 tw = bf_twiddle_uniform(p, coset, u, pbit);
+                const int idx = ch * 64 + lane;
+                if (idx < q.batch * G) {
+                    const int b = idx >> pbit, ia = ia0 | (idx & (G - 1));
+                    bf_apply<false, true>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | G, tw, true);
+                }
+            }
+        } else {
+            const int half = E >> 1;
+            for (int x = tid; x < q.batch * half; x += nt) {
+                const int b = x / half, bf = x - b * half;
+                const int low = bf & (G - 1), high = bf >> pbit;
+                const int ia = (high << (pbit + 1)) | low;
+                const size_t unit = unit0 + (size_t)(ia >> tb);
+                if (unit >= p.total_units) continue;
+                const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
+                const int li = ia & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
+                const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
+                bf_apply<false, false>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | G, bf_twiddle(p, coset, u, pbit), false);
+            }
+        }
+        __syncthreads();
+    }
+
+    for (int b = 0; b < q.batch; ++b) {
+        const uint64_t *s = iopx_smem + 3 * (size_t)E * b;
+        for (int sidx = tid; sidx < E; sidx += nt) {
+            const size_t unit = unit0 + (size_t)(sidx >> tb);
+            if (unit >= p.total_units) continue;
+            const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
+            const int tp = sidx & tmask, lo = (sidx >> p.c_top) & lomask;
+            const int top = (int)bitrev((uint32_t)tp, p.c_top);
+            const size_t v = ((size_t)bitrev((uint32_t)lo, p.a_low) << (p.d - p.a_low)) |
+                             ((size_t)bitrev((uint32_t)mid, midbits) << p.c_top) | (size_t)tp;
+            const int e = ((sidx >> tb) << tb) | (top << p.a_low) | lo;
+            gf_store(q.dsts[b] + 3 * (coset << p.d), v, lds_get(s, E, e));
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side: plans
 // ---------------------------------------------------------------------------------------------
@@ -704,7 +797,7 @@ static P2Geom phase2_geom(int d)
 // The edge pass permutes (bit reversal), so it never runs in place across workgroups: the forward
 // transform keeps the upper passes in W (one coset) or in a scratch buffer holding a group of cosets.
 template<bool INV>
-static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, size_t coset_begin = 0, size_t coset_count = 0)
+static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, size_t coset_begin = 0, size_t coset_count = 0, bool upper_only = false)
 {
     const int d = pl.d;
     const P2Geom g = phase2_geom(d);
@@ -800,6 +893,12 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         }
         rc = launch_edge(W, dst, 1, 1, 0);
         if (rc != IOPX_OK) return rc;
+    } else if (upper_only) {
+        // the caller's dst is the scratch of a batched last pass: `cosets` cosets in block order
+        for (size_t i = 0; i < ups.size(); ++i) {
+            rc = launch_upper(ups[i], i == 0 ? src : dst, dst, i == 0 ? 1 : 0, cosets, coset_begin);
+            if (rc != IOPX_OK) return rc;
+        }
     } else {
         size_t group = SCRATCH_BYTES / (nd * 24);
         if (group < 1) group = 1;
@@ -816,6 +915,68 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
             rc = launch_edge(scratch.u64(), dst + 3 * c0 * nd, 0, nc, coset_begin + c0);
             if (rc != IOPX_OK) return rc;
         }
+    }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+
+// Forward phase 2 of `batch` (2..4) polynomials over the same cosets: the upper passes run per polynomial into its own scratch, the last
+// pass once for all of them (k_bfly_edge_fwd_batch).  Only the shape the prover's extensions have (several cosets, at least one upper
+// pass); everything else goes through run_phase2 one polynomial at a time.
+static int run_phase2_fwd_batch(AddPlan &pl, const uint64_t *const *srcs, uint64_t *const *dsts, size_t batch, int nhi, size_t coset_begin, size_t coset_count)
+{
+    const int d = pl.d;
+    const size_t cosets = coset_count ? coset_count : ((size_t)1 << nhi);
+    const bool batched_edge = tuning().comb && env_int("IOPX_EDGE_BATCH", 1, 0, 1) && batch >= 2 && batch <= 4 && nhi > 0 && d >= EDGE_TILE_BITS + 1 &&
+                              cosets * (size_t)d <= ((size_t)1 << 22);
+    if (!batched_edge) {
+        for (size_t k = 0; k < batch; ++k) {
+            const int rc = run_phase2<false>(pl, srcs[k], dsts[k], nhi, coset_begin, coset_count);
+            if (rc != IOPX_OK) return rc;
+        }
+        return IOPX_OK;
+    }
+    const size_t nd = (size_t)1 << d;
+    size_t group = SCRATCH_BYTES / (nd * 24);
+    if (group < 1) group = 1;
+    if (group > cosets) group = cosets;
+    std::vector<std::unique_ptr<TmpBuf>> scratch;
+    for (size_t k = 0; k < batch; ++k) {
+        scratch.emplace_back(new TmpBuf());
+        const int rc = scratch.back()->alloc(group * nd * 24);
+        if (rc != IOPX_OK) return rc;
+    }
+    for (size_t c0 = 0; c0 < cosets; c0 += group) {
+        const size_t nc = cosets - c0 < group ? cosets - c0 : group;
+        for (size_t k = 0; k < batch; ++k) {                    // upper passes only: the scratch holds the block-order input of the last pass
+            const int rc = run_phase2<false>(pl, srcs[k], scratch[k]->u64(), nhi, coset_begin + c0, nc, /*upper_only=*/true);
+            if (rc != IOPX_OK) return rc;
+        }
+        const P2Geom g = phase2_geom(d);
+        BfBatchParams q;
+        memset(&q, 0, sizeof(q));
+        BfParams &p = q.p;
+        p.ltab = pl.ltab.u64(); p.rs = pl.rs.u64(); p.d = d; p.nhi = nhi;
+        p.a_low = g.a_low;
+        // 512 threads and batch * tile / 2 butterflies per level: whole trips for 2 and 3 tiles of 1024 (48 and 72 KB of LDS, two workgroups
+        // per CU either way); four tiles take the half size (48 KB)
+        p.c_top = batch == 4 ? g.c_top - 1 : g.c_top;
+        p.g_bits = 0;
+        const int tb = p.a_low + p.c_top;
+        p.total_units = nc << (d - tb);
+        p.coset_base = coset_begin + c0;
+        TmpBuf rs_comb;
+        int rc = rs_comb.alloc(nc * d * 24);
+        if (rc != IOPX_OK) return rc;
+        { ProfScope ps_("k_rs_combine"); hipLaunchKernelGGL(k_rs_combine, dim3(grid_for(nc * d, 256)), dim3(256), 0, stream(), rs_comb.u64(), (const uint64_t *)pl.rs.u64(), d, nhi, coset_begin + c0, nc * (size_t)d); }
+        p.rs_comb = rs_comb.u64();
+        q.batch = (int)batch;
+        for (size_t k = 0; k < batch; ++k) { q.srcs[k] = scratch[k]->u64(); q.dsts[k] = dsts[k] + 3 * c0 * nd; }
+        const size_t lds = (((size_t)24) << tb) * batch;
+        if ((rc = set_lds(k_bfly_edge_fwd_batch, lds)) != IOPX_OK) return rc;
+        { ProfScope ps_("k_bfly_edge", batch * (nc << d) * 48, batch * ((nc << d) >> 1) * (size_t)p.a_low);
+          hipLaunchKernelGGL(k_bfly_edge_fwd_batch, dim3((unsigned)p.total_units), dim3(512), lds, stream(), q); }
     }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
@@ -1004,8 +1165,12 @@ int iopx_add_lde_gf192_batch_dev(const uint64_t *const *d_coeffs, size_t n_coeff
     }
     rc = run_phase1<false>(*pl, work.u64(), batch);
     if (rc != IOPX_OK) return rc;
-    for (size_t k = 0; k < batch; ++k) {
-        rc = run_phase2<false>(*pl, work.u64() + 3 * k * nd, d_outs[k], nhi, coset_begin, coset_count);
+    for (size_t k0 = 0; k0 < batch; k0 += 4) {               // groups of up to four share the last pass
+        const size_t nb = batch - k0 < 4 ? batch - k0 : 4;
+        const uint64_t *srcs[4];
+        uint64_t *dsts[4];
+        for (size_t k = 0; k < nb; ++k) { srcs[k] = work.u64() + 3 * (k0 + k) * nd; dsts[k] = d_outs[k0 + k]; }
+        rc = run_phase2_fwd_batch(*pl, srcs, dsts, nb, nhi, coset_begin, coset_count);
         if (rc != IOPX_OK) return rc;
     }
     return IOPX_OK;
@@ -1051,8 +1216,12 @@ int iopx_add_reextend_gf192_batch_dev(const uint64_t *d_evals, size_t batch, con
     if (rc != IOPX_OK) return rc;
     rc = upload_rs(*pl, hgf192::from_words(shift), basis + 3 * (size_t)d, nhi);    // stream-ordered: after the inverse passes
     if (rc != IOPX_OK) return rc;
-    for (size_t k = 0; k < batch; ++k) {
-        rc = run_phase2<false>(*pl, work.u64() + 3 * k * nd, d_outs[k], nhi, coset_begin, coset_count);
+    for (size_t k0 = 0; k0 < batch; k0 += 4) {               // groups of up to four share the last pass
+        const size_t nb = batch - k0 < 4 ? batch - k0 : 4;
+        const uint64_t *srcs[4];
+        uint64_t *dsts[4];
+        for (size_t k = 0; k < nb; ++k) { srcs[k] = work.u64() + 3 * (k0 + k) * nd; dsts[k] = d_outs[k0 + k]; }
+        rc = run_phase2_fwd_batch(*pl, srcs, dsts, nb, nhi, coset_begin, coset_count);
         if (rc != IOPX_OK) return rc;
     }
     return IOPX_OK;

@@ -187,7 +187,9 @@ def test_batched_ifft(m, batch):
     assert np.array_equal(ev, out)
 
 
-@pytest.mark.parametrize("m,ncoef,batch,cb,cc", [(8, 50, 3, 0, 4), (10, 64, 2, 3, 5), (7, 128, 3, 0, 1), (6, 1, 2, 0, 64), (12, 1000, 4, 1, 2)])
+# the last five take the shared last pass (k_bfly_edge_fwd_batch: d >= 11, two to four polynomials; five = four + one)
+@pytest.mark.parametrize("m,ncoef,batch,cb,cc", [(8, 50, 3, 0, 4), (10, 64, 2, 3, 5), (7, 128, 3, 0, 1), (6, 1, 2, 0, 64), (12, 1000, 4, 1, 2),
+                                                 (13, 2048, 2, 1, 3), (13, 1500, 3, 0, 4), (12, 2048, 4, 0, 2), (14, 4096, 3, 2, 2), (13, 2048, 5, 0, 2)])
 def test_batched_lde(m, ncoef, batch, cb, cc):
     lib = emu()
     basis, shift = rand_elems(50 + m, m, W), rand_elems(51 + m, 1, W)[0]
