@@ -34,7 +34,7 @@ namespace iopx {
 // Tile geometry.  Defaults: 2048-element phase-2 tiles (48 KiB of LDS per workgroup), 1024-element phase-1 and edge tiles.  The IOPX_TILE_BITS /
 // IOPX_P1_COLS / IOPX_P2_COLS / IOPX_P2_TOP environment variables override them (read once): used for
 // tuning, and by the tests to exercise the multi-pass schedules at small transform sizes.
-struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols; };
+struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last; };
 static int env_int(const char *name, int dflt, int lo, int hi)
 {
     const char *v = getenv(name);
@@ -62,6 +62,7 @@ static const Tuning &tuning()
         u.p2_top = env_int("IOPX_P2_TOP", 4, 0, u.edge_tile_bits - 2);
         u.comb = env_int("IOPX_COMB", 1, 0, 1);                         // 1: asm comb multiplier where the twiddle is wave-uniform
         u.p2_threads = env_int("IOPX_P2_THREADS", u.comb ? 512 : 1024, 64, u.comb ? 512 : 1024);
+        u.small_last = env_int("IOPX_SMALL_LAST", 1, 0, 1);             // 1: one-word twiddle numerators at the last level where the basis allows
         return u;
     }();
     return t;
@@ -140,6 +141,19 @@ __global__ void k_build_ltab(uint64_t *ltab, const uint64_t *rec_betas, int d, s
             if ((b >> (l - 1 - k)) & 1) gf_add_to(acc, gf_load(rec_betas, off + k));
         }
         gf_store(ltab, e, acc);
+    }
+}
+
+// One-word numerators of the last level's twiddles, block order like ltab: entry b < 2^l is sum_k bit_{l-1-k}(b) * basis[k]
+struct SmallBasis { uint32_t v[32]; };
+__global__ void k_build_ltab_small(uint32_t *out, SmallBasis basis, int l, size_t count)
+{
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < count; b += (size_t)gridDim.x * blockDim.x) {
+        uint32_t acc = 0;
+        for (int k = 0; k < l; ++k) {
+            if ((b >> (l - 1 - k)) & 1) acc ^= basis.v[k];
+        }
+        out[b] = acc;
     }
 }
 
@@ -264,6 +278,11 @@ struct BfParams {
     int g_bits;             // last/first pass: 2^g_bits tiles per workgroup
     size_t total_units;     // cosets (of this launch) * tiles per coset
     size_t coset_base;      // global index of the first coset of this launch (src/dst are pre-offset)
+    // last level (pair bit 0) over a basis of one-word vectors ending in x^small_k: twiddle = numerator / x^small_k, the numerator the
+    // XOR of ltab_small[block] and the shift numerators (rs_small[0] the shift, rs_small[1 + v] coset basis vector v); null = not used
+    const uint32_t *ltab_small;
+    uint32_t rs_small[9];
+    int small_k;
 };
 
 // twiddle of the block that contains in-coset index u at the level with pair bit pbit
@@ -281,6 +300,17 @@ __device__ __forceinline__ gf192 bf_twiddle(const BfParams &p, size_t coset, siz
         if ((gc >> v) & 1) gf_add_to(tw, gf_load(p.rs, (size_t)(1 + v) * p.d + l));
     }
     return tw;
+}
+
+// numerator of the last level's twiddle (see BfParams::ltab_small)
+__device__ __forceinline__ uint32_t bf_twiddle_small(const BfParams &p, size_t coset, size_t u)
+{
+    uint32_t y = p.ltab_small[u >> 1] ^ p.rs_small[0];
+    const size_t gc = p.coset_base + coset;
+    for (int v = 0; v < p.nhi; ++v) {
+        if ((gc >> v) & 1) y ^= p.rs_small[1 + v];
+    }
+    return y;
 }
 
 // the same twiddle fetched through the scalar unit: `u_uniform` is wave-uniform (64 consecutive butterflies of one block)
@@ -332,6 +362,22 @@ __device__ __forceinline__ void bf_apply(uint64_t *s, int E, int ia, int ib, con
     } else {
         gf_add_to(b, a);                    // S[b] += S[a] ; S[a] += S[b] * t     (fft.tcc:164-165)
         gf_add_to(a, (COMB && uniform) ? gf_mul_uniform(b, tw) : gf_mul(b, tw));
+    }
+    lds_put(s, E, ia, a);
+    lds_put(s, E, ib, b);
+}
+
+// the butterfly of the last level with the twiddle y / x^k
+template<bool INV>
+__device__ __forceinline__ void bf_apply_small(uint64_t *s, int E, int ia, int ib, uint32_t y, int k)
+{
+    gf192 a = lds_get(s, E, ia), b = lds_get(s, E, ib);
+    if (!INV) {
+        gf_add_to(a, gf_mul_small_over_xk(b, y, k));
+        gf_add_to(b, a);
+    } else {
+        gf_add_to(b, a);
+        gf_add_to(a, gf_mul_small_over_xk(b, y, k));
     }
     lds_put(s, E, ia, a);
     lds_put(s, E, ib, b);
@@ -434,6 +480,19 @@ __global__ void __launch_bounds__(COMB ? 512 : 1024) k_bfly_edge(BfParams p)
 
     for (int t = 0; t < p.a_low; ++t) {
         const int pbit = INV ? t : p.a_low - 1 - t;
+        if (pbit == 0 && p.ltab_small) {                // adjacent pairs, one-word twiddle numerators
+            for (int bf = tid; bf < (E >> 1); bf += nt) {
+                const int ia = bf << 1;
+                const size_t unit = unit0 + (size_t)(ia >> tb);
+                if (unit >= p.total_units) continue;
+                const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
+                const int li = ia & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
+                const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
+                bf_apply_small<INV>(s, E, ia, ia | 1, bf_twiddle_small(p, coset, u), p.small_k);
+            }
+            __syncthreads();
+            continue;
+        }
         for (int bf = tid; bf < (E >> 1); bf += nt) {
             const int low = bf & ((1 << pbit) - 1), high = bf >> pbit;
             const int ia = (high << (pbit + 1)) | low, ib = ia | (1 << pbit);
@@ -531,6 +590,17 @@ __global__ void __launch_bounds__(512) k_bfly_edge_fwd_batch(BfBatchParams q)
                     bf_apply<false, true>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | G, tw, true);
                 }
             }
+        } else if (pbit == 0 && p.ltab_small) {
+            const int half = E >> 1;
+            for (int x = tid; x < q.batch * half; x += nt) {
+                const int b = x / half, ia = (x - b * half) << 1;
+                const size_t unit = unit0 + (size_t)(ia >> tb);
+                if (unit >= p.total_units) continue;
+                const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
+                const int li = ia & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
+                const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
+                bf_apply_small<false>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | 1, bf_twiddle_small(p, coset, u), p.small_k);
+            }
         } else {
             const int half = E >> 1;
             for (int x = tid; x < q.batch * half; x += nt) {
@@ -576,6 +646,11 @@ struct AddPlan {
     bool have_fwd = false, have_inv = false;
     DevBuf rs;                                  // per-call shift terms (stream ordered)
     size_t rs_cap = 0;
+    // one-word basis ending in a power of x (the standard basis): numerators of the last level's twiddles, see BfParams::ltab_small
+    DevBuf ltab_small;
+    int small_k = -1;                           // basis[d-1] = x^small_k, or -1
+    uint32_t rs_small[9] = { 0 };               // per call, like rs
+    bool rs_small_ok = false;
 
     // recursed shift of an arbitrary element: GF(2)-linear in s (fft.tcc:93-95 / :153-154)
     void recursed_shifts(const hgf192 &s, hgf192 *out_by_unwind_level) const
@@ -588,6 +663,8 @@ struct AddPlan {
         }
     }
 };
+
+static bool one_word(const hgf192 &e) { return e.w[1] == 0 && e.w[2] == 0 && (e.w[0] >> 32) == 0; }
 
 static std::mutex g_plan_mu;
 static std::map<std::vector<uint64_t>, std::unique_ptr<AddPlan>> g_plans;
@@ -684,6 +761,20 @@ static int get_plan(const uint64_t *basis, int d, AddPlan **out)
         if (rc != IOPX_OK) return rc;
         if (!rec_flat.empty()) { int urc_ = upload(drec.p, rec_flat.data(), rec_flat.size() * 8); if (urc_ != IOPX_OK) return urc_; }
         { ProfScope ps_("k_build_ltab"); hipLaunchKernelGGL(k_build_ltab, dim3(grid_for(count, 256)), dim3(256), 0, stream(), pl->ltab.u64(), (const uint64_t *)drec.u64(), d, count); }
+        // the last level's numerators when every basis vector is one word and the last one a power of x
+        bool small = d >= 2 && d <= 32 && tuning().small_last;
+        for (int i = 0; small && i < d; ++i) small = one_word(pl->basis[i]);
+        const uint64_t last = pl->basis[d - 1].w[0];
+        if (small && (last & (last - 1)) == 0) {
+            SmallBasis sb;
+            memset(&sb, 0, sizeof(sb));
+            for (int i = 0; i < d - 1; ++i) sb.v[i] = (uint32_t)pl->basis[i].w[0];
+            const size_t n_small = (size_t)1 << (d - 1);
+            rc = pl->ltab_small.alloc(n_small * 4);
+            if (rc != IOPX_OK) return rc;
+            hipLaunchKernelGGL(k_build_ltab_small, dim3(grid_for(n_small, 256)), dim3(256), 0, stream(), (uint32_t *)pl->ltab_small.p, sb, d - 1, n_small);
+            pl->small_k = __builtin_ctzll(last);
+        }
         IOPX_HIP(hipStreamSynchronize(stream()));
     }
     *out = pl.get();
@@ -694,6 +785,15 @@ static int get_plan(const uint64_t *basis, int d, AddPlan **out)
 static int upload_rs(AddPlan &pl, const hgf192 &shift, const uint64_t *hi_basis, int nhi)
 {
     const int d = pl.d;
+    pl.rs_small_ok = pl.small_k >= 0 && nhi <= 8 && one_word(shift);
+    if (pl.rs_small_ok) {
+        pl.rs_small[0] = (uint32_t)shift.w[0];
+        for (int v = 0; v < nhi && pl.rs_small_ok; ++v) {
+            const hgf192 e = hgf192::from_words(hi_basis + 3 * v);
+            pl.rs_small_ok = one_word(e);
+            pl.rs_small[1 + v] = (uint32_t)e.w[0];
+        }
+    }
     std::vector<hgf192> rs((size_t)(1 + nhi) * d);
     pl.recursed_shifts(shift, rs.data());
     for (int v = 0; v < nhi; ++v) pl.recursed_shifts(hgf192::from_words(hi_basis + 3 * v), rs.data() + (size_t)(1 + v) * d);
@@ -792,6 +892,14 @@ static P2Geom phase2_geom(int d)
     return {EDGE_TILE_BITS - P2_TOP, P2_TOP};
 }
 
+static void set_small_last(BfParams &p, const AddPlan &pl)
+{
+    if (!pl.rs_small_ok) return;            // p was zeroed: ltab_small stays null
+    p.ltab_small = (const uint32_t *)pl.ltab_small.p;
+    memcpy(p.rs_small, pl.rs_small, sizeof(p.rs_small));
+    p.small_k = pl.small_k;
+}
+
 // forward: W (2^d, block order after phase 1) -> dst (2^nhi cosets * 2^d, natural order);
 // inverse: single coset, natural-order src -> block-order dst (src != dst).
 // The edge pass permutes (bit reversal), so it never runs in place across workgroups: the forward
@@ -809,6 +917,7 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
     p.rs = pl.rs.u64();
     p.d = d; p.nhi = nhi;
     p.a_low = g.a_low; p.c_top = g.c_top;
+    set_small_last(p, pl);
     // combined per-coset shift terms (one load per twiddle instead of 1 + nhi); skipped for huge coset counts
     TmpBuf rs_comb;
     size_t comb_base = 0, comb_count = 0;
@@ -959,6 +1068,7 @@ static int run_phase2_fwd_batch(AddPlan &pl, const uint64_t *const *srcs, uint64
         BfParams &p = q.p;
         p.ltab = pl.ltab.u64(); p.rs = pl.rs.u64(); p.d = d; p.nhi = nhi;
         p.a_low = g.a_low;
+        set_small_last(p, pl);
         // 512 threads and batch * tile / 2 butterflies per level: whole trips for 2 and 3 tiles of 1024 (48 and 72 KB of LDS, two workgroups
         // per CU either way); four tiles take the half size (48 KB)
         p.c_top = batch == 4 ? g.c_top - 1 : g.c_top;

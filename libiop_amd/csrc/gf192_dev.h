@@ -200,6 +200,48 @@ __device__ __forceinline__ gf192 gf_mul(const gf192 &a, const gf192 &b)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Product by  y / x^k  for a one-word y and 0 <= k < 32.
+//
+// The last butterfly level of the additive FFT multiplies by the points of the domain divided by its last basis vector
+// (fft.tcc:55-96 normalises by betas.back()).  Over the standard basis 1, x, ..., x^(d-1) — libiop's default affine subspaces — a
+// point is a polynomial of degree < 32 and the divisor is x^(d-1): the product is six one-word carry-less products instead of
+// eighteen, and the division by x^k is exact after adding the multiple q P of the modulus that clears the low k bits
+// (q = c / (1 + x + x^2 + x^7) mod x^k: P's low part inverted as a power series, five shift-and-add steps).
+// About 0.95k issue cycles per wave against 3.25k for gf_mul.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ gf192 gf_mul_small_over_xk(const gf192 &a, uint32_t y, int k)
+{
+    const holes4 ys = holes_split(y);
+    uint32_t lo[6], hi[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) clmul32_holes(holes_split(a.w[i]), ys, lo[i], hi[i]);
+    uint32_t c[7];
+    c[0] = lo[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) c[i] = lo[i] ^ hi[i - 1];
+    // bits 192..223 fold back through x^192 = 1 + x + x^2 + x^7
+    const uint32_t h = hi[5];
+    c[0] ^= h ^ (h << 1) ^ (h << 2) ^ (h << 7);
+    c[1] ^= (h >> 31) ^ (h >> 30) ^ (h >> 25);
+    // q = c / (1 + u) mod x^32, u = x + x^2 + x^7:  1 / (1 + u) = (1 + u)(1 + u^2)(1 + u^4)(1 + u^8)(1 + u^16) mod x^32
+    uint32_t q = c[0];
+    q ^= (q << 1) ^ (q << 2) ^ (q << 7);
+    q ^= (q << 2) ^ (q << 4) ^ (q << 14);
+    q ^= (q << 4) ^ (q << 8) ^ (q << 28);
+    q ^= (q << 8) ^ (q << 16);
+    q ^= q << 16;
+    q &= (1u << k) - 1u;
+    // c + q P has k zero low bits; its bits 192.. are q
+    c[0] ^= q ^ (q << 1) ^ (q << 2) ^ (q << 7);
+    c[1] ^= (q >> 31) ^ (q >> 30) ^ (q >> 25);
+    c[6] = q;
+    gf192 r;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) r.w[j] = __builtin_amdgcn_alignbit(c[j + 1], c[j], (uint32_t)k);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Product by a WAVE-UNIFORM multiplier c (every active lane of the wavefront holds the same c): the
 // carry-less product is one hand-written asm block (iopx/gfx950_comb.h, 4-bit-window comb, table selected
 // by S_SET_GPR_IDX): ~0.57k VALU ops against ~1.7k for gf_mul.  The caller guarantees uniformity of c.

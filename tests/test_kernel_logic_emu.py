@@ -54,6 +54,39 @@ def test_fft_lde(m, ncoef):
     assert np.array_equal(emu().additive_FFT(coeffs, basis, shift), oracle.additive_fft(coeffs, basis, shift))
 
 
+def _one_word_basis(m, k, seed):
+    """m independent one-word vectors, the last one x^k: the shape that takes the one-word last level (gf_mul_small_over_xk)."""
+    rng = np.random.default_rng(seed)
+    while True:
+        vals = [int(v) for v in rng.integers(1, 1 << 32, size=m - 1)] + [1 << k]
+        rows, rank = list(vals), 0
+        for bit in range(32):
+            piv = next((i for i in range(rank, m) if (rows[i] >> bit) & 1), None)
+            if piv is None:
+                continue
+            rows[rank], rows[piv] = rows[piv], rows[rank]
+            rows = [r ^ rows[rank] if i != rank and (r >> bit) & 1 else r for i, r in enumerate(rows)]
+            rank += 1
+        if rank == m:
+            basis = np.zeros((m, W), dtype=np.uint64)
+            basis[:, 0] = vals
+            return basis
+
+
+@pytest.mark.parametrize("m,k,shift0", [(2, 0, 5), (3, 31, 0xFFFFFFFF), (7, 13, 0), (11, 1, 0x80000001), (12, 30, 77), (13, 7, 1 << 20)])
+def test_one_word_last_level(m, k, shift0):
+    basis = _one_word_basis(m, k, 900 + m)
+    shift = np.array([shift0, 0, 0], dtype=np.uint64)
+    coeffs = rand_elems(70 + m, 1 << m, W)
+    evals = oracle.additive_fft(coeffs, basis, shift)
+    assert np.array_equal(emu().additive_FFT(coeffs, basis, shift), evals)
+    assert np.array_equal(emu().additive_IFFT(evals, basis, shift), coeffs)
+    # a low-degree extension: the first d vectors span the transform, the rest index the cosets (one-word too)
+    if m >= 4:
+        short = rand_elems(71 + m, 1 << (m - 2), W)
+        assert np.array_equal(emu().additive_FFT(short, basis, shift), oracle.additive_fft(short, basis, shift))
+
+
 @pytest.mark.parametrize("m", [1, 2, 4, 7, 11, 12, 13])
 @pytest.mark.parametrize("kind", ["std0", "general"])
 def test_ifft(m, kind):
@@ -200,3 +233,17 @@ def test_batched_lde(m, ncoef, batch, cb, cc):
     for k in range(batch):
         full = oracle.additive_fft(polys[k], basis, shift)
         assert np.array_equal(outs[k], full[cb << d:(cb + cc) << d]), k
+
+
+@pytest.mark.parametrize("m,ncoef,batch", [(13, 2048, 3), (12, 2048, 2), (9, 128, 4)])
+def test_batched_lde_standard_basis(m, ncoef, batch):
+    """The prover's shape: standard basis, shift x^m — the shared last pass with one-word twiddles at pair bit 0."""
+    lib = emu()
+    basis, shift = _dom(m, "aurora", 0)
+    d = int(np.ceil(np.log2(ncoef)))
+    cc = 1 << (m - d)
+    polys = [rand_elems(80 + k, ncoef, W) for k in range(batch)]
+    outs = [np.zeros((cc << d, W), dtype=np.uint64) for _ in range(batch)]
+    lib.additive_LDE_batch_dev([p.ctypes.data for p in polys], ncoef, basis, shift, 0, cc, [o.ctypes.data for o in outs])
+    for k in range(batch):
+        assert np.array_equal(outs[k], oracle.additive_fft(polys[k], basis, shift)), k
