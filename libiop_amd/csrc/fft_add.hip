@@ -157,6 +157,18 @@ __global__ void k_build_ltab_small(uint32_t *out, SmallBasis basis, int l, size_
     }
 }
 
+struct SmallBasis64 { uint64_t v[32]; };
+__global__ void k_build_ltab_small1(uint64_t *out, SmallBasis64 basis, int l, size_t count)
+{
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < count; b += (size_t)gridDim.x * blockDim.x) {
+        uint64_t acc = 0;
+        for (int k = 0; k < l; ++k) {
+            if ((b >> (l - 1 - k)) & 1) acc ^= basis.v[k];
+        }
+        out[b] = acc;
+    }
+}
+
 __global__ void k_pad_copy(uint64_t *dst, const uint64_t *src, size_t n_src, size_t n_dst)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n_dst; i += (size_t)gridDim.x * blockDim.x) {
@@ -283,6 +295,10 @@ struct BfParams {
     const uint32_t *ltab_small;
     uint32_t rs_small[9];
     int small_k;
+    // the level above it (pair bit 1) over the standard basis: twiddle = two-word numerator / (x^(small1_k1 + small1_k2) (1 + x))
+    const uint64_t *ltab_small1;
+    uint64_t rs_small1[9];
+    int small1_k1, small1_k2;
 };
 
 // twiddle of the block that contains in-coset index u at the level with pair bit pbit
@@ -309,6 +325,16 @@ __device__ __forceinline__ uint32_t bf_twiddle_small(const BfParams &p, size_t c
     const size_t gc = p.coset_base + coset;
     for (int v = 0; v < p.nhi; ++v) {
         if ((gc >> v) & 1) y ^= p.rs_small[1 + v];
+    }
+    return y;
+}
+
+__device__ __forceinline__ uint64_t bf_twiddle_small1(const BfParams &p, size_t coset, size_t u)
+{
+    uint64_t y = p.ltab_small1[u >> 2] ^ p.rs_small1[0];
+    const size_t gc = p.coset_base + coset;
+    for (int v = 0; v < p.nhi; ++v) {
+        if ((gc >> v) & 1) y ^= p.rs_small1[1 + v];
     }
     return y;
 }
@@ -378,6 +404,21 @@ __device__ __forceinline__ void bf_apply_small(uint64_t *s, int E, int ia, int i
     } else {
         gf_add_to(b, a);
         gf_add_to(a, gf_mul_small_over_xk(b, y, k));
+    }
+    lds_put(s, E, ia, a);
+    lds_put(s, E, ib, b);
+}
+
+template<bool INV>
+__device__ __forceinline__ void bf_apply_small1(uint64_t *s, int E, int ia, int ib, uint64_t y, int k1, int k2)
+{
+    gf192 a = lds_get(s, E, ia), b = lds_get(s, E, ib);
+    if (!INV) {
+        gf_add_to(a, gf_mul_small2_over(b, (uint32_t)y, (uint32_t)(y >> 32), k1, k2));
+        gf_add_to(b, a);
+    } else {
+        gf_add_to(b, a);
+        gf_add_to(a, gf_mul_small2_over(b, (uint32_t)y, (uint32_t)(y >> 32), k1, k2));
     }
     lds_put(s, E, ia, a);
     lds_put(s, E, ib, b);
@@ -493,6 +534,19 @@ __global__ void __launch_bounds__(COMB ? 512 : 1024) k_bfly_edge(BfParams p)
             __syncthreads();
             continue;
         }
+        if (pbit == 1 && p.ltab_small1) {               // two-word twiddle numerators
+            for (int bf = tid; bf < (E >> 1); bf += nt) {
+                const int ia = ((bf >> 1) << 2) | (bf & 1);
+                const size_t unit = unit0 + (size_t)(ia >> tb);
+                if (unit >= p.total_units) continue;
+                const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
+                const int li = ia & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
+                const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
+                bf_apply_small1<INV>(s, E, ia, ia | 2, bf_twiddle_small1(p, coset, u), p.small1_k1, p.small1_k2);
+            }
+            __syncthreads();
+            continue;
+        }
         for (int bf = tid; bf < (E >> 1); bf += nt) {
             const int low = bf & ((1 << pbit) - 1), high = bf >> pbit;
             const int ia = (high << (pbit + 1)) | low, ib = ia | (1 << pbit);
@@ -601,6 +655,18 @@ __global__ void __launch_bounds__(512) k_bfly_edge_fwd_batch(BfBatchParams q)
                 const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
                 bf_apply_small<false>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | 1, bf_twiddle_small(p, coset, u), p.small_k);
             }
+        } else if (pbit == 1 && p.ltab_small1) {
+            const int half = E >> 1;
+            for (int x = tid; x < q.batch * half; x += nt) {
+                const int b = x / half, bf = x - b * half;
+                const int ia = ((bf >> 1) << 2) | (bf & 1);
+                const size_t unit = unit0 + (size_t)(ia >> tb);
+                if (unit >= p.total_units) continue;
+                const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
+                const int li = ia & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
+                const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
+                bf_apply_small1<false>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | 2, bf_twiddle_small1(p, coset, u), p.small1_k1, p.small1_k2);
+            }
         } else {
             const int half = E >> 1;
             for (int x = tid; x < q.batch * half; x += nt) {
@@ -651,6 +717,11 @@ struct AddPlan {
     int small_k = -1;                           // basis[d-1] = x^small_k, or -1
     uint32_t rs_small[9] = { 0 };               // per call, like rs
     bool rs_small_ok = false;
+    // ... and its second-to-last vector such that the next recursed basis ends in x^small1_e (1 + x) / x^(2 small_k) (the standard
+    // basis): two-word numerators of the second-to-last level, see BfParams::ltab_small1
+    DevBuf ltab_small1;
+    int small1_e = -1;
+    uint64_t rs_small1[9] = { 0 };
 
     // recursed shift of an arbitrary element: GF(2)-linear in s (fft.tcc:93-95 / :153-154)
     void recursed_shifts(const hgf192 &s, hgf192 *out_by_unwind_level) const
@@ -665,6 +736,14 @@ struct AddPlan {
 };
 
 static bool one_word(const hgf192 &e) { return e.w[1] == 0 && e.w[2] == 0 && (e.w[0] >> 32) == 0; }
+
+// n^2 + n x^k as a polynomial (k < 32): the numerator over x^(2k) of (n / x^k)^2 + n / x^k
+static uint64_t recursed_numerator(uint32_t n, int k)
+{
+    uint64_t sq = 0;
+    for (int i = 0; i < 32; ++i) sq |= (uint64_t)((n >> i) & 1) << (2 * i);
+    return sq ^ ((uint64_t)n << k);
+}
 
 static std::mutex g_plan_mu;
 static std::map<std::vector<uint64_t>, std::unique_ptr<AddPlan>> g_plans;
@@ -774,6 +853,20 @@ static int get_plan(const uint64_t *basis, int d, AddPlan **out)
             if (rc != IOPX_OK) return rc;
             hipLaunchKernelGGL(k_build_ltab_small, dim3(grid_for(n_small, 256)), dim3(256), 0, stream(), (uint32_t *)pl->ltab_small.p, sb, d - 1, n_small);
             pl->small_k = __builtin_ctzll(last);
+            // next level: vector n recurses to (n^2 + n x^k) / x^(2k); the level normalises by the last of them
+            if (d >= 3 && pl->small_k < 32) {
+                const uint64_t N = recursed_numerator((uint32_t)pl->basis[d - 2].w[0], pl->small_k);
+                if (N != 0 && (N >> __builtin_ctzll(N)) == 3) {
+                    SmallBasis64 sb1;
+                    memset(&sb1, 0, sizeof(sb1));
+                    for (int i = 0; i < d - 2; ++i) sb1.v[i] = recursed_numerator((uint32_t)pl->basis[i].w[0], pl->small_k);
+                    const size_t n1 = (size_t)1 << (d - 2);
+                    rc = pl->ltab_small1.alloc(n1 * 8);
+                    if (rc != IOPX_OK) return rc;
+                    hipLaunchKernelGGL(k_build_ltab_small1, dim3(grid_for(n1, 256)), dim3(256), 0, stream(), pl->ltab_small1.u64(), sb1, d - 2, n1);
+                    pl->small1_e = __builtin_ctzll(N);
+                }
+            }
         }
         IOPX_HIP(hipStreamSynchronize(stream()));
     }
@@ -793,6 +886,7 @@ static int upload_rs(AddPlan &pl, const hgf192 &shift, const uint64_t *hi_basis,
             pl.rs_small_ok = one_word(e);
             pl.rs_small[1 + v] = (uint32_t)e.w[0];
         }
+        for (int v = 0; v <= nhi; ++v) pl.rs_small1[v] = recursed_numerator(pl.rs_small[v], pl.small_k);
     }
     std::vector<hgf192> rs((size_t)(1 + nhi) * d);
     pl.recursed_shifts(shift, rs.data());
@@ -898,6 +992,12 @@ static void set_small_last(BfParams &p, const AddPlan &pl)
     p.ltab_small = (const uint32_t *)pl.ltab_small.p;
     memcpy(p.rs_small, pl.rs_small, sizeof(p.rs_small));
     p.small_k = pl.small_k;
+    if (pl.small1_e >= 0) {
+        p.ltab_small1 = pl.ltab_small1.u64();
+        memcpy(p.rs_small1, pl.rs_small1, sizeof(p.rs_small1));
+        p.small1_k1 = pl.small1_e >> 1;
+        p.small1_k2 = pl.small1_e - p.small1_k1;
+    }
 }
 
 // forward: W (2^d, block order after phase 1) -> dst (2^nhi cosets * 2^d, natural order);

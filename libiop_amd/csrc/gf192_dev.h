@@ -209,36 +209,95 @@ __device__ __forceinline__ gf192 gf_mul(const gf192 &a, const gf192 &b)
 // (q = c / (1 + x + x^2 + x^7) mod x^k: P's low part inverted as a power series, five shift-and-add steps).
 // About 0.95k issue cycles per wave against 3.25k for gf_mul.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ gf192 gf_mul_small_over_xk(const gf192 &a, uint32_t y, int k)
+// v / x^k in the field, 0 <= k < 32
+__device__ __forceinline__ gf192 gf_div_xk(const gf192 &v, int k)
 {
-    const holes4 ys = holes_split(y);
-    uint32_t lo[6], hi[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) clmul32_holes(holes_split(a.w[i]), ys, lo[i], hi[i]);
-    uint32_t c[7];
-    c[0] = lo[0];
-#pragma unroll
-    for (int i = 1; i < 6; ++i) c[i] = lo[i] ^ hi[i - 1];
-    // bits 192..223 fold back through x^192 = 1 + x + x^2 + x^7
-    const uint32_t h = hi[5];
-    c[0] ^= h ^ (h << 1) ^ (h << 2) ^ (h << 7);
-    c[1] ^= (h >> 31) ^ (h >> 30) ^ (h >> 25);
-    // q = c / (1 + u) mod x^32, u = x + x^2 + x^7:  1 / (1 + u) = (1 + u)(1 + u^2)(1 + u^4)(1 + u^8)(1 + u^16) mod x^32
-    uint32_t q = c[0];
+    // q = v / (1 + u) mod x^k, u = x + x^2 + x^7:  1 / (1 + u) = (1 + u)(1 + u^2)(1 + u^4)(1 + u^8)(1 + u^16) mod x^32
+    uint32_t q = v.w[0];
     q ^= (q << 1) ^ (q << 2) ^ (q << 7);
     q ^= (q << 2) ^ (q << 4) ^ (q << 14);
     q ^= (q << 4) ^ (q << 8) ^ (q << 28);
     q ^= (q << 8) ^ (q << 16);
     q ^= q << 16;
     q &= (1u << k) - 1u;
-    // c + q P has k zero low bits; its bits 192.. are q
-    c[0] ^= q ^ (q << 1) ^ (q << 2) ^ (q << 7);
-    c[1] ^= (q >> 31) ^ (q >> 30) ^ (q >> 25);
-    c[6] = q;
+    // v + q P has k zero low bits; its bits 192.. are q
+    const uint32_t c0 = v.w[0] ^ q ^ (q << 1) ^ (q << 2) ^ (q << 7);
+    const uint32_t c1 = v.w[1] ^ (q >> 31) ^ (q >> 30) ^ (q >> 25);
     gf192 r;
+    r.w[0] = __builtin_amdgcn_alignbit(c1, c0, (uint32_t)k);
+    r.w[1] = __builtin_amdgcn_alignbit(v.w[2], c1, (uint32_t)k);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) r.w[j] = __builtin_amdgcn_alignbit(c[j + 1], c[j], (uint32_t)k);
+    for (int j = 2; j < 5; ++j) r.w[j] = __builtin_amdgcn_alignbit(v.w[j + 1], v.w[j], (uint32_t)k);
+    r.w[5] = __builtin_amdgcn_alignbit(q, v.w[5], (uint32_t)k);
     return r;
+}
+
+// v / (1 + x) in the field.  P(1) = 1, so v + e P with e = the parity of v is divisible by 1 + x as a polynomial, and the quotient's bit i
+// is the XOR of bits 0..i of the dividend: a prefix XOR over the 192 bits, plus — the prefix being linear — the prefix of P's low part
+// 1 + x + x^2 + x^7 (= 0x7D, zero from bit 7 on) when e = 1.
+__device__ __forceinline__ gf192 gf_div_1px(const gf192 &v)
+{
+    gf192 r;
+    uint32_t carry = 0;                     // all ones when the bits below this word have odd parity
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        uint32_t w = v.w[j];
+        w ^= w << 1; w ^= w << 2; w ^= w << 4; w ^= w << 8; w ^= w << 16;
+        w ^= carry;
+        carry = (uint32_t)((int32_t)w >> 31);
+        r.w[j] = w;
+    }
+    r.w[0] ^= carry & 0x7Du;
+    return r;
+}
+
+__device__ __forceinline__ gf192 gf_mul_small_over_xk(const gf192 &a, uint32_t y, int k)
+{
+    const holes4 ys = holes_split(y);
+    uint32_t lo[6], hi[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) clmul32_holes(holes_split(a.w[i]), ys, lo[i], hi[i]);
+    gf192 v;
+    v.w[0] = lo[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) v.w[i] = lo[i] ^ hi[i - 1];
+    // bits 192..223 fold back through x^192 = 1 + x + x^2 + x^7
+    const uint32_t h = hi[5];
+    v.w[0] ^= h ^ (h << 1) ^ (h << 2) ^ (h << 7);
+    v.w[1] ^= (h >> 31) ^ (h >> 30) ^ (h >> 25);
+    return gf_div_xk(v, k);
+}
+
+// Product by  (y1 : y0) / (x^(k1 + k2) (1 + x))  for a two-word numerator and k1, k2 < 32: the second-to-last level over the standard
+// basis, whose recursed vectors are (n^2 + n x^k) / x^(2k) for the one-word n of the level above, normalised by the last of them,
+// x^(2k - 2) (1 + x) / x^(2k).  Nine word products (Karatsuba on word pairs) and three exact divisions: about 1.8k issue cycles.
+__device__ __forceinline__ gf192 gf_mul_small2_over(const gf192 &a, uint32_t y0, uint32_t y1, int k1, int k2)
+{
+    const holes4 ys0 = holes_split(y0), ys1 = holes_split(y1), ysm = holes_add(ys0, ys1);
+    uint32_t c[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const holes4 a0 = holes_split(a.w[2 * i]), a1 = holes_split(a.w[2 * i + 1]);
+        uint32_t l0, h0, l1, h1, lm, hm;
+        clmul32_holes(a0, ys0, l0, h0);
+        clmul32_holes(a1, ys1, l1, h1);
+        clmul32_holes(holes_add(a0, a1), ysm, lm, hm);
+        // (a0 + a1 X)(y0 + y1 X) = d0 + X (m + d0 + d1) + X^2 d1
+        c[2 * i] ^= l0;
+        c[2 * i + 1] ^= h0 ^ xor3(lm, l0, l1);
+        c[2 * i + 2] ^= l1 ^ xor3(hm, h0, h1);
+        c[2 * i + 3] ^= h1;
+    }
+    // bits 192..255 fold back through x^192 = 1 + x + x^2 + x^7
+    const uint32_t h0 = c[6], h1 = c[7];
+    gf192 v;
+    v.w[0] = c[0] ^ h0 ^ (h0 << 1) ^ (h0 << 2) ^ (h0 << 7);
+    v.w[1] = c[1] ^ h1 ^ xor3(gf_funnel(h1, h0, 1), gf_funnel(h1, h0, 2), gf_funnel(h1, h0, 7));
+    v.w[2] = c[2] ^ (h1 >> 31) ^ (h1 >> 30) ^ (h1 >> 25);
+    v.w[3] = c[3]; v.w[4] = c[4]; v.w[5] = c[5];
+    return gf_div_1px(gf_div_xk(gf_div_xk(v, k1), k2));
 }
 
 // ---------------------------------------------------------------------------------------------------

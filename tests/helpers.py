@@ -59,3 +59,25 @@ def polymod_int(a, mod):
 
 def gf_mul_int(a, b, words):
     return polymod_int(clmul_int(a, b), MODULI[words])
+
+
+def one_word_basis(m, k, seed, second=False):
+    """m independent one-word vectors, the last one x^k: the shape that takes the one-word last level (gf_mul_small_over_xk); with
+    `second` the one before it is x^(k-1), which puts the level above on two-word numerators too (gf_mul_small2_over)."""
+    rng = np.random.default_rng(seed)
+    while True:
+        vals = [int(v) for v in rng.integers(1, 1 << 32, size=m - 1)] + [1 << k]
+        if second:
+            vals[m - 2] = 1 << (k - 1)
+        rows, rank = list(vals), 0
+        for bit in range(32):
+            piv = next((i for i in range(rank, m) if (rows[i] >> bit) & 1), None)
+            if piv is None:
+                continue
+            rows[rank], rows[piv] = rows[piv], rows[rank]
+            rows = [r ^ rows[rank] if i != rank and (r >> bit) & 1 else r for i, r in enumerate(rows)]
+            rank += 1
+        if rank == m:
+            basis = np.zeros((m, 3), dtype=np.uint64)
+            basis[:, 0] = vals
+            return basis

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from helpers import rand_elems
+from helpers import rand_elems, one_word_basis
 
 pytestmark = pytest.mark.gpu
 W = 3
@@ -52,6 +52,22 @@ def test_fft_full_size(gpu, m, kind):
     basis, shift = _dom(m, kind, 100 + m)
     coeffs = rand_elems(m, 1 << m, W)
     assert np.array_equal(gpu.additive_FFT(coeffs, basis, shift), oracle.additive_fft(coeffs, basis, shift))
+
+
+@pytest.mark.parametrize("m,k,shift0,second", [(2, 0, 5, False), (3, 31, 0xFFFFFFFF, False), (11, 1, 0x80000001, False), (13, 7, 1 << 20, False),
+                                               (16, 20, 0xABCDEF01, False), (3, 1, 3, True), (4, 31, 0xFFFFFFFF, True), (12, 30, 1, True), (16, 18, 0xFFFF0000, True)])
+def test_one_word_last_levels(gpu, m, k, shift0, second):
+    """One-word bases ending in x^k (and x^(k-1), x^k): the last one / two butterfly levels multiply by one- / two-word numerators and
+    divide exactly (gf_mul_small_over_xk, gf_mul_small2_over) — forward, inverse and as a low-degree extension over one-word cosets."""
+    basis = one_word_basis(m, k, 900 + m, second)
+    shift = np.array([shift0, 0, 0], dtype=np.uint64)
+    coeffs = rand_elems(70 + m, 1 << m, W)
+    evals = oracle.additive_fft(coeffs, basis, shift)
+    assert np.array_equal(gpu.additive_FFT(coeffs, basis, shift), evals)
+    assert np.array_equal(gpu.additive_IFFT(evals, basis, shift), coeffs)
+    if m >= 4:
+        short = rand_elems(71 + m, 1 << (m - 2), W)
+        assert np.array_equal(gpu.additive_FFT(short, basis, shift), oracle.additive_fft(short, basis, shift))
 
 
 @pytest.mark.parametrize("m,ncoef", [(4, 0), (4, 1), (6, 5), (10, 255), (13, 300), (15, 4096), (17, 8195), (18, 1 << 13), (20, (1 << 15) - 1)])

@@ -6,7 +6,7 @@ import pytest
 import oracle
 import libiop_amd
 from emu_lib import emu
-from helpers import rand_elems
+from helpers import rand_elems, one_word_basis
 
 W = 3
 
@@ -54,28 +54,11 @@ def test_fft_lde(m, ncoef):
     assert np.array_equal(emu().additive_FFT(coeffs, basis, shift), oracle.additive_fft(coeffs, basis, shift))
 
 
-def _one_word_basis(m, k, seed):
-    """m independent one-word vectors, the last one x^k: the shape that takes the one-word last level (gf_mul_small_over_xk)."""
-    rng = np.random.default_rng(seed)
-    while True:
-        vals = [int(v) for v in rng.integers(1, 1 << 32, size=m - 1)] + [1 << k]
-        rows, rank = list(vals), 0
-        for bit in range(32):
-            piv = next((i for i in range(rank, m) if (rows[i] >> bit) & 1), None)
-            if piv is None:
-                continue
-            rows[rank], rows[piv] = rows[piv], rows[rank]
-            rows = [r ^ rows[rank] if i != rank and (r >> bit) & 1 else r for i, r in enumerate(rows)]
-            rank += 1
-        if rank == m:
-            basis = np.zeros((m, W), dtype=np.uint64)
-            basis[:, 0] = vals
-            return basis
-
-
-@pytest.mark.parametrize("m,k,shift0", [(2, 0, 5), (3, 31, 0xFFFFFFFF), (7, 13, 0), (11, 1, 0x80000001), (12, 30, 77), (13, 7, 1 << 20)])
-def test_one_word_last_level(m, k, shift0):
-    basis = _one_word_basis(m, k, 900 + m)
+@pytest.mark.parametrize("m,k,shift0,second", [(2, 0, 5, False), (3, 31, 0xFFFFFFFF, False), (7, 13, 0, False), (11, 1, 0x80000001, False),
+                                               (12, 30, 77, False), (13, 7, 1 << 20, False), (3, 1, 3, True), (4, 31, 0xFFFFFFFF, True),
+                                               (8, 17, 0x12345, True), (11, 2, 0xF0000000, True), (12, 30, 1, True)])
+def test_one_word_last_level(m, k, shift0, second):
+    basis = one_word_basis(m, k, 900 + m, second)
     shift = np.array([shift0, 0, 0], dtype=np.uint64)
     coeffs = rand_elems(70 + m, 1 << m, W)
     evals = oracle.additive_fft(coeffs, basis, shift)
