@@ -100,6 +100,13 @@ int iopx_add_lde_gf192_batch_dev(const uint64_t *const *d_coeffs, size_t n_coeff
  * is never materialised: the shift-independent halves of the two transforms cancel exactly, the outputs are the same field elements. */
 int iopx_add_reextend_gf192_batch_dev(const uint64_t *d_evals, size_t batch, const uint64_t *basis, size_t m, size_t d_dim, const uint64_t *eval_shift,
                                       const uint64_t *shift, size_t coset_begin, size_t coset_count, uint64_t *const *d_outs);
+/* ... and, in the same call, the codewords of `n_polys` polynomials given by n_coeffs <= 2^d_dim coefficients each (host array of device
+ * pointers): the transform of FFT_over_field_subset(coeffs, L) joins the batch after its own coefficient phase, so the last butterfly
+ * pass — shared by up to four vectors — serves both kinds (r1cs_rs_iop.tcc:567-568 next to :459-478: f_w with f_Az, f_Bz, f_Cz).
+ * d_outs: the `batch` re-extensions first, then the n_polys codewords.  Outputs equal the separate calls' bit for bit. */
+int iopx_add_reextend_lde_gf192_batch_dev(const uint64_t *d_evals, size_t batch, const uint64_t *const *d_coeffs, size_t n_coeffs, size_t n_polys,
+                                          const uint64_t *basis, size_t m, size_t d_dim, const uint64_t *eval_shift, const uint64_t *shift,
+                                          size_t coset_begin, size_t coset_count, uint64_t *const *d_outs);
 
 /* Building blocks of ONE transform sharded across GPUs (libiop_amd/dist.py).  The top log2(N) levels of
  * additive_FFT touch index bits that live on different GPUs; dist.py runs them with these calls plus peer exchanges.

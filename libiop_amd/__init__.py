@@ -52,7 +52,7 @@ EXPORTED_SYMBOLS = [
     "iopx_domain_offsets_fp3_dev", "iopx_vanishing_evals_gf192_dev", "iopx_vanishing_evals_fp3_dev", "iopx_rational_combine_gf192_dev",
     "iopx_rational_combine_fp3_dev", "iopx_rational_sumcheck_constraint_gf192_dev", "iopx_rational_sumcheck_constraint_fp3_dev",
     "iopx_gf192_vanishing_host", "iopx_gf192_inverse_host",
-    "iopx_fp3_subgroup_generator", "iopx_fp3_multiplicative_generator", "iopx_fp3_host_mul", "iopx_fp3_host_pow", "iopx_poseidon_shipped_params", "iopx_fri_domains_gf192", "iopx_add_reextend_gf192_batch_dev",
+    "iopx_fp3_subgroup_generator", "iopx_fp3_multiplicative_generator", "iopx_fp3_host_mul", "iopx_fp3_host_pow", "iopx_poseidon_shipped_params", "iopx_fri_domains_gf192", "iopx_add_reextend_gf192_batch_dev", "iopx_add_reextend_lde_gf192_batch_dev",
     "iopx_pool_alloc", "iopx_pool_free", "iopx_memcpy_d2d", "iopx_memset_dev", "iopx_upload_small", "iopx_gather_dev", "iopx_scatter_dev",
     "iopx_transfer_stats", "iopx_blake2b_host", "iopx_gf192_host_mul", "iopx_fp3_host_add", "iopx_fp3_host_sub", "iopx_fp3_host_inverse",
     "iopx_fp3_from_uint", "iopx_fp3_modulus", "iopx_pow_search_blake2b", "iopx_pow_candidate_blake2b",
@@ -708,6 +708,18 @@ class Library:
         cout = (_vp * len(d_outs))(*d_outs)
         self._check(self.c.iopx_add_reextend_gf192_batch_dev(_vp(d_evals), int(batch), basis.ctypes.data_as(_u64p), basis.shape[0], int(d_dim),
                                                              es.ctypes.data_as(_u64p), shift.ctypes.data_as(_u64p), int(coset_begin), int(coset_count), cout))
+
+    def additive_reextend_lde_batch_dev(self, d_evals, batch, d_coeffs, n_coeffs, basis, d_dim, eval_shift, shift, coset_begin, coset_count, d_outs):
+        """additive_reextend_batch_dev plus, in the same batch, the codewords of the polynomials at device pointers d_coeffs (n_coeffs
+        coefficients each, at most 2^d_dim): d_outs holds the `batch` re-extensions first, then one codeword per polynomial."""
+        basis, shift, es = _as_u64(basis), _as_u64(shift), _as_u64(eval_shift)
+        self.c.iopx_add_reextend_lde_gf192_batch_dev.argtypes = [_vp, _sz, ctypes.POINTER(_vp), _sz, _sz, _u64p, _sz, _sz, _u64p, _u64p, _sz, _sz,
+                                                                 ctypes.POINTER(_vp)]
+        cin = (_vp * max(1, len(d_coeffs)))(*d_coeffs)
+        cout = (_vp * len(d_outs))(*d_outs)
+        self._check(self.c.iopx_add_reextend_lde_gf192_batch_dev(_vp(d_evals), int(batch), cin, int(n_coeffs), len(d_coeffs), basis.ctypes.data_as(_u64p),
+                                                                 basis.shape[0], int(d_dim), es.ctypes.data_as(_u64p), shift.ctypes.data_as(_u64p),
+                                                                 int(coset_begin), int(coset_count), cout))
 
     def taylor_dev(self, d_S, log_n, d_twist=0):
         self._check(self.c.iopx_add_taylor_gf192_dev(_vp(d_S), log_n, _vp(d_twist)))

@@ -68,6 +68,31 @@ std::vector<device_vector<FieldT>> reextend_packed(const device_vector<FieldT> &
     return outs;
 }
 
+// { FFT_over_field_subset(poly, L) } followed by reextend_packed(packed, batch, H, L): one call when H is spanned by the first basis vectors
+// of L and the polynomial has at most |H| coefficients (iopx_add_reextend_lde_gf192_batch_dev: the transforms share their last passes),
+// the separate calls otherwise.  Same field elements either way.
+template<typename FieldT>
+std::vector<device_vector<FieldT>> FFT_and_reextend_packed(const device_vector<FieldT> &poly, const device_vector<FieldT> &packed, std::size_t batch,
+                                                           const field_subset<FieldT> &H, const field_subset<FieldT> &L)
+{
+    bool prefix = additive(L) && additive(H) && H.dimension() <= L.dimension() && poly.size() <= H.num_elements() && H.dimension() > 0;
+    if (prefix) for (std::size_t i = 0; i < H.dimension(); ++i) prefix = prefix && std::memcmp(&H.basis()[i], &L.basis()[i], sizeof(FieldT)) == 0;
+    std::vector<device_vector<FieldT>> outs;
+    if (!prefix) {
+        outs.push_back(FFT<FieldT>(poly, poly.size(), L));
+        for (auto &cw : reextend_packed<FieldT>(packed, batch, H, L)) outs.push_back(cw);
+        return outs;
+    }
+    std::vector<uint64_t *> ptrs(batch + 1);
+    for (std::size_t k = 0; k <= batch; ++k) outs.emplace_back(L.num_elements());
+    for (std::size_t k = 0; k < batch; ++k) ptrs[k] = outs[1 + k].words();
+    ptrs[batch] = outs[0].words();
+    const uint64_t *coeffs[1] = { poly.words() };
+    check(iopx_add_reextend_lde_gf192_batch_dev(packed.words(), batch, coeffs, poly.size(), 1, basis_words(L), L.dimension(), H.dimension(), shift_words(H),
+                                                shift_words(L), 0, (std::size_t)1 << (L.dimension() - H.dimension()), ptrs.data()));
+    return outs;
+}
+
 // IFFT_of_known_degree_over_field_subset (fft.tcc:435-475): 2^ceil(log2 degree) coefficients
 template<typename FieldT>
 device_vector<FieldT> IFFT_of_known_degree(const device_vector<FieldT> &evals, std::size_t degree, const field_subset<FieldT> &D)
@@ -569,8 +594,7 @@ public:
         const sparse_matrix<FieldT> *M[3] = { &cs_.A, &cs_.B, &cs_.C };
         for (int q = 0; q < 3; ++q) M[q]->times_vector(d_z, Mz.slice(q * nC, cs_.num_constraints()));                                       // :586-592, r1cs.tcc:236-268
         const device_vector<FieldT> fw = dev::poly_div_vanishing<FieldT>(fw_prime, V_.num_elements(), I_);                                   // :563-565
-        std::vector<device_vector<FieldT>> codewords(1, dev::FFT<FieldT>(fw, fw.size(), L_));                                               // :567-568
-        for (auto &cw : dev::reextend_packed<FieldT>(Mz, 3, C_, L_)) codewords.push_back(cw);                                                // :459-478
+        const std::vector<device_vector<FieldT>> codewords = dev::FFT_and_reextend_packed<FieldT>(fw, Mz, 3, C_, L_);                       // :567-568, :459-478
         const oracle_handle handles[4] = { fw_handle_, fAz_handle_, fBz_handle_, fCz_handle_ };
         for (int q = 0; q < 4; ++q) IOP_.submit_oracle(handles[q], oracle<FieldT>(codewords[q]));                                           // :603-606
     }

@@ -34,7 +34,7 @@ namespace iopx {
 // Tile geometry.  Defaults: 2048-element phase-2 tiles (48 KiB of LDS per workgroup), 1024-element phase-1 and edge tiles.  The IOPX_TILE_BITS /
 // IOPX_P1_COLS / IOPX_P2_COLS / IOPX_P2_TOP environment variables override them (read once): used for
 // tuning, and by the tests to exercise the multi-pass schedules at small transform sizes.
-struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last; };
+struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last, scratch_mb; };
 static int env_int(const char *name, int dflt, int lo, int hi)
 {
     const char *v = getenv(name);
@@ -63,6 +63,7 @@ static const Tuning &tuning()
         u.comb = env_int("IOPX_COMB", 1, 0, 1);                         // 1: asm comb multiplier where the twiddle is wave-uniform
         u.p2_threads = env_int("IOPX_P2_THREADS", u.comb ? 512 : 1024, 64, u.comb ? 512 : 1024);
         u.small_last = env_int("IOPX_SMALL_LAST", 1, 0, 1);             // 1: one-word twiddle numerators at the last level where the basis allows
+        u.scratch_mb = env_int("IOPX_SCRATCH_MB", 256, 1, 65536);
         return u;
     }();
     return t;
@@ -73,7 +74,7 @@ static const Tuning &tuning()
 #define P2_COLS (tuning().p2_cols)
 #define P2_TOP (tuning().p2_top)
 static const int BLOCK_THREADS = 512;
-static const size_t SCRATCH_BYTES = (size_t)256 << 20;   // block-order staging for a group of LDE cosets
+#define SCRATCH_BYTES ((size_t)tuning().scratch_mb << 20)      // block-order staging for a group of LDE cosets
 
 // ---------------------------------------------------------------------------------------------
 // LDS tile: three planes of 64-bit words (conflict-free for consecutive element indices)
@@ -1395,21 +1396,33 @@ int iopx_add_lde_gf192_batch_dev(const uint64_t *const *d_coeffs, size_t n_coeff
 int iopx_add_reextend_gf192_batch_dev(const uint64_t *d_evals, size_t batch, const uint64_t *basis, size_t m, size_t d_dim, const uint64_t *eval_shift,
                                       const uint64_t *shift, size_t coset_begin, size_t coset_count, uint64_t *const *d_outs)
 {
+    return iopx_add_reextend_lde_gf192_batch_dev(d_evals, batch, nullptr, 0, 0, basis, m, d_dim, eval_shift, shift, coset_begin, coset_count, d_outs);
+}
+
+// ... together with `n_polys` polynomials given by coefficients (fewer than 2^d_dim + 1 of them): their forward transforms over the same
+// cosets join the batch after their own phase 1, so that one set of last passes serves evaluations and polynomials alike
+// (r1cs_rs_iop.tcc:567-568 extends f_w right before f_Az, f_Bz, f_Cz).  d_outs holds the `batch` re-extensions, then the n_polys codewords.
+int iopx_add_reextend_lde_gf192_batch_dev(const uint64_t *d_evals, size_t batch, const uint64_t *const *d_coeffs, size_t n_coeffs, size_t n_polys,
+                                          const uint64_t *basis, size_t m, size_t d_dim, const uint64_t *eval_shift, const uint64_t *shift,
+                                          size_t coset_begin, size_t coset_count, uint64_t *const *d_outs)
+{
     int rc = ensure_device();
     if (rc != IOPX_OK) return rc;
     rc = check_basis_args(basis, m, shift);
     if (rc != IOPX_OK) return rc;
-    if (!d_evals || !d_outs || !eval_shift) return fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
-    if (batch == 0 || batch > 65535) return fail(IOPX_ERR_INVALID_ARGUMENT, "batch size %zu outside 1..65535", batch);
+    if (!d_evals || !d_outs || !eval_shift || (n_polys && !d_coeffs)) return fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
+    if (batch == 0 || batch > 65535 || n_polys > 65535) return fail(IOPX_ERR_INVALID_ARGUMENT, "batch size %zu + %zu outside 1..65535", batch, n_polys);
     if (d_dim > m) return fail(IOPX_ERR_INVALID_ARGUMENT, "the evaluation domain must be spanned by the first basis vectors of the codeword domain");
-    for (size_t k = 0; k < batch; ++k) if (!d_outs[k]) return fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
+    for (size_t k = 0; k < batch + n_polys; ++k) if (!d_outs[k]) return fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
+    for (size_t k = 0; k < n_polys; ++k) if (!d_coeffs[k]) return fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
     const int d = (int)d_dim, nhi = (int)m - d;
     const size_t all_cosets = (size_t)1 << nhi, nd = (size_t)1 << d;
+    if (n_polys && n_coeffs > nd) return fail(IOPX_ERR_INVALID_ARGUMENT, "%zu coefficients exceed the 2^%d of the evaluation domain", n_coeffs, d);
     if (coset_count == 0 || coset_begin >= all_cosets || coset_count > all_cosets - coset_begin)
         return fail(IOPX_ERR_INVALID_ARGUMENT, "coset range [%zu, +%zu) outside the %zu cosets of the transform", coset_begin, coset_count, all_cosets);
-    if (d == 0) {       // a constant: every evaluation equals it
-        for (size_t k = 0; k < batch; ++k) {
-            rc = iopx_add_lde_gf192_dev(d_evals + 3 * k, 1, basis, m, shift, coset_begin, coset_count, d_outs[k]);
+    if (d == 0) {       // constants: every evaluation equals them
+        for (size_t k = 0; k < batch + n_polys; ++k) {
+            rc = iopx_add_lde_gf192_dev(k < batch ? d_evals + 3 * k : d_coeffs[k - batch], k < batch ? 1 : n_coeffs, basis, m, shift, coset_begin, coset_count, d_outs[k]);
             if (rc != IOPX_OK) return rc;
         }
         return IOPX_OK;
@@ -1419,15 +1432,24 @@ int iopx_add_reextend_gf192_batch_dev(const uint64_t *d_evals, size_t batch, con
     if (rc != IOPX_OK) return rc;
     rc = upload_rs(*pl, hgf192::from_words(eval_shift), nullptr, 0);
     if (rc != IOPX_OK) return rc;
+    const size_t total = batch + n_polys;
     TmpBuf work;
-    rc = work.alloc(batch * nd * 24);
+    rc = work.alloc(total * nd * 24);
     if (rc != IOPX_OK) return rc;
     rc = run_phase2<true>(*pl, d_evals, work.u64(), 0, 0, batch);                  // H's butterflies undone: natural order -> block order
     if (rc != IOPX_OK) return rc;
     rc = upload_rs(*pl, hgf192::from_words(shift), basis + 3 * (size_t)d, nhi);    // stream-ordered: after the inverse passes
     if (rc != IOPX_OK) return rc;
-    for (size_t k0 = 0; k0 < batch; k0 += 4) {               // groups of up to four share the last pass
-        const size_t nb = batch - k0 < 4 ? batch - k0 : 4;
+    if (n_polys) {
+        for (size_t k = 0; k < n_polys; ++k) {
+            ProfScope ps_("k_pad_copy");
+            hipLaunchKernelGGL(k_pad_copy, dim3(grid_for(3 * nd, 256)), dim3(256), 0, stream(), work.u64() + 3 * (batch + k) * nd, d_coeffs[k], n_coeffs, nd);
+        }
+        rc = run_phase1<false>(*pl, work.u64() + 3 * batch * nd, n_polys);
+        if (rc != IOPX_OK) return rc;
+    }
+    for (size_t k0 = 0; k0 < total; k0 += 4) {               // groups of up to four share the last pass
+        const size_t nb = total - k0 < 4 ? total - k0 : 4;
         const uint64_t *srcs[4];
         uint64_t *dsts[4];
         for (size_t k = 0; k < nb; ++k) { srcs[k] = work.u64() + 3 * (k0 + k) * nd; dsts[k] = d_outs[k0 + k]; }

@@ -97,3 +97,15 @@ def check_reextend(lib, torch, device, m, d, batch, seed):
     for k in range(batch):
         coeffs = oracle.additive_ifft(evals[k << d:(k + 1) << d], basis[:d], es)
         assert np.array_equal(ops.download(outs[k]), oracle.additive_fft(coeffs, basis, sh)), k
+    # the same call with polynomials given by coefficients joining the batch (iopx_add_reextend_lde_gf192_batch_dev)
+    d_evals = ops.upload(evals)
+    for n_polys, n_coeffs in ((1, (1 << d) - min(3, (1 << d) - 1)), (2, 1 << d)):
+        polys = [rand_elems(seed + 10 + k, n_coeffs, 3) for k in range(n_polys)]
+        d_polys = [ops.upload(q) for q in polys]
+        d_outs = [ops.empty(1 << m) for _ in range(batch + n_polys)]
+        lib.additive_reextend_lde_batch_dev(d_evals.data_ptr(), batch, [t.data_ptr() for t in d_polys], n_coeffs, basis, d, es, sh, 0, 1 << (m - d),
+                                            [t.data_ptr() for t in d_outs])
+        for k in range(batch):
+            assert np.array_equal(ops.download(d_outs[k]), ops.download(outs[k])), k
+        for k in range(n_polys):
+            assert np.array_equal(ops.download(d_outs[batch + k]), oracle.additive_fft(polys[k], basis, sh)), k
