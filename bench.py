@@ -319,7 +319,10 @@ def main():
                              "figure: measured products/s over the ceiling of the kernel's instruction mix at the per-class issue costs measured on this GPU "
                              "(profiles/r03_alu_model.json, profiles/r03_valu_rates.txt)",
                      "kernels_ms_per_step": {k: round(v[1], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
-                     "kernel_launches_per_step": {k: v[0] for k, v in prof.items()}},
+                     "kernel_launches_per_step": {k: v[0] for k, v in prof.items()},
+                     # the profiled proof's kernel time (HIP events) against the timed loop's wall time per proof: launch gaps + host work + read-backs
+                     "kernels_ms_total": round(sum(v[1] for v in prof.values()), 3),
+                     "host_gap_ms": round(prover_s * 1e3 - sum(v[1] for v in prof.values()), 3) if prof else None},
     }
 
     if rank == 0 and world == 1 and not args.no_secondary:
