@@ -1006,7 +1006,8 @@ static void set_small_last(BfParams &p, const AddPlan &pl)
 // The edge pass permutes (bit reversal), so it never runs in place across workgroups: the forward
 // transform keeps the upper passes in W (one coset) or in a scratch buffer holding a group of cosets.
 template<bool INV>
-static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, size_t coset_begin = 0, size_t coset_count = 0, bool upper_only = false)
+static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, size_t coset_begin = 0, size_t coset_count = 0, bool upper_only = false,
+                      const uint64_t *shared_rs_comb = nullptr)
 {
     const int d = pl.d;
     const P2Geom g = phase2_geom(d);
@@ -1022,11 +1023,15 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
     // combined per-coset shift terms (one load per twiddle instead of 1 + nhi); skipped for huge coset counts
     TmpBuf rs_comb;
     size_t comb_base = 0, comb_count = 0;
-    if (!INV && nhi > 0 && cosets * (size_t)d <= ((size_t)1 << 22)) {
+    const uint64_t *rs_comb_ptr = shared_rs_comb;       // the caller's table starts at coset_begin
+    if (shared_rs_comb) {
+        comb_base = coset_begin; comb_count = cosets;
+    } else if (!INV && nhi > 0 && cosets * (size_t)d <= ((size_t)1 << 22)) {
         int rcc = rs_comb.alloc(cosets * d * 24);
         if (rcc != IOPX_OK) return rcc;
         comb_base = coset_begin; comb_count = cosets;
         { ProfScope ps_("k_rs_combine"); hipLaunchKernelGGL(k_rs_combine, dim3(grid_for(cosets * d, 256)), dim3(256), 0, stream(), rs_comb.u64(), (const uint64_t *)pl.rs.u64(), d, nhi, coset_begin, cosets * (size_t)d); }
+        rs_comb_ptr = rs_comb.u64();
     }
 
     // upper passes over pair bits [a_low, d): chunks of up to A bits, from the top (forward order)
@@ -1055,7 +1060,7 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         const int threads = elems >= 4 * maxt ? maxt : (elems >= 256 ? elems / 4 : 64);
         p.src = s; p.dst = dd; p.src_shared = shared;
         p.g_bits = g_bits; p.total_units = units; p.coset_base = cbase;
-        p.rs_comb = comb_count ? rs_comb.u64() + 3 * (cbase - comb_base) * d : nullptr;
+        p.rs_comb = comb_count ? rs_comb_ptr + 3 * (cbase - comb_base) * d : nullptr;
         int rc;
         if ((rc = set_lds(k_bfly_edge<INV, false>, lds)) != IOPX_OK) return rc;
         { ProfScope ps_("k_bfly_edge", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)p.a_low); hipLaunchKernelGGL((k_bfly_edge<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
@@ -1069,7 +1074,7 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         const size_t lds = ((size_t)24) << tbits;
         const size_t blocks = ncos << (d - tbits);
         p.total_units = blocks; p.coset_base = cbase;
-        p.rs_comb = comb_count ? rs_comb.u64() + 3 * (cbase - comb_base) * d : nullptr;
+        p.rs_comb = comb_count ? rs_comb_ptr + 3 * (cbase - comb_base) * d : nullptr;
         const int maxt = (tuning().comb && u.c < 6) ? 1024 : tuning().p2_threads;
         const int threads = (1 << tbits) >= 2 * maxt ? maxt : ((1 << tbits) >= 128 ? (1 << tbits) / 2 : 64);
         int rc;
@@ -1157,10 +1162,17 @@ static int run_phase2_fwd_batch(AddPlan &pl, const uint64_t *const *srcs, uint64
         const int rc = scratch.back()->alloc(group * nd * 24);
         if (rc != IOPX_OK) return rc;
     }
+    TmpBuf rs_comb;                                             // combined shift terms of every coset of the call, shared by all launches
+    {
+        const int rc = rs_comb.alloc(cosets * d * 24);
+        if (rc != IOPX_OK) return rc;
+        ProfScope ps_("k_rs_combine");
+        hipLaunchKernelGGL(k_rs_combine, dim3(grid_for(cosets * d, 256)), dim3(256), 0, stream(), rs_comb.u64(), (const uint64_t *)pl.rs.u64(), d, nhi, coset_begin, cosets * (size_t)d);
+    }
     for (size_t c0 = 0; c0 < cosets; c0 += group) {
         const size_t nc = cosets - c0 < group ? cosets - c0 : group;
         for (size_t k = 0; k < batch; ++k) {                    // upper passes only: the scratch holds the block-order input of the last pass
-            const int rc = run_phase2<false>(pl, srcs[k], scratch[k]->u64(), nhi, coset_begin + c0, nc, /*upper_only=*/true);
+            const int rc = run_phase2<false>(pl, srcs[k], scratch[k]->u64(), nhi, coset_begin + c0, nc, /*upper_only=*/true, rs_comb.u64() + 3 * c0 * d);
             if (rc != IOPX_OK) return rc;
         }
         const P2Geom g = phase2_geom(d);
@@ -1177,11 +1189,8 @@ static int run_phase2_fwd_batch(AddPlan &pl, const uint64_t *const *srcs, uint64
         const int tb = p.a_low + p.c_top;
         p.total_units = nc << (d - tb);
         p.coset_base = coset_begin + c0;
-        TmpBuf rs_comb;
-        int rc = rs_comb.alloc(nc * d * 24);
-        if (rc != IOPX_OK) return rc;
-        { ProfScope ps_("k_rs_combine"); hipLaunchKernelGGL(k_rs_combine, dim3(grid_for(nc * d, 256)), dim3(256), 0, stream(), rs_comb.u64(), (const uint64_t *)pl.rs.u64(), d, nhi, coset_begin + c0, nc * (size_t)d); }
-        p.rs_comb = rs_comb.u64();
+        int rc;
+        p.rs_comb = rs_comb.u64() + 3 * c0 * d;
         q.batch = (int)batch;
         for (size_t k = 0; k < batch; ++k) { q.srcs[k] = scratch[k]->u64(); q.dsts[k] = dsts[k] + 3 * c0 * nd; }
         const size_t lds = (((size_t)24) << tb) * batch;
