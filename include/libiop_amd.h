@@ -59,6 +59,11 @@ int         iopx_malloc(void **dptr, size_t bytes);
 int         iopx_free(void *dptr);
 int         iopx_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int         iopx_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+/* Transcript extraction reads back two small results per Merkle tree (iopx_query_responses_dev, iopx_merkle_membership_proof_dev).  Between
+ * _begin and _end those calls only queue their read-backs; _end drains the stream once and fills every host buffer handed to them in
+ * between (the buffers must stay alive until then).  Everything else behaves as usual inside the window. */
+int         iopx_defer_downloads_begin(void);
+int         iopx_defer_downloads_end(void);
 /* Drop every cached per-domain plan (twist-power tables, twiddle tables). */
 int         iopx_clear_plans(void);
 

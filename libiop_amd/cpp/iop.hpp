@@ -15,6 +15,7 @@
 // (iopx_transfer_stats counts them).  Non-zk, BLAKE2b digests (what default_bcs_params wires for both accelerated fields).
 // FieldT is any 24-byte type with libff::gf192's or libff::edwards_Fr's layout; field_kind<FieldT> says which.
 #pragma once
+#include <algorithm>
 #include <functional>
 #include <map>
 #include <set>
@@ -296,17 +297,28 @@ public:
         check(iopx_memcpy_d2h(d, nodes_.data(), 32));
         return hash_digest(reinterpret_cast<const char *>(d), 32);
     }
-    std::vector<hash_digest> get_set_membership_proof(const std::vector<std::size_t> &leaf_positions) const      // :242-336
+    // the auxiliary hashes of the pruned multi-membership proof as raw bytes (32 each); inside an iopx_defer_downloads window the buffer is
+    // filled by iopx_defer_downloads_end
+    std::vector<uint8_t> get_set_membership_proof_bytes(const std::vector<std::size_t> &leaf_positions) const
     {
-        std::vector<hash_digest> out;
-        if (leaf_positions.empty()) return out;
+        if (leaf_positions.empty()) return std::vector<uint8_t>();
         std::size_t depth = 0;
         while (((std::size_t)1 << depth) < num_leaves_) ++depth;
         std::vector<uint8_t> aux(32 * leaf_positions.size() * (depth + 1));
         std::size_t count = 0;
         check(iopx_merkle_membership_proof_dev(nodes_.data(), num_leaves_, leaf_positions.data(), leaf_positions.size(), aux.data(), aux.size() / 32, &count));
-        for (std::size_t i = 0; i < count; ++i) out.emplace_back(reinterpret_cast<const char *>(aux.data()) + 32 * i, 32);
+        aux.resize(32 * count);                 // shrinking keeps the storage (and the address the library writes to)
+        return aux;
+    }
+    static std::vector<hash_digest> digests_of(const std::vector<uint8_t> &bytes)
+    {
+        std::vector<hash_digest> out;
+        for (std::size_t i = 0; i + 32 <= bytes.size(); i += 32) out.emplace_back(reinterpret_cast<const char *>(bytes.data()) + i, 32);
         return out;
+    }
+    std::vector<hash_digest> get_set_membership_proof(const std::vector<std::size_t> &leaf_positions) const      // :242-336
+    {
+        return digests_of(get_set_membership_proof_bytes(leaf_positions));
     }
 };
 
@@ -458,10 +470,24 @@ private:
         return det_cache[h.id] = deterministic_positions_[h.id].second(seeds);
     }
     // get_oracle_evaluation_at_point with record = true (iop.tcc:669-714): a query to a virtual oracle touches its constituents
-    void record(const oracle_handle &h, std::size_t position, std::map<std::size_t, std::set<std::size_t>> &positions_by_oracle) const
+    // the proper oracles under a virtual one, each once: resolved on first use (the query phase asks for the same few virtual oracles at
+    // thousands of positions, on the proof's critical path)
+    mutable std::map<std::size_t, std::vector<std::size_t>> flat_constituents_;
+    void flatten(const oracle_handle &h, std::set<std::size_t> &out) const
     {
-        if (!h.is_virtual) { positions_by_oracle[h.id].insert(position); return; }
-        for (auto &c : virtual_regs_[h.id].constituents) record(c, position, positions_by_oracle);
+        if (!h.is_virtual) { out.insert(h.id); return; }
+        for (auto &c : virtual_regs_[h.id].constituents) flatten(c, out);
+    }
+    void record(const oracle_handle &h, std::size_t position, std::vector<std::vector<std::size_t>> &positions_by_oracle) const
+    {
+        if (!h.is_virtual) { positions_by_oracle[h.id].push_back(position); return; }
+        auto it = flat_constituents_.find(h.id);
+        if (it == flat_constituents_.end()) {
+            std::set<std::size_t> ids;
+            flatten(h, ids);
+            it = flat_constituents_.emplace(h.id, std::vector<std::size_t>(ids.begin(), ids.end())).first;
+        }
+        for (std::size_t id : it->second) positions_by_oracle[id].push_back(position);
     }
 
 public:
@@ -685,36 +711,45 @@ public:
         t.prover_messages_ = prover_messages_;
         t.MT_roots_ = MT_roots_;
         std::map<std::size_t, std::size_t> random_cache, det_cache;
-        std::map<std::size_t, std::set<std::size_t>> positions_by_oracle;
+        std::vector<std::vector<std::size_t>> positions_by_oracle(oracle_regs_.size());
         for (auto &q : queries_) record(q.first, obtain_query_position(q.second, random_cache, det_cache), positions_by_oracle);   // registration order
+        // the two small read-backs per tree are queued, not waited for one by one (iopx_defer_downloads_begin / _end)
+        std::vector<std::vector<FieldT>> flat_responses(MT_info_.size());
+        std::vector<std::vector<uint8_t>> proof_bytes(MT_info_.size());
+        check(iopx_defer_downloads_begin());
+        bool deferring = true;
+        struct end_on_unwind { bool &on; ~end_on_unwind() { if (on) (void)iopx_defer_downloads_end(); } } guard{ deferring };
         for (std::size_t mt = 0; mt < MT_info_.size(); ++mt) {
             const tree_info &info = MT_info_[mt];
             const std::size_t cs = get_round_parameters(info.round);
             const field_subset<FieldT> &domain = domains_[info.domain];
             const std::size_t num_leaves = domain.num_elements() / cs;
-            std::set<std::size_t> qset, lset;
-            for (std::size_t oid : info.oracle_ids) {
-                auto it = positions_by_oracle.find(oid);
-                if (it == positions_by_oracle.end()) continue;
-                for (std::size_t pos : it->second) {
-                    qset.insert(pos);
-                    lset.insert(cs == 1 ? pos : (domain.type() == affine_subspace_type ? pos / cs : pos % num_leaves));      // bcs_common.tcc:682-696
-                }
-            }
-            const std::vector<std::size_t> qpos(qset.begin(), qset.end()), lpos(lset.begin(), lset.end());
+            std::vector<std::size_t> qpos, lpos;                                             // sorted and distinct, as the reference's sets are
+            for (std::size_t oid : info.oracle_ids) qpos.insert(qpos.end(), positions_by_oracle[oid].begin(), positions_by_oracle[oid].end());
+            std::sort(qpos.begin(), qpos.end());
+            qpos.erase(std::unique(qpos.begin(), qpos.end()), qpos.end());
+            for (std::size_t pos : qpos) lpos.push_back(cs == 1 ? pos : (domain.type() == affine_subspace_type ? pos / cs : pos % num_leaves));   // bcs_common.tcc:682-696
+            std::sort(lpos.begin(), lpos.end());
+            lpos.erase(std::unique(lpos.begin(), lpos.end()), lpos.end());
             t.query_positions_.push_back(qpos);
             t.MT_leaf_positions_.push_back(lpos);
-            std::vector<std::vector<FieldT>> responses(qpos.size(), std::vector<FieldT>(info.oracle_ids.size()));
+            flat_responses[mt].resize(qpos.size() * info.oracle_ids.size());
             if (!qpos.empty()) {                                                             // bcs_prover.tcc:187-197
                 std::vector<const void *> ptrs;
                 for (std::size_t oid : info.oracle_ids) ptrs.push_back(oracles_[oid].data());
-                std::vector<FieldT> flat(qpos.size() * info.oracle_ids.size());
-                check(iopx_query_responses_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), domain.num_elements(), qpos.data(), qpos.size(), flat.data()));
-                for (std::size_t p = 0; p < qpos.size(); ++p)
-                    for (std::size_t k = 0; k < info.oracle_ids.size(); ++k) responses[p][k] = flat[p * info.oracle_ids.size() + k];
+                check(iopx_query_responses_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), domain.num_elements(), qpos.data(), qpos.size(), flat_responses[mt].data()));
             }
+            proof_bytes[mt] = MT_trees_[mt].get_set_membership_proof_bytes(lpos);
+        }
+        check(iopx_defer_downloads_end());                                                   // one drain of the stream delivers every read-back queued above
+        deferring = false;
+        for (std::size_t mt = 0; mt < MT_info_.size(); ++mt) {
+            const std::size_t width = MT_info_[mt].oracle_ids.size(), count = t.query_positions_[mt].size();
+            std::vector<std::vector<FieldT>> responses(count, std::vector<FieldT>(width));
+            for (std::size_t p = 0; p < count; ++p)
+                for (std::size_t k = 0; k < width; ++k) responses[p][k] = flat_responses[mt][p * width + k];
             t.query_responses_.push_back(responses);
-            t.MT_set_membership_proofs_.push_back(MT_trees_[mt].get_set_membership_proof(lpos));
+            t.MT_set_membership_proofs_.push_back(device_merkle_tree::digests_of(proof_bytes[mt]));
         }
         if (is_holographic_) {                                                               // remove_index_info_from_transcript (bcs_prover.tcc:119-134)
             t.prover_messages_.erase(t.prover_messages_.begin(), t.prover_messages_.begin() + num_prover_messages_at_end_of_round_[0]);

@@ -764,14 +764,13 @@ static int build_pow_table(uint64_t *out, const uint64_t *d_sq, int nb)
         { ProfScope ps_("k_pow_direct"); hipLaunchKernelGGL(k_pow_direct, dim3(grid_for(count, 256)), dim3(256), 0, stream(), out, d_sq, nb, count); }
         return IOPX_OK;
     }
-    DevBuf tmp;
+    TmpBuf tmp;                                         // pooled: recycled in stream order, no hipFree and no drain of the stream per table
     int rc = tmp.alloc(((size_t)1 << (nb - 8)) * 24);
     if (rc != IOPX_OK) return rc;
     rc = build_pow_table(tmp.u64(), d_sq + 3 * 8, nb - 8);
     if (rc != IOPX_OK) return rc;
     { ProfScope ps_("k_pow_direct"); hipLaunchKernelGGL(k_pow_direct, dim3(1), dim3(256), 0, stream(), out, d_sq, 8, (size_t)256); }
     { ProfScope ps_("k_pow_expand"); hipLaunchKernelGGL(k_pow_expand, dim3(grid_for(count - 256, 256)), dim3(256), 0, stream(), out, (const uint64_t *)tmp.u64(), count); }
-    IOPX_HIP(hipStreamSynchronize(stream()));           // tmp is freed on return
     return IOPX_OK;
 }
 

@@ -2,8 +2,12 @@
 // shifts, fold multipliers: O(m^2) field operations per plan).  Portable C++ (no intrinsics): the
 // hot path runs on the GPU, this never touches codeword-sized data.
 #pragma once
+#include <array>
 #include <cstdint>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 namespace iopx {
@@ -125,6 +129,41 @@ struct SubspacePoly {
         return r;
     }
 };
+
+// The subspace polynomial of a domain and its values at the domain's own vectors are the same in every proof over that domain, and building
+// them (dim^2 host products, then dim products per value) sat on the prover's critical path between two rounds: kept per basis.
+struct CachedSubspacePoly {
+    SubspacePoly poly;
+    std::map<std::array<uint64_t, 3>, hgf192> values;
+    std::mutex mu;
+    CachedSubspacePoly(const uint64_t *basis, size_t dim) : poly(basis, dim) {}
+    hgf192 eval(const hgf192 &x)
+    {
+        const std::array<uint64_t, 3> key = { x.w[0], x.w[1], x.w[2] };
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = values.find(key);
+        if (it != values.end()) return it->second;
+        if (values.size() >= 65536) values.clear();
+        const hgf192 v = poly.eval(x);
+        values.emplace(key, v);
+        return v;
+    }
+};
+
+inline CachedSubspacePoly &cached_subspace_poly(const uint64_t *basis, size_t dim)
+{
+    static std::mutex mu;
+    static std::map<std::vector<uint64_t>, std::unique_ptr<CachedSubspacePoly>> cache;
+    std::vector<uint64_t> key(basis, basis + 3 * dim);
+    key.push_back(dim);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        if (cache.size() >= 64) cache.clear();
+        it = cache.emplace(key, std::unique_ptr<CachedSubspacePoly>(new CachedSubspacePoly(basis, dim))).first;
+    }
+    return *it->second;
+}
 
 
 // Device layout of a subset-sum table (gf192_dev.h subset_sum_ext): the m + 1 entries, then 512 pre-summed entries for index bits

@@ -350,8 +350,7 @@ int iopx_pow_search_blake2b(const uint8_t *challenge, size_t pow_bitlen, uint64_
         { ProfScope ps_("k_pow_blake2b");
           hipLaunchKernelGGL(k_pow_blake2b, dim3((unsigned)((count + 255) / 256 > 16384 ? 16384 : (count + 255) / 256)), dim3(256), 0, stream(),
                              c, first, count, mask, (unsigned long long *)best.p); }
-        IOPX_HIP(copy_d2h(&hit, best.p, 8, stream()));
-        IOPX_HIP(hipStreamSynchronize(stream()));
+        { int drc_ = download(&hit, best.p, 8); if (drc_ != IOPX_OK) return drc_; }
     }
     *found = hit;
     return IOPX_OK;
@@ -416,8 +415,7 @@ int iopx_merkle_membership_proof_dev(const uint8_t *d_nodes, size_t num_leaves, 
     { ProfScope ps_("k_gather_nodes");
       hipLaunchKernelGGL(k_gather_nodes, dim3((unsigned)((4 * want.size() + 255) / 256)), dim3(256), 0, stream(), dout.u64(), (const uint64_t *)d_nodes,
                          (const uint64_t *)didx.u64(), want.size()); }
-    IOPX_HIP(copy_d2h(aux_hashes, dout.p, want.size() * 32, stream()));
-    IOPX_HIP(hipStreamSynchronize(stream()));
+    { int drc_ = download(aux_hashes, dout.p, want.size() * 32, /*deferrable=*/true); if (drc_ != IOPX_OK) return drc_; }
     return IOPX_OK;
 }
 
@@ -442,8 +440,7 @@ int iopx_query_responses_dev(const void *const *d_oracles, size_t num_oracles, s
     { ProfScope ps_("k_gather_responses");
       hipLaunchKernelGGL(k_gather_responses, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, stream(), dout.u64(),
                          (const uint64_t *const *)dptrs.p, (const uint64_t *)dpos.u64(), num_oracles, words, num_positions); }
-    IOPX_HIP(copy_d2h(values, dout.p, total * 8, stream()));
-    IOPX_HIP(hipStreamSynchronize(stream()));
+    { int drc_ = download(values, dout.p, total * 8, /*deferrable=*/true); if (drc_ != IOPX_OK) return drc_; }
     return IOPX_OK;
 }
 

@@ -785,16 +785,14 @@ int iopx_pow_solve_poseidon_bn128(const iopx_poseidon_params *params, const uint
         { ProfScope ps_("k_pow_poseidon");
           if (P.t == 3) hipLaunchKernelGGL(k_pow_poseidon<3>, dim3(grid), dim3(64), 0, stream(), P, c, first, batch, mask, (unsigned long long *)best.p);
           else hipLaunchKernelGGL(k_pow_poseidon<4>, dim3(grid), dim3(64), 0, stream(), P, c, first, batch, mask, (unsigned long long *)best.p); }
-        IOPX_HIP(copy_d2h(&found, best.p, 8, stream()));
-        IOPX_HIP(hipStreamSynchronize(stream()));
+        { int drc_ = download(&found, best.p, 8); if (drc_ != IOPX_OK) return drc_; }
         first += batch;
         if (batch < ((uint64_t)1 << 22)) batch <<= 2;
     }
     const uint64_t k[4] = { found, 0, 0, 0 };
     if ((rc = upload((uint64_t *)best.p + 1, k, 32)) != IOPX_OK) return rc;
     hipLaunchKernelGGL(k_bn_to_mont, dim3(1), dim3(64), 0, stream(), (uint64_t *)best.p + 1, (const uint64_t *)best.p + 1, (size_t)1);
-    IOPX_HIP(copy_d2h(pow, (uint64_t *)best.p + 1, 32, stream()));
-    IOPX_HIP(hipStreamSynchronize(stream()));
+    { int drc_ = download(pow, (uint64_t *)best.p + 1, 32); if (drc_ != IOPX_OK) return drc_; }
     return IOPX_OK;
 }
 

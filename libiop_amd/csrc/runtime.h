@@ -69,6 +69,14 @@ struct DevBuf {
 // Stream-ordered upload of a small host array (per-call constants): the bytes are copied into a pinned staging
 // chunk owned by the library, so the caller's buffer may be freed on return and the copy needs no synchronisation.
 int upload(void *dst_dev, const void *src_host, size_t bytes);
+// Blocking read-back of a small result (roots, proof-of-work answers, query responses, membership paths) through a pinned bounce buffer:
+// queued behind the stream's work, then the stream is drained.  A pageable destination would make the runtime stage the copy itself, at
+// several times the latency — and a proof has some thirty of these on its critical path.
+int download(void *dst_host, const void *src_dev, size_t bytes, bool deferrable = false);
+int defer_downloads_begin();
+int defer_downloads_end();
+// Between iopx_defer_downloads_begin() and _end(), deferrable read-backs (transcript extraction: query responses, membership paths) are only
+// queued; _end() drains the stream once and delivers all of them — one synchronisation for the whole query phase instead of two per tree.
 
 // Per-call temporary in device memory.  All work of the library is enqueued on ONE stream in program order, so a
 // temporary released by one call may be handed to a later call without any synchronisation: the later call's

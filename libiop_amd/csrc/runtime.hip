@@ -167,6 +167,78 @@ int upload(void *dst_dev, const void *src_host, size_t bytes)
     return IOPX_OK;
 }
 
+static void *g_bounce = nullptr;
+static size_t g_bounce_cap = 0;
+// deferred read-backs: pinned chunks filled by asynchronous copies, delivered by iopx_defer_downloads_end
+struct DeferChunk { char *p; size_t cap, used; };
+struct DeferItem { void *dst; const char *src; size_t bytes; };
+static bool g_defer_on = false;
+static std::vector<DeferChunk> g_defer_chunks;
+static std::vector<DeferItem> g_defer_items;
+
+int download(void *dst_host, const void *src_dev, size_t bytes, bool deferrable)
+{
+    if (bytes == 0) return IOPX_OK;
+    std::unique_lock<std::mutex> lk(g_stage_mu);
+    if (deferrable && g_defer_on) {
+        DeferChunk *c = nullptr;
+        for (auto &ch : g_defer_chunks) if (ch.cap - ch.used >= bytes) { c = &ch; break; }
+        if (!c) {
+            DeferChunk ch;
+            ch.cap = bytes < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes;
+            ch.used = 0;
+            hipError_t e = hipHostMalloc((void **)&ch.p, ch.cap, 0);
+            if (e != hipSuccess) return fail(IOPX_ERR_RUNTIME, "hipHostMalloc(%zu) failed: %s", ch.cap, hipGetErrorString(e));
+            g_defer_chunks.push_back(ch);
+            c = &g_defer_chunks.back();
+        }
+        char *slot = c->p + c->used;
+        c->used += (bytes + 63) & ~(size_t)63;
+        IOPX_HIP(copy_d2h(slot, src_dev, bytes, g_stream));
+        g_defer_items.push_back({dst_host, slot, bytes});
+        return IOPX_OK;
+    }
+    if (bytes > ((size_t)4 << 20)) {                    // large read-backs (test helpers): the plain path
+        lk.unlock();
+        IOPX_HIP(copy_d2h(dst_host, src_dev, bytes, g_stream));
+        IOPX_HIP(hipStreamSynchronize(g_stream));
+        return IOPX_OK;
+    }
+    if (bytes > g_bounce_cap) {
+        if (g_bounce) (void)hipHostFree(g_bounce);
+        g_bounce = nullptr; g_bounce_cap = 0;
+        const size_t cap = bytes < 65536 ? 65536 : bytes;
+        hipError_t e = hipHostMalloc(&g_bounce, cap, 0);
+        if (e != hipSuccess) return fail(IOPX_ERR_RUNTIME, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+        g_bounce_cap = cap;
+    }
+    IOPX_HIP(copy_d2h(g_bounce, src_dev, bytes, g_stream));
+    IOPX_HIP(hipStreamSynchronize(g_stream));
+    memcpy(dst_host, g_bounce, bytes);
+    return IOPX_OK;
+}
+
+int defer_downloads_begin()
+{
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    if (g_defer_on) return fail(IOPX_ERR_LOGIC, "iopx_defer_downloads_begin: already deferring");
+    g_defer_on = true;
+    return IOPX_OK;
+}
+
+int defer_downloads_end()
+{
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    if (!g_defer_on) return fail(IOPX_ERR_LOGIC, "iopx_defer_downloads_end without begin");
+    g_defer_on = false;
+    const hipError_t e = hipStreamSynchronize(g_stream);
+    if (e == hipSuccess) for (auto &it : g_defer_items) memcpy(it.dst, it.src, it.bytes);
+    g_defer_items.clear();
+    for (auto &ch : g_defer_chunks) ch.used = 0;
+    IOPX_HIP(e);
+    return IOPX_OK;
+}
+
 // ---- per-kernel profiling -----------------------------------------------------------------------
 struct ProfRec { const char *name; hipEvent_t a, b; size_t bytes, products; };
 static bool g_prof_on = false;
@@ -293,6 +365,20 @@ int iopx_free(void *dptr)
     return IOPX_OK;
 }
 
+int iopx_defer_downloads_begin(void)
+{
+    int rc = iopx::ensure_device();
+    if (rc != IOPX_OK) return rc;
+    return iopx::defer_downloads_begin();
+}
+
+int iopx_defer_downloads_end(void)
+{
+    int rc = iopx::ensure_device();
+    if (rc != IOPX_OK) return rc;
+    return iopx::defer_downloads_end();
+}
+
 int iopx_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes)
 {
     int rc = iopx::ensure_device();
@@ -306,9 +392,7 @@ int iopx_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes)
 {
     int rc = iopx::ensure_device();
     if (rc != IOPX_OK) return rc;
-    IOPX_HIP(iopx::copy_d2h(dst_host, src_dev, bytes, iopx::stream()));
-    IOPX_HIP(hipStreamSynchronize(iopx::stream()));
-    return IOPX_OK;
+    return iopx::download(dst_host, src_dev, bytes);
 }
 
 } // extern "C"

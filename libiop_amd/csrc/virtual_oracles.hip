@@ -219,6 +219,24 @@ static int vo_grid(size_t n)
 
 using namespace iopx;
 
+// Montgomery's trick on the host: every element (all non-zero) replaced by its inverse with one field inversion
+template<typename H>
+static void host_batch_inverse(std::vector<H> &v)
+{
+    if (v.empty()) return;
+    std::vector<H> prefix(v.size());
+    H acc = v[0];
+    prefix[0] = v[0];
+    for (size_t i = 1; i < v.size(); ++i) { acc = acc * v[i]; prefix[i] = acc; }
+    H inv = acc.inverse();
+    for (size_t i = v.size(); i-- > 1; ) {
+        const H vi = v[i];
+        v[i] = inv * prefix[i - 1];
+        inv = inv * vi;
+    }
+    v[0] = inv;
+}
+
 extern "C" {
 
 int iopx_rowcheck_gf192_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const uint64_t *d_Cz, const uint64_t *basis, size_t m,
@@ -231,18 +249,19 @@ int iopx_rowcheck_gf192_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const ui
     const size_t h = constraint_dim, cosets = (size_t)1 << (m - h);
     // Z_H = prod_{v in H} (X - v): the subspace polynomial of span(basis[0..h)) built factor by factor, Z <- Z(X) (Z(X) + Z(b)),
     // shifted by its value at shift_H (vanishing_polynomial.tcc:373-395)
-    const SubspacePoly lin(basis, h);
+    CachedSubspacePoly &lin = cached_subspace_poly(basis, h);
     auto eval = [&](const hgf192 &x) { return lin.eval(x); };
     const hgf192 z_shift = eval(hgf192::from_words(constraint_shift));
-    std::vector<uint64_t> zinv(3 * cosets);
+    std::vector<hgf192> z(cosets);
     for (size_t c = 0; c < cosets; ++c) {
         hgf192 x = hgf192::from_words(shift);               // first element of the coset: index c << h (utils.tcc:8-30)
         for (size_t k = h; k < m; ++k) if ((c >> (k - h)) & 1) x += hgf192::from_words(basis + 3 * k);
-        const hgf192 z = eval(x) + z_shift;
-        if (z.is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the codeword domain intersects the constraint domain");
-        const hgf192 zi = z.inverse();
-        memcpy(&zinv[3 * c], zi.w, 24);
+        z[c] = eval(x) + z_shift;
+        if (z[c].is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the codeword domain intersects the constraint domain");
     }
+    host_batch_inverse(z);                                  // one field inversion for all cosets (this sits on the proof's critical path)
+    std::vector<uint64_t> zinv(3 * cosets);
+    for (size_t c = 0; c < cosets; ++c) memcpy(&zinv[3 * c], z[c].w, 24);
     TmpBuf dz;
     if ((rc = dz.alloc(zinv.size() * 8)) != IOPX_OK) return rc;
     if ((rc = upload(dz.p, zinv.data(), zinv.size() * 8)) != IOPX_OK) return rc;
@@ -265,13 +284,17 @@ int iopx_rowcheck_fp3_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const uint
     // Z_H(shift g^j) = (shift g^j)^|H| - shift_H^|H| for j < |L| / |H|
     const hfp3 vp_shift = hs.pow(order_h), g_h = g.pow(order_h);
     hfp3 cur = s.pow(order_h);
+    std::vector<hfp3> z(cosets);
+    for (size_t j = 0; j < cosets; ++j) {
+        z[j] = cur - vp_shift;
+        if (z[j].is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the codeword domain intersects the constraint domain");
+        cur = cur * g_h;
+    }
+    host_batch_inverse(z);
     std::vector<uint64_t> zinv(3 * cosets);
     for (size_t j = 0; j < cosets; ++j) {
-        const hfp3 z = cur - vp_shift;
-        if (z.is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the codeword domain intersects the constraint domain");
-        const hfp3 zi = z.inverse().table_form().table_form();
+        const hfp3 zi = z[j].table_form().table_form();
         memcpy(&zinv[3 * j], zi.w, 24);
-        cur = cur * g_h;
     }
     const hfp3 one = hfp3::one();
     TmpBuf dz, done;
@@ -294,7 +317,7 @@ int iopx_fz_gf192_dev(const uint64_t *d_fw, const uint64_t *d_f1v, const uint64_
     if (!d_fw || !d_f1v || !d_out || (m > 0 && !basis) || !shift || (input_dim > 0 && !input_basis) || !input_shift)
         return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
     if (input_dim > m || m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "Codeword domain must be bigger than the input variable domain.");
-    const SubspacePoly lin(input_basis, input_dim);       // Z_I's linear part
+    CachedSubspacePoly &lin = cached_subspace_poly(input_basis, input_dim);       // Z_I's linear part
     auto eval = [&](const hgf192 &x) { return lin.eval(x); };
     std::vector<hgf192> entries;
     entries.push_back(eval(hgf192::from_words(shift)) + eval(hgf192::from_words(input_shift)));    // Z_I(shift) = lin(shift) + lin(shift_I)
@@ -341,8 +364,9 @@ int iopx_sumcheck_g_gf192_dev(const uint64_t *d_f, const uint64_t *d_h, const ui
     if (!d_f || !d_h || !d_out || (m > 0 && !basis) || !shift || (summation_dim > 0 && !summation_basis) || !summation_shift || !claimed_sum)
         return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
     if (m > 40 || summation_dim > 63) return fail(IOPX_ERR_INVALID_ARGUMENT, "domain dimension too large");
-    const SubspacePoly lin(summation_basis, summation_dim);   // Z_H's linear part
-    auto eval = [&](const hgf192 &x) { return lin.eval(x); };
+    CachedSubspacePoly &lin_cached = cached_subspace_poly(summation_basis, summation_dim);   // Z_H's linear part
+    const SubspacePoly &lin = lin_cached.poly;
+    auto eval = [&](const hgf192 &x) { return lin_cached.eval(x); };
     if (lin.coeff[0].is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the summation domain's basis is linearly dependent");
     const hgf192 c = lin.coeff[0].inverse() * hgf192::from_words(claimed_sum);   // eps^-1 mu (sumcheck.tcc:52-54)
     std::vector<hgf192> xe, he, ze;

@@ -104,6 +104,7 @@ static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int
 typedef void *hipEvent_t;
 enum { hipEventDisableTiming = 2 };
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 8); return *p ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hipSuccess; }

@@ -7,6 +7,7 @@ import argparse, glob, sqlite3
 ap = argparse.ArgumentParser()
 ap.add_argument("path")
 ap.add_argument("--min-us", type=float, default=100.0)
+ap.add_argument("--context", type=int, default=0, help="also print this many kernels before and after each listed gap")
 ap.add_argument("--last-ms", type=float, default=120.0, help="look at the kernels of the last this-many milliseconds of the trace")
 a = ap.parse_args()
 path = a.path if a.path.endswith(".db") else glob.glob(a.path + "/**/*.db", recursive=True)[0]
@@ -19,10 +20,14 @@ rows = [r for r in rows if r[0] >= t_end - a.last_ms * 1e6]
 busy = sum(r[1] - r[0] for r in rows)
 span = rows[-1][1] - rows[0][0]
 short = lambda n: n.split("iopx")[-1][:40]
-gaps = [(rows[i + 1][0] - rows[i][1], short(rows[i][2]), short(rows[i + 1][2])) for i in range(len(rows) - 1)]
+gaps = [(rows[i + 1][0] - rows[i][1], short(rows[i][2]), short(rows[i + 1][2]), i) for i in range(len(rows) - 1)]
 print("window %.2f ms, kernels busy %.2f ms, idle %.2f ms in %d gaps (%d >= %.0f us)" % (span / 1e6, busy / 1e6, (span - busy) / 1e6, len(gaps),
       sum(1 for g in gaps if g[0] >= a.min_us * 1e3), a.min_us))
-for g, before, after in sorted(gaps, reverse=True):
+for g, before, after, i in sorted(gaps, reverse=True):
     if g < a.min_us * 1e3:
         break
     print("%8.1f us  after %-42s before %s" % (g / 1e3, before, after))
+    if a.context:
+        lo, hi = max(0, i - a.context + 1), min(len(rows), i + 1 + a.context)
+        print("             " + " | ".join("%s (%.0f us)" % (short(r[2])[:28], (r[1] - r[0]) / 1e3) for r in rows[lo:i + 1]) + "  >>>  " +
+              " | ".join("%s (%.0f us)" % (short(r[2])[:28], (r[1] - r[0]) / 1e3) for r in rows[i + 1:hi]))
