@@ -473,6 +473,14 @@ class Library:
         self._check(self.c.iopx_merkle_membership_proof_dev(_vp(d_nodes), int(num_leaves), pos, len(positions), _vp(out.ctypes.data), cap, ctypes.byref(cnt)))
         return out[:cnt.value].copy()
 
+    def defer_downloads_begin(self):
+        """Until defer_downloads_end(), iopx_query_responses_dev / iopx_merkle_membership_proof_dev only queue their read-backs (call them through
+        self.c with buffers that stay alive: the wrappers above copy their results at once)."""
+        self._check(self.c.iopx_defer_downloads_begin())
+
+    def defer_downloads_end(self):
+        self._check(self.c.iopx_defer_downloads_end())
+
     def query_responses_dev(self, d_oracles, elem_bytes, n, positions):
         """values[p][k] = oracle_k[positions[p]] as a (positions, oracles, elem_bytes / 8) uint64 array."""
         pos = (_sz * max(len(positions), 1))(*[int(p) for p in positions])

@@ -169,7 +169,8 @@ __global__ void k_merkle_level(uint64_t *nodes, size_t first, size_t count)
     }
 }
 
-// the top of the tree in one workgroup: levels of `count`, count/2, ..., 1 nodes
+// the top of the tree in one workgroup: levels of `count`, count/2, ..., 1 nodes (one node per thread at the widest level: the kernel sits
+// between the last wide level and the root's read-back, on the proof's critical path)
 __global__ void k_merkle_top(uint64_t *nodes, size_t count)
 {
     for (size_t c = count; c >= 1; c >>= 1) {
@@ -293,7 +294,7 @@ int iopx_merkle_inner_blake2b_dev(uint8_t *d_nodes, size_t num_leaves)
         { ProfScope ps_("k_merkle_level"); hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)g), dim3(256), 0, stream(), (uint64_t *)d_nodes, count - 1, count); }
         count >>= 1;
     }
-    { ProfScope ps_("k_merkle_top"); hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(count >= 256 ? 256 : 64), 0, stream(), (uint64_t *)d_nodes, count); }
+    { ProfScope ps_("k_merkle_top"); hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(count >= 1024 ? 1024 : (count >= 256 ? 256 : 64)), 0, stream(), (uint64_t *)d_nodes, count); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
 }

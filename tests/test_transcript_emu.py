@@ -19,6 +19,10 @@ def test_empty_and_errors():
     tc.check_empty_and_errors(emu())
 
 
+def test_deferred_downloads():
+    tc.check_deferred_downloads(emu())
+
+
 def test_query_responses():
     tc.check_query_responses(emu(), 256, 3, 5)
 

@@ -50,6 +50,48 @@ def check_all_subsets_of_small_tree(lib):
         lib.free(d)
 
 
+def check_deferred_downloads(lib):
+    """iopx_defer_downloads_begin / _end: the read-backs of the extraction calls in between arrive with _end, equal to the immediate ones."""
+    import ctypes
+    L, cs = 64, 2
+    oracles = [rand_elems(5, L * cs, 3), rand_elems(6, L * cs, 3)]
+    nodes, d = _device_tree(lib, oracles, cs, True)
+    d_or = [lib.malloc(o.nbytes) for o in oracles]
+    try:
+        for ptr, o in zip(d_or, oracles):
+            lib.h2d(ptr, o)
+        leaf_positions, positions = [3, 17, 18, 40], [6, 7, 34, 35, 36, 81]
+        want_proof = lib.get_set_membership_proof_dev(d, L, leaf_positions)
+        want_resp = lib.query_responses_dev(d_or, 24, L * cs, positions)
+        with pytest.raises(AssertionError):
+            lib.defer_downloads_end()                                               # not deferring
+        lib.defer_downloads_begin()
+        with pytest.raises(AssertionError):
+            lib.defer_downloads_begin()                                             # already deferring
+        _sz, _vp = ctypes.c_size_t, ctypes.c_void_p
+        proof = np.zeros((len(leaf_positions) * 7, 32), dtype=np.uint8)
+        cnt = _sz(0)
+        lp = (_sz * len(leaf_positions))(*leaf_positions)
+        lib._check(lib.c.iopx_merkle_membership_proof_dev(_vp(d), L, lp, len(leaf_positions), _vp(proof.ctypes.data), proof.shape[0], ctypes.byref(cnt)))
+        resp = np.zeros((len(positions), 2, 3), dtype=np.uint64)
+        qp = (_sz * len(positions))(*positions)
+        ptrs = (_vp * 2)(*d_or)
+        lib._check(lib.c.iopx_query_responses_dev(ptrs, 2, 24, L * cs, qp, len(positions), _vp(resp.ctypes.data)))
+        assert cnt.value == want_proof.shape[0]                                     # the count is known at once
+        assert not proof.any() and not resp.any()                                   # nothing delivered yet
+        root = np.zeros(32, dtype=np.uint8)                                         # an ordinary read-back inside the window is immediate
+        lib.d2h(root, d)
+        assert np.array_equal(root, nodes[0])
+        lib.defer_downloads_end()
+        assert np.array_equal(proof[:cnt.value], want_proof)
+        assert np.array_equal(resp, want_resp)
+        assert np.array_equal(lib.query_responses_dev(d_or, 24, L * cs, positions), want_resp)    # and the immediate form is back
+    finally:
+        lib.free(d)
+        for ptr in d_or:
+            lib.free(ptr)
+
+
 def check_empty_and_errors(lib):
     nodes, d = _device_tree(lib, [rand_elems(1, 8, 3)], 1, True)
     try:
