@@ -218,15 +218,15 @@ def test_batched_lde(m, ncoef, batch, cb, cc):
         assert np.array_equal(outs[k], full[cb << d:(cb + cc) << d]), k
 
 
-@pytest.mark.parametrize("m,ncoef,batch", [(13, 2048, 3), (12, 2048, 2), (9, 128, 4)])
-def test_batched_lde_standard_basis(m, ncoef, batch):
-    """The prover's shape: standard basis, shift x^m — the shared last pass with one-word twiddles at pair bit 0."""
+@pytest.mark.parametrize("m,ncoef,batch,cb,cc", [(13, 2048, 3, 0, 4), (12, 2048, 2, 0, 2), (9, 128, 4, 0, 4), (13, 2048, 3, 1, 2), (14, 2048, 4, 5, 3)])
+def test_batched_lde_standard_basis(m, ncoef, batch, cb, cc):
+    """The prover's shape: standard basis, shift x^m — the shared last pass with one- and two-word twiddle numerators at pair bits 0 and 1,
+    over the whole codeword and over a rank's coset range (the numerators of a coset's shift take its global index)."""
     lib = emu()
     basis, shift = _dom(m, "aurora", 0)
     d = int(np.ceil(np.log2(ncoef)))
-    cc = 1 << (m - d)
     polys = [rand_elems(80 + k, ncoef, W) for k in range(batch)]
     outs = [np.zeros((cc << d, W), dtype=np.uint64) for _ in range(batch)]
-    lib.additive_LDE_batch_dev([p.ctypes.data for p in polys], ncoef, basis, shift, 0, cc, [o.ctypes.data for o in outs])
+    lib.additive_LDE_batch_dev([p.ctypes.data for p in polys], ncoef, basis, shift, cb, cc, [o.ctypes.data for o in outs])
     for k in range(batch):
-        assert np.array_equal(outs[k], oracle.additive_fft(polys[k], basis, shift)), k
+        assert np.array_equal(outs[k], oracle.additive_fft(polys[k], basis, shift)[cb << d:(cb + cc) << d]), k
