@@ -302,8 +302,9 @@ __device__ __forceinline__ gf192 gf_mul_small2_over(const gf192 &a, uint32_t y0,
 
 // ---------------------------------------------------------------------------------------------------
 // Product by a WAVE-UNIFORM multiplier c (every active lane of the wavefront holds the same c): the
-// carry-less product is one hand-written asm block (iopx/gfx950_comb.h, 4-bit-window comb, table selected
-// by S_SET_GPR_IDX): ~0.57k VALU ops against ~1.7k for gf_mul.  The caller guarantees uniformity of c.
+// carry-less product is one hand-written asm block (iopx/gfx950_comb.h, generated by tools/gen_comb_asm.py): a 4-bit-window comb whose
+// window value, being wave-uniform, selects a code block by a scalar jump instead of a table entry by relative addressing — about 0.45k
+// VALU ops, most of them fast-class, against ~1.0k for gf_mul (1.6k against 3.4k issue cycles).  The caller guarantees uniformity of c.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ gf192 gf_mul_uniform(const gf192 &a, const gf192 &c_uniform)
 {
