@@ -34,7 +34,7 @@ namespace iopx {
 // Tile geometry.  Defaults: 2048-element phase-2 tiles (48 KiB of LDS per workgroup), 1024-element phase-1 and edge tiles.  The IOPX_TILE_BITS /
 // IOPX_P1_COLS / IOPX_P2_COLS / IOPX_P2_TOP environment variables override them (read once): used for
 // tuning, and by the tests to exercise the multi-pass schedules at small transform sizes.
-struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last, scratch_mb; };
+struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last, scratch_mb, p1_comb; };
 static int env_int(const char *name, int dflt, int lo, int hi)
 {
     const char *v = getenv(name);
@@ -64,6 +64,7 @@ static const Tuning &tuning()
         u.p2_threads = env_int("IOPX_P2_THREADS", u.comb ? 512 : 1024, 64, u.comb ? 512 : 1024);
         u.small_last = env_int("IOPX_SMALL_LAST", 1, 0, 1);             // 1: one-word twiddle numerators at the last level where the basis allows
         u.scratch_mb = env_int("IOPX_SCRATCH_MB", 256, 1, 65536);
+        u.p1_comb = env_int("IOPX_P1_COMB", 1, 0, 1);                   // 1: comb product for the phase-1 twists with a wave-uniform multiplier
         return u;
     }();
     return t;
@@ -197,7 +198,41 @@ struct P1Params {
     int j0, j1;             // levels handled by this pass
     int k_start, k_end;     // first op of level j0, last op of level j1 (ops run k = d-2 .. j)
     int xcd_remap;
+    int comb;               // 1: the twists whose multiplier is the same in all 64 lanes of a wavefront take the comb product
+    int extra;              // >= 0: this pass also applies the twist of that level (the one after its own), see phase1_schedule
+    int skip_j0;            // 1: level j0's twist was applied by the pass before
 };
+
+// the twist of one level: element gi times pow_j[gi >> j]; `uniform`: the 64 lanes of a wavefront share the multiplier — its index goes
+// through the scalar unit and the product is the comb
+__device__ __forceinline__ void p1_twist(uint64_t *s, int E, int tid, int nt, const P1Params &p, size_t base, int cmask, int j, bool uniform)
+{
+    const uint64_t *powj = p.pow + 3 * ((((size_t)2) << p.d) - (((size_t)2) << (p.d - j)));
+    if (uniform) {
+#pragma unroll 1
+        for (int li = tid; li < E; li += nt) {
+            const int li_u = (int)__builtin_amdgcn_readfirstlane((uint32_t)(li & ~63));
+            const size_t gi_u = base | ((size_t)(li_u >> p.c) << p.h) | (size_t)(li_u & cmask);
+            const uint64_t *t = powj + 3 * (gi_u >> j);
+            const uint64_t w0 = uniform_load64(t), w1 = uniform_load64(t + 1), w2 = uniform_load64(t + 2);
+            gf192 tw;
+            tw.w[0] = (uint32_t)w0; tw.w[1] = (uint32_t)(w0 >> 32); tw.w[2] = (uint32_t)w1; tw.w[3] = (uint32_t)(w1 >> 32); tw.w[4] = (uint32_t)w2; tw.w[5] = (uint32_t)(w2 >> 32);
+            lds_put(s, E, li, gf_mul_uniform(lds_get(s, E, li), tw));
+        }
+    } else {
+        for (int li = tid; li < E; li += nt) {
+            const size_t gi = base | ((size_t)(li >> p.c) << p.h) | (size_t)(li & cmask);
+            lds_put(s, E, li, gf_mul(lds_get(s, E, li), gf_load(powj, gi >> j)));
+        }
+    }
+}
+
+// A wavefront holds 64 consecutive tile slots: 2^c columns (bits 0..c-1 of gi) and 2^(6-c) rows (bits h..h+5-c); when all of those bits lie
+// below j the 64 lanes share the multiplier of level j
+__device__ __forceinline__ bool p1_twist_is_uniform(const P1Params &p, int E, int j)
+{
+    return p.comb && E >= 64 && p.c <= j && j >= p.h + 6 - p.c;
+}
 
 template<bool INV>
 __global__ void __launch_bounds__(512) k_phase1(P1Params p)
@@ -225,14 +260,13 @@ __global__ void __launch_bounds__(512) k_phase1(P1Params p)
     for (int j = jb; j != je; j += js) {
         const int ks = (j == p.j0) ? p.k_start : p.d - 2;
         const int ke = (j == p.j1) ? p.k_end : j;
-        const bool twist = (ks == p.d - 2);
-        const uint64_t *powj = p.pow ? p.pow + 3 * ((((size_t)2) << p.d) - (((size_t)2) << (p.d - j))) : nullptr;
-        if (!INV && twist && p.pow) {
-            for (int li = tid; li < E; li += nt) {
-                const size_t gi = base | ((size_t)(li >> p.c) << p.h) | (size_t)(li & cmask);
-                const size_t q = gi >> j;
-                lds_put(s, E, li, gf_mul(lds_get(s, E, li), gf_load(powj, q)));
-            }
+        const bool twist = (ks == p.d - 2) && p.pow && !(p.skip_j0 && j == p.j0);
+        if (INV && p.extra >= 0 && j == p.j1 && p.pow) {           // the level undone before this one: its twist comes off here (see phase1_schedule)
+            p1_twist(s, E, tid, nt, p, base, cmask, p.extra, p1_twist_is_uniform(p, E, p.extra));
+            __syncthreads();
+        }
+        if (!INV && twist) {
+            p1_twist(s, E, tid, nt, p, base, cmask, j, p1_twist_is_uniform(p, E, j));
             __syncthreads();
         }
         // forward: k = ks down to ke; inverse: k = ke up to ks
@@ -258,12 +292,12 @@ __global__ void __launch_bounds__(512) k_phase1(P1Params p)
             }
             __syncthreads();
         }
-        if (INV && twist && p.pow) {
-            for (int li = tid; li < E; li += nt) {
-                const size_t gi = base | ((size_t)(li >> p.c) << p.h) | (size_t)(li & cmask);
-                const size_t q = gi >> j;
-                lds_put(s, E, li, gf_mul(lds_get(s, E, li), gf_load(powj, q)));
-            }
+        if (INV && twist) {
+            p1_twist(s, E, tid, nt, p, base, cmask, j, p1_twist_is_uniform(p, E, j));
+            __syncthreads();
+        }
+        if (!INV && p.extra >= 0 && j == p.j1 && p.pow) {          // the next level's twist, while 64 consecutive elements are in one wavefront
+            p1_twist(s, E, tid, nt, p, base, cmask, p.extra, p1_twist_is_uniform(p, E, p.extra));
             __syncthreads();
         }
     }
@@ -910,13 +944,13 @@ static int set_lds(K kernel, size_t bytes)
 }
 
 // ---- phase-1 schedule --------------------------------------------------------------------------
-struct P1Pass { int c, h, A, j0, j1, k_start, k_end; };
+struct P1Pass { int c, h, A, j0, j1, k_start, k_end, extra, skip_j0; };
 
 static std::vector<P1Pass> phase1_schedule(int d)
 {
     std::vector<P1Pass> sched;
     if (d <= P1_TILE_BITS) {
-        sched.push_back({0, 0, d, 0, d - 1, d - 2, d - 1});
+        sched.push_back({0, 0, d, 0, d - 1, d - 2, d - 1, -1, 0});
         return sched;
     }
     const int A = P1_TILE_BITS - P1_COLS;
@@ -927,16 +961,27 @@ static std::vector<P1Pass> phase1_schedule(int d)
         int k = d - 2;
         while (k >= j) {
             if (k + 1 <= P1_TILE_BITS - 1) {   // the rest of this level fits a contiguous tile
-                sched.push_back({0, 0, P1_TILE_BITS, j, j, k, j});
+                sched.push_back({0, 0, P1_TILE_BITS, j, j, k, j, -1, 0});
                 break;
             }
             const int h = k + 2 - A;
             const int ke = h > j ? h : j;
-            sched.push_back({P1_COLS, h, A, j, j, k, ke});
+            sched.push_back({P1_COLS, h, A, j, j, k, ke, -1, 0});
             k = ke - 1;
         }
     }
-    sched.push_back({fin_cols, hfin, Afin, hfin, d - 1, d - 2, d - 1});
+    sched.push_back({fin_cols, hfin, Afin, hfin, d - 1, d - 2, d - 1, -1, 0});
+    // The twist of level j multiplies element i by a power indexed by i >> j: from level 6 on, 64 consecutive elements share it.  The pass
+    // that twists level j holds 8-element runs (its tile wants rows on high bits), but the last pass of level j - 1 holds a contiguous
+    // tile: when there is one, level j's twist moves there — wave-uniform multipliers, comb product — and the pass after skips it.
+    // (Forward: after that pass's own steps; inverse: before them.)
+    if (tuning().comb && tuning().p1_comb) {
+        for (size_t i = 0; i + 1 < sched.size(); ++i) {
+            P1Pass &a = sched[i], &b = sched[i + 1];
+            const bool contiguous_last = a.c == 0 && a.h == 0 && a.j0 == a.j1 && b.j0 == a.j0 + 1 && b.k_start == d - 2;
+            if (contiguous_last && b.j0 >= 6) { a.extra = b.j0; b.skip_j0 = 1; }
+        }
+    }
     return sched;
 }
 
@@ -961,6 +1006,8 @@ static int run_phase1(AddPlan &pl, uint64_t *S, size_t batch = 1)
         p.d = d; p.c = ps.c; p.h = ps.h; p.A = ps.A;
         p.j0 = ps.j0; p.j1 = ps.j1; p.k_start = ps.k_start; p.k_end = ps.k_end;
         p.xcd_remap = env_int("IOPX_XCD_REMAP", 1, 0, 1);
+        p.comb = tuning().comb && tuning().p1_comb;
+        p.extra = ps.extra; p.skip_j0 = ps.skip_j0;
         const int tbits = ps.c + ps.A;
         const size_t lds = ((size_t)24) << tbits;
         const size_t blocks = (size_t)1 << (d - tbits);
@@ -1566,7 +1613,7 @@ int iopx_add_taylor_gf192_dev(uint64_t *d_S, size_t log_n, const uint64_t *d_twi
     const int d = (int)log_n;
     std::vector<P1Pass> sched;
     if (d <= P1_TILE_BITS) {
-        sched.push_back({0, 0, d, 0, 0, d - 2, 0});
+        sched.push_back({0, 0, d, 0, 0, d - 2, 0, -1, 0});
     } else {
         for (const P1Pass &ps : phase1_schedule(d)) if (ps.j0 == 0 && ps.j1 == 0) sched.push_back(ps);
     }
@@ -1576,6 +1623,7 @@ int iopx_add_taylor_gf192_dev(uint64_t *d_S, size_t log_n, const uint64_t *d_twi
         p.d = d; p.c = ps.c; p.h = ps.h; p.A = ps.A;
         p.j0 = 0; p.j1 = 0; p.k_start = ps.k_start; p.k_end = ps.k_end;
         p.xcd_remap = 0;
+        p.comb = 0; p.extra = -1; p.skip_j0 = 0;            // the caller's table is per element: nothing is shared or moved
         const int tbits = ps.c + ps.A;
         const size_t lds = ((size_t)24) << tbits;
         const size_t blocks = (size_t)1 << (d - tbits);
