@@ -70,9 +70,9 @@ def test_one_word_last_level(m, k, shift0, second):
         assert np.array_equal(emu().additive_FFT(short, basis, shift), oracle.additive_fft(short, basis, shift))
 
 
-@pytest.mark.parametrize("m,kind", [(16, "std0"), (17, "general")])
+@pytest.mark.parametrize("m,kind", [(17, "std0"), (18, "general")])
 def test_phase1_relocated_twists(m, kind):
-    """From 2^16 on a level's twist (levels 6..9) moves into the contiguous last pass of the level before it, where 64 consecutive elements
+    """From 2^17 on a level's twist (levels 6..9) moves into the contiguous last pass of the level before it, where 64 consecutive elements
     share the multiplier (phase1_schedule): forward and inverse against the oracle."""
     basis, shift = _dom(m, kind, 300 + m)
     coeffs = rand_elems(m, 1 << m, W)
