@@ -10,7 +10,8 @@ wave JUMPS (s_setpc_b64 into a 16 x 128-byte block table per word offset) to cod
   * all 336 window XORs are plain fast-class ops;
   * an entry that is the XOR of two materialised entries is applied with one three-input XOR per word, so only
     2a, 4a, 8a, 3a, 12a are materialised next to a itself: 35 table VGPRs instead of 112, 35 build ops instead of 124;
-  * each block ends with the dispatch of the next window (one taken branch per window, 56 per product); the branch latency
+  * each block carries the dispatch of the next window, its scalar ops between the block's XORs (one taken branch per window, 56 per
+    product); the branch latency
     (~58 cycles) is hidden by the other wavefronts of the SIMD: the callers run 5-6 waves per SIMD, which the small table permits.
 Measured (uniform products/s, chip-wide): 5.9e10 (round 2 schedule, 3 waves/SIMD) -> 8.8e10 at 6 waves/SIMD, 9.2e10 at 8.
 """
@@ -44,13 +45,32 @@ def shl1(dst, src):
     A("v_lshlrev_b32 %s, 1, %s" % (E(dst, 0), E(src, 0)))
 
 
-def dispatch(k):
+def dispatch_ops(k):
     """jump to block (nibble of c[k] selected by the field descriptor in s[SB+16]) of table k"""
-    A("s_bfe_u32 s%d, %%[c%d], s%d" % (SB + 17, k, SB + 16))
-    A("s_lshl_b32 s%d, s%d, 7" % (SB + 17, SB + 17))
-    A("s_add_u32 s%d, s%d, s%d" % (SB, SB + 2 + 2 * k, SB + 17))
-    A("s_addc_u32 s%d, s%d, 0" % (SB + 1, SB + 3 + 2 * k))
-    A("s_setpc_b64 s[%d:%d]" % (SB, SB + 1))
+    return ["s_bfe_u32 s%d, %%[c%d], s%d" % (SB + 17, k, SB + 16),
+            "s_lshl_b32 s%d, s%d, 7" % (SB + 17, SB + 17),
+            "s_add_u32 s%d, s%d, s%d" % (SB, SB + 2 + 2 * k, SB + 17),
+            "s_addc_u32 s%d, s%d, 0" % (SB + 1, SB + 3 + 2 * k),
+            "s_setpc_b64 s[%d:%d]" % (SB, SB + 1)]
+
+
+def dispatch(k):
+    for l in dispatch_ops(k):
+        A(l)
+
+
+def block(valu, k_next):
+    """One window block: its XORs with the four scalar ops of the next window's dispatch between them (they depend on c only, and a
+    wavefront's scalar op issues while its vector op occupies the SIMD), the jump last.  Against XORs-then-dispatch: +4 % products/s at
+    6 waves per SIMD (tools/ubench/comb_rates: variants j0 / j1)."""
+    d = dispatch_ops(k_next)
+    sal = d[:4]
+    for i, v in enumerate(valu):
+        if i < len(sal):
+            A(sal[i])
+        A(v)
+    for l in sal[len(valu):] + d[4:]:
+        A(l)
 
 
 shl1(2, 1); shl1(4, 2); shl1(8, 4)
@@ -76,21 +96,24 @@ for k in range(6):
     A(L + "t%d:" % k)
     for u in range(16):
         A(".p2align 7")
+        valu = []
         if u:
             if u in BASIS:
                 for i in range(7):
                     if E(u, i):
-                        A("v_xor_b32 %%[r%d], %%[r%d], %s" % (k + i, k + i, E(u, i)))
+                        valu.append("v_xor_b32 %%[r%d], %%[r%d], %s" % (k + i, k + i, E(u, i)))
             else:
                 x, y = SPLIT[u]
                 for i in range(7):
                     if E(y, i):
-                        A("v_bitop3_b32 %%[r%d], %%[r%d], %s, %s bitop3:0x96" % (k + i, k + i, E(x, i), E(y, i)))
+                        valu.append("v_bitop3_b32 %%[r%d], %%[r%d], %s, %s bitop3:0x96" % (k + i, k + i, E(x, i), E(y, i)))
                     else:
-                        A("v_xor_b32 %%[r%d], %%[r%d], %s" % (k + i, k + i, E(x, i)))
+                        valu.append("v_xor_b32 %%[r%d], %%[r%d], %s" % (k + i, k + i, E(x, i)))
         if k < 5:
-            dispatch(k + 1)
+            block(valu, k + 1)
         else:
+            for l in valu:
+                A(l)
             A("s_branch %srend" % L)
 A(".p2align 7")
 A(L + "rend:")

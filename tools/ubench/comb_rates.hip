@@ -101,6 +101,8 @@ __device__ __forceinline__ gf192 mulv(const gf192 &a, const gf192 &cu)
     if (V == 4) comb_v4(r, a.w, c);
     if (V == 5) comb_v3hi(r, a.w, c);
     if (V == 6) comb_j0(r, a.w, c);
+    if (V == 7) comb_j1(r, a.w, c);
+    if (V == 8) comb_j2(r, a.w, c);
     return gf_reduce(r);
 }
 
@@ -188,14 +190,16 @@ template<int V> static void run_mul(const char *name, const uint64_t *in, uint64
     printf("\n");
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const bool products_only = argc > 1 && !strcmp(argv[1], "products");
     uint32_t *d; CK(hipMalloc(&d, (size_t)256 * 8 * 4 * 256 * 4));
     uint64_t *in, *out; CK(hipMalloc(&in, (size_t)65536 * 24)); CK(hipMalloc(&out, (size_t)256 * 8 * 4 * 256 * 24));
     uint64_t *h = (uint64_t *)malloc((size_t)65536 * 24);
     uint64_t s = 0x9e3779b97f4a7c15ull;
     for (size_t i = 0; i < 65536 * 3; ++i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[i] = s; }
     CK(hipMemcpy(in, h, (size_t)65536 * 24, hipMemcpyHostToDevice));
+    if (!products_only) {
     printf("== issue patterns (cycles at 2.4 GHz per VALU wave-instruction per SIMD; SIMD-32 floor = 2.0) ==\n");
     run_plain<0>("plain v_xor x42", d, 42);
     run_plain<1>("plain alignbit chain x48", d, 48);
@@ -207,6 +211,7 @@ int main()
     run_issue<11>("round: 6x(7 + set_idx) + shift12", d, 54);
     run_issue<12>("round: 6x(7 + bfe,set_idx) + shift12", d, 54);
     run_issue<13>("round: 6x(7 + bfe,mul,set_idx) + shift12", d, 54);
+    }
     printf("== whole products (uniform-multiplier products per second, chip-wide) ==\n");
     run_mul<-1>("general(u unif)", in, out, h, 4);
     run_mul<-2>("general", in, out, h, 4);
@@ -217,5 +222,7 @@ int main()
     run_mul<3>("v3", in, out, h, 4);
     run_mul<4>("v4", in, out, h, 4);
     run_mul<6>("j0", in, out, h, 8);
+    run_mul<7>("j1", in, out, h, 8);
+    run_mul<8>("j2", in, out, h, 8);
     return 0;
 }

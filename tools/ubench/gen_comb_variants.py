@@ -147,8 +147,10 @@ class GenJump:
     BASIS = {1: None, 2: 0, 4: 1, 8: 2, 3: 3, 12: 4}      # entry -> slot in the VGPR window (a itself is the input operand)
     SPLIT = {5: (4, 1), 6: (4, 2), 7: (4, 3), 9: (8, 1), 10: (8, 2), 11: (8, 3), 13: (12, 1), 14: (12, 2), 15: (12, 3)}
 
-    def __init__(self, name, TB, SB=36):
-        self.name, self.TB, self.SB = name, TB, SB
+    def __init__(self, name, TB, SB=36, mode=0):
+        # mode 0: a block's XORs, then the dispatch of the next window; 1: the dispatch's scalar ops interleaved with the XORs (they do
+        # not depend on them), the jump last; 2: the scalar ops first, the XORs, the jump
+        self.name, self.TB, self.SB, self.mode = name, TB, SB, mode
         self.lines = []
         self.build()
 
@@ -170,13 +172,34 @@ class GenJump:
                 self.A("v_alignbit_b32 %s, %s, %s, 31" % (self.E(dst, i), hi, self.E(src, i - 1)))
         self.A("v_lshlrev_b32 %s, 1, %s" % (self.E(dst, 0), self.E(src, 0)))
 
-    def dispatch(self, k):
+    def dispatch_ops(self, k):
         SB = self.SB
-        self.A("s_bfe_u32 s%d, %%[c%d], s%d" % (SB + 17, k, SB + 16))
-        self.A("s_lshl_b32 s%d, s%d, 7" % (SB + 17, SB + 17))
-        self.A("s_add_u32 s%d, s%d, s%d" % (SB, SB + 2 + 2 * k, SB + 17))
-        self.A("s_addc_u32 s%d, s%d, 0" % (SB + 1, SB + 3 + 2 * k))
-        self.A("s_setpc_b64 s[%d:%d]" % (SB, SB + 1))
+        return ["s_bfe_u32 s%d, %%[c%d], s%d" % (SB + 17, k, SB + 16),
+                "s_lshl_b32 s%d, s%d, 7" % (SB + 17, SB + 17),
+                "s_add_u32 s%d, s%d, s%d" % (SB, SB + 2 + 2 * k, SB + 17),
+                "s_addc_u32 s%d, s%d, 0" % (SB + 1, SB + 3 + 2 * k),
+                "s_setpc_b64 s[%d:%d]" % (SB, SB + 1)]
+
+    def dispatch(self, k):
+        for l in self.dispatch_ops(k):
+            self.A(l)
+
+    def block(self, valu, k_next):
+        """one window block: its XORs and the dispatch of table k_next, ordered by self.mode"""
+        d = self.dispatch_ops(k_next)
+        if self.mode == 0:
+            seq = valu + d
+        elif self.mode == 2:
+            seq = d[:4] + valu + d[4:]
+        else:
+            seq, sal = [], d[:4]
+            for i, v in enumerate(valu):
+                if i < len(sal):
+                    seq.append(sal[i])
+                seq.append(v)
+            seq += sal[len(valu):] + d[4:]
+        for l in seq:
+            self.A(l)
 
     def build(self):
         A, E, SB = self.A, self.E, self.SB
@@ -203,21 +226,24 @@ class GenJump:
             A(L + "t%d:" % k)
             for u in range(16):
                 A(".p2align 7")
+                valu = []
                 if u:
                     if u in self.BASIS:
                         for i in range(7):
                             if E(u, i):
-                                A("v_xor_b32 %%[r%d], %%[r%d], %s" % (k + i, k + i, E(u, i)))
+                                valu.append("v_xor_b32 %%[r%d], %%[r%d], %s" % (k + i, k + i, E(u, i)))
                     else:
                         x, y = self.SPLIT[u]
                         for i in range(7):
                             if E(y, i):
-                                A("v_bitop3_b32 %%[r%d], %%[r%d], %s, %s bitop3:0x96" % (k + i, k + i, E(x, i), E(y, i)))
+                                valu.append("v_bitop3_b32 %%[r%d], %%[r%d], %s, %s bitop3:0x96" % (k + i, k + i, E(x, i), E(y, i)))
                             else:
-                                A("v_xor_b32 %%[r%d], %%[r%d], %s" % (k + i, k + i, E(x, i)))
+                                valu.append("v_xor_b32 %%[r%d], %%[r%d], %s" % (k + i, k + i, E(x, i)))
                 if k < 5:
-                    self.dispatch(k + 1)
+                    self.block(valu, k + 1)
                 else:
+                    for l in valu:
+                        A(l)
                     A("s_branch %srend" % L)
         A(".p2align 7")
         A(L + "rend:")
@@ -248,7 +274,7 @@ __device__ __forceinline__ void comb_%s(uint32_t (&r)[12], const uint32_t (&a)[6
 """ % (self.name, self.TB, self.TB + 34, self.SB, self.SB + 17, self.name, body, outs, ins, ", ".join(clob)), nvalu, 0
 
 
-VARIANTS += [GenJump("j0", 40)]
+VARIANTS += [GenJump("j0", 40), GenJump("j1", 40, mode=1), GenJump("j2", 40, mode=2)]
 
 
 if __name__ == "__main__":
