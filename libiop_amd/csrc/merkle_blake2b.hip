@@ -211,6 +211,9 @@ __global__ void k_pow_blake2b(PowChallenge c, uint64_t first, uint64_t count, ui
 {
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t idx = first + g;
+        // the grid walks the candidates in increasing order, about one resident wave of threads at a time: once a hit is known, everything
+        // above it is irrelevant (the answer is the FIRST hit, pow.tcc:86-112), so the launch ends soon after the hit instead of with the batch
+        if (idx > *(volatile unsigned long long *)best) break;
         uint64_t h[8], m[16];
         b2b_init(h);
         m[0] = c.w[0]; m[1] = c.w[1]; m[2] = c.w[2]; m[3] = c.w[3];
@@ -349,7 +352,7 @@ int iopx_pow_search_blake2b(const uint8_t *challenge, size_t pow_bitlen, uint64_
     unsigned long long hit = none;
     if (count) {
         { ProfScope ps_("k_pow_blake2b");
-          hipLaunchKernelGGL(k_pow_blake2b, dim3((unsigned)((count + 255) / 256 > 16384 ? 16384 : (count + 255) / 256)), dim3(256), 0, stream(),
+          hipLaunchKernelGGL(k_pow_blake2b, dim3((unsigned)((count + 255) / 256 > 1536 ? 1536 : (count + 255) / 256)), dim3(256), 0, stream(),   // <= one resident set of workgroups (256 CUs x 6): the grid advances through the candidates together
                              c, first, count, mask, (unsigned long long *)best.p); }
         { int drc_ = download(&hit, best.p, 8); if (drc_ != IOPX_OK) return drc_; }
     }
@@ -369,12 +372,13 @@ int iopx_pow_candidate_blake2b(const uint8_t *challenge, uint64_t index, uint8_t
 int iopx_pow_solve_blake2b(const uint8_t *challenge, size_t pow_bitlen, uint8_t *pow)
 {
     if (!challenge || !pow) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
-    uint64_t found = ~0ull, first = 0, batch = (uint64_t)1 << 16;      // the first batch is small: low difficulties finish in one launch
+    // the first batch is small: low difficulties finish in one launch; the later ones are large — a launch stops soon after its first hit
+    uint64_t found = ~0ull, first = 0, batch = (uint64_t)1 << 16;
     while (found == ~0ull) {
         const int rc = iopx_pow_search_blake2b(challenge, pow_bitlen, first, batch, &found);
         if (rc != IOPX_OK) return rc;
         first += batch;
-        if (batch < ((uint64_t)1 << 24)) batch <<= 2;
+        if (batch < ((uint64_t)1 << 28)) batch <<= 4;
     }
     return iopx_pow_candidate_blake2b(challenge, found, pow);
 }
