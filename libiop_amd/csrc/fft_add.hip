@@ -34,7 +34,7 @@ namespace iopx {
 // Tile geometry.  Defaults: 2048-element phase-2 tiles (48 KiB of LDS per workgroup), 1024-element phase-1 and edge tiles.  The IOPX_TILE_BITS /
 // IOPX_P1_COLS / IOPX_P2_COLS / IOPX_P2_TOP environment variables override them (read once): used for
 // tuning, and by the tests to exercise the multi-pass schedules at small transform sizes.
-struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last, scratch_mb, p1_comb; };
+struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last, scratch_mb, p1_comb, rs_comb_cap_log2; };
 static int env_int(const char *name, int dflt, int lo, int hi)
 {
     const char *v = getenv(name);
@@ -66,6 +66,7 @@ static const Tuning &tuning()
         u.p2_threads = env_int("IOPX_P2_THREADS", u.comb ? 512 : 1024, 64, u.comb ? 512 : 1024);
         u.small_last = env_int("IOPX_SMALL_LAST", 1, 0, 1);             // 1: one-word twiddle numerators at the last level where the basis allows
         u.scratch_mb = env_int("IOPX_SCRATCH_MB", 256, 1, 65536);
+        u.rs_comb_cap_log2 = env_int("IOPX_RS_COMB_CAP_LOG2", 22, 0, 30);  // per-coset combined shift terms up to 2^this entries, byte tables beyond
         u.p1_comb = env_int("IOPX_P1_COMB", 1, 0, 1);                   // 1: comb product for the phase-1 twists with a wave-uniform multiplier
         return u;
     }();
@@ -330,12 +331,16 @@ struct BfParams {
     // last level (pair bit 0) over a basis of one-word vectors ending in x^small_k: twiddle = numerator / x^small_k, the numerator the
     // XOR of ltab_small[block] and the shift numerators (rs_small[0] the shift, rs_small[1 + v] coset basis vector v); null = not used
     const uint32_t *ltab_small;
-    uint32_t rs_small[9];
+    uint32_t rs_small[25];
     int small_k;
     // the level above it (pair bit 1) over the standard basis: twiddle = two-word numerator / (x^(small1_k1 + small1_k2) (1 + x))
     const uint64_t *ltab_small1;
-    uint64_t rs_small1[9];
+    uint64_t rs_small1[25];
     int small1_k1, small1_k2;
+    // shift terms by byte of the (global) coset index, for transforms with too many cosets for rs_comb: entry [(g * 256 + byte) * d + l] is the
+    // sum of the terms of the set bits of byte g (plus the shift's own term in group 0); null = not used
+    const uint64_t *rs_tab;
+    int rs_tab_groups;
 };
 
 // twiddle of the block that contains in-coset index u at the level with pair bit pbit
@@ -347,8 +352,12 @@ __device__ __forceinline__ gf192 bf_twiddle(const BfParams &p, size_t coset, siz
         gf_add_to(tw, gf_load(p.rs_comb, coset * p.d + l));
         return tw;
     }
-    gf_add_to(tw, gf_load(p.rs, (size_t)l));
     const size_t gc = p.coset_base + coset;
+    if (p.rs_tab) {
+        for (int g = 0; g < p.rs_tab_groups; ++g) gf_add_to(tw, gf_load(p.rs_tab, ((size_t)g * 256 + ((gc >> (8 * g)) & 255)) * p.d + l));
+        return tw;
+    }
+    gf_add_to(tw, gf_load(p.rs, (size_t)l));
     for (int v = 0; v < p.nhi; ++v) {
         if ((gc >> v) & 1) gf_add_to(tw, gf_load(p.rs, (size_t)(1 + v) * p.d + l));
     }
@@ -410,6 +419,21 @@ __global__ void k_rs_combine(uint64_t *out, const uint64_t *rs, int d, int nhi, 
         gf192 acc = gf_load(rs, l);
         for (int v = 0; v < nhi; ++v) {
             if ((gc >> v) & 1) gf_add_to(acc, gf_load(rs, (size_t)(1 + v) * d + l));
+        }
+        gf_store(out, e, acc);
+    }
+}
+
+// rs_tab[(g * 256 + b) * d + l] = (g == 0 ? rs[l] : 0) + sum_{bit k of b, 8 g + k < nhi} rs[(1 + 8 g + k) * d + l]
+__global__ void k_rs_tables(uint64_t *out, const uint64_t *rs, int d, int nhi, size_t count)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t l = e % d, gb = e / d, b = gb & 255, g = gb >> 8;
+        gf192 acc = gf_zero();
+        if (g == 0) acc = gf_load(rs, l);
+        for (int k = 0; k < 8; ++k) {
+            const int v = (int)(8 * g) + k;
+            if (v < nhi && ((b >> k) & 1)) gf_add_to(acc, gf_load(rs, (size_t)(1 + v) * d + l));
         }
         gf_store(out, e, acc);
     }
@@ -752,13 +776,13 @@ struct AddPlan {
     // one-word basis ending in a power of x (the standard basis): numerators of the last level's twiddles, see BfParams::ltab_small
     DevBuf ltab_small;
     int small_k = -1;                           // basis[d-1] = x^small_k, or -1
-    uint32_t rs_small[9] = { 0 };               // per call, like rs
+    uint32_t rs_small[25] = { 0 };              // per call, like rs
     bool rs_small_ok = false;
     // ... and its second-to-last vector such that the next recursed basis ends in x^small1_e (1 + x) / x^(2 small_k) (the standard
     // basis): two-word numerators of the second-to-last level, see BfParams::ltab_small1
     DevBuf ltab_small1;
     int small1_e = -1;
-    uint64_t rs_small1[9] = { 0 };
+    uint64_t rs_small1[25] = { 0 };
 
     // recursed shift of an arbitrary element: GF(2)-linear in s (fft.tcc:93-95 / :153-154)
     void recursed_shifts(const hgf192 &s, hgf192 *out_by_unwind_level) const
@@ -914,7 +938,7 @@ static int get_plan(const uint64_t *basis, int d, AddPlan **out)
 static int upload_rs(AddPlan &pl, const hgf192 &shift, const uint64_t *hi_basis, int nhi)
 {
     const int d = pl.d;
-    pl.rs_small_ok = pl.small_k >= 0 && nhi <= 8 && one_word(shift);
+    pl.rs_small_ok = pl.small_k >= 0 && nhi <= 24 && one_word(shift);
     if (pl.rs_small_ok) {
         pl.rs_small[0] = (uint32_t)shift.w[0];
         for (int v = 0; v < nhi && pl.rs_small_ok; ++v) {
@@ -1074,12 +1098,24 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
     const uint64_t *rs_comb_ptr = shared_rs_comb;       // the caller's table starts at coset_begin
     if (shared_rs_comb) {
         comb_base = coset_begin; comb_count = cosets;
-    } else if (!INV && nhi > 0 && cosets * (size_t)d <= ((size_t)1 << 22)) {
+    } else if (!INV && nhi > 0 && cosets * (size_t)d <= ((size_t)1 << tuning().rs_comb_cap_log2)) {
         int rcc = rs_comb.alloc(cosets * d * 24);
         if (rcc != IOPX_OK) return rcc;
         comb_base = coset_begin; comb_count = cosets;
         { ProfScope ps_("k_rs_combine"); hipLaunchKernelGGL(k_rs_combine, dim3(grid_for(cosets * d, 256)), dim3(256), 0, stream(), rs_comb.u64(), (const uint64_t *)pl.rs.u64(), d, nhi, coset_begin, cosets * (size_t)d); }
         rs_comb_ptr = rs_comb.u64();
+    }
+    // too many cosets for that table (a short polynomial over a long domain: the prover's f_1v, 16 coefficients over 2^25 points): shift terms
+    // by byte of the coset index, 1 + nhi / 8 loads per twiddle instead of 1 + nhi conditional ones
+    TmpBuf rs_tab;
+    if (!INV && nhi > 0 && !comb_count) {
+        const int groups = (nhi + 7) / 8;
+        const size_t count = (size_t)groups * 256 * d;
+        int rct = rs_tab.alloc(count * 24);
+        if (rct != IOPX_OK) return rct;
+        { ProfScope ps_("k_rs_combine"); hipLaunchKernelGGL(k_rs_tables, dim3(grid_for(count, 256)), dim3(256), 0, stream(), rs_tab.u64(), (const uint64_t *)pl.rs.u64(), d, nhi, count); }
+        p.rs_tab = rs_tab.u64();
+        p.rs_tab_groups = groups;
     }
 
     // upper passes over pair bits [a_low, d): chunks of up to A bits, from the top (forward order)
@@ -1192,7 +1228,7 @@ static int run_phase2_fwd_batch(AddPlan &pl, const uint64_t *const *srcs, uint64
     const int d = pl.d;
     const size_t cosets = coset_count ? coset_count : ((size_t)1 << nhi);
     const bool batched_edge = tuning().comb && env_int("IOPX_EDGE_BATCH", 1, 0, 1) && batch >= 2 && batch <= 4 && nhi > 0 && d >= EDGE_TILE_BITS + 1 &&
-                              cosets * (size_t)d <= ((size_t)1 << 22);
+                              cosets * (size_t)d <= ((size_t)1 << tuning().rs_comb_cap_log2);
     if (!batched_edge) {
         for (size_t k = 0; k < batch; ++k) {
             const int rc = run_phase2<false>(pl, srcs[k], dsts[k], nhi, coset_begin, coset_count);
