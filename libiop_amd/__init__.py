@@ -466,6 +466,7 @@ class Library:
     # ---- transcript extraction (merkle_tree.tcc:242-336, bcs_prover.tcc:187-197) ----
     def get_set_membership_proof_dev(self, d_nodes, num_leaves, positions):
         """Auxiliary hashes of merkle_tree::get_set_membership_proof as a (count, 32) uint8 array; d_nodes on the device."""
+        self._refuse_inside_defer_window("get_set_membership_proof_dev")
         pos = (_sz * max(len(positions), 1))(*[int(p) for p in positions])
         cap = max(1, len(positions) * max(1, int(num_leaves).bit_length()))
         out = np.zeros((cap, 32), dtype=np.uint8)
@@ -474,15 +475,26 @@ class Library:
         return out[:cnt.value].copy()
 
     def defer_downloads_begin(self):
-        """Until defer_downloads_end(), iopx_query_responses_dev / iopx_merkle_membership_proof_dev only queue their read-backs (call them through
-        self.c with buffers that stay alive: the wrappers above copy their results at once)."""
+        """Until defer_downloads_end(), iopx_query_responses_dev / iopx_merkle_membership_proof_dev only queue their read-backs: call them
+        through self.c with buffers that stay alive until defer_downloads_end().  The array-returning wrappers get_set_membership_proof_dev /
+        query_responses_dev would hand back unfilled arrays and let _end() write into freed memory, so they raise inside a window."""
         self._check(self.c.iopx_defer_downloads_begin())
+        self._deferring = True
 
     def defer_downloads_end(self):
-        self._check(self.c.iopx_defer_downloads_end())
+        try:
+            self._check(self.c.iopx_defer_downloads_end())
+        finally:
+            self._deferring = False
+
+    def _refuse_inside_defer_window(self, what):
+        if getattr(self, "_deferring", False):
+            raise RuntimeError("%s returns its result at once and cannot run inside a defer_downloads window: call the C entry point "
+                               "with a buffer that outlives defer_downloads_end()" % what)
 
     def query_responses_dev(self, d_oracles, elem_bytes, n, positions):
         """values[p][k] = oracle_k[positions[p]] as a (positions, oracles, elem_bytes / 8) uint64 array."""
+        self._refuse_inside_defer_window("query_responses_dev")
         pos = (_sz * max(len(positions), 1))(*[int(p) for p in positions])
         ptrs = (_vp * len(d_oracles))(*d_oracles)
         out = np.zeros((len(positions), len(d_oracles), elem_bytes // 8), dtype=np.uint64)

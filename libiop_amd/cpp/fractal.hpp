@@ -123,6 +123,7 @@ struct fractal_snark_parameters {
     {
         typedef aurora_snark_parameters<FieldT> A;
         const std::size_t n = cs.num_constraints();
+        if (security_parameter != 128) throw std::invalid_argument("libiop_amd: security_parameter must be 128 (32-byte BLAKE2b digests)");
         if (!A::is_pow2(n)) throw std::invalid_argument("Fractal requires the number of constraints to be a power of two");
         if (n != cs.num_variables() + 1) throw std::invalid_argument("Fractal requires the matrices to be square");
         num_constraints_ = n; num_variables_ = cs.num_variables(); num_inputs_ = cs.num_inputs();

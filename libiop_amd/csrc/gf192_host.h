@@ -150,19 +150,20 @@ struct CachedSubspacePoly {
     }
 };
 
-inline CachedSubspacePoly &cached_subspace_poly(const uint64_t *basis, size_t dim)
+// Returned by value: a caller keeps its entry alive while another thread's 65th distinct basis clears the cache.
+inline std::shared_ptr<CachedSubspacePoly> cached_subspace_poly(const uint64_t *basis, size_t dim)
 {
     static std::mutex mu;
-    static std::map<std::vector<uint64_t>, std::unique_ptr<CachedSubspacePoly>> cache;
+    static std::map<std::vector<uint64_t>, std::shared_ptr<CachedSubspacePoly>> cache;
     std::vector<uint64_t> key(basis, basis + 3 * dim);
     key.push_back(dim);
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(key);
     if (it == cache.end()) {
         if (cache.size() >= 64) cache.clear();
-        it = cache.emplace(key, std::unique_ptr<CachedSubspacePoly>(new CachedSubspacePoly(basis, dim))).first;
+        it = cache.emplace(key, std::make_shared<CachedSubspacePoly>(basis, dim)).first;
     }
-    return *it->second;
+    return it->second;
 }
 
 

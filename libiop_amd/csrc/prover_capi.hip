@@ -17,6 +17,16 @@ namespace {
 
 using namespace libiop_amd;
 
+// The BCS layer of libiop_amd/cpp/iop.hpp works with 32-byte BLAKE2b digests — hashchain state, roots, paths, proof of work — which is
+// digest_len_bytes = 2 * security_parameter / 8 of the reference (blake2b.tcc:15, hash_enum.tcc) for security_parameter = 128 only; any
+// other value would run and return a transcript the reference does not produce, so it is refused.
+void require_supported_security(size_t security_parameter)
+{
+    if (security_parameter != 128)
+        throw std::invalid_argument("security_parameter " + std::to_string(security_parameter) + " is not supported: the native BCS layer uses 32-byte digests "
+                                    "(digest_len_bytes = 2 * security_parameter / 8 for security_parameter = 128)");
+}
+
 struct InstanceBase {
     virtual ~InstanceBase() {}
     virtual std::string prove(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) = 0;
@@ -46,6 +56,7 @@ struct Instance : InstanceBase {
     size_t num_constraints() const override { return cs.num_constraints(); }
     std::vector<std::string> fractal_index(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) override
     {
+        require_supported_security(security_parameter);
         const fractal_snark_parameters<F> params(cs, security_parameter, RS_extra_dimensions, FRI_localization_parameter);
         auto made = fractal_snark_indexer<F>(cs, params);
         index.reset(new bcs_prover_index<F>(std::move(made.first)));
@@ -54,6 +65,7 @@ struct Instance : InstanceBase {
     }
     std::string fractal_prove(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) override
     {
+        require_supported_security(security_parameter);
         if (!index || index_params[0] != security_parameter || index_params[1] != RS_extra_dimensions || index_params[2] != FRI_localization_parameter)
             throw std::logic_error("iopx_fractal_prove: no index for these parameters (call iopx_fractal_index first)");
         const fractal_snark_parameters<F> params(cs, security_parameter, RS_extra_dimensions, FRI_localization_parameter);
@@ -61,6 +73,7 @@ struct Instance : InstanceBase {
     }
     std::string prove(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) override
     {
+        require_supported_security(security_parameter);
         const aurora_snark_parameters<F> params(cs.num_constraints(), cs.num_variables(), cs.num_inputs(), security_parameter, RS_extra_dimensions,
                                                 FRI_localization_parameter);
         return aurora_snark_prover<F>(cs, primary, auxiliary, params, &d_assignment).serialize();
@@ -70,7 +83,14 @@ struct Instance : InstanceBase {
 template<typename F>
 InstanceBase *make_from_csr(const iopx_r1cs *r, const uint64_t *assignment)
 {
-    auto *inst = new Instance<F>();
+    for (int q = 0; q < 3; ++q) {                                // the offsets are trusted by every later matrix kernel: check them here
+        const uint64_t *rp = r->row_ptr[q];
+        if (rp[0] != 0) throw std::invalid_argument("iopx_aurora_instance_create: row_ptr must start at 0");
+        for (size_t i = 0; i < r->num_constraints; ++i)
+            if (rp[i + 1] < rp[i]) throw std::invalid_argument("iopx_aurora_instance_create: row_ptr must be non-decreasing");
+    }
+    std::unique_ptr<Instance<F>> holder(new Instance<F>());      // released to the caller only when fully built
+    Instance<F> *inst = holder.get();
     inst->cs.primary_input_size_ = r->num_inputs;
     inst->cs.auxiliary_input_size_ = r->num_variables - r->num_inputs;
     sparse_matrix<F> *M[3] = { &inst->cs.A, &inst->cs.B, &inst->cs.C };
@@ -88,19 +108,20 @@ InstanceBase *make_from_csr(const iopx_r1cs *r, const uint64_t *assignment)
     if (r->num_inputs) std::memcpy((void *)inst->primary.data(), assignment, r->num_inputs * 24);
     if (r->num_variables > r->num_inputs) std::memcpy((void *)inst->auxiliary.data(), assignment + 3 * r->num_inputs, (r->num_variables - r->num_inputs) * 24);
     inst->finish();
-    return inst;
+    return holder.release();
 }
 
 template<typename F>
 InstanceBase *make_example(size_t num_constraints, size_t num_inputs, size_t num_variables, uint64_t seed)
 {
-    auto *inst = new Instance<F>();
+    std::unique_ptr<Instance<F>> holder(new Instance<F>());
+    Instance<F> *inst = holder.get();
     r1cs_example<F> ex = generate_r1cs_example<F>(num_constraints, num_inputs, num_variables, seed);
     inst->cs = std::move(ex.constraint_system);
     inst->primary = std::move(ex.primary_input);
     inst->auxiliary = std::move(ex.auxiliary_input);
     inst->finish();
-    return inst;
+    return holder.release();
 }
 
 template<typename Fn>

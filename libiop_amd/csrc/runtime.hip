@@ -182,10 +182,11 @@ int download(void *dst_host, const void *src_dev, size_t bytes, bool deferrable)
     std::unique_lock<std::mutex> lk(g_stage_mu);
     if (deferrable && g_defer_on) {
         DeferChunk *c = nullptr;
-        for (auto &ch : g_defer_chunks) if (ch.cap - ch.used >= bytes) { c = &ch; break; }
+        const size_t need = (bytes + 63) & ~(size_t)63;          // slots are 64-byte aligned: capacity and occupancy count whole slots
+        for (auto &ch : g_defer_chunks) if (ch.used <= ch.cap && ch.cap - ch.used >= need) { c = &ch; break; }
         if (!c) {
             DeferChunk ch;
-            ch.cap = bytes < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes;
+            ch.cap = need < ((size_t)1 << 20) ? ((size_t)1 << 20) : need;
             ch.used = 0;
             hipError_t e = hipHostMalloc((void **)&ch.p, ch.cap, 0);
             if (e != hipSuccess) return fail(IOPX_ERR_RUNTIME, "hipHostMalloc(%zu) failed: %s", ch.cap, hipGetErrorString(e));
@@ -193,7 +194,7 @@ int download(void *dst_host, const void *src_dev, size_t bytes, bool deferrable)
             c = &g_defer_chunks.back();
         }
         char *slot = c->p + c->used;
-        c->used += (bytes + 63) & ~(size_t)63;
+        c->used += need;
         IOPX_HIP(copy_d2h(slot, src_dev, bytes, g_stream));
         g_defer_items.push_back({dst_host, slot, bytes});
         return IOPX_OK;

@@ -249,7 +249,8 @@ int iopx_rowcheck_gf192_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const ui
     const size_t h = constraint_dim, cosets = (size_t)1 << (m - h);
     // Z_H = prod_{v in H} (X - v): the subspace polynomial of span(basis[0..h)) built factor by factor, Z <- Z(X) (Z(X) + Z(b)),
     // shifted by its value at shift_H (vanishing_polynomial.tcc:373-395)
-    CachedSubspacePoly &lin = cached_subspace_poly(basis, h);
+    const std::shared_ptr<CachedSubspacePoly> lin_entry = cached_subspace_poly(basis, h);
+    CachedSubspacePoly &lin = *lin_entry;
     auto eval = [&](const hgf192 &x) { return lin.eval(x); };
     const hgf192 z_shift = eval(hgf192::from_words(constraint_shift));
     std::vector<hgf192> z(cosets);
@@ -317,7 +318,8 @@ int iopx_fz_gf192_dev(const uint64_t *d_fw, const uint64_t *d_f1v, const uint64_
     if (!d_fw || !d_f1v || !d_out || (m > 0 && !basis) || !shift || (input_dim > 0 && !input_basis) || !input_shift)
         return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
     if (input_dim > m || m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "Codeword domain must be bigger than the input variable domain.");
-    CachedSubspacePoly &lin = cached_subspace_poly(input_basis, input_dim);       // Z_I's linear part
+    const std::shared_ptr<CachedSubspacePoly> lin_entry = cached_subspace_poly(input_basis, input_dim);       // Z_I's linear part
+    CachedSubspacePoly &lin = *lin_entry;
     auto eval = [&](const hgf192 &x) { return lin.eval(x); };
     std::vector<hgf192> entries;
     entries.push_back(eval(hgf192::from_words(shift)) + eval(hgf192::from_words(input_shift)));    // Z_I(shift) = lin(shift) + lin(shift_I)
@@ -364,7 +366,8 @@ int iopx_sumcheck_g_gf192_dev(const uint64_t *d_f, const uint64_t *d_h, const ui
     if (!d_f || !d_h || !d_out || (m > 0 && !basis) || !shift || (summation_dim > 0 && !summation_basis) || !summation_shift || !claimed_sum)
         return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
     if (m > 40 || summation_dim > 63) return fail(IOPX_ERR_INVALID_ARGUMENT, "domain dimension too large");
-    CachedSubspacePoly &lin_cached = cached_subspace_poly(summation_basis, summation_dim);   // Z_H's linear part
+    const std::shared_ptr<CachedSubspacePoly> lin_entry = cached_subspace_poly(summation_basis, summation_dim);   // Z_H's linear part
+    CachedSubspacePoly &lin_cached = *lin_entry;
     const SubspacePoly &lin = lin_cached.poly;
     auto eval = [&](const hgf192 &x) { return lin_cached.eval(x); };
     if (lin.coeff[0].is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the summation domain's basis is linearly dependent");

@@ -17,6 +17,6 @@ def emu():
         if override:
             _emu = libiop_amd.Library(override)
         else:
-            subprocess.check_call(["make", "-s", "-C", _EMU_DIR])
+            subprocess.check_call(["make", "-s", "-j8", "-C", _EMU_DIR])
             _emu = libiop_amd.Library(os.path.join(_EMU_DIR, "libiopx_emu.so"))
     return _emu

@@ -1,0 +1,98 @@
+"""Worker of tests/test_gpu_sharded.py: one rank of a `python -m torch.distributed.run` job on the MI355X box (backend nccl = RCCL).
+Proves one instance with the multi-GPU operator sets and writes what rank 0 produced to --out as JSON (hex transcripts).
+
+  --impl python   libiop_amd/dist.py: ShardedDeviceOps (GF(2^192), contiguous cosets) / ResidueShardedDeviceOps (181-bit field, residue classes)
+  --impl native   iopx_aurora_prove_dist / iopx_fractal_{index,prove}_dist: the C++ prover inside the library, RCCL communicator through the C ABI
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--protocol", choices=["aurora", "fractal"], required=True)
+    ap.add_argument("--field", choices=["gf192", "edwards_Fr"], required=True)
+    ap.add_argument("--impl", choices=["python", "native"], default="python")
+    ap.add_argument("--log-n", type=int, required=True)
+    ap.add_argument("--inputs", type=int, required=True)
+    ap.add_argument("--seed", type=lambda v: int(v, 0), required=True)
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    os.environ.setdefault("NCCL_DEBUG", "WARN")
+
+    import torch
+    import torch.distributed as dist
+    import libiop_amd
+    from libiop_amd import aurora, domains, fractal, r1cs
+    from libiop_amd import dist as idist
+
+    rank, local_rank, world = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    lib = libiop_amd.lib()
+    lib.init(local_rank)
+    lib.set_stream(torch.cuda.current_stream().cuda_stream)
+    field = domains.GF192() if a.field == "gf192" else domains.EdwardsFr()
+    n = 1 << a.log_n
+    res = {"world": world, "impl": a.impl}
+    try:
+        if a.impl == "python":
+            ops = idist.sharded_ops(lib, torch, dev, field, idist.AuroraShard(dist, rank, world))
+            res["ops"] = type(ops).__name__
+            cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, n, a.inputs, n - 1, a.seed)
+            d_z = ops.upload(aurora.assignment_vector(field, primary, auxiliary))
+            if a.protocol == "aurora":
+                params = aurora.AuroraParameters(field, n, n - 1, a.inputs)
+                t = idist.sharded_aurora_snark_prover(ops, cs, primary, params, d_z).serialize()
+                roots = []
+            else:
+                params = fractal.FractalParameters(field, cs)
+                index, (roots, _) = idist.sharded_fractal_snark_indexer(ops, cs, params)
+                t = idist.sharded_fractal_snark_prover(ops, index, cs, primary, params, d_z).serialize()
+                roots = [bytes(r).hex() for r in roots]
+        else:
+            comm = lib.comm_create_rccl_from_torch(dist, rank, world, dev)
+            inst = lib.aurora_example_instance(0 if a.field == "gf192" else 1, n, a.inputs, n - 1, a.seed)
+            try:
+                if a.protocol == "aurora":
+                    t = lib.aurora_prove_dist(inst, comm)
+                    roots = []
+                else:
+                    roots = [r.hex() for r in lib.fractal_index_dist(inst, comm)]
+                    t = lib.fractal_prove_dist(inst, comm)
+            finally:
+                lib.aurora_instance_free(inst)
+                lib.comm_destroy(comm)
+        torch.cuda.synchronize()
+        # every rank must hold the same transcript: compare digests across the ranks
+        h = torch.tensor(list(hashlib.blake2b(t, digest_size=32).digest()), dtype=torch.uint8, device=dev)
+        hs = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(hs, h)
+        res["ranks_agree"] = all(bool(torch.equal(x, h)) for x in hs)
+        if rank == 0:
+            # the single-GPU native prover on the same seeded instance, for sizes at which the oracle prover takes minutes
+            inst = lib.aurora_example_instance(0 if a.field == "gf192" else 1, n, a.inputs, n - 1, a.seed)
+            try:
+                if a.protocol == "aurora":
+                    single = lib.aurora_prove(inst)
+                else:
+                    lib.fractal_index(inst)
+                    single = lib.fractal_prove(inst)
+            finally:
+                lib.aurora_instance_free(inst)
+            res.update({"transcript": t.hex(), "index_roots": roots, "equals_single_gpu_native_prover": single == t})
+            with open(a.out, "w") as f:
+                json.dump(res, f)
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -369,6 +369,7 @@ def test_membership_proofs(gpu):
     tc.check_all_subsets_of_small_tree(gpu)
     tc.check_empty_and_errors(gpu)
     tc.check_deferred_downloads(gpu)
+    tc.check_large_odd_deferred_downloads(gpu)
 
 
 def test_query_responses(gpu):

@@ -1,0 +1,74 @@
+"""The multi-GPU provers on the MI355X box under RCCL (`torch.distributed.run`, backend nccl; one rank per visible GPU — one on the
+driver's box — and, when the box has more, every power of two up to the visible count).  Each case runs tests/gpu_sharded_worker.py in
+child processes and compares rank 0's transcript (every rank's digest is cross-checked inside the worker) with
+
+  * oracle.aurora_prove / oracle.fractal_prove byte for byte at sizes the CPU oracle finishes in seconds, and
+  * the single-GPU native prover (itself oracle-equal up to 2^14, tests/test_gpu_fullsize.py) at 2^16.
+
+Operator sets: libiop_amd/dist.py (ShardedDeviceOps over GF(2^192): contiguous cosets; ResidueShardedDeviceOps over the 181-bit field:
+residue classes) and the native ones inside the library (libiop_amd/cpp/dist.hpp; RCCL communicator created through the C ABI)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "gpu_sharded_worker.py")
+
+
+def _worlds():
+    import torch
+    n = torch.cuda.device_count()          # counting devices does not initialise the GPU in this process
+    out, w = [], 1
+    while w <= max(n, 1):
+        out.append(w)
+        w *= 2
+    return out
+
+
+def _run(world, protocol, field, impl, log_n, inputs, seed, tmp_path):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = os.path.join(str(tmp_path), "w%d_%s_%s_%s_%d.json" % (world, protocol, field, impl, log_n))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           WORKER, "--protocol", protocol, "--field", field, "--impl", impl, "--log-n", str(log_n), "--inputs", str(inputs), "--seed", hex(seed), "--out", out]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (cmd, r.stdout[-2000:], r.stderr[-6000:])
+    with open(out) as f:
+        res = json.load(f)
+    assert res["world"] == world and res["ranks_agree"], res
+    return res
+
+
+@pytest.mark.parametrize("impl", ["python", "native"])
+@pytest.mark.parametrize("protocol,field,log_n,inputs,seed", [("aurora", "gf192", 12, 15, 0x2204), ("fractal", "edwards_Fr", 12, 0, 0x2205),
+                                                              ("fractal", "gf192", 10, 15, 0x2205), ("aurora", "edwards_Fr", 11, 15, 0x2204)])
+def test_sharded_prover_under_rccl_equals_the_oracle(impl, protocol, field, log_n, inputs, seed, tmp_path):
+    code = oracle.FIELD_GF192 if field == "gf192" else oracle.FIELD_EDWARDS
+    if protocol == "aurora":
+        ref, ref_roots = oracle.aurora_prove(code, log_n, inputs, seed), []
+    else:
+        ref, ref_roots = oracle.fractal_prove(code, log_n, inputs, seed)
+    for world in _worlds():
+        res = _run(world, protocol, field, impl, log_n, inputs, seed, tmp_path)
+        assert bytes.fromhex(res["transcript"]) == ref, (impl, world, "transcript differs from the oracle prover's")
+        assert [bytes.fromhex(r) for r in res["index_roots"]] == ref_roots, (impl, world)
+        assert res["equals_single_gpu_native_prover"]
+        if impl == "python":
+            assert res["ops"] == ("ShardedDeviceOps" if field == "gf192" else "ResidueShardedDeviceOps")
+
+
+@pytest.mark.parametrize("impl", ["python", "native"])
+def test_sharded_aurora_2p16_equals_the_single_gpu_prover(impl, tmp_path):
+    for world in _worlds():
+        res = _run(world, "aurora", "gf192", impl, 16, 15, 0x2204, tmp_path)
+        assert res["equals_single_gpu_native_prover"], (impl, world)

@@ -23,6 +23,10 @@ def test_deferred_downloads():
     tc.check_deferred_downloads(emu())
 
 
+def test_large_odd_deferred_downloads():
+    tc.check_large_odd_deferred_downloads(emu())
+
+
 def test_query_responses():
     tc.check_query_responses(emu(), 256, 3, 5)
 

@@ -78,6 +78,10 @@ def check_deferred_downloads(lib):
         ptrs = (_vp * 2)(*d_or)
         lib._check(lib.c.iopx_query_responses_dev(ptrs, 2, 24, L * cs, qp, len(positions), _vp(resp.ctypes.data)))
         assert cnt.value == want_proof.shape[0]                                     # the count is known at once
+        with pytest.raises(RuntimeError):                                           # the array-returning wrappers refuse a window
+            lib.query_responses_dev(d_or, 24, L * cs, positions)
+        with pytest.raises(RuntimeError):
+            lib.get_set_membership_proof_dev(d, L, leaf_positions)
         assert not proof.any() and not resp.any()                                   # nothing delivered yet
         root = np.zeros(32, dtype=np.uint8)                                         # an ordinary read-back inside the window is immediate
         lib.d2h(root, d)
@@ -90,6 +94,36 @@ def check_deferred_downloads(lib):
         lib.free(d)
         for ptr in d_or:
             lib.free(ptr)
+
+
+def check_large_odd_deferred_downloads(lib):
+    """A deferred read-back above 1 MiB whose size is not a multiple of 64 gets a pinned chunk of its own; the next deferred read-back of the
+    window must not be placed past that chunk's end (the occupancy is counted in whole 64-byte slots)."""
+    import ctypes
+    n = 1 << 16
+    oracle_ = rand_elems(9, n, 3)
+    d = lib.malloc(oracle_.nbytes)
+    try:
+        lib.h2d(d, oracle_)
+        rng = np.random.Generator(np.random.PCG64(4))
+        big = [int(v) for v in rng.integers(0, n, size=43700)]                      # 43700 x 24 = 1,048,800 bytes: above 1 MiB, = 8 mod 64
+        small = [int(v) for v in rng.integers(0, n, size=1000)]
+        _sz, _vp = ctypes.c_size_t, ctypes.c_void_p
+        ptrs = (_vp * 1)(d)
+        outs = []
+        lib.defer_downloads_begin()
+        try:
+            for pos in (big, small, big[:5000], small):
+                out = np.zeros((len(pos), 1, 3), dtype=np.uint64)
+                qp = (_sz * len(pos))(*pos)
+                lib._check(lib.c.iopx_query_responses_dev(ptrs, 1, 24, n, qp, len(pos), _vp(out.ctypes.data)))
+                outs.append((pos, out))
+        finally:
+            lib.defer_downloads_end()
+        for pos, out in outs:
+            assert np.array_equal(out[:, 0, :], oracle_[pos])
+    finally:
+        lib.free(d)
 
 
 def check_empty_and_errors(lib):
