@@ -15,7 +15,8 @@ prover's wall-clock seconds: prover seconds and FFT field-ops/s in one number; `
 The roofline line is for the dominant kernel of THAT run; config.secondary holds configs[1] (one 2^22 FFT) and
 config.secondary_fractal configs[4]'s Fractal prover on this GPU.
 
-N > 1 (one process per GPU): see libiop_amd/dist.py — the proof is sharded by contiguous cosets; "strong" scaling.
+N > 1 (one process per GPU): the SAME native prover, iopx_aurora_prove_dist, with every codeword-domain vector split over the ranks by
+contiguous cosets (libiop_amd/cpp/dist.hpp) and an RCCL communicator created through the C ABI; "strong" scaling: one proof.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python bench.py --gpus N ...                      (starts torch.distributed.run itself, as a child process, when RANK is unset)
@@ -182,9 +183,12 @@ def main():
     lib.set_stream(torch.cuda.current_stream().cuda_stream)
 
     field = domains.GF192()
-    if world > 1 or args.force_sharded:
+    sharded = world > 1 or args.force_sharded
+    comm = None
+    if sharded:
         from libiop_amd import dist as idist
-        ops = idist.ShardedDeviceOps(lib, torch, dev, field, idist.AuroraShard(dist, rank, world))
+        ops = idist.ShardedDeviceOps(lib, torch, dev, field, idist.AuroraShard(dist, rank, world))      # the Python prover's operator set: cross-check only
+        comm = lib.comm_create_rccl_from_torch(dist, rank, world, dev)                                  # the native prover's RCCL communicator
     else:
         ops = domains.DeviceOps(lib, torch, dev, field)
     n = 1 << args.log_n
@@ -193,12 +197,10 @@ def main():
     d_assignment = ops.upload(aurora.assignment_vector(field, primary, auxiliary))      # resident in HBM before the timed region
     torch.cuda.synchronize()
 
-    sharded = world > 1 or args.force_sharded
-    native = None
-    if not sharded:
-        # N = 1: the native prover behind the C ABI (iopx_aurora_prove: libiop_amd/cpp/aurora.hpp inside the library) on its own copy of
-        # the same seeded instance; the Python prover (libiop_amd/aurora.py) proves it once below as a cross-check of the transcript bytes
-        native = lib.aurora_example_instance(0, n, 15, n - 1, SEED)
+    # Every N: the native prover behind the C ABI (libiop_amd/cpp/aurora.hpp inside the library; iopx_aurora_prove on one GPU,
+    # iopx_aurora_prove_dist over the communicator otherwise — the same code, libiop_amd/cpp/dist.hpp) on its own copy of the same seeded
+    # instance; the Python prover (libiop_amd/aurora.py) proves it once below as a cross-check of the transcript bytes
+    native = lib.aurora_example_instance(0, n, 15, n - 1, SEED)
 
     class _Bytes:
         def __init__(self, b):
@@ -207,10 +209,10 @@ def main():
         def serialize(self):
             return self.b
 
-    def step():          # with ShardedDeviceOps the Python prover runs block-distributed (libiop_amd/dist.py)
-        if native is not None:
-            return _Bytes(lib.aurora_prove(native, 128, params.RS_extra_dimensions, 2))
-        return aurora.aurora_snark_prover(ops, cs, primary, None, params, d_assignment=d_assignment)
+    def step():
+        if comm is not None:
+            return _Bytes(lib.aurora_prove_dist(native, comm, 128, params.RS_extra_dimensions, 2))
+        return _Bytes(lib.aurora_prove(native, 128, params.RS_extra_dimensions, 2))
 
     transcript = None
     import gc
@@ -236,14 +238,16 @@ def main():
         dt = float(t.item())
     prover_s = dt / args.steps
 
-    if native is not None:
-        check = aurora.aurora_snark_prover(ops, cs, primary, None, params, d_assignment=d_assignment).serialize()
-        assert check == transcript.serialize(), "native prover's transcript differs from the Python prover's"
+    # the second, independently written prover (libiop_amd/aurora.py; over libiop_amd/dist.py's operators when sharded) on the same instance
+    check = aurora.aurora_snark_prover(ops, cs, primary, None, params, d_assignment=d_assignment).serialize()
+    assert check == transcript.serialize(), "native prover's transcript differs from the Python prover's"
 
     # per-kernel durations of one more proof, live, with HIP events on the stream the kernels are launched on
+    lib.comm_stats(reset=True)
     lib.profile_begin()
     step()
     prof = lib.profile_report()
+    comm_calls, comm_bytes = lib.comm_stats()
     dom_name, (dom_cnt, dom_ms, dom_bytes) = max(prof.items(), key=lambda kv: kv[1][1])
     dom_avg_s = dom_ms / dom_cnt / 1e3
     alg_bytes_per_launch = dom_bytes / dom_cnt if dom_bytes else None
@@ -261,6 +265,7 @@ def main():
     # ALU ceiling: the rate measured live in this run (field products of the launches / their HIP-event time) against the VALU-issue
     # ceiling of the kernel's instruction mix (tools/alu_model.py: ISA histogram x per-class cycles measured by tools/ubench/valu_rates)
     products = getattr(lib, "last_profile_products", {})
+    device_products = sum(products.values())          # every field multiplication the profiled proof's kernels reported (this rank)
     model = alu_model()
     alu = {}
     if model:
@@ -282,6 +287,8 @@ def main():
         "metric": "aurora_prover_fft_field_ops_per_s",
         "value": value,
         "unit": "field-ops/s",
+        "unit_note": "numerator = the REFERENCE's operation count for the proof's transforms (eight zero-padded 2^25-point FFTs, ...: config.ref_fft_*), not "
+                     "the device's own work: the device evaluates the same codewords by cosets with far fewer products (config.device_field_products_per_proof)",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -296,15 +303,20 @@ def main():
                         "security 128, RS_extra_dimensions 5, FRI localization 2, non-zk, BLAKE2b: one complete proof per step, "
                         "instance and witness resident in HBM" % (args.log_n, SEED),
             "log_n": args.log_n, "field": "gf192", "prover_s": prover_s,
-            "prover": "native: iopx_aurora_prove (libiop_amd/cpp/aurora.hpp behind the C ABI); transcript equal to libiop_amd/aurora.py's" if native is not None
-                      else "libiop_amd/aurora.py over libiop_amd/dist.py's sharded operators",
+            "prover": ("native: iopx_aurora_prove (libiop_amd/cpp/aurora.hpp behind the C ABI); transcript equal to libiop_amd/aurora.py's" if comm is None else
+                       "native: iopx_aurora_prove_dist (libiop_amd/cpp/aurora.hpp + dist.hpp behind the C ABI, RCCL communicator of %d rank(s)); transcript equal to "
+                       "libiop_amd/aurora.py's over libiop_amd/dist.py's operators" % world),
+            "device_field_products_per_proof": device_products if world == 1 else None,
+            "device_field_products_per_proof_this_rank": device_products,
+            "device_products_per_s": device_products * world / prover_s if device_products else None,
+            "collectives_per_proof": comm_calls, "collective_payload_bytes_per_proof_this_rank": comm_bytes,
             "codeword_domain_dim": params.codeword_domain_dim, "localization": params.localization_parameters,
             "fri_query_repetitions": params.fri_query_repetitions, "pow_bits": params.pow_bits,
             "argument_bytes": len(transcript.serialize()) if transcript is not None else None,
             "ref_fft_mults_per_proof": mults, "ref_fft_adds_per_proof": adds,
             "fft_stage": {"ms": fft_ms, "field_ops_per_s": (mults + adds) / (fft_ms / 1e3) if fft_ms else None,
                           "note": "transform kernels only (k_phase1, k_bfly_upper, k_bfly_edge, padding): HIP-event time inside one proof"},
-            "multi_gpu": "one proof sharded over %d ranks by contiguous cosets of every codeword (libiop_amd/dist.py)" % world if world > 1
+            "multi_gpu": "one proof sharded over %d ranks by contiguous cosets of every codeword (libiop_amd/cpp/dist.hpp)" % world if world > 1
                          else "single GPU",
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -417,10 +429,12 @@ def main():
                           "bound on what a multi-threaded port could reach)" % (ac["log_n"], ac["seconds_for_one_proof_per_core"])}
     if rank == 0:
         print(json.dumps(out))
-    if args.force_sharded and rank == 0:          # the sharded operator set must produce the single-GPU prover's transcript
-        plain = aurora.aurora_snark_prover(domains.DeviceOps(lib, torch, dev, field), cs, primary, None, params, d_assignment=d_assignment)
-        assert plain.serialize() == transcript.serialize(), "sharded transcript differs from the single-GPU transcript"
+    if args.force_sharded and rank == 0 and world == 1:          # the distributed code path must produce the single-GPU prover's transcript
+        assert lib.aurora_prove(native, 128, params.RS_extra_dimensions, 2) == transcript.serialize(), "sharded transcript differs from the single-GPU transcript"
         print("force-sharded: transcript equals the single-GPU prover's", file=sys.stderr)
+    lib.aurora_instance_free(native)
+    if comm is not None:
+        lib.comm_destroy(comm)
     if world > 1 or args.force_sharded:
         dist.destroy_process_group()
 

@@ -59,6 +59,8 @@ int         iopx_malloc(void **dptr, size_t bytes);
 int         iopx_free(void *dptr);
 int         iopx_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int         iopx_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+/* iopx_memcpy_d2h that takes part in an iopx_defer_downloads window (below): queued there, delivered by iopx_defer_downloads_end */
+int         iopx_memcpy_d2h_deferrable(void *dst_host, const void *src_dev, size_t bytes);
 /* Transcript extraction reads back two small results per Merkle tree (iopx_query_responses_dev, iopx_merkle_membership_proof_dev).  Between
  * _begin and _end those calls only queue their read-backs; _end drains the stream once and fills every host buffer handed to them in
  * between (the buffers must stay alive until then).  Everything else behaves as usual inside the window. */
@@ -483,6 +485,65 @@ int iopx_fractal_prove(iopx_aurora_instance *instance, size_t security_parameter
                        uint8_t **transcript, size_t *transcript_bytes);
 int iopx_aurora_instance_free(iopx_aurora_instance *instance);
 int iopx_host_free(void *p);
+
+/* ---- multi-GPU: one process per GPU, one communicator per process -------------------------------------
+ * The reference prover is a single process (snark/aurora_snark.tcc:119-146); its counterpart over N GPUs runs the same call in N
+ * processes, each holding 1/N of every codeword-domain vector: contiguous cosets of the systematic sub-domain for affine subspaces
+ * (subspace.tcc:73-91: FRI cosets and Merkle leaves are contiguous runs), residue classes for multiplicative cosets (subgroup.tcc:175-197:
+ * coset {j + k n/c} lies in one residue class).  What crosses GPUs is exchanged through an iopx_comm:
+ *   iopx_comm_create_rccl        RCCL over xGMI, created from a 128-byte ncclUniqueId that rank 0 obtains with iopx_comm_rccl_unique_id and
+ *                                hands to the other ranks by whatever the host program has (torch.distributed store, MPI, a file);
+ *                                collectives take DEVICE pointers and are enqueued on the library's stream (no host synchronisation).
+ *                                librccl is resolved at run time (the copy already loaded into the process when there is one).
+ *   iopx_comm_create_callbacks   the host program's own transport (it already holds a communicator; or the CPU test-suite's gloo group):
+ *                                every collective is forwarded to the callbacks with the pointers as given and the library's stream.
+ * Every collective below is collective over all ranks of the communicator and must be called in the same order on every rank. */
+typedef struct iopx_comm iopx_comm;
+#define IOPX_COMM_UNIQUE_ID_BYTES 128
+#define IOPX_COMM_SUM 0        /* wrapping sum of uint64 words */
+#define IOPX_COMM_MIN 1        /* minimum of uint64 words */
+typedef struct iopx_comm_callbacks {
+    void *user;
+    /* recv[r * bytes .. (r+1) * bytes) = rank r's send[0 .. bytes) */
+    int (*all_gather)(void *user, const void *send, void *recv, size_t bytes_per_rank, void *hip_stream);
+    /* in place over `count` uint64 words */
+    int (*all_reduce_u64)(void *user, void *buf, size_t count, int op, void *hip_stream);
+    int (*broadcast)(void *user, void *buf, size_t bytes, int root, void *hip_stream);
+    /* recv[r * bytes ..) = rank r's send[my_rank * bytes ..) */
+    int (*all_to_all)(void *user, const void *send, void *recv, size_t bytes_per_rank, void *hip_stream);
+    /* symmetric exchange with one peer (the peer calls it with this rank as its peer) */
+    int (*sendrecv)(void *user, const void *send, void *recv, size_t bytes, int peer, void *hip_stream);
+} iopx_comm_callbacks;
+int iopx_comm_rccl_unique_id(uint8_t *unique_id /* IOPX_COMM_UNIQUE_ID_BYTES */);
+int iopx_comm_create_rccl(int rank, int world, const uint8_t *unique_id, iopx_comm **out);
+int iopx_comm_create_callbacks(int rank, int world, const iopx_comm_callbacks *callbacks, iopx_comm **out);
+int iopx_comm_destroy(iopx_comm *comm);
+int iopx_comm_rank(const iopx_comm *comm, int *rank, int *world);
+int iopx_comm_all_gather_dev(iopx_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank);
+int iopx_comm_all_reduce_u64_dev(iopx_comm *comm, void *d_buf, size_t count, int op);
+int iopx_comm_broadcast_dev(iopx_comm *comm, void *d_buf, size_t bytes, int root);
+int iopx_comm_all_to_all_dev(iopx_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank);
+int iopx_comm_sendrecv_dev(iopx_comm *comm, const void *d_send, void *d_recv, size_t bytes, int peer);
+/* collectives issued and payload bytes sent by this rank through any communicator since the last reset (reset != 0 clears them) */
+int iopx_comm_stats(uint64_t *num_collectives, uint64_t *bytes, int reset);
+/* d_dst[(i * parts + r) * elem_bytes ..] = d_src[(r * count + i) * elem_bytes ..]: `parts` residue classes stored back to back
+ * (an all-gather's output) -> natural order */
+int iopx_interleave_dev(const void *d_src, size_t parts, size_t count, size_t elem_bytes, void *d_dst);
+/* d_out[(dst_row[i] * num_srcs + k) * elem_bytes ..] = d_srcs[k][src_index[i] * elem_bytes ..] for i < count: the rows of a query answer
+ * or an authentication path this rank owns, placed into a zeroed buffer that an all-reduce completes (every row has one owner).
+ * src_index, dst_row: host arrays. */
+int iopx_gather_rows_dev(const void *const *d_srcs, size_t num_srcs, size_t elem_bytes, const uint64_t *src_index, const uint64_t *dst_row,
+                         size_t count, void *d_out);
+/* The provers with every codeword-domain vector distributed over the ranks of `comm` (libiop_amd/cpp/dist.hpp): every rank calls with
+ * the same instance and parameters and receives the same transcript, byte-identical to the single-GPU call's.  comm == NULL or a
+ * one-rank communicator is the single-GPU prover (through the same code path).  iopx_fractal_index_dist leaves this rank's part of
+ * the index inside the instance. */
+int iopx_aurora_prove_dist(iopx_aurora_instance *instance, iopx_comm *comm, size_t security_parameter, size_t RS_extra_dimensions,
+                           size_t FRI_localization_parameter, uint8_t **transcript, size_t *transcript_bytes);
+int iopx_fractal_index_dist(iopx_aurora_instance *instance, iopx_comm *comm, size_t security_parameter, size_t RS_extra_dimensions,
+                            size_t FRI_localization_parameter, uint8_t *index_roots, size_t root_capacity, size_t *num_roots);
+int iopx_fractal_prove_dist(iopx_aurora_instance *instance, iopx_comm *comm, size_t security_parameter, size_t RS_extra_dimensions,
+                            size_t FRI_localization_parameter, uint8_t **transcript, size_t *transcript_bytes);
 
 #ifdef __cplusplus
 }

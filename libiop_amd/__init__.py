@@ -58,6 +58,9 @@ EXPORTED_SYMBOLS = [
     "iopx_fp3_from_uint", "iopx_fp3_modulus", "iopx_pow_search_blake2b", "iopx_pow_candidate_blake2b",
     "iopx_aurora_instance_create", "iopx_aurora_example_instance_create", "iopx_aurora_prove", "iopx_aurora_instance_free", "iopx_host_free",
     "iopx_fractal_index", "iopx_fractal_prove",
+    "iopx_memcpy_d2h_deferrable", "iopx_comm_rccl_unique_id", "iopx_comm_create_rccl", "iopx_comm_create_callbacks", "iopx_comm_destroy", "iopx_comm_rank",
+    "iopx_comm_all_gather_dev", "iopx_comm_all_reduce_u64_dev", "iopx_comm_broadcast_dev", "iopx_comm_all_to_all_dev", "iopx_comm_sendrecv_dev", "iopx_comm_stats",
+    "iopx_interleave_dev", "iopx_gather_rows_dev", "iopx_aurora_prove_dist", "iopx_fractal_index_dist", "iopx_fractal_prove_dist",
 ]
 
 
@@ -666,6 +669,145 @@ class Library:
         finally:
             self.c.iopx_host_free.argtypes = [ctypes.c_void_p]
             self.c.iopx_host_free(buf)
+
+    # ---- multi-GPU: the communicator of include/libiop_amd.h ("multi-GPU") and the provers distributed over it ----
+    def comm_rccl_unique_id(self):
+        """The 128-byte ncclUniqueId rank 0 creates and hands to the other ranks."""
+        buf = (ctypes.c_uint8 * 128)()
+        self.c.iopx_comm_rccl_unique_id.argtypes = [ctypes.c_void_p]
+        self._check(self.c.iopx_comm_rccl_unique_id(ctypes.addressof(buf)))
+        return bytes(buf)
+
+    def comm_create_rccl(self, rank, world, unique_id):
+        h = ctypes.c_void_p()
+        uid = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self.c.iopx_comm_create_rccl.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        self._check(self.c.iopx_comm_create_rccl(int(rank), int(world), ctypes.addressof(uid), ctypes.byref(h)))
+        return h
+
+    def comm_create_rccl_from_torch(self, dist, rank, world, device):
+        """One RCCL communicator over the ranks of an initialised torch.distributed group: rank 0's unique id travels through the group
+        (a byte tensor broadcast), the collectives of the provers then go through the library's own communicator on the library's stream."""
+        import torch
+        uid = torch.zeros(128, dtype=torch.uint8, device=device)
+        if rank == 0:
+            uid = torch.tensor(list(self.comm_rccl_unique_id()), dtype=torch.uint8, device=device)
+        if world > 1:
+            dist.broadcast(uid, src=0)
+        return self.comm_create_rccl(rank, world, bytes(uid.cpu().numpy().tobytes()))
+
+    def comm_create_torch_callbacks(self, dist, rank, world):
+        """A communicator whose collectives are forwarded to an initialised torch.distributed group through callbacks on HOST pointers:
+        what the CPU test-suite uses (gloo group, kernels compiled for the CPU).  The returned handle keeps the callbacks alive."""
+        import torch
+        _i, _vp_, _szt = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+
+        def view(ptr, nbytes):
+            return torch.from_numpy(np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(ptr)))
+
+        def all_gather(user, send, recv, nbytes, stream):
+            parts = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(parts, view(send, nbytes).clone())
+            view(recv, nbytes * world).copy_(torch.cat(parts))
+            return 0
+
+        def all_reduce_u64(user, buf, count, op, stream):
+            t = view(buf, count * 8).view(torch.int64)
+            if op == 0:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)                # wrapping int64 sum = wrapping uint64 sum
+            else:                                                       # unsigned minimum through the order-preserving map x -> x ^ 2^63
+                flipped = t ^ torch.tensor(-(1 << 63), dtype=torch.int64)
+                dist.all_reduce(flipped, op=dist.ReduceOp.MIN)
+                t.copy_(flipped ^ torch.tensor(-(1 << 63), dtype=torch.int64))
+            return 0
+
+        def broadcast(user, buf, nbytes, root, stream):
+            dist.broadcast(view(buf, nbytes), src=root)
+            return 0
+
+        def all_to_all(user, send, recv, nbytes, stream):
+            out = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+            src = view(send, nbytes * world)
+            ins = [src[q * nbytes:(q + 1) * nbytes].clone() for q in range(world)]
+            if dist.get_backend() == "gloo":                            # gloo has no all_to_all for CPU tensors in every build: gather per destination
+                for q in range(world):
+                    got = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)] if rank == q else None
+                    dist.gather(ins[q], got, dst=q)
+                    if rank == q:
+                        out = got
+            else:
+                dist.all_to_all(out, ins)
+            view(recv, nbytes * world).copy_(torch.cat(out))
+            return 0
+
+        def sendrecv(user, send, recv, nbytes, peer, stream):
+            r = torch.empty(nbytes, dtype=torch.uint8)
+            ops = [dist.P2POp(dist.isend, view(send, nbytes).clone(), peer), dist.P2POp(dist.irecv, r, peer)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            view(recv, nbytes).copy_(r)
+            return 0
+
+        def guard(fn):
+            def wrapped(*a):
+                try:
+                    return fn(*a)
+                except Exception:                                       # an exception must not unwind through the C caller
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return wrapped
+
+        types = [ctypes.CFUNCTYPE(_i, _vp_, _vp_, _vp_, _szt, _vp_), ctypes.CFUNCTYPE(_i, _vp_, _vp_, _szt, _i, _vp_), ctypes.CFUNCTYPE(_i, _vp_, _vp_, _szt, _i, _vp_),
+                 ctypes.CFUNCTYPE(_i, _vp_, _vp_, _vp_, _szt, _vp_), ctypes.CFUNCTYPE(_i, _vp_, _vp_, _vp_, _szt, _i, _vp_)]
+        fns = [t(guard(f)) for t, f in zip(types, (all_gather, all_reduce_u64, broadcast, all_to_all, sendrecv))]
+
+        class Callbacks(ctypes.Structure):
+            _fields_ = [("user", _vp_), ("all_gather", types[0]), ("all_reduce_u64", types[1]), ("broadcast", types[2]), ("all_to_all", types[3]), ("sendrecv", types[4])]
+
+        cbs = Callbacks(None, *fns)
+        h = ctypes.c_void_p()
+        self.c.iopx_comm_create_callbacks.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        self._check(self.c.iopx_comm_create_callbacks(int(rank), int(world), ctypes.addressof(cbs), ctypes.byref(h)))
+        self._comm_keepalive = getattr(self, "_comm_keepalive", []) + [(cbs, fns)]
+        return h
+
+    def comm_destroy(self, comm):
+        self.c.iopx_comm_destroy.argtypes = [ctypes.c_void_p]
+        self._check(self.c.iopx_comm_destroy(comm))
+
+    def comm_stats(self, reset=False):
+        """(collectives issued, payload bytes sent by this rank) since the last reset."""
+        n, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self.c.iopx_comm_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+        self._check(self.c.iopx_comm_stats(ctypes.byref(n), ctypes.byref(b), 1 if reset else 0))
+        return int(n.value), int(b.value)
+
+    def _transcript_call(self, fn, *args):
+        buf, n = ctypes.c_void_p(), _sz(0)
+        self._check(fn(*args, ctypes.byref(buf), ctypes.byref(n)))
+        try:
+            return ctypes.string_at(buf, n.value)
+        finally:
+            self.c.iopx_host_free.argtypes = [ctypes.c_void_p]
+            self.c.iopx_host_free(buf)
+
+    def aurora_prove_dist(self, instance, comm, security_parameter=128, RS_extra_dimensions=5, FRI_localization_parameter=2):
+        """aurora_snark_prover with the codeword-domain vectors distributed over `comm`: every rank calls it and gets the same transcript."""
+        self.c.iopx_aurora_prove_dist.argtypes = [ctypes.c_void_p, ctypes.c_void_p, _sz, _sz, _sz, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_sz)]
+        return self._transcript_call(self.c.iopx_aurora_prove_dist, instance, comm, int(security_parameter), int(RS_extra_dimensions), int(FRI_localization_parameter))
+
+    def fractal_index_dist(self, instance, comm, security_parameter=128, RS_extra_dimensions=3, FRI_localization_parameter=2):
+        roots = (ctypes.c_uint8 * (32 * 8))()
+        n = _sz(0)
+        self.c.iopx_fractal_index_dist.argtypes = [ctypes.c_void_p, ctypes.c_void_p, _sz, _sz, _sz, ctypes.c_void_p, _sz, ctypes.POINTER(_sz)]
+        self._check(self.c.iopx_fractal_index_dist(instance, comm, int(security_parameter), int(RS_extra_dimensions), int(FRI_localization_parameter),
+                                                   ctypes.addressof(roots), 8, ctypes.byref(n)))
+        return [bytes(roots[32 * i:32 * (i + 1)]) for i in range(n.value)]
+
+    def fractal_prove_dist(self, instance, comm, security_parameter=128, RS_extra_dimensions=3, FRI_localization_parameter=2):
+        self.c.iopx_fractal_prove_dist.argtypes = [ctypes.c_void_p, ctypes.c_void_p, _sz, _sz, _sz, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_sz)]
+        return self._transcript_call(self.c.iopx_fractal_prove_dist, instance, comm, int(security_parameter), int(RS_extra_dimensions), int(FRI_localization_parameter))
 
     def aurora_instance_free(self, instance):
         self.c.iopx_aurora_instance_free.argtypes = [ctypes.c_void_p]

@@ -31,6 +31,18 @@ template<typename FieldT> inline bool additive(const field_subset<FieldT> &D) { 
 template<typename FieldT>
 device_vector<FieldT> FFT(const device_vector<FieldT> &coeffs, std::size_t n_coeffs, const field_subset<FieldT> &D)            // fft.tcc:407-419
 {
+    if (D.distributed()) {                                                                   // dist.hpp: this rank's part of the codeword
+        device_vector<FieldT> out(dist::local_size(D));
+        if (additive(D)) {                                                                   // its coset range of the transform; phase 1 on the coefficients is replicated
+            const auto range = dist::coset_range(D, detail::log2_ceil(n_coeffs));
+            check(iopx_add_lde_gf192_dev(coeffs.words(), n_coeffs, basis_words(D), D.dimension(), shift_words(D), range.first, range.second, out.words()));
+        } else {                                                                             // one ordinary transform over the rank's sub-coset
+            if (n_coeffs > out.size()) throw std::invalid_argument("more coefficients than a residue class holds");
+            const field_subset<FieldT> loc = dist::local_domain(D);
+            check(iopx_mul_fft_fp3_dev(coeffs.words(), n_coeffs, loc.dimension(), gen_words(loc), shift_words(loc), out.words()));
+        }
+        return out;
+    }
     device_vector<FieldT> out(D.num_elements());
     if (additive(D)) check(iopx_add_fft_gf192_dev(coeffs.words(), n_coeffs, basis_words(D), D.dimension(), shift_words(D), out.words()));
     else check(iopx_mul_fft_fp3_dev(coeffs.words(), n_coeffs, D.dimension(), gen_words(D), shift_words(D), out.words()));
@@ -40,6 +52,7 @@ device_vector<FieldT> FFT(const device_vector<FieldT> &coeffs, std::size_t n_coe
 template<typename FieldT>
 device_vector<FieldT> IFFT(const device_vector<FieldT> &evals, const field_subset<FieldT> &D)                                   // fft.tcc:421-433
 {
+    if (D.distributed()) throw std::logic_error("inverse transform of a distributed vector: gather it first");
     if (evals.size() != D.num_elements()) throw std::invalid_argument("IFFT: evaluation count != domain size");
     device_vector<FieldT> out(D.num_elements());
     if (additive(D)) check(iopx_add_ifft_gf192_dev(evals.words(), basis_words(D), D.dimension(), shift_words(D), out.words()));
@@ -59,9 +72,10 @@ std::vector<device_vector<FieldT>> reextend_packed(const device_vector<FieldT> &
     if (prefix) for (std::size_t i = 0; i < H.dimension(); ++i) prefix = prefix && std::memcmp(&H.basis()[i], &L.basis()[i], sizeof(FieldT)) == 0;
     if (prefix) {
         std::vector<uint64_t *> ptrs;
-        for (std::size_t k = 0; k < batch; ++k) { outs.emplace_back(L.num_elements()); ptrs.push_back(outs.back().words()); }
-        check(iopx_add_reextend_gf192_batch_dev(packed.words(), batch, basis_words(L), L.dimension(), H.dimension(), shift_words(H), shift_words(L), 0,
-                                                (std::size_t)1 << (L.dimension() - H.dimension()), ptrs.data()));
+        const auto range = dist::coset_range(L, H.dimension());
+        for (std::size_t k = 0; k < batch; ++k) { outs.emplace_back(range.second << H.dimension()); ptrs.push_back(outs.back().words()); }
+        check(iopx_add_reextend_gf192_batch_dev(packed.words(), batch, basis_words(L), L.dimension(), H.dimension(), shift_words(H), shift_words(L), range.first,
+                                                range.second, ptrs.data()));
         return outs;
     }
     for (std::size_t k = 0; k < batch; ++k) outs.push_back(FFT<FieldT>(IFFT<FieldT>(packed.slice(k * n, n), H), n, L));
@@ -84,12 +98,13 @@ std::vector<device_vector<FieldT>> FFT_and_reextend_packed(const device_vector<F
         return outs;
     }
     std::vector<uint64_t *> ptrs(batch + 1);
-    for (std::size_t k = 0; k <= batch; ++k) outs.emplace_back(L.num_elements());
+    const auto range = dist::coset_range(L, H.dimension());
+    for (std::size_t k = 0; k <= batch; ++k) outs.emplace_back(range.second << H.dimension());
     for (std::size_t k = 0; k < batch; ++k) ptrs[k] = outs[1 + k].words();
     ptrs[batch] = outs[0].words();
     const uint64_t *coeffs[1] = { poly.words() };
     check(iopx_add_reextend_lde_gf192_batch_dev(packed.words(), batch, coeffs, poly.size(), 1, basis_words(L), L.dimension(), H.dimension(), shift_words(H),
-                                                shift_words(L), 0, (std::size_t)1 << (L.dimension() - H.dimension()), ptrs.data()));
+                                                shift_words(L), range.first, range.second, ptrs.data()));
     return outs;
 }
 
@@ -97,16 +112,40 @@ std::vector<device_vector<FieldT>> FFT_and_reextend_packed(const device_vector<F
 template<typename FieldT>
 device_vector<FieldT> IFFT_of_known_degree(const device_vector<FieldT> &evals, std::size_t degree, const field_subset<FieldT> &D)
 {
-    const std::size_t k = detail::log2_ceil(degree);
-    if (additive(D)) return IFFT<FieldT>(evals.slice(0, (std::size_t)1 << k), D.get_subset_of_order((std::size_t)1 << k));
-    device_vector<FieldT> out((std::size_t)1 << k);
+    const std::size_t k = detail::log2_ceil(degree), count = (std::size_t)1 << k;
+    if (D.distributed()) {
+        // Subspaces read the first 2^k evaluations (fft.tcc:458-475): rank 0's head.  Cosets read every (|D| / 2^k)-th (fft.tcc:435-456):
+        // all on rank 0 while that stride is a multiple of N, at stride / N in its sub-coset (whose shift is the domain's).  Rank 0
+        // interpolates, the coefficients are broadcast; otherwise the vector is gathered first.
+        const dist::context &c = dist::ctx();
+        field_subset<FieldT> whole = D;
+        whole.set_distributed(false);
+        const bool on_rank0 = additive(D) ? count <= dist::local_size(D) : (D.num_elements() >> k) % c.world == 0;
+        if (!on_rank0) return IFFT_of_known_degree<FieldT>(dist::gather<FieldT>(evals, D), degree, whole);
+        device_vector<FieldT> out(count);
+        if (c.rank == 0) {
+            if (additive(D)) out = IFFT<FieldT>(evals.slice(0, count), whole.get_subset_of_order(count));
+            else out = IFFT_of_known_degree<FieldT>(evals, degree, dist::local_domain(D, 0));
+        }
+        dist::broadcast<FieldT>(out, 0);
+        return out;
+    }
+    if (additive(D)) return IFFT<FieldT>(evals.slice(0, count), D.get_subset_of_order(count));
+    device_vector<FieldT> out(count);
     check(iopx_mul_ifft_known_degree_fp3_dev(evals.words(), degree, D.dimension(), gen_words(D), shift_words(D), out.words()));
     return out;
 }
 
+// Over a distributed domain the rank's cosets are whole (dist.hpp), so its part folds as the local sub-domain with the same x_i and is the
+// rank's part of f_(i+1); when the next domain is kept whole the parts are gathered.
 template<typename FieldT>
-device_vector<FieldT> fold(const device_vector<FieldT> &f, const field_subset<FieldT> &D, std::size_t coset_size, const FieldT &x_i)        // fri_aux.tcc:5-34
+device_vector<FieldT> fold(const device_vector<FieldT> &f, const field_subset<FieldT> &D_in, std::size_t coset_size, const FieldT &x_i, bool next_distributed = false)   // fri_aux.tcc:5-34
 {
+    if (D_in.distributed()) {
+        const device_vector<FieldT> part = fold<FieldT>(f, dist::local_domain(D_in), coset_size, x_i);
+        return next_distributed ? part : dist::gather_layout<FieldT>(part, D_in.type());
+    }
+    const field_subset<FieldT> &D = D_in;
     device_vector<FieldT> out(D.num_elements() / coset_size);
     if (additive(D)) check(iopx_fri_fold_add_gf192_dev(f.words(), basis_words(D), D.dimension(), shift_words(D), coset_size, detail::words(&x_i), out.words()));
     else check(iopx_fri_fold_mul_fp3_dev(f.words(), D.dimension(), gen_words(D), shift_words(D), coset_size, detail::words(&x_i), out.words()));
@@ -239,8 +278,9 @@ public:
     {
         if (constituents.size() != 1) throw std::invalid_argument("fz_virtual_oracle has one constituent oracle.");
         if (!primary_input_set_) throw std::logic_error("Evaluation requested before primary_input is set.");
-        const field_subset<FieldT> &L = codeword_domain_, &I = input_variable_domain_;
-        const device_vector<FieldT> f1v = dev::FFT<FieldT>(f1v_coefficients_, I.num_elements(), L);      // :211-212
+        const field_subset<FieldT> &I = input_variable_domain_;
+        const device_vector<FieldT> f1v = dev::FFT<FieldT>(f1v_coefficients_, I.num_elements(), codeword_domain_);      // :211-212
+        const field_subset<FieldT> L = dist::local_domain(codeword_domain_);                  // pointwise: this rank's part is a domain of its own
         device_vector<FieldT> out(L.num_elements());
         if (dev::additive(L))
             check(iopx_fz_gf192_dev(constituents[0].words(), f1v.words(), dev::basis_words(L), L.dimension(), dev::shift_words(L), dev::basis_words(I),
@@ -261,7 +301,8 @@ public:
     device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
     {
         if (c.size() != 3) throw std::invalid_argument("rowcheck_ABC has three constituent oracles.");
-        const field_subset<FieldT> &L = codeword_domain_, &H = constraint_domain_;
+        const field_subset<FieldT> L = dist::local_domain(codeword_domain_);
+        const field_subset<FieldT> &H = constraint_domain_;
         device_vector<FieldT> out(L.num_elements());
         if (dev::additive(L))
             check(iopx_rowcheck_gf192_dev(c[0].words(), c[1].words(), c[2].words(), dev::basis_words(L), L.dimension(), dev::shift_words(L), H.dimension(),
@@ -349,7 +390,8 @@ public:
     device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
     {
         if (c.size() != 2) throw std::invalid_argument("sumcheck_g_oracle has two constituent oracles");
-        const field_subset<FieldT> &L = codeword_domain_, &H = summation_domain_;
+        const field_subset<FieldT> L = dist::local_domain(codeword_domain_);
+        const field_subset<FieldT> &H = summation_domain_;
         device_vector<FieldT> out(L.num_elements());
         if (dev::additive(L))
             check(iopx_sumcheck_g_gf192_dev(c[0].words(), c[1].words(), dev::basis_words(L), L.dimension(), dev::shift_words(L), dev::basis_words(H), H.dimension(),
@@ -378,7 +420,7 @@ public:
     device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
     {
         if (c.size() != degrees_.size()) throw std::invalid_argument("Expected same number of evaluations as in registration.");
-        const field_subset<FieldT> &L = codeword_domain_;
+        const field_subset<FieldT> L = dist::local_domain(codeword_domain_);
         const std::vector<const void *> ptrs = dev::pointers(c);
         device_vector<FieldT> out(L.num_elements());
         if (dev::additive(L))
@@ -648,6 +690,7 @@ class FRI_protocol {                                                            
                 domains_.push_back(field_subset<FieldT>((std::size_t)1 << logn, sh));
             }
         }
+        dist::mark_fri_domains(domains_, localization_);                                    // which L^(i) stay split over the ranks (dist.hpp)
     }
 public:
     FRI_protocol(bcs_prover<FieldT> &IOP, const domain_handle &codeword_domain_handle, const std::vector<oracle_handle> &poly_handles,
@@ -729,7 +772,7 @@ public:
             }
             for (std::size_t j = 0; j < interactive_repetitions_; ++j) {
                 const FieldT x_i = IOP_.obtain_verifier_random_message(verifier_challenge_handles_[i][j])[0];
-                for (std::size_t l = 0; l < poly_handles_.size(); ++l) by_interaction[j][l] = dev::fold<FieldT>(by_interaction[j][l], domains_[i], cs, x_i);       // :522-526
+                for (std::size_t l = 0; l < poly_handles_.size(); ++l) by_interaction[j][l] = dev::fold<FieldT>(by_interaction[j][l], domains_[i], cs, x_i, domains_[i + 1].distributed());   // :522-526
             }
         }
         for (std::size_t j = 0; j < interactive_repetitions_; ++j)
@@ -795,7 +838,8 @@ public:
         const FieldT codeword_domain_shift = field_subset<FieldT>((std::size_t)1 << params.codeword_domain_dim_).element_outside_of_subset();   // :282-283
         const domain_handle constraint_h = IOP.register_domain(field_subset<FieldT>((std::size_t)1 << params.constraint_domain_dim_));
         const domain_handle variable_h = IOP.register_domain(field_subset<FieldT>((std::size_t)1 << params.variable_domain_dim_));
-        codeword_domain_handle_ = IOP.register_domain(field_subset<FieldT>((std::size_t)1 << params.codeword_domain_dim_, codeword_domain_shift));
+        codeword_domain_handle_ = IOP.register_domain(dist::mark_codeword_domain(field_subset<FieldT>((std::size_t)1 << params.codeword_domain_dim_, codeword_domain_shift),
+                                                                                 (std::size_t)1 << params.localization_parameters_[0]));
         protocol_ = std::make_shared<encoded_aurora_protocol<FieldT>>(IOP, constraint_h, variable_h, codeword_domain_handle_, constraint_system,
                                                                       params.multi_lincheck_repetitions_);
         LDT_reducer_ = std::make_shared<LDT_instance_reducer<FieldT>>(IOP, codeword_domain_handle_, params.num_output_LDT_instances_, params.max_tested_degree_bound_);

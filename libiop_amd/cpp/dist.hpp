@@ -1,0 +1,212 @@
+// The provers over N GPUs, one process per GPU (BASELINE configs[3] and configs[4]).
+//
+// The reference prover is one process with every oracle in one std::vector (libiop/snark/aurora_snark.tcc:119-146).  Here every rank runs
+// the SAME prover code (aurora.hpp / fractal.hpp) and holds 1/N of every vector over the codeword domain L and over the FRI domains L^(i):
+//
+//   affine subspaces (GF(2^192))          rank g holds positions [g |D| / N, (g + 1) |D| / N): the affine sub-domain spanned by the first
+//                                         m - log2 N basis vectors, shifted by element_by_index(g 2^(m - log2 N)) (subspace.tcc:56-71).  A
+//                                         low-degree extension is the rank's coset range of the transform, FRI cosets and Merkle leaves are
+//                                         contiguous runs (subspace.tcc:73-91) and stay on one rank.
+//   multiplicative cosets (181-bit field)  rank r holds the positions p = r (mod N) at local index p / N: the sub-coset (shift g^r) <g^N>, a
+//                                         multiplicative coset in its own right.  An FRI coset / Merkle leaf {j + k n / 2^eta}
+//                                         (subgroup.tcc:175-197) lies on rank j mod N whole; leaf digests are exchanged once per tree
+//                                         (all-to-all) so that each rank builds a contiguous sub-tree.
+//
+// A domain carries the mark (field_subset::distributed()); the device operators of aurora.hpp / fractal.hpp act on dist::local_domain(D)
+// and the BCS layer (iop.hpp) assembles roots, authentication paths and query answers across the ranks.  What is exchanged per proof:
+// N x 32-byte sub-roots per tree (all-gather), the sumcheck polynomial's coefficients (one broadcast), FRI tails below 64 elements per rank
+// (all-gather), answers and paths (one all-reduce per tree each: every row of a zeroed buffer has exactly one owner), the proof-of-work
+// hit (min all-reduce).  Everything over the small domains (<= 2^20 elements), the hashchain and the query bookkeeping are replicated: every
+// rank derives the same challenges and returns the same transcript.
+//
+// dist::scope binds a communicator (iopx_comm, include/libiop_amd.h) for the calls of this host thread; without one the same code is the
+// single-GPU prover (rank 0 of 1, nothing marked).
+#pragma once
+#include "device.hpp"
+
+namespace libiop_amd {
+namespace dist {
+
+struct context {
+    iopx_comm *comm = nullptr;
+    std::size_t rank = 0, world = 1, log_world = 0;
+    bool active() const { return comm != nullptr; }      // a one-rank communicator still takes the distributed code path
+};
+inline context &ctx() { static thread_local context c; return c; }
+
+class scope {
+    context saved_;
+public:
+    explicit scope(iopx_comm *comm) : saved_(ctx())
+    {
+        context c;
+        if (comm) {
+            int r = 0, w = 1;
+            check(iopx_comm_rank(comm, &r, &w));
+            c.comm = comm; c.rank = (std::size_t)r; c.world = (std::size_t)w; c.log_world = detail::log2_ceil((std::size_t)w);
+        }
+        ctx() = c;
+    }
+    scope(const scope &) = delete;
+    scope &operator=(const scope &) = delete;
+    ~scope() { ctx() = saved_; }
+};
+
+static const std::size_t MIN_BLOCK = 64;      // elements per rank below which a domain is kept whole on every rank
+
+// Can vectors over D, committed in Merkle leaves of coset_size elements, be split over the ranks?  Subspaces: enough elements per rank.
+// Cosets: also at least N leaves per rank, so that the digest exchange splits evenly.
+template<typename FieldT>
+bool can_distribute(const field_subset<FieldT> &D, std::size_t coset_size)
+{
+    const context &c = ctx();
+    if (!c.active()) return false;
+    const std::size_t n = D.num_elements(), W = c.world;
+    if (n / W < MIN_BLOCK || coset_size == 0 || n < coset_size) return false;
+    if (D.type() == affine_subspace_type) return (n / W) % coset_size == 0;
+    return (n / coset_size) % (W * W) == 0;
+}
+
+// the codeword domain of a proof; first_coset_size: the Merkle leaves of the first round (2^localization[0]).  When the domain is too
+// small for the communicator it stays whole and every rank computes the whole proof.
+template<typename FieldT>
+field_subset<FieldT> mark_codeword_domain(field_subset<FieldT> D, std::size_t first_coset_size)
+{
+    D.set_distributed(can_distribute(D, first_coset_size));
+    return D;
+}
+
+// FRI's domain chain: L^(i+1) stays distributed while its own tree can be; the last domain carries no oracle (the final polynomial is
+// interpolated from it on every rank), so the fold into it gathers.
+template<typename FieldT>
+void mark_fri_domains(std::vector<field_subset<FieldT>> &domains, const std::vector<std::size_t> &localization)
+{
+    for (std::size_t i = 1; i < domains.size(); ++i) {
+        const std::size_t cs = i < localization.size() ? (std::size_t)1 << localization[i] : 1;
+        domains[i].set_distributed(domains[i - 1].distributed() && i < localization.size() && can_distribute(domains[i], cs));
+    }
+}
+
+template<typename FieldT>
+std::size_t local_size(const field_subset<FieldT> &D) { return D.distributed() ? D.num_elements() / ctx().world : D.num_elements(); }
+
+// this rank's part of D as a domain of its own (D itself when it is not distributed); `rank` = another rank's part
+template<typename FieldT>
+field_subset<FieldT> local_domain(const field_subset<FieldT> &D, std::size_t rank = (std::size_t)-1)
+{
+    if (!D.distributed()) return D;
+    const context &c = ctx();
+    if (rank == (std::size_t)-1) rank = c.rank;
+    if (D.type() == affine_subspace_type) {
+        const std::size_t m = D.dimension(), r = c.log_world;
+        uint64_t s[3];
+        std::memcpy(s, detail::words(&D.shift()), 24);
+        for (std::size_t k = 0; k < r; ++k)
+            if ((rank >> k) & 1) for (int w = 0; w < 3; ++w) s[w] ^= detail::words(&D.basis()[m - r + k])[w];
+        return field_subset<FieldT>(affine_subspace<FieldT>(std::vector<FieldT>(D.basis().begin(), D.basis().begin() + (m - r)), field_host<FieldT>::from_words(s)));
+    }
+    // (shift g^rank) <g^N>: the default generator of order n / N is g^N (subgroup.tcc:55-59: multiplicative_generator^((p - 1) / order))
+    const FieldT shift = field_host<FieldT>::mul(D.shift(), field_host<FieldT>::pow(D.generator(), rank));
+    return field_subset<FieldT>(D.num_elements() / c.world, shift);
+}
+
+// the cosets of span(basis[0..d)) of an affine codeword domain this rank holds: (first, count)
+template<typename FieldT>
+std::pair<std::size_t, std::size_t> coset_range(const field_subset<FieldT> &L, std::size_t d)
+{
+    const std::size_t cosets = (std::size_t)1 << (L.dimension() - d);
+    if (!L.distributed()) return { 0, cosets };
+    const context &c = ctx();
+    if (cosets % c.world) throw std::invalid_argument("fewer cosets than ranks: this transform needs the exchange steps");
+    return { c.rank * (cosets / c.world), cosets / c.world };
+}
+
+// ---- collectives on device vectors (enqueued on the library's stream) ------------------------------------------------------------
+template<typename T>
+device_array<T> all_gather(const device_array<T> &local)                                     // rank-major concatenation
+{
+    const context &c = ctx();
+    device_array<T> out(local.size() * c.world);
+    check(iopx_comm_all_gather_dev(c.comm, local.data(), out.data(), local.size() * sizeof(T)));
+    return out;
+}
+
+// the whole vector, in natural order, from the ranks' parts: rank-major blocks for subspaces, residue classes for cosets
+template<typename FieldT>
+device_vector<FieldT> gather_layout(const device_vector<FieldT> &local, field_subset_type type)
+{
+    const context &c = ctx();
+    const device_vector<FieldT> parts(all_gather<FieldT>(local));
+    if (type == affine_subspace_type || c.world == 1) return parts;
+    device_vector<FieldT> out(parts.size());
+    check(iopx_interleave_dev(parts.data(), c.world, local.size(), sizeof(FieldT), out.data()));
+    return out;
+}
+
+template<typename FieldT>
+device_vector<FieldT> gather(const device_vector<FieldT> &local, const field_subset<FieldT> &D)
+{
+    return D.distributed() ? gather_layout<FieldT>(local, D.type()) : local;
+}
+
+template<typename FieldT>
+void broadcast(const device_vector<FieldT> &v, int root) { check(iopx_comm_broadcast_dev(ctx().comm, v.data(), v.size() * sizeof(FieldT), root)); }
+
+// ---- merkle_tree::get_set_membership_proof's node walk (merkle_tree.tcc:256-336): heap indices of the auxiliary hashes in the
+// reference's order — level by level from the leaves, a left node whose right sibling is not queried takes the sibling, a right node
+// takes its left sibling ----
+inline std::vector<std::size_t> membership_proof_node_indices(std::size_t num_leaves, const std::vector<std::size_t> &positions)
+{
+    std::vector<std::size_t> out, S = positions;
+    std::sort(S.begin(), S.end());
+    S.erase(std::unique(S.begin(), S.end()), S.end());
+    if (S.empty()) return out;
+    for (std::size_t &p : S) {
+        if (p >= num_leaves) throw std::invalid_argument("All positions must be between 0 and num_leaves-1.");
+        p += num_leaves - 1;
+    }
+    while (!(S.size() == 1 && S[0] == 0)) {
+        std::vector<std::size_t> next;
+        for (std::size_t i = 0; i < S.size();) {
+            const std::size_t pos = S[i];
+            next.push_back((pos - 1) / 2);
+            if (pos % 2 == 0) { out.push_back(pos - 1); ++i; }
+            else if (i + 1 == S.size() || S[i + 1] != pos + 1) { out.push_back(pos + 1); ++i; }
+            else i += 2;
+        }
+        S.swap(next);
+    }
+    return out;
+}
+
+// pow::solve_pow (bcs/pow.tcc:67-103) split by candidate range: in super-batch s rank r searches candidates [(s N + r) B_s, (s N + r + 1) B_s);
+// a min all-reduce of the hits ends the search at the first super-batch that has one, and the minimum is the reference's first hit (the
+// candidates of earlier super-batches all failed).  32-byte challenge -> 32-byte answer.
+inline std::string solve_pow(const std::string &challenge, std::size_t pow_bitlen)
+{
+    const context &c = ctx();
+    uint8_t answer[32];
+    if (!c.active() || c.world == 1) {
+        check(iopx_pow_solve_blake2b(reinterpret_cast<const uint8_t *>(challenge.data()), pow_bitlen, answer));
+        return std::string(reinterpret_cast<const char *>(answer), 32);
+    }
+    const uint64_t none = ~(uint64_t)0;
+    uint64_t first = 0, batch = (uint64_t)1 << 14;
+    const device_array<uint64_t> d_hit(1);
+    for (;;) {
+        uint64_t hit = none;
+        check(iopx_pow_search_blake2b(reinterpret_cast<const uint8_t *>(challenge.data()), pow_bitlen, first + c.rank * batch, batch, &hit));
+        check(iopx_upload_small(d_hit.data(), &hit, 8));
+        check(iopx_comm_all_reduce_u64_dev(c.comm, d_hit.data(), 1, IOPX_COMM_MIN));
+        check(iopx_memcpy_d2h(&hit, d_hit.data(), 8));
+        if (hit != none) {
+            check(iopx_pow_candidate_blake2b(reinterpret_cast<const uint8_t *>(challenge.data()), hit, answer));
+            return std::string(reinterpret_cast<const char *>(answer), 32);
+        }
+        first += c.world * batch;
+        if (batch < ((uint64_t)1 << 22)) batch <<= 2;
+    }
+}
+
+} // namespace dist
+} // namespace libiop_amd

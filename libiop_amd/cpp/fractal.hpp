@@ -38,8 +38,9 @@ device_vector<FieldT> mul(const device_vector<FieldT> &a, const device_vector<Fi
 }
 
 template<typename FieldT>
-device_vector<FieldT> domain_offsets(const field_subset<FieldT> &D, const FieldT &point)             // point - x over the whole domain
+device_vector<FieldT> domain_offsets(const field_subset<FieldT> &D_in, const FieldT &point)          // point - x over the domain (this rank's part of it)
 {
+    const field_subset<FieldT> D = dist::local_domain(D_in);
     device_vector<FieldT> out(D.num_elements());
     if (additive(D)) check(iopx_domain_offsets_gf192_dev(basis_words(D), D.dimension(), shift_words(D), detail::words(&point), out.words()));
     else check(iopx_domain_offsets_fp3_dev(D.dimension(), gen_words(D), shift_words(D), detail::words(&point), out.words()));
@@ -54,8 +55,9 @@ device_vector<FieldT> domain_elements(const field_subset<FieldT> &D)            
 }
 
 template<typename FieldT>
-device_vector<FieldT> vanishing_evals(const field_subset<FieldT> &S, const field_subset<FieldT> &D, const FieldT &constant)     // constant - Z_S(x) over D
+device_vector<FieldT> vanishing_evals(const field_subset<FieldT> &S, const field_subset<FieldT> &D_in, const FieldT &constant)  // constant - Z_S(x) over D (this rank's part)
 {
+    const field_subset<FieldT> D = dist::local_domain(D_in);
     device_vector<FieldT> out(D.num_elements());
     if (additive(D))
         check(iopx_vanishing_evals_gf192_dev(basis_words(D), D.dimension(), shift_words(D), basis_words(S), S.dimension(), shift_words(S), detail::words(&constant),
@@ -309,9 +311,11 @@ public:
     device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
     {
         if (c.size() != 3) throw std::invalid_argument("sumcheck_constraint_oracle has three constituent oracles");
-        const field_subset<FieldT> &L = codeword_domain_, &K = summation_domain_;
+        const field_subset<FieldT> L = dist::local_domain(codeword_domain_);
+        const field_subset<FieldT> &K = summation_domain_;
         device_vector<FieldT> out(L.num_elements());
         if (dev::additive(L)) {
+            if (K.dimension() > L.dimension()) throw std::invalid_argument("the summation domain exceeds this rank's part of the codeword domain");
             for (std::size_t i = 0; i < K.dimension(); ++i)
                 if (std::memcmp(&K.basis()[i], &L.basis()[i], sizeof(FieldT)) != 0) throw std::invalid_argument("the summation domain must be spanned by a prefix of the codeword domain's basis");
             const device_vector<FieldT> xinv = dev::div<FieldT>(nullptr, dev::domain_offsets<FieldT>(L, field_host<FieldT>::zero()));
@@ -610,7 +614,8 @@ public:
     {
         const field_subset<FieldT> index_domain((std::size_t)1 << params.index_domain_dim_), matrix_domain(params.num_constraints_);
         const FieldT codeword_domain_shift = field_subset<FieldT>((std::size_t)1 << params.codeword_domain_dim_).element_outside_of_subset();
-        const field_subset<FieldT> codeword_domain((std::size_t)1 << params.codeword_domain_dim_, codeword_domain_shift);
+        const field_subset<FieldT> codeword_domain = dist::mark_codeword_domain(field_subset<FieldT>((std::size_t)1 << params.codeword_domain_dim_, codeword_domain_shift),
+                                                                                (std::size_t)1 << params.localization_parameters_[0]);
         index_domain_handle_ = IOP.register_domain(index_domain);
         matrix_domain_handle_ = IOP.register_domain(matrix_domain);
         codeword_domain_handle_ = IOP.register_domain(codeword_domain);

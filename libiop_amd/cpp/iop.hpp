@@ -20,160 +20,9 @@
 #include <map>
 #include <set>
 
-#include "libiop_amd.hpp"
+#include "dist.hpp"
 
 namespace libiop_amd {
-
-// ---- host scalars of FieldT (per-proof constants only) --------------------------------------------------------------------------
-template<typename FieldT>
-struct field_host {
-    static_assert(sizeof(FieldT) == 24, "libiop_amd accelerates 24-byte field elements (libff::gf192 / libff::edwards_Fr layout)");
-    static bool additive() { return field_kind<FieldT>::type == affine_subspace_type; }
-    static FieldT from_words(const uint64_t *w) { FieldT r; std::memcpy((void *)&r, w, 24); return r; }
-    static FieldT zero() { const uint64_t w[3] = { 0, 0, 0 }; return from_words(w); }
-    static FieldT from_uint(uint64_t v)
-    {
-        uint64_t w[3] = { v, 0, 0 };
-        if (!additive()) check(iopx_fp3_from_uint(v, w));
-        return from_words(w);
-    }
-    static FieldT one() { return from_uint(1); }
-    static bool is_zero(const FieldT &a) { const uint64_t *w = detail::words(&a); return (w[0] | w[1] | w[2]) == 0; }
-    static FieldT add(const FieldT &a, const FieldT &b)
-    {
-        uint64_t w[3];
-        if (additive()) for (int i = 0; i < 3; ++i) w[i] = detail::words(&a)[i] ^ detail::words(&b)[i];
-        else check(iopx_fp3_host_add(detail::words(&a), detail::words(&b), w));
-        return from_words(w);
-    }
-    static FieldT mul(const FieldT &a, const FieldT &b)
-    {
-        uint64_t w[3];
-        if (additive()) check(iopx_gf192_host_mul(detail::words(&a), detail::words(&b), w));
-        else check(iopx_fp3_host_mul(detail::words(&a), detail::words(&b), w));
-        return from_words(w);
-    }
-    static FieldT pow(const FieldT &a, uint64_t e)
-    {
-        if (!additive()) { uint64_t w[3]; check(iopx_fp3_host_pow(detail::words(&a), e, w)); return from_words(w); }
-        FieldT r = one(), b = a;
-        for (; e; e >>= 1) { if (e & 1) r = mul(r, b); b = mul(b, b); }
-        return r;
-    }
-    static FieldT sub(const FieldT &a, const FieldT &b)
-    {
-        if (additive()) return add(a, b);
-        uint64_t w[3];
-        check(iopx_fp3_host_sub(detail::words(&a), detail::words(&b), w));
-        return from_words(w);
-    }
-    static FieldT neg(const FieldT &a) { return sub(zero(), a); }
-    static FieldT inverse(const FieldT &a)
-    {
-        uint64_t w[3];
-        if (additive()) check(iopx_gf192_inverse_host(detail::words(&a), w));
-        else check(iopx_fp3_host_inverse(detail::words(&a), w));
-        return from_words(w);
-    }
-    // Z_S(x) for the domain S (vanishing_polynomial::evaluation_at_point): the linearized polynomial of the subspace through the
-    // library's host helper / x^|S| - shift^|S| (vanishing_polynomial.tcc:14-25)
-    static FieldT vanishing_eval(const field_subset<FieldT> &S, const FieldT &x)
-    {
-        if (S.type() == affine_subspace_type) {
-            uint64_t w[3];
-            check(iopx_gf192_vanishing_host(detail::words(S.basis().data()), S.dimension(), detail::words(&S.shift()), detail::words(&x), w, nullptr));
-            return from_words(w);
-        }
-        return sub(pow(x, S.num_elements()), pow(S.shift(), S.num_elements()));
-    }
-    // (DZ_S)(x): the linear coefficient for subspaces (vanishing_polynomial.tcc:63-72), |S| x^(|S| - 1) for cosets (:57-62)
-    static FieldT vanishing_derivative(const field_subset<FieldT> &S, const FieldT &x)
-    {
-        if (S.type() == affine_subspace_type) {
-            uint64_t w[3];
-            check(iopx_gf192_vanishing_host(detail::words(S.basis().data()), S.dimension(), detail::words(&S.shift()), detail::words(&x), nullptr, w));
-            return from_words(w);
-        }
-        return mul(from_uint(S.num_elements()), pow(x, S.num_elements() - 1));
-    }
-    // membership of x in S: standard-basis subspaces (x + shift below 2^dim) / (x / shift)^|S| = 1
-    static bool element_in_domain(const field_subset<FieldT> &S, const FieldT &x)
-    {
-        if (S.type() == affine_subspace_type) {
-            if (!S.subspace().is_standard_basis()) throw std::logic_error("membership test for a non-standard basis");
-            const FieldT v = add(x, S.shift());
-            const uint64_t *w = detail::words(&v);
-            return w[1] == 0 && w[2] == 0 && (S.dimension() >= 64 || w[0] < ((uint64_t)1 << S.dimension()));
-        }
-        const FieldT r = pow(mul(x, inverse(S.shift())), S.num_elements());
-        const FieldT o = one();
-        return std::memcmp(&r, &o, sizeof(FieldT)) == 0;
-    }
-    // libff::soundness_log_of_field_size_helper: the extension degree for binary fields, floor(log2 p) for prime fields
-    static std::size_t soundness_bits() { return additive() ? 192 : 180; }
-};
-
-// ---- device memory -----------------------------------------------------------------------------------------------------------------
-namespace detail {
-struct pooled_block {
-    void *p = nullptr;
-    explicit pooled_block(std::size_t bytes) { check(iopx_pool_alloc(&p, bytes)); }
-    pooled_block(const pooled_block &) = delete;
-    pooled_block &operator=(const pooled_block &) = delete;
-    ~pooled_block() { if (p) iopx_pool_free(p); }
-};
-} // namespace detail
-
-// `count` elements of elem_bytes in HBM; copies share the block, slice() is a view
-template<typename T>
-class device_array {
-    std::shared_ptr<detail::pooled_block> block_;
-    std::size_t offset_ = 0, size_ = 0;
-public:
-    device_array() {}
-    explicit device_array(std::size_t count) : block_(std::make_shared<detail::pooled_block>((count ? count : 1) * sizeof(T))), size_(count) {}
-    std::size_t size() const { return size_; }
-    bool empty() const { return size_ == 0; }
-    T *data() const { return block_ ? reinterpret_cast<T *>(block_->p) + offset_ : nullptr; }
-    device_array slice(std::size_t begin, std::size_t count) const
-    {
-        if (begin + count > size_) throw std::invalid_argument("device_array::slice out of range");
-        device_array r;
-        r.block_ = block_; r.offset_ = offset_ + begin; r.size_ = count;
-        return r;
-    }
-    static device_array from_host(const T *src, std::size_t count)
-    {
-        device_array r(count);
-        if (count) check(iopx_memcpy_h2d(r.data(), src, count * sizeof(T)));
-        return r;
-    }
-    static device_array from_host(const std::vector<T> &v) { return from_host(v.data(), v.size()); }
-    std::vector<T> to_host(std::size_t count = (std::size_t)-1) const
-    {
-        if (count == (std::size_t)-1) count = size_;
-        if (count > size_) throw std::invalid_argument("device_array::to_host out of range");
-        std::vector<T> out(count);
-        if (count) check(iopx_memcpy_d2h(out.data(), data(), count * sizeof(T)));
-        return out;
-    }
-    void fill_zero() const { if (size_) check(iopx_memset_dev(data(), 0, size_ * sizeof(T))); }
-    void copy_from(const device_array &src) const
-    {
-        if (src.size() != size_) throw std::invalid_argument("device_array::copy_from: size mismatch");
-        if (size_) check(iopx_memcpy_d2d(data(), src.data(), size_ * sizeof(T)));
-    }
-};
-
-template<typename FieldT>
-class device_vector : public device_array<FieldT> {
-public:
-    device_vector() {}
-    explicit device_vector(std::size_t count) : device_array<FieldT>(count) {}
-    device_vector(const device_array<FieldT> &a) : device_array<FieldT>(a) {}
-    uint64_t *words() const { return reinterpret_cast<uint64_t *>(this->data()); }
-    device_vector slice(std::size_t begin, std::size_t count) const { return device_vector(device_array<FieldT>::slice(begin, count)); }
-};
 
 // ---- oracles (libiop/iop/oracles.hpp) -------------------------------------------------------------------------------------------
 template<typename FieldT>
@@ -276,25 +125,59 @@ public:
 };
 
 // ---- a BCS Merkle tree resident in HBM (bcs/merkle_tree.tcc:92-229) -------------------------------------------------------------
+// Over a distributed domain (dist.hpp) the tree is N sub-trees, one per rank over a contiguous run of leaves, under log2 N top levels:
+// the N sub-roots are all-gathered (32 bytes each) and the top levels are hashed on every rank.  Subspaces: the rank's block of every
+// oracle IS a contiguous run of leaves.  Cosets: local leaf l' is global leaf rank + N l' (the sub-coset's own coset structure), so the
+// leaf digests are exchanged once (all-to-all, 32 bytes per leaf instead of coset_size x oracles x 24) into contiguous runs.
 class device_merkle_tree {
-    device_array<uint8_t> nodes_;
-    std::size_t num_leaves_ = 0;
+    device_array<uint8_t> nodes_;              // the whole tree, or this rank's sub-tree
+    std::size_t num_leaves_ = 0;               // leaves of nodes_
+    bool distributed_ = false;
+    std::size_t global_leaves_ = 0;
+    device_array<uint8_t> top_nodes_;          // heap order over the N sub-roots (2N - 1 digests), replicated
 public:
     device_merkle_tree() {}
     template<typename FieldT>
     device_merkle_tree(const std::vector<device_vector<FieldT>> &oracles, const field_subset<FieldT> &domain, std::size_t coset_size)
-        : nodes_((2 * (domain.num_elements() / coset_size) - 1) * 32), num_leaves_(domain.num_elements() / coset_size)
+        : distributed_(domain.distributed()), global_leaves_(domain.num_elements() / coset_size)
     {
         std::vector<const void *> ptrs;
         for (auto &o : oracles) ptrs.push_back(o.data());
-        check(iopx_merkle_blake2b_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), domain.num_elements(), coset_size,
-                                      domain.type() == affine_subspace_type ? IOPX_DOMAIN_ADDITIVE : IOPX_DOMAIN_MULTIPLICATIVE, nullptr, 0, nodes_.data()));
+        const int type = domain.type() == affine_subspace_type ? IOPX_DOMAIN_ADDITIVE : IOPX_DOMAIN_MULTIPLICATIVE;
+        if (!distributed_) {
+            num_leaves_ = global_leaves_;
+            nodes_ = device_array<uint8_t>((2 * num_leaves_ - 1) * 32);
+            check(iopx_merkle_blake2b_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), domain.num_elements(), coset_size, type, nullptr, 0, nodes_.data()));
+            return;
+        }
+        const dist::context &c = dist::ctx();
+        const std::size_t W = c.world, n_local = domain.num_elements() / W;
+        num_leaves_ = global_leaves_ / W;
+        nodes_ = device_array<uint8_t>((2 * num_leaves_ - 1) * 32);
+        if (domain.type() == affine_subspace_type) {
+            check(iopx_merkle_blake2b_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), n_local, coset_size, type, nullptr, 0, nodes_.data()));
+        } else {
+            if (num_leaves_ % W) throw std::logic_error("fewer leaves per rank than ranks");
+            check(iopx_merkle_leaves_blake2b_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), n_local, coset_size, type, nullptr, 0, nodes_.data()));
+            if (W > 1) {
+                // chunk q of this rank's leaf digests holds the leaves that fall into rank q's run; entry u of the chunk received from rank s
+                // is global leaf rank L/N + s + N u -> position s + N u of the run
+                const device_array<uint8_t> mine(num_leaves_ * 32), got(num_leaves_ * 32);
+                check(iopx_memcpy_d2d(mine.data(), nodes_.data() + (num_leaves_ - 1) * 32, num_leaves_ * 32));
+                check(iopx_comm_all_to_all_dev(c.comm, mine.data(), got.data(), (num_leaves_ / W) * 32));
+                check(iopx_interleave_dev(got.data(), W, num_leaves_ / W, 32, nodes_.data() + (num_leaves_ - 1) * 32));
+            }
+            check(iopx_merkle_inner_blake2b_dev(nodes_.data(), num_leaves_));
+        }
+        top_nodes_ = device_array<uint8_t>((2 * W - 1) * 32);
+        check(iopx_comm_all_gather_dev(c.comm, nodes_.data(), top_nodes_.data() + (W - 1) * 32, 32));
+        if (W > 1) check(iopx_merkle_inner_blake2b_dev(top_nodes_.data(), W));
     }
-    std::size_t num_leaves() const { return num_leaves_; }
+    std::size_t num_leaves() const { return distributed_ ? global_leaves_ : num_leaves_; }
     hash_digest get_root() const                                                              // merkle_tree.tcc:231-240
     {
         uint8_t d[32];
-        check(iopx_memcpy_d2h(d, nodes_.data(), 32));
+        check(iopx_memcpy_d2h(d, distributed_ ? top_nodes_.data() : nodes_.data(), 32));
         return hash_digest(reinterpret_cast<const char *>(d), 32);
     }
     // the auxiliary hashes of the pruned multi-membership proof as raw bytes (32 each); inside an iopx_defer_downloads window the buffer is
@@ -302,6 +185,7 @@ public:
     std::vector<uint8_t> get_set_membership_proof_bytes(const std::vector<std::size_t> &leaf_positions) const
     {
         if (leaf_positions.empty()) return std::vector<uint8_t>();
+        if (distributed_) return distributed_membership_proof_bytes(leaf_positions);
         std::size_t depth = 0;
         while (((std::size_t)1 << depth) < num_leaves_) ++depth;
         std::vector<uint8_t> aux(32 * leaf_positions.size() * (depth + 1));
@@ -319,6 +203,40 @@ public:
     std::vector<hash_digest> get_set_membership_proof(const std::vector<std::size_t> &leaf_positions) const      // :242-336
     {
         return digests_of(get_set_membership_proof_bytes(leaf_positions));
+    }
+private:
+    // merkle_tree::get_set_membership_proof over the distributed tree: the index walk on the host (the same on every rank); every rank
+    // writes the auxiliary nodes it owns into a zeroed (count, 32) device buffer — the nodes of the top levels come from the replicated top
+    // table and are written by rank 0 — and one all-reduce (sum: exactly one owner per row) completes it everywhere.
+    std::vector<uint8_t> distributed_membership_proof_bytes(const std::vector<std::size_t> &leaf_positions) const
+    {
+        const dist::context &c = dist::ctx();
+        const std::vector<std::size_t> idx = dist::membership_proof_node_indices(global_leaves_, leaf_positions);
+        std::vector<uint8_t> aux(32 * idx.size());
+        if (idx.empty()) return aux;
+        std::vector<uint64_t> rows, local_nodes, top_rows, top_nodes;
+        for (std::size_t row = 0; row < idx.size(); ++row) {
+            const std::size_t node = idx[row];
+            std::size_t depth = 0;
+            while ((((std::size_t)2 << depth) - 1) <= node) ++depth;                        // node is at depth floor(log2(node + 1))
+            if (depth <= c.log_world) {
+                if (c.rank == 0) { top_rows.push_back(row); top_nodes.push_back(node); }
+                continue;
+            }
+            const std::size_t j = node - (((std::size_t)1 << depth) - 1), loc_depth = depth - c.log_world;
+            if ((j >> loc_depth) == c.rank) {
+                rows.push_back(row);
+                local_nodes.push_back((((std::size_t)1 << loc_depth) - 1) + (j & (((std::size_t)1 << loc_depth) - 1)));
+            }
+        }
+        const device_array<uint8_t> buf(aux.size());
+        buf.fill_zero();
+        const void *src = nodes_.data(), *top = top_nodes_.data();
+        if (!rows.empty()) check(iopx_gather_rows_dev(&src, 1, 32, local_nodes.data(), rows.data(), rows.size(), buf.data()));
+        if (!top_rows.empty()) check(iopx_gather_rows_dev(&top, 1, 32, top_nodes.data(), top_rows.data(), top_rows.size(), buf.data()));
+        check(iopx_comm_all_reduce_u64_dev(c.comm, buf.data(), aux.size() / 8, IOPX_COMM_SUM));
+        check(iopx_memcpy_d2h_deferrable(aux.data(), buf.data(), aux.size()));
+        return aux;
     }
 };
 
@@ -596,7 +514,7 @@ public:
         if (oid < begin) throw std::invalid_argument("submitting an oracle for a previous round");
         if (oid >= num_oracles_at_end_of_round_[num_prover_rounds_done_])
             throw std::invalid_argument("submitting an oracle for a future round (did you forget to call signal_prover_round_done?)");
-        if (domains_[oracle_regs_[oid].domain].num_elements() != contents.size()) throw std::invalid_argument("oracle evaluations don't match the domain size");
+        if (dist::local_size(domains_[oracle_regs_[oid].domain]) != contents.size()) throw std::invalid_argument("oracle evaluations don't match the domain size");
         oracles_[oid] = contents.device_contents();
         oracle_submitted_[oid] = true;
     }
@@ -676,10 +594,7 @@ private:
         run_hashchain_for_round(ended, num_roots);
         // bcs_prover.tcc:52-59; the indexer's one-round protocol registers no proof of work (bcs_common.tcc:426-431)
         if (num_prover_rounds_done_ == num_interaction_rounds_ && !(is_holographic_ && num_interaction_rounds_ == 1)) {
-            const hash_digest challenge = hashchain_.squeeze_root_type();
-            uint8_t answer[32];
-            check(iopx_pow_solve_blake2b(reinterpret_cast<const uint8_t *>(challenge.data()), pow_bitlen_, answer));
-            pow_answer_ = hash_digest(reinterpret_cast<const char *>(answer), 32);
+            pow_answer_ = dist::solve_pow(hashchain_.squeeze_root_type(), pow_bitlen_);      // split by candidate range over the ranks
         }
     }
 public:
@@ -737,7 +652,24 @@ public:
             if (!qpos.empty()) {                                                             // bcs_prover.tcc:187-197
                 std::vector<const void *> ptrs;
                 for (std::size_t oid : info.oracle_ids) ptrs.push_back(oracles_[oid].data());
-                check(iopx_query_responses_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), domain.num_elements(), qpos.data(), qpos.size(), flat_responses[mt].data()));
+                if (!domain.distributed()) {
+                    check(iopx_query_responses_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), domain.num_elements(), qpos.data(), qpos.size(), flat_responses[mt].data()));
+                } else {
+                    // every rank writes the rows it owns into a zeroed (positions, oracles) device buffer; one all-reduce completes it everywhere
+                    const dist::context &c = dist::ctx();
+                    const std::size_t block = domain.num_elements() / c.world;
+                    std::vector<uint64_t> rows, local_index;
+                    for (std::size_t row = 0; row < qpos.size(); ++row) {
+                        const std::size_t p = qpos[row];
+                        const bool mine = domain.type() == affine_subspace_type ? p / block == c.rank : p % c.world == c.rank;
+                        if (mine) { rows.push_back(row); local_index.push_back(domain.type() == affine_subspace_type ? p - c.rank * block : p / c.world); }
+                    }
+                    const device_vector<FieldT> buf(flat_responses[mt].size());
+                    buf.fill_zero();
+                    if (!rows.empty()) check(iopx_gather_rows_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), local_index.data(), rows.data(), rows.size(), buf.data()));
+                    check(iopx_comm_all_reduce_u64_dev(c.comm, buf.data(), buf.size() * sizeof(FieldT) / 8, IOPX_COMM_SUM));
+                    check(iopx_memcpy_d2h_deferrable(flat_responses[mt].data(), buf.data(), buf.size() * sizeof(FieldT)));
+                }
             }
             proof_bytes[mt] = MT_trees_[mt].get_set_membership_proof_bytes(lpos);
         }

@@ -169,6 +169,7 @@ class field_subset {
     field_subset_type type_;
     std::shared_ptr<affine_subspace<FieldT>> subspace_;
     std::shared_ptr<multiplicative_coset<FieldT>> coset_;
+    bool distributed_ = false;               // multi-GPU provers: vectors over this domain are split over the ranks (dist.hpp); copies keep the mark
     void construct_internal(std::size_t num_elements, const FieldT &shift)                  // field_subset.tcc:33-62
     {
         if (num_elements == 0 || (num_elements & (num_elements - 1))) throw std::invalid_argument("field_subset: size must be a power of two");
@@ -192,6 +193,8 @@ public:
     field_subset(std::size_t num_elements, const FieldT &coset_shift) { construct_internal(num_elements, coset_shift); }
 
     field_subset_type type() const { return type_; }
+    bool distributed() const { return distributed_; }
+    void set_distributed(bool on) { distributed_ = on; }
     const affine_subspace<FieldT> &subspace() const
     {
         if (type_ != affine_subspace_type) throw std::invalid_argument("field_subset is not an affine subspace");

@@ -29,10 +29,11 @@ void require_supported_security(size_t security_parameter)
 
 struct InstanceBase {
     virtual ~InstanceBase() {}
-    virtual std::string prove(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) = 0;
+    // comm: the communicator the codeword-domain vectors are distributed over (libiop_amd/cpp/dist.hpp); null = one GPU
+    virtual std::string prove(iopx_comm *comm, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) = 0;
     virtual size_t num_constraints() const = 0;
-    virtual std::vector<std::string> fractal_index(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) = 0;
-    virtual std::string fractal_prove(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) = 0;
+    virtual std::vector<std::string> fractal_index(iopx_comm *comm, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) = 0;
+    virtual std::string fractal_prove(iopx_comm *comm, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) = 0;
 };
 
 template<typename F>
@@ -52,28 +53,34 @@ struct Instance : InstanceBase {
     // the Fractal prover index (twelve index oracles, their tree, their evaluations over the index domain) for one parameter set
     std::unique_ptr<bcs_prover_index<F>> index;
     size_t index_params[3] = { 0, 0, 0 };
+    iopx_comm *index_comm = nullptr;        // the index holds this rank's part of the twelve index oracles: it belongs to one communicator
 
     size_t num_constraints() const override { return cs.num_constraints(); }
-    std::vector<std::string> fractal_index(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) override
+    std::vector<std::string> fractal_index(iopx_comm *comm, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) override
     {
         require_supported_security(security_parameter);
+        const dist::scope bound(comm);
+        index_comm = comm;
         const fractal_snark_parameters<F> params(cs, security_parameter, RS_extra_dimensions, FRI_localization_parameter);
         auto made = fractal_snark_indexer<F>(cs, params);
         index.reset(new bcs_prover_index<F>(std::move(made.first)));
         index_params[0] = security_parameter; index_params[1] = RS_extra_dimensions; index_params[2] = FRI_localization_parameter;
         return made.second.index_MT_roots_;
     }
-    std::string fractal_prove(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) override
+    std::string fractal_prove(iopx_comm *comm, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) override
     {
         require_supported_security(security_parameter);
+        if (index && index_comm != comm) throw std::logic_error("iopx_fractal_prove: the index was built for another communicator");
+        const dist::scope bound(comm);
         if (!index || index_params[0] != security_parameter || index_params[1] != RS_extra_dimensions || index_params[2] != FRI_localization_parameter)
             throw std::logic_error("iopx_fractal_prove: no index for these parameters (call iopx_fractal_index first)");
         const fractal_snark_parameters<F> params(cs, security_parameter, RS_extra_dimensions, FRI_localization_parameter);
         return fractal_snark_prover<F>(*index, cs, primary, auxiliary, params, &d_assignment).serialize();
     }
-    std::string prove(size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) override
+    std::string prove(iopx_comm *comm, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) override
     {
         require_supported_security(security_parameter);
+        const dist::scope bound(comm);
         const aurora_snark_parameters<F> params(cs.num_constraints(), cs.num_variables(), cs.num_inputs(), security_parameter, RS_extra_dimensions,
                                                 FRI_localization_parameter);
         return aurora_snark_prover<F>(cs, primary, auxiliary, params, &d_assignment).serialize();
@@ -173,14 +180,16 @@ int iopx_aurora_example_instance_create(int field, size_t num_constraints, size_
     });
 }
 
-int iopx_aurora_prove(iopx_aurora_instance *instance, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter,
-                      uint8_t **transcript, size_t *transcript_bytes)
+static int prove_entry(iopx_aurora_instance *instance, iopx_comm *comm, bool fractal, size_t security_parameter, size_t RS_extra_dimensions,
+                       size_t FRI_localization_parameter, uint8_t **transcript, size_t *transcript_bytes)
 {
     int rc = iopx::ensure_device();
     if (rc != IOPX_OK) return rc;
     if (!instance || !transcript || !transcript_bytes) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
     return guarded([&] {
-        const std::string t = reinterpret_cast<InstanceBase *>(instance)->prove(security_parameter, RS_extra_dimensions, FRI_localization_parameter);
+        InstanceBase *inst = reinterpret_cast<InstanceBase *>(instance);
+        const std::string t = fractal ? inst->fractal_prove(comm, security_parameter, RS_extra_dimensions, FRI_localization_parameter)
+                                      : inst->prove(comm, security_parameter, RS_extra_dimensions, FRI_localization_parameter);
         uint8_t *buf = static_cast<uint8_t *>(std::malloc(t.size() ? t.size() : 1));
         if (!buf) throw std::bad_alloc();
         std::memcpy(buf, t.data(), t.size());
@@ -189,14 +198,14 @@ int iopx_aurora_prove(iopx_aurora_instance *instance, size_t security_parameter,
     });
 }
 
-int iopx_fractal_index(iopx_aurora_instance *instance, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter,
+static int index_entry(iopx_aurora_instance *instance, iopx_comm *comm, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter,
                        uint8_t *index_roots, size_t root_capacity, size_t *num_roots)
 {
     int rc = iopx::ensure_device();
     if (rc != IOPX_OK) return rc;
     if (!instance || !num_roots) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
     return guarded([&] {
-        const std::vector<std::string> roots = reinterpret_cast<InstanceBase *>(instance)->fractal_index(security_parameter, RS_extra_dimensions, FRI_localization_parameter);
+        const std::vector<std::string> roots = reinterpret_cast<InstanceBase *>(instance)->fractal_index(comm, security_parameter, RS_extra_dimensions, FRI_localization_parameter);
         *num_roots = roots.size();
         if (index_roots) {
             if (root_capacity < roots.size()) throw std::invalid_argument("iopx_fractal_index: root buffer too small");
@@ -205,20 +214,40 @@ int iopx_fractal_index(iopx_aurora_instance *instance, size_t security_parameter
     });
 }
 
+int iopx_aurora_prove(iopx_aurora_instance *instance, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter,
+                      uint8_t **transcript, size_t *transcript_bytes)
+{
+    return prove_entry(instance, nullptr, false, security_parameter, RS_extra_dimensions, FRI_localization_parameter, transcript, transcript_bytes);
+}
+
+int iopx_aurora_prove_dist(iopx_aurora_instance *instance, iopx_comm *comm, size_t security_parameter, size_t RS_extra_dimensions,
+                           size_t FRI_localization_parameter, uint8_t **transcript, size_t *transcript_bytes)
+{
+    return prove_entry(instance, comm, false, security_parameter, RS_extra_dimensions, FRI_localization_parameter, transcript, transcript_bytes);
+}
+
+int iopx_fractal_index(iopx_aurora_instance *instance, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter,
+                       uint8_t *index_roots, size_t root_capacity, size_t *num_roots)
+{
+    return index_entry(instance, nullptr, security_parameter, RS_extra_dimensions, FRI_localization_parameter, index_roots, root_capacity, num_roots);
+}
+
+int iopx_fractal_index_dist(iopx_aurora_instance *instance, iopx_comm *comm, size_t security_parameter, size_t RS_extra_dimensions,
+                            size_t FRI_localization_parameter, uint8_t *index_roots, size_t root_capacity, size_t *num_roots)
+{
+    return index_entry(instance, comm, security_parameter, RS_extra_dimensions, FRI_localization_parameter, index_roots, root_capacity, num_roots);
+}
+
 int iopx_fractal_prove(iopx_aurora_instance *instance, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter,
                        uint8_t **transcript, size_t *transcript_bytes)
 {
-    int rc = iopx::ensure_device();
-    if (rc != IOPX_OK) return rc;
-    if (!instance || !transcript || !transcript_bytes) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
-    return guarded([&] {
-        const std::string t = reinterpret_cast<InstanceBase *>(instance)->fractal_prove(security_parameter, RS_extra_dimensions, FRI_localization_parameter);
-        uint8_t *buf = static_cast<uint8_t *>(std::malloc(t.size() ? t.size() : 1));
-        if (!buf) throw std::bad_alloc();
-        std::memcpy(buf, t.data(), t.size());
-        *transcript = buf;
-        *transcript_bytes = t.size();
-    });
+    return prove_entry(instance, nullptr, true, security_parameter, RS_extra_dimensions, FRI_localization_parameter, transcript, transcript_bytes);
+}
+
+int iopx_fractal_prove_dist(iopx_aurora_instance *instance, iopx_comm *comm, size_t security_parameter, size_t RS_extra_dimensions,
+                            size_t FRI_localization_parameter, uint8_t **transcript, size_t *transcript_bytes)
+{
+    return prove_entry(instance, comm, true, security_parameter, RS_extra_dimensions, FRI_localization_parameter, transcript, transcript_bytes);
 }
 
 int iopx_aurora_instance_free(iopx_aurora_instance *instance)

@@ -396,4 +396,12 @@ int iopx_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes)
     return iopx::download(dst_host, src_dev, bytes);
 }
 
+// the same read-back, queued (not waited for) between iopx_defer_downloads_begin and _end; immediate outside such a window
+int iopx_memcpy_d2h_deferrable(void *dst_host, const void *src_dev, size_t bytes)
+{
+    int rc = iopx::ensure_device();
+    if (rc != IOPX_OK) return rc;
+    return iopx::download(dst_host, src_dev, bytes, /*deferrable=*/true);
+}
+
 } // extern "C"

@@ -369,3 +369,72 @@ def test_membership_proof_node_indices_match_oracle():
         for _ in range(20):
             pos = sorted(set(int(p) for p in rng.integers(0, num_leaves, size=int(rng.integers(1, 12)))))
             assert idist.membership_proof_node_indices(num_leaves, pos) == [int(v) for v in oracle.membership_proof_indices(num_leaves, pos)]
+
+
+# ---- the NATIVE provers distributed over the ranks (libiop_amd/cpp/dist.hpp behind iopx_aurora_prove_dist / iopx_fractal_*_dist): the C++
+# prover inside the (CPU-compiled) library, its collectives forwarded to the gloo group through iopx_comm_create_callbacks ----
+def _native_worker(rank, world, port, ret, protocol, field_code, log_n, num_inputs, seed, rs_extra):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from emu_lib import emu
+        lib = emu()
+        comm = lib.comm_create_torch_callbacks(dist, rank, world)
+        n = 1 << log_n
+        inst = lib.aurora_example_instance(field_code, n, num_inputs, n - 1, seed)
+        try:
+            lib.comm_stats(reset=True)
+            if protocol == "aurora":
+                t = lib.aurora_prove_dist(inst, comm, 128, rs_extra, 2)
+                roots = []
+            else:
+                roots = lib.fractal_index_dist(inst, comm, 128, rs_extra, 2)
+                t = lib.fractal_prove_dist(inst, comm, 128, rs_extra, 2)
+            ret[rank] = (t, roots, lib.comm_stats())
+        finally:
+            lib.aurora_instance_free(inst)
+            lib.comm_destroy(comm)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,log_n,rs_extra", [(1, 6, 5), (2, 7, 5), (4, 8, 5), (8, 7, 5), (2, 7, 8)])
+def test_native_sharded_aurora_prover_equals_oracle(world, log_n, rs_extra):
+    """GF(2^192), contiguous cosets; (8, 7): config 4's own split; rs_extra 8: the last FRI domain is large enough to stay distributed by size."""
+    import oracle
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_native_worker, args=(world, _free_port(), ret, "aurora", 0, log_n, 15, 0x2204, rs_extra), nprocs=world, join=True)
+    ref = oracle.aurora_prove(oracle.FIELD_GF192, log_n, 15, 0x2204, rs_extra=rs_extra)
+    for r in range(world):
+        assert ret[r][0] == ref, "rank %d" % r
+        assert ret[r][2][0] > 0, "no collective was issued"
+
+
+@pytest.mark.parametrize("world,log_n", [(2, 9), (4, 10)])
+def test_native_sharded_aurora_prover_over_the_prime_field_equals_oracle(world, log_n):
+    """181-bit field, residue classes (leaf digests exchanged by all-to-all)."""
+    import oracle
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_native_worker, args=(world, _free_port(), ret, "aurora", 1, log_n, 15, 0x2204, 5), nprocs=world, join=True)
+    ref = oracle.aurora_prove(oracle.FIELD_EDWARDS, log_n, 15, 0x2204)
+    for r in range(world):
+        assert ret[r][0] == ref, "rank %d" % r
+
+
+@pytest.mark.parametrize("world,field_code,log_n,num_inputs", [(2, 0, 6, 15), (4, 0, 7, 15), (8, 0, 7, 15), (2, 1, 7, 0), (4, 1, 8, 15)])
+def test_native_sharded_fractal_prover_equals_oracle(world, field_code, log_n, num_inputs):
+    import oracle
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_native_worker, args=(world, _free_port(), ret, "fractal", field_code, log_n, num_inputs, 0x2205, 3), nprocs=world, join=True)
+    ref, ref_roots = oracle.fractal_prove(oracle.FIELD_GF192 if field_code == 0 else oracle.FIELD_EDWARDS, log_n, num_inputs, 0x2205)
+    for r in range(world):
+        assert ret[r][1] == ref_roots, "rank %d index root" % r
+        assert ret[r][0] == ref, "rank %d" % r
