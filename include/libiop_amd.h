@@ -123,6 +123,12 @@ int iopx_add_reextend_lde_gf192_batch_dev(const uint64_t *d_evals, size_t batch,
  *   iopx_add_combine_gf192_dev  one butterfly level across shards (fft.tcc:116-117): tw_i = shift_term + sum_k
  *                               bit_k(index_base + i) * basis[k]; out = a + tw*b (upper = 0) or a + tw*b + b (upper = 1) */
 int iopx_add_taylor_gf192_dev(uint64_t *d_S, size_t log_n, const uint64_t *d_twist);
+/* ... and their inverses (additive_IFFT, fft.tcc:126-204), for ONE inverse transform sharded across GPUs:
+ *   iopx_add_taylor_inv_gf192_dev    in place: the network undone over all index bits of the shard, then S[i] *= d_twist[i] (inverse powers)
+ *   iopx_add_combine_inv_gf192_dev   one butterfly level across shards undone: from lo = a + tw*b and up = lo + b, out = a (upper = 0) or b (upper = 1) */
+int iopx_add_taylor_inv_gf192_dev(uint64_t *d_S, size_t log_n, const uint64_t *d_twist);
+int iopx_add_combine_inv_gf192_dev(const uint64_t *d_lo, const uint64_t *d_up, uint64_t *d_out, size_t count, size_t index_base,
+                                   const uint64_t *basis, size_t nb, const uint64_t *shift_term, int upper);
 int iopx_gf192_pow_table_dev(uint64_t *d_out, size_t count, const uint64_t *base, const uint64_t *init);
 int iopx_add_combine_gf192_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count, size_t index_base,
                                const uint64_t *basis, size_t nb, const uint64_t *shift_term, int upper);
@@ -524,6 +530,13 @@ int iopx_comm_all_reduce_u64_dev(iopx_comm *comm, void *d_buf, size_t count, int
 int iopx_comm_broadcast_dev(iopx_comm *comm, void *d_buf, size_t bytes, int root);
 int iopx_comm_all_to_all_dev(iopx_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank);
 int iopx_comm_sendrecv_dev(iopx_comm *comm, const void *d_send, void *d_recv, size_t bytes, int peer);
+/* While a communicator of N > 1 ranks is bound, every additive transform of the library splits its Gao-Mateer phase 1 (the twists and
+ * Taylor expansions on the 2^d coefficients, fft.tcc:62-83 / :172-200) over the ranks when d >= 16: the first log2 N levels run on the
+ * whole vector on every rank, from then on the sub-polynomials of different residues of the coefficient index mod N never mix, so rank
+ * r runs the remaining levels on the residue class r (a contiguous copy) and one all-gather reassembles the vector.  REQUIRES that every
+ * rank issues the same sequence of transforms on the same (replicated) inputs — what the distributed provers do for everything over
+ * the <= 2^21-element domains; a section that only one rank executes must unbind first.  NULL unbinds. */
+int iopx_comm_bind_transforms(iopx_comm *comm);
 /* collectives issued and payload bytes sent by this rank through any communicator since the last reset (reset != 0 clears them) */
 int iopx_comm_stats(uint64_t *num_collectives, uint64_t *bytes, int reset);
 /* d_dst[(i * parts + r) * elem_bytes ..] = d_src[(r * count + i) * elem_bytes ..]: `parts` residue classes stored back to back

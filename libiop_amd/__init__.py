@@ -59,7 +59,7 @@ EXPORTED_SYMBOLS = [
     "iopx_aurora_instance_create", "iopx_aurora_example_instance_create", "iopx_aurora_prove", "iopx_aurora_instance_free", "iopx_host_free",
     "iopx_fractal_index", "iopx_fractal_prove",
     "iopx_memcpy_d2h_deferrable", "iopx_comm_rccl_unique_id", "iopx_comm_create_rccl", "iopx_comm_create_callbacks", "iopx_comm_destroy", "iopx_comm_rank",
-    "iopx_comm_all_gather_dev", "iopx_comm_all_reduce_u64_dev", "iopx_comm_broadcast_dev", "iopx_comm_all_to_all_dev", "iopx_comm_sendrecv_dev", "iopx_comm_stats",
+    "iopx_comm_all_gather_dev", "iopx_comm_all_reduce_u64_dev", "iopx_comm_broadcast_dev", "iopx_comm_all_to_all_dev", "iopx_comm_sendrecv_dev", "iopx_comm_stats", "iopx_comm_bind_transforms", "iopx_add_taylor_inv_gf192_dev", "iopx_add_combine_inv_gf192_dev",
     "iopx_interleave_dev", "iopx_gather_rows_dev", "iopx_aurora_prove_dist", "iopx_fractal_index_dist", "iopx_fractal_prove_dist",
 ]
 
@@ -159,6 +159,8 @@ class Library:
         c.iopx_add_fft_gf192.argtypes = [_u64p, _sz, _u64p, _sz, _u64p, _u64p]
         c.iopx_add_lde_gf192_dev.argtypes = [_vp, _sz, _u64p, _sz, _u64p, _sz, _sz, _vp]
         c.iopx_add_taylor_gf192_dev.argtypes = [_vp, _sz, _vp]
+        c.iopx_add_taylor_inv_gf192_dev.argtypes = [_vp, _sz, _vp]
+        c.iopx_add_combine_inv_gf192_dev.argtypes = [_vp, _vp, _vp, _sz, _sz, _u64p, _sz, _u64p, ctypes.c_int]
         c.iopx_gf192_pow_table_dev.argtypes = [_vp, _sz, _u64p, _u64p]
         c.iopx_add_combine_gf192_dev.argtypes = [_vp, _vp, _vp, _sz, _sz, _u64p, _sz, _u64p, ctypes.c_int]
         c.iopx_add_ifft_gf192_dev.argtypes = [_vp, _u64p, _sz, _u64p, _vp]
@@ -885,6 +887,14 @@ class Library:
 
     def taylor_dev(self, d_S, log_n, d_twist=0):
         self._check(self.c.iopx_add_taylor_gf192_dev(_vp(d_S), log_n, _vp(d_twist)))
+
+    def taylor_inv_dev(self, d_S, log_n, d_twist=0):
+        self._check(self.c.iopx_add_taylor_inv_gf192_dev(_vp(d_S), log_n, _vp(d_twist)))
+
+    def combine_inv_dev(self, d_lo, d_up, d_out, count, index_base, basis, shift_term, upper):
+        basis, shift_term = _as_u64(basis), _as_u64(shift_term)
+        self._check(self.c.iopx_add_combine_inv_gf192_dev(_vp(d_lo), _vp(d_up), _vp(d_out), count, index_base, basis.ctypes.data_as(_u64p),
+                                                          basis.shape[0], shift_term.ctypes.data_as(_u64p), int(upper)))
 
     def pow_table_dev(self, d_out, count, base, init):
         base, init = _as_u64(base), _as_u64(init)

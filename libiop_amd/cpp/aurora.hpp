@@ -108,6 +108,33 @@ std::vector<device_vector<FieldT>> FFT_and_reextend_packed(const device_vector<F
     return outs;
 }
 
+template<typename FieldT> device_vector<FieldT> IFFT_of_known_degree(const device_vector<FieldT> &evals, std::size_t degree, const field_subset<FieldT> &D);
+template<typename FieldT> device_vector<FieldT> poly_div_vanishing(const device_vector<FieldT> &poly, std::size_t n_coeffs, const field_subset<FieldT> &D);
+
+// polynomial_over_vanishing_polynomial(IFFT_of_known_degree(evals, degree, L), Z_H).first — the sumcheck's h (sumcheck.tcc:351-365).  Over a
+// distributed L whose needed evaluations all sit on rank 0, rank 0 interpolates AND divides, and h's coefficients are broadcast
+// (degree - |H| elements: the one codeword-derived exchange of a proof) instead of the interpolant's.
+template<typename FieldT>
+device_vector<FieldT> interpolate_and_divide(const device_vector<FieldT> &evals, std::size_t degree, const field_subset<FieldT> &L, const field_subset<FieldT> &H)
+{
+    const std::size_t k = detail::log2_ceil(degree);
+    const bool on_rank0 = L.distributed() && degree > H.num_elements() &&
+                          (additive(L) ? ((std::size_t)1 << k) <= dist::local_size(L) : (L.num_elements() >> k) % dist::ctx().world == 0);
+    if (!on_rank0) return poly_div_vanishing<FieldT>(IFFT_of_known_degree<FieldT>(evals, degree, L), degree, H);
+    const dist::context &c = dist::ctx();
+    device_vector<FieldT> h(degree - H.num_elements());
+    if (c.rank == 0) {
+        const dist::one_rank_section alone;
+        field_subset<FieldT> whole = L;
+        whole.set_distributed(false);
+        const device_vector<FieldT> poly = additive(L) ? IFFT<FieldT>(evals.slice(0, (std::size_t)1 << k), whole.get_subset_of_order((std::size_t)1 << k))
+                                                       : IFFT_of_known_degree<FieldT>(evals, degree, dist::local_domain(L, 0));
+        h = poly_div_vanishing<FieldT>(poly, degree, H);
+    }
+    dist::broadcast<FieldT>(h, 0);
+    return h;
+}
+
 // IFFT_of_known_degree_over_field_subset (fft.tcc:435-475): 2^ceil(log2 degree) coefficients
 template<typename FieldT>
 device_vector<FieldT> IFFT_of_known_degree(const device_vector<FieldT> &evals, std::size_t degree, const field_subset<FieldT> &D)
@@ -124,6 +151,7 @@ device_vector<FieldT> IFFT_of_known_degree(const device_vector<FieldT> &evals, s
         if (!on_rank0) return IFFT_of_known_degree<FieldT>(dist::gather<FieldT>(evals, D), degree, whole);
         device_vector<FieldT> out(count);
         if (c.rank == 0) {
+            const dist::one_rank_section alone;
             if (additive(D)) out = IFFT<FieldT>(evals.slice(0, count), whole.get_subset_of_order(count));
             else out = IFFT_of_known_degree<FieldT>(evals, degree, dist::local_domain(D, 0));
         }
@@ -476,12 +504,11 @@ public:
         const std::vector<FieldT> challenge = IOP_.obtain_verifier_random_message(challenge_handle_);
         combined_f_oracle_->set_random_coefficients(challenge);
         const device_vector<FieldT> evals = IOP_.get_oracle_evaluations(combined_f_handle_);
-        const device_vector<FieldT> poly = dev::IFFT_of_known_degree<FieldT>(evals, degree_bound_, L_);                    // :351-354
         FieldT combined_claimed_sum = field_host<FieldT>::zero();                            // :327-341
         for (std::size_t i = 0; i < challenge.size(); ++i)
             combined_claimed_sum = field_host<FieldT>::add(combined_claimed_sum, field_host<FieldT>::mul(challenge[i], claimed_sums_[i]));
         g_oracle_->set_claimed_sum(combined_claimed_sum);
-        const device_vector<FieldT> h = dev::poly_div_vanishing<FieldT>(poly, degree_bound_, H_);                          // :359-365
+        const device_vector<FieldT> h = dev::interpolate_and_divide<FieldT>(evals, degree_bound_, L_, H_);                 // :351-354, :359-365
         IOP_.submit_oracle(h_handle_, oracle<FieldT>(dev::FFT<FieldT>(h, h.size(), L_)));                                  // :384-387
     }
     std::vector<oracle_handle> get_all_oracle_handles() const { return { h_handle_, g_handle_ }; }

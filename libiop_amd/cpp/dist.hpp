@@ -46,10 +46,20 @@ public:
             c.comm = comm; c.rank = (std::size_t)r; c.world = (std::size_t)w; c.log_world = detail::log2_ceil((std::size_t)w);
         }
         ctx() = c;
+        check(iopx_comm_bind_transforms(c.comm));            // the replicated transforms split their phase 1 over the ranks (include/libiop_amd.h)
     }
     scope(const scope &) = delete;
     scope &operator=(const scope &) = delete;
-    ~scope() { ctx() = saved_; }
+    ~scope() { ctx() = saved_; (void)iopx_comm_bind_transforms(saved_.comm); }
+};
+
+// A stretch of work that only some ranks execute (rank 0 interpolating for everybody): transforms inside it must not take part in collectives.
+class one_rank_section {
+public:
+    one_rank_section() { check(iopx_comm_bind_transforms(nullptr)); }
+    one_rank_section(const one_rank_section &) = delete;
+    one_rank_section &operator=(const one_rank_section &) = delete;
+    ~one_rank_section() { (void)iopx_comm_bind_transforms(ctx().comm); }
 };
 
 static const std::size_t MIN_BLOCK = 64;      // elements per rank below which a domain is kept whole on every rank

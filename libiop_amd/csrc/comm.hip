@@ -96,6 +96,16 @@ struct iopx_comm {
     iopx_comm_callbacks cb{};
 };
 
+namespace iopx {
+static iopx_comm *g_transform_comm = nullptr;
+CommInfo transform_comm()
+{
+    CommInfo ci{ g_transform_comm, 0, 1 };
+    if (g_transform_comm) { ci.rank = g_transform_comm->rank; ci.world = g_transform_comm->world; }
+    return ci;
+}
+} // namespace iopx
+
 namespace {
 
 __global__ void k_interleave(const uint64_t *src, size_t parts, size_t count, size_t words, uint64_t *dst)
@@ -172,9 +182,16 @@ int iopx_comm_create_callbacks(int rank, int world, const iopx_comm_callbacks *c
     return IOPX_OK;
 }
 
+int iopx_comm_bind_transforms(iopx_comm *comm)
+{
+    iopx::g_transform_comm = comm;
+    return IOPX_OK;
+}
+
 int iopx_comm_destroy(iopx_comm *comm)
 {
     if (!comm) return IOPX_OK;
+    if (iopx::g_transform_comm == comm) iopx::g_transform_comm = nullptr;
     if (comm->nccl) {
         (void)hipStreamSynchronize(iopx::stream());          // collectives in flight hold the communicator
         (void)g_api.CommDestroy(comm->nccl);

@@ -27,6 +27,7 @@
 #include <vector>
 #include "gf192_dev.h"
 #include "gf192_host.h"
+#include <algorithm>
 #include "runtime.h"
 
 namespace iopx {
@@ -1011,8 +1012,62 @@ static std::vector<P1Pass> phase1_schedule(int d)
     return sched;
 }
 
+// One phase-1 launch.  d_eff / pow: the transform the pass belongs to — the plan's own (d, table base) or, for a residue class of the
+// coefficient index (run_phase1 below), the sub-transform of dimension d - r whose tables are the plan's from level r on.
+template<bool INV>
+static int launch_phase1_pass(const P1Pass &ps, uint64_t *S, const uint64_t *pow, int d_eff, size_t batch)
+{
+    P1Params p;
+    p.S = S;
+    p.pow = pow;
+    p.d = d_eff; p.c = ps.c; p.h = ps.h; p.A = ps.A;
+    p.j0 = ps.j0; p.j1 = ps.j1; p.k_start = ps.k_start; p.k_end = ps.k_end;
+    p.xcd_remap = env_int("IOPX_XCD_REMAP", 1, 0, 1);
+    p.comb = tuning().comb && tuning().p1_comb;
+    p.extra = ps.extra; p.skip_j0 = ps.skip_j0;
+    const int tbits = ps.c + ps.A;
+    const size_t lds = ((size_t)24) << tbits;
+    const size_t blocks = (size_t)1 << (d_eff - tbits);
+    const int threads = (1 << tbits) >= 4 * BLOCK_THREADS ? BLOCK_THREADS : ((1 << tbits) >= 256 ? 64 * ((1 << tbits) / 256) : 64);
+    int rc = set_lds(k_phase1<INV>, lds);
+    if (rc != IOPX_OK) return rc;
+    static char names[64][2][32];
+    char *nm = names[ps.j0 & 63][ps.k_start == d_eff - 2 ? 1 : 0];
+    if (!nm[0]) snprintf(nm, 32, getenv("IOPX_PROFILE_LEVELS") ? "k_phase1_L%02d_%s" : "k_phase1", ps.j0, ps.k_start == d_eff - 2 ? "tw" : "x");
+    { ProfScope ps_(nm, (batch << d_eff) * 48); hipLaunchKernelGGL(k_phase1<INV>, dim3((unsigned)blocks, (unsigned)batch), dim3(threads), lds, stream(), p); }
+    return IOPX_OK;
+}
+
+// dst[b][l] = src[b][(l << r) | cls]  (the residue class cls of the index mod 2^r, as a contiguous vector); batch vectors of 2^d / 2^(d-r) elements
+__global__ void k_class_extract(const uint64_t *src, uint64_t *dst, int d, int r, size_t cls, size_t batch)
+{
+    const size_t per = (size_t)1 << (d - r), total = batch * per * 3;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t w = t % 3, e = t / 3, l = e & (per - 1), b = e >> (d - r);
+        dst[t] = src[3 * ((b << d) | (l << r) | cls) + w];
+    }
+}
+
+// dst[b][(l << r) | q] = src[q][b][l]  (an all-gather's output, rank-major, back to index order)
+__global__ void k_class_merge(const uint64_t *src, uint64_t *dst, int d, int r, size_t batch)
+{
+    const size_t per = (size_t)1 << (d - r), n = (size_t)1 << d, total = batch * n * 3;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t w = t % 3, e = t / 3, i = e & (n - 1), b = e >> d, q = i & (((size_t)1 << r) - 1), l = i >> r;
+        dst[t] = src[3 * ((q * batch + b) * per + l) + w];
+    }
+}
+
+extern "C" int iopx_comm_all_gather_dev(iopx_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank);
+
 // `batch` vectors of 2^d elements stored back to back share every launch (grid.y): small transforms are latency-bound per
-// pass, so a batch costs little more than one
+// pass, so a batch costs little more than one.
+//
+// With a communicator of N = 2^r ranks bound for transforms (iopx_comm_bind_transforms) and d large enough, the levels are split over the
+// ranks: level j multiplies element i by a power indexed by i >> j and its Taylor operations pair index bits k, k + 1 for k >= j, so from
+// level r on elements of different residues i mod N never meet.  Levels < r run on the whole vector on every rank; then rank q runs levels
+// r .. d - 1 on the residue class q — as a contiguous vector it is phase 1 of a 2^(d-r)-point transform whose level-j' table is the plan's
+// level r + j' table — and an all-gather brings the classes back (inverse: the other way round).  Every rank must hold the same input.
 template<bool INV>
 static int run_phase1(AddPlan &pl, uint64_t *S, size_t batch = 1)
 {
@@ -1022,29 +1077,52 @@ static int run_phase1(AddPlan &pl, uint64_t *S, size_t batch = 1)
         int rc = build_pow_tables(pl, INV);
         if (rc != IOPX_OK) return rc;
     }
+    const uint64_t *pow = INV ? pl.pow_inv.u64() : pl.pow_fwd.u64();
     std::vector<P1Pass> sched = phase1_schedule(d);
     const int n = (int)sched.size();
-    for (int i = 0; i < n; ++i) {
-        const P1Pass &ps = sched[INV ? n - 1 - i : i];
-        P1Params p;
-        p.S = S;
-        p.pow = INV ? pl.pow_inv.u64() : pl.pow_fwd.u64();
-        p.d = d; p.c = ps.c; p.h = ps.h; p.A = ps.A;
-        p.j0 = ps.j0; p.j1 = ps.j1; p.k_start = ps.k_start; p.k_end = ps.k_end;
-        p.xcd_remap = env_int("IOPX_XCD_REMAP", 1, 0, 1);
-        p.comb = tuning().comb && tuning().p1_comb;
-        p.extra = ps.extra; p.skip_j0 = ps.skip_j0;
-        const int tbits = ps.c + ps.A;
-        const size_t lds = ((size_t)24) << tbits;
-        const size_t blocks = (size_t)1 << (d - tbits);
-        const int threads = (1 << tbits) >= 4 * BLOCK_THREADS ? BLOCK_THREADS : ((1 << tbits) >= 256 ? 64 * ((1 << tbits) / 256) : 64);
-        int rc = set_lds(k_phase1<INV>, lds);
-        if (rc != IOPX_OK) return rc;
-        static char names[64][2][32];
-        char *nm = names[ps.j0 & 63][ps.k_start == d - 2 ? 1 : 0];
-        if (!nm[0]) snprintf(nm, 32, getenv("IOPX_PROFILE_LEVELS") ? "k_phase1_L%02d_%s" : "k_phase1", ps.j0, ps.k_start == d - 2 ? "tw" : "x");
-        { ProfScope ps_(nm, (batch << d) * 48); hipLaunchKernelGGL(k_phase1<INV>, dim3((unsigned)blocks, (unsigned)batch), dim3(threads), lds, stream(), p); }
+    const CommInfo ci = transform_comm();
+    int r = 0;
+    while ((1 << r) < ci.world) ++r;
+    // the head (levels < r) must be whole passes of the schedule: true while each of those levels has passes of its own
+    bool split = ci.comm && ci.world > 1 && d >= env_int("IOPX_P1_SHARD_MIN_D", 16, 2, 40) && r < 6 && d - r >= 2;
+    for (const P1Pass &ps : sched) if (ps.j0 < r && ps.j1 >= r) split = false;
+    if (!split) {
+        for (int i = 0; i < n; ++i) {
+            int rc = launch_phase1_pass<INV>(sched[INV ? n - 1 - i : i], S, pow, d, batch);
+            if (rc != IOPX_OK) return rc;
+        }
+        IOPX_HIP(hipGetLastError());
+        return IOPX_OK;
     }
+    const int dt = d - r;
+    const size_t per = (size_t)1 << dt;
+    const uint64_t *pow_tail = pow + 3 * ((((size_t)2) << d) - (((size_t)2) << dt));
+    const std::vector<P1Pass> tail = phase1_schedule(dt);
+    TmpBuf cls, all;
+    int rc = cls.alloc(batch * per * 24);
+    if (rc != IOPX_OK) return rc;
+    rc = all.alloc((batch * 24) << d);
+    if (rc != IOPX_OK) return rc;
+    auto head = [&]() -> int {
+        for (int i = 0; i < n; ++i) {
+            const P1Pass &ps = sched[INV ? n - 1 - i : i];
+            if (ps.j0 >= r) continue;
+            int hrc = launch_phase1_pass<INV>(ps, S, pow, d, batch);
+            if (hrc != IOPX_OK) return hrc;
+        }
+        return IOPX_OK;
+    };
+    if (!INV && (rc = head()) != IOPX_OK) return rc;
+    { ProfScope ps_("k_class_extract", batch * per * 48); hipLaunchKernelGGL(k_class_extract, dim3(grid_for(batch * per * 3, 256)), dim3(256), 0, stream(), (const uint64_t *)S, cls.u64(), d, r, (size_t)ci.rank, batch); }
+    const int nt = (int)tail.size();
+    for (int i = 0; i < nt; ++i) {
+        rc = launch_phase1_pass<INV>(tail[INV ? nt - 1 - i : i], cls.u64(), pow_tail, dt, batch);
+        if (rc != IOPX_OK) return rc;
+    }
+    rc = iopx_comm_all_gather_dev(ci.comm, cls.p, all.p, batch * per * 24);
+    if (rc != IOPX_OK) return rc;
+    { ProfScope ps_("k_class_merge", (batch << d) * 48); hipLaunchKernelGGL(k_class_merge, dim3(grid_for((batch * 3) << d, 256)), dim3(256), 0, stream(), (const uint64_t *)all.u64(), S, d, r, batch); }
+    if (INV && (rc = head()) != IOPX_OK) return rc;
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
 }
@@ -1622,8 +1700,40 @@ __global__ void k_combine(CombineParams p)
     }
 }
 
+// the level undone (fft.tcc:150-163 with stride >= the shard size): from lo = a + tw * b and up = lo + b,  upper = 0: out = a = lo + tw * (lo + up),
+// upper = 1: out = b = lo + up
+__global__ void k_combine_inv(CombineParams p)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.count; i += (size_t)gridDim.x * blockDim.x) {
+        const gf192 lo = gf_load(p.a, i), up = gf_load(p.b, i);
+        const gf192 b = gf_add(lo, up);
+        if (p.upper) { gf_store(p.out, i, b); continue; }
+        const size_t idx = p.index_base + i;
+        gf192 tw = gf_load(p.consts, 0);
+        for (int k = 0; k < p.nb; ++k) {
+            if ((idx >> k) & 1) gf_add_to(tw, gf_load(p.consts, 1 + k));
+        }
+        gf_store(p.out, i, gf_add(lo, gf_mul(b, tw)));
+    }
+}
+
+static int combine_common(bool inverse, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count, size_t index_base,
+                          const uint64_t *basis, size_t nb, const uint64_t *shift_term, int upper);
+
 int iopx_add_combine_gf192_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count, size_t index_base,
                                const uint64_t *basis, size_t nb, const uint64_t *shift_term, int upper)
+{
+    return combine_common(false, d_a, d_b, d_out, count, index_base, basis, nb, shift_term, upper);
+}
+
+int iopx_add_combine_inv_gf192_dev(const uint64_t *d_lo, const uint64_t *d_up, uint64_t *d_out, size_t count, size_t index_base,
+                                   const uint64_t *basis, size_t nb, const uint64_t *shift_term, int upper)
+{
+    return combine_common(true, d_lo, d_up, d_out, count, index_base, basis, nb, shift_term, upper);
+}
+
+static int combine_common(bool inverse, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count, size_t index_base,
+                          const uint64_t *basis, size_t nb, const uint64_t *shift_term, int upper)
 {
     int rc = ensure_device();
     if (rc != IOPX_OK) return rc;
@@ -1636,14 +1746,22 @@ int iopx_add_combine_gf192_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_
     if ((rc = upload(dc.p, hc.data(), hc.size() * 8)) != IOPX_OK) return rc;
     CombineParams p;
     p.a = d_a; p.b = d_b; p.consts = dc.u64(); p.out = d_out; p.count = count; p.index_base = index_base; p.nb = (int)nb; p.upper = upper;
-    { ProfScope ps_("k_combine"); hipLaunchKernelGGL(k_combine, dim3(grid_for(count, 256)), dim3(256), 0, stream(), p); }
+    if (inverse) { ProfScope ps_("k_combine_inv"); hipLaunchKernelGGL(k_combine_inv, dim3(grid_for(count, 256)), dim3(256), 0, stream(), p); }
+    else { ProfScope ps_("k_combine"); hipLaunchKernelGGL(k_combine, dim3(grid_for(count, 256)), dim3(256), 0, stream(), p); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
 }
 
 // In place on 2^log_n elements: S[i] *= d_twist[i] (skipped when d_twist is null), then the Taylor-expansion network of
 // one Gao–Mateer level over ALL index bits (ops k = log_n - 2 .. 0, fft.tcc:73-83 with j = 0).
-int iopx_add_taylor_gf192_dev(uint64_t *d_S, size_t log_n, const uint64_t *d_twist)
+static int taylor_common(bool inverse, uint64_t *d_S, size_t log_n, const uint64_t *d_twist);
+
+int iopx_add_taylor_gf192_dev(uint64_t *d_S, size_t log_n, const uint64_t *d_twist) { return taylor_common(false, d_S, log_n, d_twist); }
+
+// the inverse: the network undone (ops k = 0 .. log_n - 2, fft.tcc:172-188 with j = 0), then S[i] *= d_twist[i] (the inverse powers)
+int iopx_add_taylor_inv_gf192_dev(uint64_t *d_S, size_t log_n, const uint64_t *d_twist) { return taylor_common(true, d_S, log_n, d_twist); }
+
+static int taylor_common(bool inverse, uint64_t *d_S, size_t log_n, const uint64_t *d_twist)
 {
     int rc = ensure_device();
     if (rc != IOPX_OK) return rc;
@@ -1655,6 +1773,7 @@ int iopx_add_taylor_gf192_dev(uint64_t *d_S, size_t log_n, const uint64_t *d_twi
     } else {
         for (const P1Pass &ps : phase1_schedule(d)) if (ps.j0 == 0 && ps.j1 == 0) sched.push_back(ps);
     }
+    if (inverse) std::reverse(sched.begin(), sched.end());
     for (const P1Pass &ps : sched) {
         P1Params p;
         p.S = d_S; p.pow = d_twist;
@@ -1666,8 +1785,9 @@ int iopx_add_taylor_gf192_dev(uint64_t *d_S, size_t log_n, const uint64_t *d_twi
         const size_t lds = ((size_t)24) << tbits;
         const size_t blocks = (size_t)1 << (d - tbits);
         const int threads = (1 << tbits) >= 4 * BLOCK_THREADS ? BLOCK_THREADS : ((1 << tbits) >= 256 ? 64 * ((1 << tbits) / 256) : 64);
-        if ((rc = set_lds(k_phase1<false>, lds)) != IOPX_OK) return rc;
-        { ProfScope ps_("k_phase1"); hipLaunchKernelGGL(k_phase1<false>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        if ((rc = set_lds(k_phase1<false>, lds)) != IOPX_OK || (rc = set_lds(k_phase1<true>, lds)) != IOPX_OK) return rc;
+        if (inverse) { ProfScope ps_("k_phase1"); hipLaunchKernelGGL(k_phase1<true>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        else { ProfScope ps_("k_phase1"); hipLaunchKernelGGL(k_phase1<false>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
     }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;

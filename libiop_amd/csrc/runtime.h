@@ -144,6 +144,11 @@ int build_two_level(const hfp3 &base, const hfp3 &init, int logc, TmpBuf &hi, Tm
 void clear_mul_plans();
 void clear_poseidon_sets();
 
+// comm.hip: the communicator bound for transforms (iopx_comm_bind_transforms), or null; its rank / world; collectives for library-internal
+// use (same semantics as the C entry points)
+struct CommInfo { iopx_comm *comm; int rank, world; };
+CommInfo transform_comm();
+
 static inline size_t ceil_log2(size_t n)
 {
     size_t r = ((n & (n - 1)) == 0 ? 0 : 1);

@@ -125,7 +125,7 @@ class DistributedFFTPlan:
         self.n_loc = 1 << (m - r)
         b = [host.gf_from_words(w) for w in basis]
         sh = host.gf_from_words(np.asarray(shift, dtype=np.uint64))
-        self.rec, self.rs, self.twist = [], [], []
+        self.rec, self.rs, self.twist, self.twist_inv = [], [], [], []
         for j in range(r):                      # fft.tcc:57-96 for the top r levels
             beta = b[m - 1 - j]
             binv = host.gf_inv(beta)
@@ -143,6 +143,10 @@ class DistributedFFTPlan:
             tab = torch.empty((self.n_loc, 3), dtype=torch.int64, device=device)
             lib.pow_table_dev(tab.data_ptr(), self.n_loc, host.gf_to_words(base), host.gf_to_words(init))
             self.twist.append(tab)
+            # the inverse transform multiplies by the inverse powers (fft.tcc:189-199)
+            itab = torch.empty((self.n_loc, 3), dtype=torch.int64, device=device)
+            lib.pow_table_dev(itab.data_ptr(), self.n_loc, host.gf_to_words(host.gf_inv(base)), host.gf_to_words(host.gf_inv(init)))
+            self.twist_inv.append(itab)
             newb = []
             for i in range(m - 1 - j):
                 nb = host.gf_mul(b[i], binv)
@@ -255,6 +259,72 @@ def distributed_fft(lib, torch, dist, plan, d_block):
         _lib_to_torch(lib, torch)
         cur = out
     return cur
+
+
+def distributed_ifft(lib, torch, dist, plan, d_block):
+    """The inverse of distributed_fft (additive_IFFT, fft.tcc:126-204, on a codeword as long as its domain — IFFT_over_field_subset on a
+    full codeword, fft.tcc:421-433): d_block is this rank's contiguous block of the 2^m evaluations, the result its contiguous block of
+    the coefficients.  Every step of the forward transform undone in reverse order: the last r butterfly levels across blocks (peer
+    exchange + iopx_add_combine_inv_gf192_dev), a complete local IFFT over the depth-r recursed domain, the top r levels (network
+    operations on rank bits as shard exchanges — each is its own inverse in characteristic 2 — then iopx_add_taylor_inv_gf192_dev),
+    and the transpose back (ONE all-to-all)."""
+    r, m, s, world, rank, n_loc = plan.r, plan.m, plan.s, plan.world, plan.rank, plan.n_loc
+    peer_of = lambda s2: _rev(s2, r)
+    # 4'. the last r butterfly levels across blocks, outermost first
+    cur = d_block.contiguous()
+    for t in range(r - 1, -1, -1):
+        peer = rank ^ (1 << t)
+        _lib_to_torch(lib, torch)
+        other = _exchange(torch, dist, cur, peer, cur)
+        upper = (rank >> t) & 1
+        lo, up = (other, cur) if upper else (cur, other)
+        lvl = r - 1 - t
+        B = np.array([host.gf_to_words(v) for v in plan.rec[lvl]], dtype=np.uint64).reshape(-1, 3)
+        out = torch.empty_like(cur)
+        _torch_to_lib(lib, torch, other)
+        lib.combine_inv_dev(lo.data_ptr(), up.data_ptr(), out.data_ptr(), n_loc, (rank & ((1 << t) - 1)) * n_loc, B, host.gf_to_words(plan.rs[lvl]), upper)
+        _lib_to_torch(lib, torch)
+        cur = out
+    # 3'. local inverse transform over the recursed domain
+    S = torch.empty_like(cur)
+    _torch_to_lib(lib, torch, cur)
+    lib.additive_IFFT_dev(cur.data_ptr(), plan.local_basis, plan.local_shift, S.data_ptr())
+    _lib_to_torch(lib, torch)
+    # 2'. top r levels, innermost first; within a level the operations on global index bits (k+1, k) run k = j .. r-1
+    for j in range(r - 1, -1, -1):
+        for k in range(j, r):
+            if k + 1 < r:       # both bits select ranks: (0,1) += (1,0), then (1,0) += (1,1)
+                hi, lo_ = (s >> (k + 1)) & 1, (s >> k) & 1
+                if (hi, lo_) == (1, 0):
+                    _send(torch, dist, S, peer_of(s ^ (3 << k)))
+                elif (hi, lo_) == (0, 1):
+                    S ^= _recv(torch, dist, S, peer_of(s ^ (3 << k)))
+                if (hi, lo_) == (1, 1):
+                    _send(torch, dist, S, peer_of(s ^ (1 << k)))
+                elif (hi, lo_) == (1, 0):
+                    S ^= _recv(torch, dist, S, peer_of(s | (1 << k)))
+            else:               # bit k selects the rank, bit k+1 is local index bit 0: (0,1) += (1,0), then (1,0) += (1,1)
+                bit = (s >> k) & 1
+                peer = peer_of(s ^ (1 << k))
+                if bit == 0:
+                    _send(torch, dist, S[1::2].contiguous(), peer)                     # this rank's (1,0) quarter to the holder of (0,1)
+                    S[1::2] ^= _recv(torch, dist, S[1::2].contiguous(), peer)           # (1,0) += (1,1)
+                else:
+                    S[0::2] ^= _recv(torch, dist, S[1::2].contiguous(), peer)           # (0,1) += (1,0)
+                    _send(torch, dist, S[1::2].contiguous(), peer)
+        _torch_to_lib(lib, torch, S)
+        lib.taylor_inv_dev(S.data_ptr(), m - r, plan.twist_inv[j].data_ptr())
+        _lib_to_torch(lib, torch)
+    # 1'. transpose back: s-cyclic -> block distribution
+    x = S.reshape(world, n_loc // world, 3)                                              # chunk q: local slots [q n_loc/N, ...) came from rank q
+    back = torch.empty_like(x)
+    if world > 1:
+        dist.all_to_all_single(back.view(-1), x.contiguous().view(-1))
+    else:
+        back.copy_(x)
+    # chunk q received from the rank of sub-polynomial rev(q): its entries are coefficients rank * n_loc + t with t mod N = rev(q)
+    back = back[[_rev(q, r) for q in range(world)]]                                      # [s', t // N, :]
+    return back.permute(1, 0, 2).contiguous().reshape(n_loc, 3)
 
 
 # ---------------------------------------------------------------------------------------------------------------

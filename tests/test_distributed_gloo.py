@@ -94,19 +94,27 @@ def _fft_worker(rank, world, port, ret):
             plan = idist.DistributedFFTPlan(lib, torch, basis, shift, rank, world, torch.device("cpu"))
             mine = idist.distributed_fft(lib, torch, dist, plan, torch.from_numpy(coeffs[lo:lo + per].view(np.int64).copy()))
             ok.append(bool(np.array_equal(mine.numpy().view(np.uint64), full[lo:lo + per])))
+            # the inverse direction (IFFT_over_field_subset on a full codeword, fft.tcc:126-204, 421-433): back to the coefficients, and
+            # independent evaluations against the oracle's additive_IFFT
+            back = idist.distributed_ifft(lib, torch, dist, plan, mine)
+            ok.append(bool(np.array_equal(back.numpy().view(np.uint64), coeffs[lo:lo + per])))
+            evals = rand_elems(73 + m, 1 << m, W)
+            inv = idist.distributed_ifft(lib, torch, dist, plan, torch.from_numpy(evals[lo:lo + per].view(np.int64).copy()))
+            ok.append(bool(np.array_equal(inv.numpy().view(np.uint64), oracle.additive_ifft(evals, basis, shift)[lo:lo + per])))
         ret[rank] = ok
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_distributed_full_size_fft(world):
+    """One transform as long as its domain, forward and inverse, sharded by contiguous blocks: all-to-all transpose + peer exchanges."""
     mgr = mp.Manager()
     ret = mgr.dict()
     port = _free_port()
     mp.spawn(_fft_worker, args=(world, port, ret), nprocs=world, join=True)
     for r in range(world):
-        assert ret[r] == [True, True], (r, ret[r])
+        assert ret[r] == [True] * 6, (r, ret[r])
 
 
 def _mul_worker(rank, world, port, ret):
@@ -438,3 +446,83 @@ def test_native_sharded_fractal_prover_equals_oracle(world, field_code, log_n, n
     for r in range(world):
         assert ret[r][1] == ref_roots, "rank %d index root" % r
         assert ret[r][0] == ref, "rank %d" % r
+
+
+# ---- phase 1 of the replicated transforms split over the ranks (iopx_comm_bind_transforms; fft_add.hip run_phase1) ----
+P1_SHARD_ENV = {"IOPX_P1_SHARD_MIN_D": "6", "IOPX_TILE_BITS": "5", "IOPX_P1_COLS": "2", "IOPX_P2_COLS": "2", "IOPX_P2_TOP": "2"}
+
+
+def _phase1_worker(rank, world, port, ret):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes
+        import oracle
+        from emu_lib import emu
+        from helpers import rand_elems
+        lib = emu()
+        comm = lib.comm_create_torch_callbacks(dist, rank, world)
+        lib.c.iopx_comm_bind_transforms.argtypes = [ctypes.c_void_p]
+        ok, calls = [], []
+        for m, kind in ((8, "std"), (9, "general"), (11, "std"), (5, "std")):         # m = 5: below the threshold, stays whole
+            basis = oracle.standard_basis(m, W) if kind == "std" else rand_elems(70 + m, m, W)
+            shift = rand_elems(71 + m, 1, W)[0]
+            coeffs = rand_elems(72 + m, 1 << m, W)
+            full = oracle.additive_fft(coeffs, basis, shift)
+            lib.comm_stats(reset=True)
+            lib._check(lib.c.iopx_comm_bind_transforms(comm))
+            try:
+                got = lib.additive_FFT(coeffs, basis, shift)
+                back = lib.additive_IFFT(full, basis, shift)
+                short = coeffs[: (1 << (m - 2)) - 3]                                  # a low-degree extension: phase 1 on 2^(m-2) coefficients
+                lde = lib.additive_FFT(short, basis, shift)
+            finally:
+                lib._check(lib.c.iopx_comm_bind_transforms(None))
+            calls.append(lib.comm_stats()[0])
+            ok.append(bool(np.array_equal(got, full) and np.array_equal(back, coeffs) and np.array_equal(lde, oracle.additive_fft(short, basis, shift))))
+        ret[rank] = (ok, calls)
+        lib.comm_destroy(comm)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_phase1_split_over_the_ranks(world, monkeypatch):
+    """Forward and inverse transforms with their phase 1 split by residue class of the coefficient index (levels < log2 N on the whole vector,
+    the rest on the rank's class, one all-gather): results equal the oracle's on every rank, and the collectives were really issued."""
+    for k, v in P1_SHARD_ENV.items():
+        monkeypatch.setenv(k, v)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_phase1_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        ok, calls = ret[r]
+        assert ok == [True] * 4, (r, ok)
+        assert calls[0] >= 2 and calls[1] >= 2 and calls[2] >= 3 and calls[3] == 0, (r, calls)
+
+
+@pytest.mark.parametrize("world,protocol,field_code,log_n", [(2, "aurora", 0, 7), (8, "aurora", 0, 9), (4, "fractal", 0, 7)])
+def test_native_sharded_provers_with_phase1_split(world, protocol, field_code, log_n, monkeypatch):
+    """The native distributed provers with the phase-1 split active at test sizes (the 2^20 proof takes it by default, d >= 16)."""
+    import oracle
+    mgr = mp.Manager()
+    plain, ret = mgr.dict(), mgr.dict()
+    seed = 0x2204 if protocol == "aurora" else 0x2205
+    args = (protocol, field_code, log_n, 15, seed, 5 if protocol == "aurora" else 3)
+    mp.spawn(_native_worker, args=(world, _free_port(), plain) + args, nprocs=world, join=True)       # default tuning: transforms stay whole at this size
+    for k, v in P1_SHARD_ENV.items():
+        monkeypatch.setenv(k, v)
+    mp.spawn(_native_worker, args=(world, _free_port(), ret) + args, nprocs=world, join=True)
+    if protocol == "aurora":
+        ref, ref_roots = oracle.aurora_prove(oracle.FIELD_GF192, log_n, 15, seed), []
+    else:
+        ref, ref_roots = oracle.fractal_prove(oracle.FIELD_GF192, log_n, 15, seed)
+    for r in range(world):
+        assert ret[r][0] == ref and ret[r][1] == ref_roots, "rank %d" % r
+        assert plain[r][0] == ref
+        assert ret[r][2][0] > plain[r][2][0], "the transforms issued no collective: %r vs %r" % (ret[r][2], plain[r][2])
