@@ -35,7 +35,7 @@ namespace iopx {
 // Tile geometry.  Defaults: 2048-element phase-2 tiles (48 KiB of LDS per workgroup), 1024-element phase-1 and edge tiles.  The IOPX_TILE_BITS /
 // IOPX_P1_COLS / IOPX_P2_COLS / IOPX_P2_TOP environment variables override them (read once): used for
 // tuning, and by the tests to exercise the multi-pass schedules at small transform sizes.
-struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last, scratch_mb, p1_comb, rs_comb_cap_log2; };
+struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last, scratch_mb, p1_comb, rs_comb_cap_log2, p2_radix4; };
 static int env_int(const char *name, int dflt, int lo, int hi)
 {
     const char *v = getenv(name);
@@ -69,6 +69,7 @@ static const Tuning &tuning()
         u.scratch_mb = env_int("IOPX_SCRATCH_MB", 256, 1, 65536);
         u.rs_comb_cap_log2 = env_int("IOPX_RS_COMB_CAP_LOG2", 22, 0, 30);  // per-coset combined shift terms up to 2^this entries, byte tables beyond
         u.p1_comb = env_int("IOPX_P1_COMB", 1, 0, 1);                   // 1: comb product for the phase-1 twists with a wave-uniform multiplier
+        u.p2_radix4 = env_int("IOPX_P2_RADIX4", 1, 0, 1);               // 1: the comb upper passes take two levels per LDS round trip (four elements per lane in registers)
         return u;
     }();
     return t;
@@ -325,6 +326,7 @@ struct BfParams {
     int d, nhi;
     int c, h, A;            // upper pass tile geometry
     int p_hi, p_lo;         // pair bits handled (forward: p_hi down to p_lo)
+    int radix4;             // comb upper passes: two levels per LDS round trip
     int a_low, c_top;       // last/first pass tile: low a_low bits x top c_top bits
     int g_bits;             // last/first pass: 2^g_bits tiles per workgroup
     size_t total_units;     // cosets (of this launch) * tiles per coset
@@ -510,7 +512,57 @@ __global__ void __launch_bounds__(COMB ? 512 : 1024, COMB ? 6 : 1) k_bfly_upper(
     __syncthreads();
 
     const int nlev = p.p_hi - p.p_lo + 1;
-    for (int t = 0; t < nlev; ++t) {
+    int t = 0;
+    if (COMB && p.radix4) {
+        // Two levels per LDS round trip: a lane takes the four elements e[y][x] that differ in the two pair bits (A the higher), runs the
+        // two butterflies of each level in registers and writes them back — half the LDS traffic and half the barriers of the one-level
+        // loop.  The level with pair bit A has one twiddle for both of its butterflies (it depends on the bits above A only), the level
+        // with pair bit B = A - 1 one per value of bit A; all wave-uniform (the lanes of a wavefront differ in the column bits only).
+        for (; t + 1 < nlev; t += 2) {
+            const int pbA = INV ? p.p_lo + t + 1 : p.p_hi - t, pbB = pbA - 1;
+            const int plA = pbA - p.h + p.c, plB = plA - 1;
+#pragma unroll 1
+            for (int g = tid; g < (E >> 2); g += nt) {
+                const int i0 = ((g >> plB) << (plA + 1)) | (g & ((1 << plB) - 1));
+                const int i1 = i0 | (1 << plB), i2 = i0 | (1 << plA), i3 = i2 | (1 << plB);
+                const uint32_t i0_u = __builtin_amdgcn_readfirstlane((uint32_t)(i0 & ~63));
+                const size_t u0 = base | ((size_t)(i0_u >> p.c) << p.h) | (size_t)(i0_u & cmask);
+                gf192 e0 = lds_get(s, E, i0), e1 = lds_get(s, E, i1), e2 = lds_get(s, E, i2), e3 = lds_get(s, E, i3);
+                if (!INV) {
+                    {
+                        const gf192 tw = bf_twiddle_uniform(p, coset, u0, pbA);
+                        gf_add_to(e0, gf_mul_uniform(e2, tw)); gf_add_to(e2, e0);
+                        gf_add_to(e1, gf_mul_uniform(e3, tw)); gf_add_to(e3, e1);
+                    }
+                    {
+                        const gf192 tw = bf_twiddle_uniform(p, coset, u0, pbB);
+                        gf_add_to(e0, gf_mul_uniform(e1, tw)); gf_add_to(e1, e0);
+                    }
+                    {
+                        const gf192 tw = bf_twiddle_uniform(p, coset, u0 | ((size_t)1 << pbA), pbB);
+                        gf_add_to(e2, gf_mul_uniform(e3, tw)); gf_add_to(e3, e2);
+                    }
+                } else {
+                    {
+                        const gf192 tw = bf_twiddle_uniform(p, coset, u0, pbB);
+                        gf_add_to(e1, e0); gf_add_to(e0, gf_mul_uniform(e1, tw));
+                    }
+                    {
+                        const gf192 tw = bf_twiddle_uniform(p, coset, u0 | ((size_t)1 << pbA), pbB);
+                        gf_add_to(e3, e2); gf_add_to(e2, gf_mul_uniform(e3, tw));
+                    }
+                    {
+                        const gf192 tw = bf_twiddle_uniform(p, coset, u0, pbA);
+                        gf_add_to(e2, e0); gf_add_to(e0, gf_mul_uniform(e2, tw));
+                        gf_add_to(e3, e1); gf_add_to(e1, gf_mul_uniform(e3, tw));
+                    }
+                }
+                lds_put(s, E, i0, e0); lds_put(s, E, i1, e1); lds_put(s, E, i2, e2); lds_put(s, E, i3, e3);
+            }
+            __syncthreads();
+        }
+    }
+    for (; t < nlev; ++t) {
         const int pbit = INV ? p.p_lo + t : p.p_hi - t;
         const int pl = pbit - p.h + p.c;
         if (COMB) {
@@ -1232,13 +1284,16 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         p.src = s; p.dst = dd; p.src_shared = shared;
         p.c = u.c; p.h = u.h; p.A = u.A;
         p.p_hi = u.h + u.A - 1; p.p_lo = u.h;
+        p.radix4 = tuning().p2_radix4;
         const int tbits = u.c + u.A;
         const size_t lds = ((size_t)24) << tbits;
         const size_t blocks = ncos << (d - tbits);
         p.total_units = blocks; p.coset_base = cbase;
         p.rs_comb = comb_count ? rs_comb_ptr + 3 * (cbase - comb_base) * d : nullptr;
         const int maxt = (tuning().comb && u.c < 6) ? 1024 : tuning().p2_threads;
-        const int threads = (1 << tbits) >= 2 * maxt ? maxt : ((1 << tbits) >= 128 ? (1 << tbits) / 2 : 64);
+        int threads = (1 << tbits) >= 2 * maxt ? maxt : ((1 << tbits) >= 128 ? (1 << tbits) / 2 : 64);
+        // two levels per trip: a tile has 2^tbits / 4 four-element groups; threads beyond that would idle through the paired levels
+        if (tuning().comb && u.c >= 6 && p.radix4 && u.A >= 2 && threads > (1 << tbits) / 4) threads = (1 << tbits) / 4 >= 64 ? (1 << tbits) / 4 : 64;
         int rc;
         if (tuning().comb && u.c >= 6) {
             if ((rc = set_lds(k_bfly_upper<INV, true>, lds)) != IOPX_OK) return rc;

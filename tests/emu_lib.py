@@ -17,6 +17,9 @@ def emu():
         if override:
             _emu = libiop_amd.Library(override)
         else:
-            subprocess.check_call(["make", "-s", "-j8", "-C", _EMU_DIR])
+            import fcntl
+            with open(os.path.join(_EMU_DIR, ".build.lock"), "w") as lock:       # ranks and xdist workers start together: one build at a time
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                subprocess.check_call(["make", "-s", "-j8", "-C", _EMU_DIR])
             _emu = libiop_amd.Library(os.path.join(_EMU_DIR, "libiopx_emu.so"))
     return _emu
