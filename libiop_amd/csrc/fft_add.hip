@@ -69,7 +69,11 @@ static const Tuning &tuning()
         u.scratch_mb = env_int("IOPX_SCRATCH_MB", 256, 1, 65536);
         u.rs_comb_cap_log2 = env_int("IOPX_RS_COMB_CAP_LOG2", 22, 0, 30);  // per-coset combined shift terms up to 2^this entries, byte tables beyond
         u.p1_comb = env_int("IOPX_P1_COMB", 1, 0, 1);                   // 1: comb product for the phase-1 twists with a wave-uniform multiplier
-        u.p2_radix4 = env_int("IOPX_P2_RADIX4", 1, 0, 1);               // 1: the comb upper passes take two levels per LDS round trip (four elements per lane in registers)
+        // 1: the comb upper passes take two levels per LDS round trip (four elements per lane in registers: half the LDS traffic and half the
+        // barriers).  Measured SLOWER on the MI355X — k_bfly_upper 21.9 -> 25.9 ms per proof at 6 waves per SIMD (the four live elements spill),
+        // 25.0 ms at 5 waves without spills (profiles/r04_ab_radix4*.txt): the LDS round trip and the per-level barrier are not what separates
+        // the kernel from its VALU ceiling.  Kept as an experiment, off by default.
+        u.p2_radix4 = env_int("IOPX_P2_RADIX4", 0, 0, 1);
         return u;
     }();
     return t;
@@ -488,8 +492,8 @@ __device__ __forceinline__ void bf_apply_small1(uint64_t *s, int E, int ia, int 
     lds_put(s, E, ib, b);
 }
 
-template<bool INV, bool COMB>
-__global__ void __launch_bounds__(COMB ? 512 : 1024, COMB ? 6 : 1) k_bfly_upper(BfParams p)
+template<bool INV, bool COMB, bool R4>
+__global__ void __launch_bounds__(COMB ? 512 : 1024, COMB ? (R4 ? 5 : 6) : 1) k_bfly_upper(BfParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
     uint64_t *s = iopx_smem;
@@ -513,7 +517,7 @@ __global__ void __launch_bounds__(COMB ? 512 : 1024, COMB ? 6 : 1) k_bfly_upper(
 
     const int nlev = p.p_hi - p.p_lo + 1;
     int t = 0;
-    if (COMB && p.radix4) {
+    if (COMB && R4) {
         // Two levels per LDS round trip: a lane takes the four elements e[y][x] that differ in the two pair bits (A the higher), runs the
         // two butterflies of each level in registers and writes them back — half the LDS traffic and half the barriers of the one-level
         // loop.  The level with pair bit A has one twiddle for both of its butterflies (it depends on the bits above A only), the level
@@ -1295,12 +1299,15 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         // two levels per trip: a tile has 2^tbits / 4 four-element groups; threads beyond that would idle through the paired levels
         if (tuning().comb && u.c >= 6 && p.radix4 && u.A >= 2 && threads > (1 << tbits) / 4) threads = (1 << tbits) / 4 >= 64 ? (1 << tbits) / 4 : 64;
         int rc;
-        if (tuning().comb && u.c >= 6) {
-            if ((rc = set_lds(k_bfly_upper<INV, true>, lds)) != IOPX_OK) return rc;
-            { ProfScope ps_("k_bfly_upper", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, true>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        if (tuning().comb && u.c >= 6 && p.radix4 && u.A >= 2) {
+            if ((rc = set_lds(k_bfly_upper<INV, true, true>, lds)) != IOPX_OK) return rc;
+            { ProfScope ps_("k_bfly_upper", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, true, true>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        } else if (tuning().comb && u.c >= 6) {
+            if ((rc = set_lds(k_bfly_upper<INV, true, false>, lds)) != IOPX_OK) return rc;
+            { ProfScope ps_("k_bfly_upper", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, true, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         } else {
-            if ((rc = set_lds(k_bfly_upper<INV, false>, lds)) != IOPX_OK) return rc;
-            { ProfScope ps_("k_bfly_upper", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+            if ((rc = set_lds(k_bfly_upper<INV, false, false>, lds)) != IOPX_OK) return rc;
+            { ProfScope ps_("k_bfly_upper", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, false, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         }
         return IOPX_OK;
     };

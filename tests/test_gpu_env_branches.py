@@ -7,6 +7,7 @@ against the oracle in a CHILD process with the environment that takes the branch
   IOPX_EDGE_BATCH=0         every polynomial of a batch takes its own last pass
   IOPX_SMALL_LAST=0         general product at the last two levels (no one- / two-word numerators)
   IOPX_COMB=0               general product everywhere (fft.tcc:39-124 has one multiplier; every branch must agree with it)
+  IOPX_P2_RADIX4=1          two butterfly levels per LDS round trip in the upper passes (an experiment that measured slower; kept correct)
 
 and, with the default environment, the exact f_1v shape (16 coefficients over the 2^25-point codeword domain) sampled against
 oracle.poly_eval."""
@@ -127,7 +128,7 @@ def _run(script, extra_env, timeout=1500):
 
 
 @pytest.mark.parametrize("env", [{"IOPX_RS_COMB_CAP_LOG2": "3"}, {"IOPX_P1_COMB": "0"}, {"IOPX_EDGE_BATCH": "0"}, {"IOPX_SMALL_LAST": "0"},
-                                 {"IOPX_COMB": "0"}, {"IOPX_RS_COMB_CAP_LOG2": "3", "IOPX_SMALL_LAST": "0"}],
+                                 {"IOPX_COMB": "0"}, {"IOPX_RS_COMB_CAP_LOG2": "3", "IOPX_SMALL_LAST": "0"}, {"IOPX_P2_RADIX4": "1"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_env_gated_branches_equal_the_oracle(env):
     _run(SHAPES, env)

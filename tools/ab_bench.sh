@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B of tuning environment variables on the Aurora 2^20 bench (one box, same session): tools/ab_bench.sh OUT "ENV1" "ENV2" ...
+out=$1; shift
+: > "$out"
+for e in "$@"; do
+  echo "== $e" >> "$out"
+  env $e python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "
+import sys, json
+j = json.loads(sys.stdin.read().strip().splitlines()[-1])
+r = j['roofline']
+print('ms_per_step %.3f  upper %.3f  edge %.3f  phase1 %.3f  kernels %.3f  host_gap %.3f  alu_frac %s' % (j['ms_per_step'], r['kernels_ms_per_step'].get('k_bfly_upper', 0), r['kernels_ms_per_step'].get('k_bfly_edge', 0), r['kernels_ms_per_step'].get('k_phase1', 0), r['kernels_ms_total'], r['host_gap_ms'], r.get('alu_ceiling_frac')))
+" >> "$out"
+done
+cat "$out"
