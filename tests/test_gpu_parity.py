@@ -26,6 +26,12 @@ def _dom(m, kind, seed):
     return rand_elems(seed + 1, m, W), rand_elems(seed, 1, W)[0]
 
 
+def test_integer_only_golden_vectors(gpu):
+    """tests/golden/gf192_tiny.json: FFT / IFFT / LDE / folds / a Merkle tree computed with Python integers and hashlib only."""
+    import golden_cases
+    golden_cases.check(gpu.additive_FFT, gpu.additive_IFFT, gpu.evaluate_next_f_i_over_entire_domain, gpu.merkle_tree)
+
+
 def test_field_mul(gpu):
     a, b = rand_elems(1, 1 << 16, W), rand_elems(2, 1 << 16, W)
     a[0] = 0xFFFFFFFFFFFFFFFF
