@@ -256,10 +256,10 @@ def main():
     # committed PMC run of the same kernels and labelled with its file; null when that run covered other kernel sources
     traffic, traffic_source = None, None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic_aurora.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic_aurora.json")))
         if tj.get("log_n") == args.log_n and dom_name in tj.get("kernels", {}) and tj.get("kernel_sources_sha256") == kernel_sources_digest():
             traffic = tj["kernels"][dom_name]["traffic_bytes_per_launch"]
-            traffic_source = "profiles/r03_traffic_aurora.json (rocprofv3 --pmc passes of this command, collected %s)" % tj.get("collected", "?")
+            traffic_source = "profiles/r04_traffic_aurora.json (rocprofv3 --pmc passes of this command, collected %s)" % tj.get("collected", "?")
     except (OSError, ValueError):
         pass
     # ALU ceiling: the rate measured live in this run (field products of the launches / their HIP-event time) against the VALU-issue
@@ -270,8 +270,12 @@ def main():
     alu = {}
     if model:
         for kname, kmod in model["kernels"].items():
-            if kname in prof and products.get(kname):
-                rate = products[kname] / (prof[kname][1] / 1e3)
+            # the model's kernels are templates; the profile has one name per instantiation that ran (k_bfly_upper_fwd / _inv, ...): the batch form
+            # of the edge pass has an instruction mix of its own and is left out
+            members = [k for k in prof if k.startswith(kname) and not k.endswith("_batch")]
+            p_sum, ms_sum = sum(products.get(k, 0) for k in members), sum(prof[k][1] for k in members)
+            if p_sum and ms_sum:
+                rate = p_sum / (ms_sum / 1e3)
                 alu[kname] = {"products_per_s": rate, "ceiling_products_per_s": kmod["alu_ceiling_products_per_s"],
                               "alu_ceiling_frac": rate / kmod["alu_ceiling_products_per_s"], "cycles_per_wave_product_model": kmod["cycles_per_wave_butterfly"]}
     fft_kernels = ("k_phase1", "k_bfly_upper", "k_bfly_edge", "k_pad_copy", "k_rs_combine", "k_fill")
@@ -325,13 +329,14 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                      "traffic_source": traffic_source,
                      "binding": "integer VALU issue (gfx950 has no carry-less multiply: a GF(2^192) product is ~450-1000 VALU ops)",
-                     "alu_ceiling_frac": alu.get(dom_name, {}).get("alu_ceiling_frac"),
+                     "alu_ceiling_frac": next((v["alu_ceiling_frac"] for k, v in alu.items() if dom_name.startswith(k)), None),
                      "alu": alu,
                      "note": "frac = algorithmic bytes / HBM peak as the contract asks; the kernel is bound by VALU issue, for which alu_ceiling_frac is the "
                              "figure: measured products/s over the ceiling of the kernel's instruction mix at the per-class issue costs measured on this GPU "
                              "(profiles/r03_alu_model.json, profiles/r03_valu_rates.txt)",
                      "kernels_ms_per_step": {k: round(v[1], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
                      "kernel_launches_per_step": {k: v[0] for k, v in prof.items()},
+                     "kernel_algorithmic_bytes_per_launch": {k: round(v[2] / v[0]) for k, v in prof.items() if v[2]},
                      # the profiled proof's kernel time (HIP events) against the timed loop's wall time per proof: launch gaps + host work + read-backs
                      "kernels_ms_total": round(sum(v[1] for v in prof.values()), 3),
                      "host_gap_ms": round(prover_s * 1e3 - sum(v[1] for v in prof.values()), 3) if prof else None},

@@ -305,8 +305,8 @@ static int lincomb_common(const void *const *d_oracles, size_t num, const uint64
     memset(&p, 0, sizeof(p));
     for (size_t i = 0; i < num; ++i) { if (!d_oracles[i]) return fail(IOPX_ERR_INVALID_ARGUMENT, "null oracle"); p.o[i] = (const uint64_t *)d_oracles[i]; }
     p.c = dc.u64(); p.out = d_out; p.num = (int)num; p.n = n; p.has_constant = constant ? 1 : 0;
-    if (prime_field) { ProfScope ps_("k_lincomb_fp3"); hipLaunchKernelGGL(k_lincomb_fp3, dim3(eo_grid(n)), dim3(256), 0, stream(), p); }
-    else { ProfScope ps_("k_lincomb_gf192"); hipLaunchKernelGGL(k_lincomb_gf192, dim3(eo_grid(n)), dim3(256), 0, stream(), p); }
+    if (prime_field) { ProfScope ps_("k_lincomb_fp3", (num + 1) * n * 24); hipLaunchKernelGGL(k_lincomb_fp3, dim3(eo_grid(n)), dim3(256), 0, stream(), p); }
+    else { ProfScope ps_("k_lincomb_gf192", (num + 1) * n * 24); hipLaunchKernelGGL(k_lincomb_gf192, dim3(eo_grid(n)), dim3(256), 0, stream(), p); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
 }
@@ -413,7 +413,7 @@ int iopx_poly_div_vanishing_gf192_dev(const uint64_t *d_poly, size_t n_coeffs, c
         return t;
     };
     auto launch = [&](const PolyDivParams &p) -> int {
-        { ProfScope ps_("k_polydiv_pass_gf192"); hipLaunchKernelGGL(k_polydiv_pass_gf192, dim3(eo_grid(p.M)), dim3(256), 0, stream(), p); }
+        { ProfScope ps_("k_polydiv_pass_gf192", 2 * (size_t)p.M * 24); hipLaunchKernelGGL(k_polydiv_pass_gf192, dim3(eo_grid(p.M)), dim3(256), 0, stream(), p); }
         IOPX_HIP(hipGetLastError());
         return IOPX_OK;
     };

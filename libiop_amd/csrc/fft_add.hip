@@ -1087,9 +1087,9 @@ static int launch_phase1_pass(const P1Pass &ps, uint64_t *S, const uint64_t *pow
     const int threads = (1 << tbits) >= 4 * BLOCK_THREADS ? BLOCK_THREADS : ((1 << tbits) >= 256 ? 64 * ((1 << tbits) / 256) : 64);
     int rc = set_lds(k_phase1<INV>, lds);
     if (rc != IOPX_OK) return rc;
-    static char names[64][2][32];
+    static char names[64][2][40];
     char *nm = names[ps.j0 & 63][ps.k_start == d_eff - 2 ? 1 : 0];
-    if (!nm[0]) snprintf(nm, 32, getenv("IOPX_PROFILE_LEVELS") ? "k_phase1_L%02d_%s" : "k_phase1", ps.j0, ps.k_start == d_eff - 2 ? "tw" : "x");
+    if (!nm[0]) snprintf(nm, 40, getenv("IOPX_PROFILE_LEVELS") ? "k_phase1_%s_L%02d_%s" : "k_phase1_%s", INV ? "inv" : "fwd", ps.j0, ps.k_start == d_eff - 2 ? "tw" : "x");
     { ProfScope ps_(nm, (batch << d_eff) * 48); hipLaunchKernelGGL(k_phase1<INV>, dim3((unsigned)blocks, (unsigned)batch), dim3(threads), lds, stream(), p); }
     return IOPX_OK;
 }
@@ -1281,7 +1281,7 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         p.rs_comb = comb_count ? rs_comb_ptr + 3 * (cbase - comb_base) * d : nullptr;
         int rc;
         if ((rc = set_lds(k_bfly_edge<INV, false>, lds)) != IOPX_OK) return rc;
-        { ProfScope ps_("k_bfly_edge", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)p.a_low); hipLaunchKernelGGL((k_bfly_edge<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        { ProfScope ps_(INV ? "k_bfly_edge_inv" : "k_bfly_edge_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)p.a_low); hipLaunchKernelGGL((k_bfly_edge<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         return IOPX_OK;
     };
     auto launch_upper = [&](const Up &u, const uint64_t *s, uint64_t *dd, int shared, size_t ncos, size_t cbase) -> int {
@@ -1301,13 +1301,13 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         int rc;
         if (tuning().comb && u.c >= 6 && p.radix4 && u.A >= 2) {
             if ((rc = set_lds(k_bfly_upper<INV, true, true>, lds)) != IOPX_OK) return rc;
-            { ProfScope ps_("k_bfly_upper", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, true, true>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+            { ProfScope ps_(INV ? "k_bfly_upper_inv" : "k_bfly_upper_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, true, true>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         } else if (tuning().comb && u.c >= 6) {
             if ((rc = set_lds(k_bfly_upper<INV, true, false>, lds)) != IOPX_OK) return rc;
-            { ProfScope ps_("k_bfly_upper", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, true, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+            { ProfScope ps_(INV ? "k_bfly_upper_inv" : "k_bfly_upper_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, true, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         } else {
             if ((rc = set_lds(k_bfly_upper<INV, false, false>, lds)) != IOPX_OK) return rc;
-            { ProfScope ps_("k_bfly_upper", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, false, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+            { ProfScope ps_(INV ? "k_bfly_upper_inv" : "k_bfly_upper_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, false, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         }
         return IOPX_OK;
     };
@@ -1419,7 +1419,7 @@ static int run_phase2_fwd_batch(AddPlan &pl, const uint64_t *const *srcs, uint64
         for (size_t k = 0; k < batch; ++k) { q.srcs[k] = scratch[k]->u64(); q.dsts[k] = dsts[k] + 3 * c0 * nd; }
         const size_t lds = (((size_t)24) << tb) * batch;
         if ((rc = set_lds(k_bfly_edge_fwd_batch, lds)) != IOPX_OK) return rc;
-        { ProfScope ps_("k_bfly_edge", batch * (nc << d) * 48, batch * ((nc << d) >> 1) * (size_t)p.a_low);
+        { ProfScope ps_("k_bfly_edge_fwd_batch", batch * (nc << d) * 48, batch * ((nc << d) >> 1) * (size_t)p.a_low);
           hipLaunchKernelGGL(k_bfly_edge_fwd_batch, dim3((unsigned)p.total_units), dim3(512), lds, stream(), q); }
     }
     IOPX_HIP(hipGetLastError());
@@ -1848,8 +1848,8 @@ static int taylor_common(bool inverse, uint64_t *d_S, size_t log_n, const uint64
         const size_t blocks = (size_t)1 << (d - tbits);
         const int threads = (1 << tbits) >= 4 * BLOCK_THREADS ? BLOCK_THREADS : ((1 << tbits) >= 256 ? 64 * ((1 << tbits) / 256) : 64);
         if ((rc = set_lds(k_phase1<false>, lds)) != IOPX_OK || (rc = set_lds(k_phase1<true>, lds)) != IOPX_OK) return rc;
-        if (inverse) { ProfScope ps_("k_phase1"); hipLaunchKernelGGL(k_phase1<true>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
-        else { ProfScope ps_("k_phase1"); hipLaunchKernelGGL(k_phase1<false>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        if (inverse) { ProfScope ps_("k_phase1_inv"); hipLaunchKernelGGL(k_phase1<true>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        else { ProfScope ps_("k_phase1_fwd"); hipLaunchKernelGGL(k_phase1<false>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
     }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;

@@ -338,7 +338,7 @@ int iopx_ldt_combine_fp3_dev(const void *const *d_oracles, size_t num_oracles, c
     p.out = d_out;
     p.coef = dcoef.u64();
     p.n = (size_t)1 << log_n; p.num_oracles = (int)num_oracles;
-    { ProfScope ps_("k_ldt_combine_fp"); hipLaunchKernelGGL(k_ldt_combine_fp, dim3(ldt_grid(p.n)), dim3(256), 0, stream(), p); }
+    { ProfScope ps_("k_ldt_combine_fp", (num_oracles + 1) * p.n * 24); hipLaunchKernelGGL(k_ldt_combine_fp, dim3(ldt_grid(p.n)), dim3(256), 0, stream(), p); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
 }

@@ -260,7 +260,7 @@ static int merkle_blake2b_impl(const void *const *d_oracles, size_t num_oracles,
     p.additive = (domain_type == IOPX_DOMAIN_ADDITIVE);
     size_t grid = (L + 255) / 256;
     if (grid > 65536) grid = 65536;
-    { ProfScope ps_("k_merkle_leaves"); hipLaunchKernelGGL(k_merkle_leaves, dim3((unsigned)grid), dim3(256), 0, stream(), p); }
+    { ProfScope ps_("k_merkle_leaves", num_oracles * n * elem_bytes + L * 32); hipLaunchKernelGGL(k_merkle_leaves, dim3((unsigned)grid), dim3(256), 0, stream(), p); }
 
     if (leaves_only) return IOPX_OK;
     return iopx_merkle_inner_blake2b_dev(d_nodes, L);   // the pointer table is released in stream order
@@ -294,10 +294,10 @@ int iopx_merkle_inner_blake2b_dev(uint8_t *d_nodes, size_t num_leaves)
     while (count > 1024) {
         size_t g = (count + 255) / 256;
         if (g > 65536) g = 65536;
-        { ProfScope ps_("k_merkle_level"); hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)g), dim3(256), 0, stream(), (uint64_t *)d_nodes, count - 1, count); }
+        { ProfScope ps_("k_merkle_level", count * 96); hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)g), dim3(256), 0, stream(), (uint64_t *)d_nodes, count - 1, count); }
         count >>= 1;
     }
-    { ProfScope ps_("k_merkle_top"); hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(count >= 1024 ? 1024 : (count >= 256 ? 256 : 64)), 0, stream(), (uint64_t *)d_nodes, count); }
+    { ProfScope ps_("k_merkle_top", count * 96); hipLaunchKernelGGL(k_merkle_top, dim3(1), dim3(count >= 1024 ? 1024 : (count >= 256 ? 256 : 64)), 0, stream(), (uint64_t *)d_nodes, count); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
 }

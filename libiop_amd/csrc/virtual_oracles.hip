@@ -267,7 +267,7 @@ int iopx_rowcheck_gf192_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const ui
     if ((rc = dz.alloc(zinv.size() * 8)) != IOPX_OK) return rc;
     if ((rc = upload(dz.p, zinv.data(), zinv.size() * 8)) != IOPX_OK) return rc;
     const size_t n = (size_t)1 << m;
-    { ProfScope ps_("k_rowcheck_add"); hipLaunchKernelGGL(k_rowcheck_add, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_Az, d_Bz, d_Cz, (const uint64_t *)dz.u64(), (int)h, n); }
+    { ProfScope ps_("k_rowcheck_add", 4 * n * 24); hipLaunchKernelGGL(k_rowcheck_add, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_Az, d_Bz, d_Cz, (const uint64_t *)dz.u64(), (int)h, n); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
 }
@@ -304,7 +304,7 @@ int iopx_rowcheck_fp3_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const uint
     if ((rc = upload(dz.p, zinv.data(), zinv.size() * 8)) != IOPX_OK) return rc;
     if ((rc = upload(done.p, one.w, 24)) != IOPX_OK) return rc;
     const size_t n = (size_t)1 << log_n;
-    { ProfScope ps_("k_rowcheck_fp"); hipLaunchKernelGGL(k_rowcheck_fp, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_Az, d_Bz, d_Cz, (const uint64_t *)dz.u64(),
+    { ProfScope ps_("k_rowcheck_fp", 4 * n * 24); hipLaunchKernelGGL(k_rowcheck_fp, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_Az, d_Bz, d_Cz, (const uint64_t *)dz.u64(),
                                                         (const uint64_t *)done.u64(), cosets, n); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
@@ -330,7 +330,7 @@ int iopx_fz_gf192_dev(const uint64_t *d_fw, const uint64_t *d_f1v, const uint64_
     if ((rc = dt.alloc(tab.size() * 8)) != IOPX_OK) return rc;
     if ((rc = upload(dt.p, tab.data(), tab.size() * 8)) != IOPX_OK) return rc;
     const size_t n = (size_t)1 << m;
-    { ProfScope ps_("k_fz_add"); hipLaunchKernelGGL(k_fz_add, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_fw, d_f1v, (const uint64_t *)dt.u64(), (int)m, n); }
+    { ProfScope ps_("k_fz_add", 3 * n * 24); hipLaunchKernelGGL(k_fz_add, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_fw, d_f1v, (const uint64_t *)dt.u64(), (int)m, n); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
 }
@@ -351,7 +351,7 @@ int iopx_fz_fp3_dev(const uint64_t *d_fw, const uint64_t *d_f1v, size_t log_n, c
     if ((rc = dc.alloc(24)) != IOPX_OK) return rc;
     if ((rc = upload(dc.p, c.w, 24)) != IOPX_OK) return rc;
     const size_t n = (size_t)1 << log_n;
-    { ProfScope ps_("k_fz_fp"); hipLaunchKernelGGL(k_fz_fp, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_fw, d_f1v, (const uint64_t *)hi.u64(),
+    { ProfScope ps_("k_fz_fp", 3 * n * 24); hipLaunchKernelGGL(k_fz_fp, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_fw, d_f1v, (const uint64_t *)hi.u64(),
                                                   (const uint64_t *)lo.u64(), (const uint64_t *)dc.u64(), n); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
@@ -399,7 +399,7 @@ int iopx_sumcheck_g_gf192_dev(const uint64_t *d_f, const uint64_t *d_h, const ui
     p.xtab = dx.u64(); p.htab = dh.u64(); p.ztab = dz.u64(); p.c = dc.u64();
     p.m = (int)m; p.n = (size_t)1 << m;
     if (c.is_zero()) {
-        { ProfScope ps_("k_sumcheck_g_add_zero_sum"); hipLaunchKernelGGL(k_sumcheck_g_add_zero_sum, dim3(vo_grid(p.n)), dim3(256), 0, stream(), p); }
+        { ProfScope ps_("k_sumcheck_g_add_zero_sum", 3 * p.n * 24); hipLaunchKernelGGL(k_sumcheck_g_add_zero_sum, dim3(vo_grid(p.n)), dim3(256), 0, stream(), p); }
         IOPX_HIP(hipGetLastError());
         return IOPX_OK;
     }
@@ -431,7 +431,7 @@ int iopx_sumcheck_g_fp3_dev(const uint64_t *d_f, const uint64_t *d_h, size_t log
     if ((rc = dc.alloc(48)) != IOPX_OK) return rc;
     if ((rc = upload(dc.p, consts, 48)) != IOPX_OK) return rc;
     const size_t n = (size_t)1 << log_n;
-    { ProfScope ps_("k_sumcheck_g_fp"); hipLaunchKernelGGL(k_sumcheck_g_fp, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_f, d_h, (const uint64_t *)zhi.u64(),
+    { ProfScope ps_("k_sumcheck_g_fp", 3 * n * 24); hipLaunchKernelGGL(k_sumcheck_g_fp, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_f, d_h, (const uint64_t *)zhi.u64(),
                                                           (const uint64_t *)zlo.u64(), (const uint64_t *)ihi.u64(), (const uint64_t *)ilo.u64(), (const uint64_t *)dc.u64(), n); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
@@ -459,8 +459,8 @@ static int lincheck_common(const uint64_t *d_fz, const void *const *d_Mz, size_t
     p.fz = d_fz; p.p1 = d_p1; p.p2 = d_p2; p.out = d_out; p.r = dr.u64();
     for (size_t m = 0; m < num_matrices; ++m) p.mz[m] = (const uint64_t *)d_Mz[m];
     p.num_matrices = (int)num_matrices; p.n = n;
-    if (prime_field) { ProfScope ps_("k_lincheck_fp"); hipLaunchKernelGGL(k_lincheck_fp, dim3(vo_grid(n)), dim3(256), 0, stream(), p); }
-    else { ProfScope ps_("k_lincheck_add"); hipLaunchKernelGGL(k_lincheck_add, dim3(vo_grid(n)), dim3(256), 0, stream(), p); }
+    if (prime_field) { ProfScope ps_("k_lincheck_fp", (num_matrices + 4) * n * 24); hipLaunchKernelGGL(k_lincheck_fp, dim3(vo_grid(n)), dim3(256), 0, stream(), p); }
+    else { ProfScope ps_("k_lincheck_add", (num_matrices + 4) * n * 24); hipLaunchKernelGGL(k_lincheck_add, dim3(vo_grid(n)), dim3(256), 0, stream(), p); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
 }

@@ -1,18 +1,29 @@
 #!/bin/bash
-# Round-3 profile collection on the GPU box (run from the repo root through gpurun): the rocprofv3 --kernel-trace --stats summary of
-# the bench command, the FETCH_SIZE / WRITE_SIZE passes (separate, as the guide prescribes) and one SQ pass.  Outputs under gpurun_out/.
+# Profile collection on the GPU box (run from the repo root through gpurun): for the Aurora bench command and for the Fractal prover
+# (tools/fractal_bench.py, BASELINE configs[4] on one GPU) — the rocprofv3 --kernel-trace --stats summary, the FETCH_SIZE / WRITE_SIZE passes
+# (separate, as the guide prescribes) and one SQ pass.  Outputs under gpurun_out/ with the round prefix given as $1 (default r04).
 set -u
+P=${1:-r04}
 R=$PWD
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary"
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r03_prof -- $BENCH > $R/gpurun_out/r03_bench_under_rocprof.json 2> $R/gpurun_out/r03_prof.err
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/r03_pmc_fetch -- $BENCH > /dev/null 2> $R/gpurun_out/r03_pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/r03_pmc_write -- $BENCH > /dev/null 2> $R/gpurun_out/r03_pmc_write.err
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $R/gpurun_out/r03_pmc_sq -- $BENCH > /dev/null 2> $R/gpurun_out/r03_pmc_sq.err
+STEPS=5; WARM=2
+BENCH="python3 $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-secondary"
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${P}_prof -- $BENCH > $R/gpurun_out/${P}_bench_under_rocprof.json 2> $R/gpurun_out/${P}_prof.err
+rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${P}_pmc_fetch -- $BENCH > /dev/null 2> $R/gpurun_out/${P}_pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${P}_pmc_write -- $BENCH > /dev/null 2> $R/gpurun_out/${P}_pmc_write.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $R/gpurun_out/${P}_pmc_sq -- $BENCH > /dev/null 2> $R/gpurun_out/${P}_pmc_sq.err
+# the Fractal prover: 2 indexer runs + 3 proofs per command, the last one under the library's own profiler (algorithmic bytes per kernel)
+FR="python3 $R/tools/fractal_bench.py --log-n 20 --reps 3 --profile"
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${P}_fr_prof -- $FR --out $R/gpurun_out/${P}_fractal_2p20.json > /dev/null 2> $R/gpurun_out/${P}_fr_prof.err
+rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${P}_fr_fetch -- $FR > /dev/null 2> $R/gpurun_out/${P}_fr_fetch.err
+rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${P}_fr_write -- $FR > /dev/null 2> $R/gpurun_out/${P}_fr_write.err
 cd $R
-python3 tools/rocprof_summary.py $(find gpurun_out/r03_prof -name "*.db" | head -1) > gpurun_out/r03_rocprofv3_bench_aurora2p20.txt
-python3 tools/make_traffic_json.py gpurun_out/r03_pmc_fetch gpurun_out/r03_pmc_write 20 gpurun_out/r03_traffic_aurora.json k_bfly_upper k_bfly_edge k_phase1 k_ldt_combine_add_slots k_merkle_leaves k_lincheck_add k_fri_fold_fused > /dev/null
-python3 tools/make_sq_json.py gpurun_out/r03_pmc_sq gpurun_out/r03_sq_aurora.json k_bfly_upper k_bfly_edge k_phase1 k_ldt_combine_add_slots k_merkle_leaves k_lincheck_add > /dev/null
-rm -rf gpurun_out/r03_prof gpurun_out/r03_pmc_fetch gpurun_out/r03_pmc_write gpurun_out/r03_pmc_sq
-head -12 gpurun_out/r03_rocprofv3_bench_aurora2p20.txt
+# bench.py also proves once more for its cross-check and once under its own profiler: STEPS + WARM + 2 proofs per command
+python3 tools/rocprof_summary.py $(find gpurun_out/${P}_prof -name "*.db" | head -1) > gpurun_out/${P}_rocprofv3_bench_aurora2p20.txt
+python3 tools/rocprof_summary.py $(find gpurun_out/${P}_fr_prof -name "*.db" | head -1) > gpurun_out/${P}_rocprofv3_fractal2p20.txt
+python3 tools/make_traffic_json.py gpurun_out/${P}_pmc_fetch gpurun_out/${P}_pmc_write 20 gpurun_out/${P}_traffic_aurora.json --bench-json gpurun_out/${P}_bench_under_rocprof.json --steps $((STEPS + WARM + 2)) > /dev/null
+python3 tools/make_traffic_json.py gpurun_out/${P}_fr_fetch gpurun_out/${P}_fr_write 20 gpurun_out/${P}_traffic_fractal.json --bench-json gpurun_out/${P}_fractal_2p20.json --steps 3 --min-ms 0.5 > /dev/null
+python3 tools/make_sq_json.py gpurun_out/${P}_pmc_sq gpurun_out/${P}_sq_aurora.json k_bfly_upperILb0 k_bfly_edgeILb0 k_bfly_edge_fwd_batch k_phase1 k_ldt_combine_add_slots k_merkle_leaves k_lincheck_add > /dev/null
+rm -rf gpurun_out/${P}_prof gpurun_out/${P}_pmc_fetch gpurun_out/${P}_pmc_write gpurun_out/${P}_pmc_sq gpurun_out/${P}_fr_prof gpurun_out/${P}_fr_fetch gpurun_out/${P}_fr_write
+head -14 gpurun_out/${P}_rocprofv3_bench_aurora2p20.txt

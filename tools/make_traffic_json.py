@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
-"""profiles/r01_traffic.json from the FETCH_SIZE / WRITE_SIZE rocprofv3 passes (rocpd databases): per-launch HBM bytes of the
-phase-1 kernel with the guide's gfx950 correction (FETCH_SIZE counts half of a coalesced streaming read: doubled; WRITE_SIZE
-exact), both in KiB.  Usage: make_traffic_json.py <fetch_dir> <write_dir> <log_n> <out.json> [kernel substring ...]"""
+"""profiles/rNN_traffic_*.json from the FETCH_SIZE / WRITE_SIZE rocprofv3 passes (rocpd databases) of one command: HBM bytes per launch of
+EVERY kernel symbol that takes at least --min-ms of the run (default 0.2 ms per profiled step), one entry per symbol (template instantiations
+are kept apart: k_bfly_edge<false, false>, k_bfly_edge<true, false> and k_bfly_edge_fwd_batch are three kernels), with the guide's gfx950
+correction (MI355X_MICROARCH.md, HBM section: FETCH_SIZE counts half of a coalesced streaming read: doubled; WRITE_SIZE exact; both KiB) and,
+beside each, the kernel's ALGORITHMIC bytes per launch as the library's own profiler reports them in the bench / tool JSON of the same
+command (--bench-json: `roofline.kernel_algorithmic_bytes_per_launch` of bench.py, or `runs[-1].kernels` of tools/fractal_bench.py).
+
+Usage: make_traffic_json.py <fetch_dir> <write_dir> <log_n> <out.json> [--bench-json FILE] [--min-ms X] [--steps N]
+The JSON is keyed by the library's profile name of the symbol (k_bfly_upper_fwd = k_bfly_upper<false, ...>), which is what bench.py looks up."""
+import argparse
 import glob
 import hashlib
 import json
 import os
+import re
 import sqlite3
-import sys
 import time
 
 
@@ -22,31 +29,86 @@ def kernel_sources_digest():
     return h.hexdigest()
 
 
-def avg_counter(d, counter, kernel_like):
+def per_symbol(d, counter):
+    """{kernel symbol: (average counter value per launch, launches, total ms)}"""
     path = glob.glob(d + "/**/*.db", recursive=True)[0]
     c = sqlite3.connect(path)
     tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
     suf = [t for t in tabs if t.startswith("rocpd_metadata")][0][len("rocpd_metadata"):]
-    q = ("select avg(e.value), count(*) from rocpd_pmc_event%s e join rocpd_info_pmc%s p on e.pmc_id = p.id join rocpd_kernel_dispatch%s d "
-         "on e.event_id = d.event_id join rocpd_info_kernel_symbol%s s on d.kernel_id = s.id where p.name = ? and s.kernel_name like ?" % (suf, suf, suf, suf))
-    return c.execute(q, (counter, kernel_like)).fetchone()
+    q = ("select s.kernel_name, avg(e.value), count(*), sum(d.end - d.start) / 1e6 from rocpd_pmc_event%s e join rocpd_info_pmc%s p on e.pmc_id = p.id "
+         "join rocpd_kernel_dispatch%s d on e.event_id = d.event_id join rocpd_info_kernel_symbol%s s on d.kernel_id = s.id where p.name = ? "
+         "group by s.kernel_name" % (suf, suf, suf, suf))
+    return {r[0]: (r[1], r[2], r[3]) for r in c.execute(q, (counter,))}
 
 
-kernels = sys.argv[5:] or ["k_phase1"]
-out = {
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over bench.py (summaries next to this file in profiles/)",
-    "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE reports 1/2 of the bytes of a coalesced streaming read on gfx950 -> doubled; WRITE_SIZE exact; both KiB",
-    "log_n": int(sys.argv[3]),
-    "kernel_sources_sha256": kernel_sources_digest(),
-    "collected": time.strftime("%Y-%m-%d"),
-    "kernels": {},
-}
-for k in kernels:
-    fetch, nf = avg_counter(sys.argv[1], "FETCH_SIZE", "%" + k + "%")
-    write, nw = avg_counter(sys.argv[2], "WRITE_SIZE", "%" + k + "%")
-    if fetch is None or write is None:
-        continue
-    out["kernels"][k] = {"fetch_size_kib_avg": round(fetch, 1), "write_size_kib_avg": round(write, 1), "launches": nf,
-                         "traffic_bytes_per_launch": int(round((2 * fetch + write) * 1024))}
-json.dump(out, open(sys.argv[4], "w"), indent=1)
-print(json.dumps(out))
+def profile_name(symbol):
+    """The library's profile name (runtime.h ProfScope) of a kernel symbol — mangled, as rocprofv3's database holds it, or demangled: the
+    bare kernel name, with _fwd / _inv for the transform kernels whose first template argument is the direction."""
+    sym = symbol.strip()
+    name, first = None, None
+    if sym.startswith("_ZN"):                                 # nested name: <len><identifier> ..., the last one is the kernel
+        pos, ident = 3, None
+        while pos < len(sym) and sym[pos].isdigit():
+            m = re.match(r"\d+", sym[pos:])
+            n = int(m.group(0))
+            ident = sym[pos + len(m.group(0)):pos + len(m.group(0)) + n]
+            pos += len(m.group(0)) + n
+        if ident:
+            name = ident
+            t = re.match(r"ILb([01])E", sym[pos:])
+            first = t.group(1) if t else None
+    if name is None:
+        m = re.match(r"(?:void\s+)?(?:iopx::)?(?:\(anonymous namespace\)::)?(\w+)(?:<(.*)>)?", sym)
+        name = m.group(1)
+        targ = (m.group(2) or "").split(",")[0].strip()
+        first = "1" if targ in ("true", "1", "(bool)1") else ("0" if targ in ("false", "0", "(bool)0") else None)
+    if name in ("k_bfly_upper", "k_bfly_edge", "k_phase1"):
+        return name + ("_inv" if first == "1" else "_fwd")
+    return name
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("fetch_dir")
+    ap.add_argument("write_dir")
+    ap.add_argument("log_n", type=int)
+    ap.add_argument("out")
+    ap.add_argument("--bench-json", default=None)
+    ap.add_argument("--min-ms", type=float, default=0.2)
+    ap.add_argument("--steps", type=int, default=None, help="proofs the profiled command ran (warm-up included): per-proof figures = totals / steps")
+    a = ap.parse_args()
+    fetch, write = per_symbol(a.fetch_dir, "FETCH_SIZE"), per_symbol(a.write_dir, "WRITE_SIZE")
+    alg = {}
+    if a.bench_json:
+        text = open(a.bench_json).read().strip()
+        j = json.loads(text.splitlines()[-1]) if not text.startswith("{\n") else json.loads(text)
+        if "roofline" in j:
+            alg = dict(j["roofline"].get("kernel_algorithmic_bytes_per_launch", {}))
+        elif "runs" in j:
+            alg = {k: v["bytes"] / v["launches"] for k, v in j["runs"][-1].get("kernels", {}).items() if v.get("bytes")}
+    steps = a.steps or 1
+    out = {
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over the command (tools/collect_profiles.sh); one entry per kernel SYMBOL",
+        "correction": "MI355X_MICROARCH.md HBM section: FETCH_SIZE reports 1/2 of the bytes of a coalesced streaming read on gfx950 -> doubled; WRITE_SIZE exact; both KiB",
+        "log_n": a.log_n, "kernel_sources_sha256": kernel_sources_digest(), "collected": time.strftime("%Y-%m-%d"),
+        "steps_in_profiled_command": steps, "kernels": {},
+    }
+    for sym, (f_avg, n, ms) in sorted(fetch.items(), key=lambda kv: -kv[1][2]):
+        if sym not in write or ms / steps < a.min_ms:
+            continue
+        name = profile_name(sym)
+        traffic = int(round((2 * f_avg + write[sym][0]) * 1024))
+        entry = {"symbol": sym, "launches": n, "launches_per_step": n / steps, "ms_per_step_under_pmc": round(ms / steps, 3),
+                 "fetch_size_kib_avg": round(f_avg, 1), "write_size_kib_avg": round(write[sym][0], 1), "traffic_bytes_per_launch": traffic}
+        if name in alg:
+            entry["algorithmic_bytes_per_launch"] = int(round(alg[name]))
+            entry["traffic_over_algorithmic"] = round(traffic / alg[name], 3)
+        if name in out["kernels"]:          # two symbols with one profile name (comb / general instantiations): keep both, the busier one under the plain key
+            name = name + " [" + sym + "]"
+        out["kernels"][name] = entry
+    json.dump(out, open(a.out, "w"), indent=1)
+    print(json.dumps({k: (v["traffic_bytes_per_launch"], v.get("traffic_over_algorithmic")) for k, v in out["kernels"].items()}))
+
+
+if __name__ == "__main__":
+    main()
