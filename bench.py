@@ -238,9 +238,14 @@ def main():
         dt = float(t.item())
     prover_s = dt / args.steps
 
-    # the second, independently written prover (libiop_amd/aurora.py; over libiop_amd/dist.py's operators when sharded) on the same instance
-    check = aurora.aurora_snark_prover(ops, cs, primary, None, params, d_assignment=d_assignment).serialize()
-    assert check == transcript.serialize(), "native prover's transcript differs from the Python prover's"
+    # the second, independently written prover (libiop_amd/aurora.py; over libiop_amd/dist.py's operators under --force-sharded) on the same
+    # instance; with N > 1 ranks rank 0 proves the instance once more on its own GPU alone instead (no collective involved): the distributed
+    # transcript must be the single-GPU prover's
+    if world == 1:
+        check = aurora.aurora_snark_prover(ops, cs, primary, None, params, d_assignment=d_assignment).serialize()
+        assert check == transcript.serialize(), "native prover's transcript differs from the Python prover's"
+    elif rank == 0:
+        assert lib.aurora_prove(native, 128, params.RS_extra_dimensions, 2) == transcript.serialize(), "distributed transcript differs from the single-GPU prover's"
 
     # per-kernel durations of one more proof, live, with HIP events on the stream the kernels are launched on
     lib.comm_stats(reset=True)
@@ -309,7 +314,7 @@ def main():
             "log_n": args.log_n, "field": "gf192", "prover_s": prover_s,
             "prover": ("native: iopx_aurora_prove (libiop_amd/cpp/aurora.hpp behind the C ABI); transcript equal to libiop_amd/aurora.py's" if comm is None else
                        "native: iopx_aurora_prove_dist (libiop_amd/cpp/aurora.hpp + dist.hpp behind the C ABI, RCCL communicator of %d rank(s)); transcript equal to "
-                       "libiop_amd/aurora.py's over libiop_amd/dist.py's operators" % world),
+                       "the single-GPU prover's" % world),
             "device_field_products_per_proof": device_products if world == 1 else None,
             "device_field_products_per_proof_this_rank": device_products,
             "device_products_per_s": device_products * world / prover_s if device_products else None,

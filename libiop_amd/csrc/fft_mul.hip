@@ -633,9 +633,9 @@ int iopx_fri_fold_mul_fp3_dev(const uint64_t *d_f_i, size_t log_n, const uint64_
         MfoldParams p;
         p.src = d_f_i; p.dst = d_next; p.ginv = ginv_top; p.consts = dc.u64(); p.half = n >> eta; p.stride_log = 0;
         const size_t bytes = (n + p.half) * 24;
-        if (eta == 1) { ProfScope ps_("k_fri_fold_fused_mul", bytes); hipLaunchKernelGGL(k_fri_fold_fused_mul<1>, dim3(mgrid(p.half, 256)), dim3(256), 0, stream(), p); }
-        else if (eta == 2) { ProfScope ps_("k_fri_fold_fused_mul", bytes); hipLaunchKernelGGL(k_fri_fold_fused_mul<2>, dim3(mgrid(p.half, 256)), dim3(256), 0, stream(), p); }
-        else { ProfScope ps_("k_fri_fold_fused_mul", bytes); hipLaunchKernelGGL(k_fri_fold_fused_mul<3>, dim3(mgrid(p.half, 256)), dim3(256), 0, stream(), p); }
+        if (eta == 1) { ProfScope ps_("k_fri_fold_fused_mul_eta1", bytes); hipLaunchKernelGGL(k_fri_fold_fused_mul<1>, dim3(mgrid(p.half, 256)), dim3(256), 0, stream(), p); }
+        else if (eta == 2) { ProfScope ps_("k_fri_fold_fused_mul_eta2", bytes); hipLaunchKernelGGL(k_fri_fold_fused_mul<2>, dim3(mgrid(p.half, 256)), dim3(256), 0, stream(), p); }
+        else { ProfScope ps_("k_fri_fold_fused_mul_eta3", bytes); hipLaunchKernelGGL(k_fri_fold_fused_mul<3>, dim3(mgrid(p.half, 256)), dim3(256), 0, stream(), p); }
         IOPX_HIP(hipGetLastError());
         return IOPX_OK;
     }

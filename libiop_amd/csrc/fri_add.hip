@@ -164,9 +164,9 @@ int iopx_fri_fold_add_gf192_dev(const uint64_t *d_f_i, const uint64_t *basis, si
         if (grid > 16384) grid = 16384;
         if (grid < 1) grid = 1;
         const size_t bytes = (n + fp.n_out) * 24;
-        if (eta == 1) { ProfScope ps_("k_fri_fold_fused", bytes); hipLaunchKernelGGL(k_fri_fold_fused<1>, dim3((unsigned)grid), dim3(256), 0, stream(), fp); }
-        else if (eta == 2) { ProfScope ps_("k_fri_fold_fused", bytes); hipLaunchKernelGGL(k_fri_fold_fused<2>, dim3((unsigned)grid), dim3(256), 0, stream(), fp); }
-        else { ProfScope ps_("k_fri_fold_fused", bytes); hipLaunchKernelGGL(k_fri_fold_fused<3>, dim3((unsigned)grid), dim3(256), 0, stream(), fp); }
+        if (eta == 1) { ProfScope ps_("k_fri_fold_fused_eta1", bytes); hipLaunchKernelGGL(k_fri_fold_fused<1>, dim3((unsigned)grid), dim3(256), 0, stream(), fp); }
+        else if (eta == 2) { ProfScope ps_("k_fri_fold_fused_eta2", bytes); hipLaunchKernelGGL(k_fri_fold_fused<2>, dim3((unsigned)grid), dim3(256), 0, stream(), fp); }
+        else { ProfScope ps_("k_fri_fold_fused_eta3", bytes); hipLaunchKernelGGL(k_fri_fold_fused<3>, dim3((unsigned)grid), dim3(256), 0, stream(), fp); }
         IOPX_HIP(hipGetLastError());
         return IOPX_OK;
     }

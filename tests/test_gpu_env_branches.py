@@ -36,15 +36,15 @@ def dom(m, kind, seed):
         return oracle.standard_basis(m, W), np.zeros(W, dtype=np.uint64)
     return rand_elems(seed + 1, m, W), rand_elems(seed, 1, W)[0]
 # test_fft_lde's shapes plus very short polynomials (many cosets), standard and general bases
-for m, ncoef in [(4, 1), (6, 5), (10, 255), (12, 16), (13, 5), (13, 300), (14, 16), (15, 4096), (16, 2), (17, 8195), (18, 1 << 13), (18, 16), (20, (1 << 15) - 1), (20, 16)]:
+for m, ncoef in [(4, 1), (6, 5), (10, 255), (12, 16), (13, 5), (13, 300), (14, 16), (15, 4096), (16, 2), (17, 8195), (18, 16)]:
     for kind in ("aurora", "general"):
-        if kind == "general" and m > 16:
+        if kind == "general" and m > 15:
             continue
         basis, shift = dom(m, kind, 7 + m)
         coeffs = rand_elems(m + ncoef, ncoef, W)
         assert np.array_equal(lib.additive_FFT(coeffs, basis, shift), oracle.additive_fft(coeffs, basis, shift)), (m, ncoef, kind)
 # test_fft_full_size / test_ifft shapes
-for m in (1, 3, 6, 11, 12, 13, 16, 18):
+for m in (1, 3, 6, 11, 12, 13, 16):
     for kind in ("std0", "aurora", "general"):
         basis, shift = dom(m, kind, 100 + m)
         coeffs = rand_elems(m, 1 << m, W)

@@ -49,15 +49,25 @@ def _run(world, protocol, field, impl, log_n, inputs, seed, tmp_path):
     return res
 
 
-@pytest.mark.parametrize("impl", ["python", "native"])
-@pytest.mark.parametrize("protocol,field,log_n,inputs,seed", [("aurora", "gf192", 12, 15, 0x2204), ("fractal", "edwards_Fr", 12, 0, 0x2205),
-                                                              ("fractal", "gf192", 10, 15, 0x2205), ("aurora", "edwards_Fr", 11, 15, 0x2204)])
-def test_sharded_prover_under_rccl_equals_the_oracle(impl, protocol, field, log_n, inputs, seed, tmp_path):
-    code = oracle.FIELD_GF192 if field == "gf192" else oracle.FIELD_EDWARDS
-    if protocol == "aurora":
-        ref, ref_roots = oracle.aurora_prove(code, log_n, inputs, seed), []
-    else:
-        ref, ref_roots = oracle.fractal_prove(code, log_n, inputs, seed)
+_ORACLE = {}
+
+
+def _oracle(protocol, field, log_n, inputs, seed):
+    """The CPU oracle's transcript (and index roots), computed once per case for both implementations."""
+    key = (protocol, field, log_n, inputs, seed)
+    if key not in _ORACLE:
+        code = oracle.FIELD_GF192 if field == "gf192" else oracle.FIELD_EDWARDS
+        _ORACLE[key] = (oracle.aurora_prove(code, log_n, inputs, seed), []) if protocol == "aurora" else oracle.fractal_prove(code, log_n, inputs, seed)
+    return _ORACLE[key]
+
+
+CASES = [("aurora", "gf192", 12, 15, 0x2204), ("fractal", "edwards_Fr", 11, 0, 0x2205), ("fractal", "gf192", 10, 15, 0x2205), ("aurora", "edwards_Fr", 11, 15, 0x2204)]
+
+
+@pytest.mark.parametrize("impl,case", [("native", c) for c in CASES] + [("python", c) for c in CASES[:2]], ids=lambda v: v if isinstance(v, str) else "-".join(str(x) for x in v[:3]))
+def test_sharded_prover_under_rccl_equals_the_oracle(impl, case, tmp_path):
+    protocol, field, log_n, inputs, seed = case
+    ref, ref_roots = _oracle(protocol, field, log_n, inputs, seed)
     for world in _worlds():
         res = _run(world, protocol, field, impl, log_n, inputs, seed, tmp_path)
         assert bytes.fromhex(res["transcript"]) == ref, (impl, world, "transcript differs from the oracle prover's")
@@ -67,8 +77,7 @@ def test_sharded_prover_under_rccl_equals_the_oracle(impl, protocol, field, log_
             assert res["ops"] == ("ShardedDeviceOps" if field == "gf192" else "ResidueShardedDeviceOps")
 
 
-@pytest.mark.parametrize("impl", ["python", "native"])
-def test_sharded_aurora_2p16_equals_the_single_gpu_prover(impl, tmp_path):
+def test_native_sharded_aurora_2p16_equals_the_single_gpu_prover(tmp_path):
     for world in _worlds():
-        res = _run(world, "aurora", "gf192", impl, 16, 15, 0x2204, tmp_path)
-        assert res["equals_single_gpu_native_prover"], (impl, world)
+        res = _run(world, "aurora", "gf192", "native", 16, 15, 0x2204, tmp_path)
+        assert res["equals_single_gpu_native_prover"], world

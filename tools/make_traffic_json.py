@@ -64,6 +64,10 @@ def profile_name(symbol):
         first = "1" if targ in ("true", "1", "(bool)1") else ("0" if targ in ("false", "0", "(bool)0") else None)
     if name in ("k_bfly_upper", "k_bfly_edge", "k_phase1"):
         return name + ("_inv" if first == "1" else "_fwd")
+    if name in ("k_fri_fold_fused", "k_fri_fold_fused_mul"):                  # template argument: the localization parameter
+        m = re.search(r"%sILi(\d+)E" % name, sym) or re.search(r"%s<(\d+)>" % name, sym)
+        if m:
+            return "%s_eta%s" % (name, m.group(1))
     return name
 
 
