@@ -489,6 +489,14 @@ int iopx_fractal_index(iopx_aurora_instance *instance, size_t security_parameter
                        uint8_t *index_roots, size_t root_capacity, size_t *num_roots);
 int iopx_fractal_prove(iopx_aurora_instance *instance, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter,
                        uint8_t **transcript, size_t *transcript_bytes);
+/* FRI_snark_prover (libiop/snark/fri_snark.tcc:43-77, protocols/fri_iop.tcc:3-101; BASELINE configs[2]): the FRI-only SNARK for the polynomial
+ * with the given coefficients (device memory, at most 2^(codeword_domain_dim - RS_extra_dimensions)) over the unshifted default codeword
+ * domain of 2^codeword_domain_dim points: extension, commitment, LDT reduction, FRI rounds, proof of work (codeword_domain_dim + 3 bits),
+ * queries.  The repetitions are the harness's (profiling/instrument_fri_snark.cpp:84-148: 1 interactive, 10 query).  Transcript as above.
+ * The _dist form distributes the codeword over `comm` like the other provers (NULL = one GPU). */
+int iopx_fri_snark_prove(int field, const uint64_t *d_poly_coeffs, size_t n_coeffs, size_t codeword_domain_dim, size_t RS_extra_dimensions,
+                         size_t FRI_localization_parameter, size_t num_interactive_repetitions, size_t num_query_repetitions, uint8_t **transcript,
+                         size_t *transcript_bytes);
 int iopx_aurora_instance_free(iopx_aurora_instance *instance);
 int iopx_host_free(void *p);
 
@@ -557,6 +565,9 @@ int iopx_fractal_index_dist(iopx_aurora_instance *instance, iopx_comm *comm, siz
                             size_t FRI_localization_parameter, uint8_t *index_roots, size_t root_capacity, size_t *num_roots);
 int iopx_fractal_prove_dist(iopx_aurora_instance *instance, iopx_comm *comm, size_t security_parameter, size_t RS_extra_dimensions,
                             size_t FRI_localization_parameter, uint8_t **transcript, size_t *transcript_bytes);
+int iopx_fri_snark_prove_dist(int field, iopx_comm *comm, const uint64_t *d_poly_coeffs, size_t n_coeffs, size_t codeword_domain_dim, size_t RS_extra_dimensions,
+                              size_t FRI_localization_parameter, size_t num_interactive_repetitions, size_t num_query_repetitions, uint8_t **transcript,
+                              size_t *transcript_bytes);
 
 #ifdef __cplusplus
 }

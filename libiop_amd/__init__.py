@@ -60,7 +60,7 @@ EXPORTED_SYMBOLS = [
     "iopx_fractal_index", "iopx_fractal_prove",
     "iopx_memcpy_d2h_deferrable", "iopx_comm_rccl_unique_id", "iopx_comm_create_rccl", "iopx_comm_create_callbacks", "iopx_comm_destroy", "iopx_comm_rank",
     "iopx_comm_all_gather_dev", "iopx_comm_all_reduce_u64_dev", "iopx_comm_broadcast_dev", "iopx_comm_all_to_all_dev", "iopx_comm_sendrecv_dev", "iopx_comm_stats", "iopx_comm_bind_transforms", "iopx_add_taylor_inv_gf192_dev", "iopx_add_combine_inv_gf192_dev",
-    "iopx_interleave_dev", "iopx_gather_rows_dev", "iopx_aurora_prove_dist", "iopx_fractal_index_dist", "iopx_fractal_prove_dist",
+    "iopx_interleave_dev", "iopx_gather_rows_dev", "iopx_fri_snark_prove", "iopx_fri_snark_prove_dist", "iopx_aurora_prove_dist", "iopx_fractal_index_dist", "iopx_fractal_prove_dist",
 ]
 
 
@@ -810,6 +810,14 @@ class Library:
     def fractal_prove_dist(self, instance, comm, security_parameter=128, RS_extra_dimensions=3, FRI_localization_parameter=2):
         self.c.iopx_fractal_prove_dist.argtypes = [ctypes.c_void_p, ctypes.c_void_p, _sz, _sz, _sz, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(_sz)]
         return self._transcript_call(self.c.iopx_fractal_prove_dist, instance, comm, int(security_parameter), int(RS_extra_dimensions), int(FRI_localization_parameter))
+
+    def fri_snark_prove(self, field_code, d_poly_coeffs, n_coeffs, codeword_domain_dim, RS_extra_dimensions, FRI_localization_parameter=2,
+                        num_interactive_repetitions=1, num_query_repetitions=10, comm=None):
+        """FRI_snark_prover through the C ABI (libiop_amd/cpp/fri.hpp inside the library): the canonical transcript bytes; `comm`: distributed."""
+        self.c.iopx_fri_snark_prove_dist.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, _sz, _sz, _sz, _sz, _sz, _sz, ctypes.POINTER(ctypes.c_void_p),
+                                                      ctypes.POINTER(_sz)]
+        return self._transcript_call(self.c.iopx_fri_snark_prove_dist, int(field_code), comm, _vp(d_poly_coeffs), int(n_coeffs), int(codeword_domain_dim),
+                                     int(RS_extra_dimensions), int(FRI_localization_parameter), int(num_interactive_repetitions), int(num_query_repetitions))
 
     def aurora_instance_free(self, instance):
         self.c.iopx_aurora_instance_free.argtypes = [ctypes.c_void_p]

@@ -10,6 +10,7 @@
 
 #include "../cpp/aurora.hpp"
 #include "../cpp/fractal.hpp"
+#include "../cpp/fri.hpp"
 #include "../cpp/fields.hpp"
 #include "runtime.h"
 
@@ -149,6 +150,15 @@ int guarded(Fn fn)
     }
 }
 
+template<typename F>
+std::string fri_prove(iopx_comm *comm, const uint64_t *d_coeffs, size_t n_coeffs, const FRI_snark_parameters &params)
+{
+    const dist::scope bound(comm);
+    device_vector<F> coeffs(n_coeffs);
+    if (n_coeffs) check(iopx_memcpy_d2d(coeffs.data(), d_coeffs, n_coeffs * 24));
+    return FRI_snark_prover<F>(coeffs, params).serialize();
+}
+
 } // namespace
 
 extern "C" {
@@ -248,6 +258,36 @@ int iopx_fractal_prove_dist(iopx_aurora_instance *instance, iopx_comm *comm, siz
                             size_t FRI_localization_parameter, uint8_t **transcript, size_t *transcript_bytes)
 {
     return prove_entry(instance, comm, true, security_parameter, RS_extra_dimensions, FRI_localization_parameter, transcript, transcript_bytes);
+}
+
+int iopx_fri_snark_prove_dist(int field, iopx_comm *comm, const uint64_t *d_poly_coeffs, size_t n_coeffs, size_t codeword_domain_dim, size_t RS_extra_dimensions,
+                              size_t FRI_localization_parameter, size_t num_interactive_repetitions, size_t num_query_repetitions, uint8_t **transcript,
+                              size_t *transcript_bytes)
+{
+    int rc = iopx::ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!transcript || !transcript_bytes || (n_coeffs && !d_poly_coeffs)) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (codeword_domain_dim > 40) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "codeword domain dimension %zu too large", codeword_domain_dim);
+    return guarded([&] {
+        const FRI_snark_parameters params(codeword_domain_dim, RS_extra_dimensions, FRI_localization_parameter, num_interactive_repetitions, num_query_repetitions);
+        std::string t;
+        if (field == IOPX_FIELD_GF192) t = fri_prove<gf192_element>(comm, d_poly_coeffs, n_coeffs, params);
+        else if (field == IOPX_FIELD_EDWARDS_FR) t = fri_prove<edwards_Fr_element>(comm, d_poly_coeffs, n_coeffs, params);
+        else throw std::invalid_argument("unknown field");
+        uint8_t *buf = static_cast<uint8_t *>(std::malloc(t.size() ? t.size() : 1));
+        if (!buf) throw std::bad_alloc();
+        std::memcpy(buf, t.data(), t.size());
+        *transcript = buf;
+        *transcript_bytes = t.size();
+    });
+}
+
+int iopx_fri_snark_prove(int field, const uint64_t *d_poly_coeffs, size_t n_coeffs, size_t codeword_domain_dim, size_t RS_extra_dimensions,
+                         size_t FRI_localization_parameter, size_t num_interactive_repetitions, size_t num_query_repetitions, uint8_t **transcript,
+                         size_t *transcript_bytes)
+{
+    return iopx_fri_snark_prove_dist(field, nullptr, d_poly_coeffs, n_coeffs, codeword_domain_dim, RS_extra_dimensions, FRI_localization_parameter,
+                                     num_interactive_repetitions, num_query_repetitions, transcript, transcript_bytes);
 }
 
 int iopx_aurora_instance_free(iopx_aurora_instance *instance)

@@ -54,3 +54,16 @@ def prove_and_verify(lib, torch, device, field_name, dim, rs_extra, loc_param, i
         bad = fri.fri_snark_prover(ops, params, d_codeword=far).serialize()
         assert not oracle.fri_snark_verify(*args, bad), "degree 4d codeword accepted"
     return True
+
+
+def native_prove_equals_oracle(lib, torch, device, field_name, dim, rs_extra, loc_param, interactions, queries, seed, comm=None):
+    """FRI_snark_prover through the C ABI (libiop_amd/cpp/fri.hpp inside the library) against the oracle prover, byte for byte."""
+    code, cls = FIELDS[field_name]
+    ops = domains.DeviceOps(lib, torch, device, cls())
+    params = fri.FRISnarkParameters(dim, rs_extra, loc_param, interactions, queries)
+    coeffs = ops.upload(r1cs.seeded_elements(ops.field, seed, params.poly_degree_bound))
+    mine = lib.fri_snark_prove(0 if field_name == "gf192" else 1, coeffs.data_ptr(), params.poly_degree_bound, dim, rs_extra, loc_param, interactions, queries, comm=comm)
+    ref = oracle.fri_snark_prove(code, dim, rs_extra, loc_param, interactions, queries, seed)
+    assert mine == ref, "native FRI SNARK transcript differs from the oracle prover's"
+    assert oracle.fri_snark_verify(code, dim, rs_extra, loc_param, interactions, queries, mine)
+    return True

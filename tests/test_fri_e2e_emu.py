@@ -14,3 +14,10 @@ CPU = torch.device("cpu")
     ("edwards_Fr", 8, 2, 2, 1, 6), ("edwards_Fr", 9, 3, 1, 1, 8), ("edwards_Fr", 10, 2, 3, 2, 10)])
 def test_fri_snark(field_name, dim, rs_extra, loc_param, interactions, queries):
     assert fc.prove_and_verify(emu(), torch, CPU, field_name, dim, rs_extra, loc_param, interactions, queries, 5)
+
+
+@pytest.mark.parametrize("field_name,dim,rs_extra,loc_param,interactions,queries", [
+    ("gf192", 8, 2, 2, 1, 6), ("gf192", 10, 3, 2, 1, 10), ("gf192", 7, 2, 1, 2, 4), ("edwards_Fr", 8, 2, 2, 1, 6), ("edwards_Fr", 10, 2, 3, 2, 10)])
+def test_native_fri_snark(field_name, dim, rs_extra, loc_param, interactions, queries):
+    """The native prover (libiop_amd/cpp/fri.hpp behind iopx_fri_snark_prove) produces the oracle prover's transcript."""
+    assert fc.native_prove_equals_oracle(emu(), torch, CPU, field_name, dim, rs_extra, loc_param, interactions, queries, 5)

@@ -252,10 +252,13 @@ def test_fri_snark_cfg3_full_size_accepted_by_the_oracle_verifier(env):
     params = fri.FRISnarkParameters(dim, rs_extra, loc, interactions, queries)
     assert params.poly_degree_bound == 1 << 20 and params.localization_parameters == [1] + [2] * 9
     coeffs = r1cs.seeded_elements(ops.field, seed, params.poly_degree_bound)
-    transcript = fri.fri_snark_prover(ops, params, d_poly_coeffs=ops.upload(coeffs))
+    d_coeffs = ops.upload(coeffs)
+    transcript = fri.fri_snark_prover(ops, params, d_poly_coeffs=d_coeffs)
     assert len(transcript.MT_roots) == 10
     args = (oracle.FIELD_GF192, dim, rs_extra, loc, interactions, queries)
     assert oracle.fri_snark_verify(*args, transcript.serialize())
+    # the native prover (libiop_amd/cpp/fri.hpp behind iopx_fri_snark_prove) at the same size: the same bytes
+    assert lib.fri_snark_prove(0, d_coeffs.data_ptr(), params.poly_degree_bound, dim, rs_extra, loc, interactions, queries) == transcript.serialize()
     t = copy.deepcopy(transcript)
     t.query_responses[1] = t.query_responses[1].copy(); t.query_responses[1][0, 0, 1] ^= np.uint64(1)
     assert not oracle.fri_snark_verify(*args, t.serialize())

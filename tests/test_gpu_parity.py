@@ -395,6 +395,14 @@ def test_fri_snark(gpu, field_name, dim, rs_extra, loc_param, interactions, quer
     assert fc.prove_and_verify(gpu, torch, torch.device("cuda:0"), field_name, dim, rs_extra, loc_param, interactions, queries, 0x2203)
 
 
+@pytest.mark.parametrize("field_name,dim,rs_extra,loc_param,interactions,queries", [("gf192", 16, 2, 2, 1, 10), ("gf192", 13, 2, 2, 2, 6), ("edwards_Fr", 16, 2, 2, 1, 10)])
+def test_native_fri_snark(gpu, field_name, dim, rs_extra, loc_param, interactions, queries):
+    """FRI_snark_prover through the C ABI (libiop_amd/cpp/fri.hpp inside the library) == the oracle prover's transcript."""
+    import torch
+    gpu.set_stream(torch.cuda.current_stream().cuda_stream)
+    assert fc.native_prove_equals_oracle(gpu, torch, torch.device("cuda:0"), field_name, dim, rs_extra, loc_param, interactions, queries, 0x2203)
+
+
 # ---- R1CS row check (rowcheck.tcc:16-88) -------------------------------------------------------------------------
 @pytest.mark.parametrize("m,h,seed,kind", [(5, 2, 1, "aurora"), (8, 3, 2, "general"), (7, 7, 3, "aurora"), (6, 0, 4, "general"), (16, 11, 5, "aurora")])
 def test_rowcheck_additive(gpu, m, h, seed, kind):
