@@ -397,7 +397,16 @@ def _native_worker(rank, world, port, ret, protocol, field_code, log_n, num_inpu
         inst = lib.aurora_example_instance(field_code, n, num_inputs, n - 1, seed)
         try:
             lib.comm_stats(reset=True)
-            if protocol == "aurora":
+            if protocol == "fri":                          # log_n = the codeword domain dimension; the seeded polynomial of degree 2^(dim - rs_extra)
+                from libiop_amd import domains, r1cs
+                f = domains.GF192() if field_code == 0 else domains.EdwardsFr()
+                coeffs = np.ascontiguousarray(r1cs.seeded_elements(f, seed, 1 << (log_n - rs_extra)), dtype=np.uint64)
+                d = lib.malloc(coeffs.nbytes)
+                lib.h2d(d, coeffs)
+                t = lib.fri_snark_prove(field_code, d, coeffs.shape[0], log_n, rs_extra, 2, 1, num_inputs, comm=comm)      # num_inputs carries the query repetitions
+                lib.free(d)
+                roots = []
+            elif protocol == "aurora":
                 t = lib.aurora_prove_dist(inst, comm, 128, rs_extra, 2)
                 roots = []
             else:
@@ -526,3 +535,16 @@ def test_native_sharded_provers_with_phase1_split(world, protocol, field_code, l
         assert ret[r][0] == ref and ret[r][1] == ref_roots, "rank %d" % r
         assert plain[r][0] == ref
         assert ret[r][2][0] > plain[r][2][0], "the transforms issued no collective: %r vs %r" % (ret[r][2], plain[r][2])
+
+
+@pytest.mark.parametrize("world,field_code,dim", [(2, 0, 10), (4, 0, 11), (2, 1, 12)])
+def test_native_sharded_fri_snark_equals_oracle(world, field_code, dim):
+    """BASELINE config 3's prover (iopx_fri_snark_prove_dist) distributed over the ranks."""
+    import oracle
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_native_worker, args=(world, _free_port(), ret, "fri", field_code, dim, 8, 5, 2), nprocs=world, join=True)
+    ref = oracle.fri_snark_prove(oracle.FIELD_GF192 if field_code == 0 else oracle.FIELD_EDWARDS, dim, 2, 2, 1, 8, 5)
+    for r in range(world):
+        assert ret[r][0] == ref, "rank %d" % r
+        assert ret[r][2][0] > 0
