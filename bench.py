@@ -322,6 +322,8 @@ def main():
             "codeword_domain_dim": params.codeword_domain_dim, "localization": params.localization_parameters,
             "fri_query_repetitions": params.fri_query_repetitions, "pow_bits": params.pow_bits,
             "argument_bytes": len(transcript.serialize()) if transcript is not None else None,
+            # tests/golden/oracle_aurora_transcript_digests_large.json holds the CPU oracle prover's digest for this instance (2^16, 2^18, 2^20)
+            "transcript_blake2b": __import__("hashlib").blake2b(transcript.serialize(), digest_size=32).hexdigest() if transcript is not None else None,
             "ref_fft_mults_per_proof": mults, "ref_fft_adds_per_proof": adds,
             "fft_stage": {"ms": fft_ms, "field_ops_per_s": (mults + adds) / (fft_ms / 1e3) if fft_ms else None,
                           "note": "transform kernels only (k_phase1, k_bfly_upper, k_bfly_edge, padding): HIP-event time inside one proof"},

@@ -311,3 +311,29 @@ def test_cpp_prover_transcripts_equal_the_python_provers_at_2p20(env):
         assert out["argument_bytes"] == len(mine)
         assert out["transcript_blake2b"] == hashlib.blake2b(mine, digest_size=32).hexdigest(), flag
         assert out["pcie_h2d_bytes_per_proof"] + out["pcie_d2h_bytes_per_proof"] < (1 << 20)      # a codeword is 768 MiB
+
+
+@pytest.mark.parametrize("log_n", [16, 18, 20])
+def test_aurora_transcript_equals_the_oracle_provers_at_large_sizes(env, log_n):
+    """Byte-equality with the oracle prover AT BASELINE's full size: tests/golden/oracle_aurora_transcript_digests_large.json holds BLAKE2b-256 of
+    the oracle prover's transcript for 2^16, 2^18 and 2^20 constraints (42 minutes of one host core for 2^20, tools/cpu_baseline_sizes.py on the GPU
+    box); the native device prover's transcript of the same seeded instance must hash to it — and so must the Python prover's at 2^20."""
+    import json
+    import os
+    from libiop_amd import aurora, r1cs
+    lib, torch, dev, ops, _ = env
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_aurora_transcript_digests_large.json")) as f:
+        want = json.load(f)["digests"][str(log_n)]
+    n = 1 << log_n
+    inst = lib.aurora_example_instance(0, n, 15, n - 1, 0x2204)
+    try:
+        t = lib.aurora_prove(inst)
+    finally:
+        lib.aurora_instance_free(inst)
+    assert len(t) == want["argument_bytes"]
+    assert hashlib.blake2b(t, digest_size=32).hexdigest() == want["transcript_blake2b"], "native device transcript differs from the oracle prover's"
+    if log_n == 20:
+        cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, n, 15, n - 1, 0x2204)
+        params = aurora.AuroraParameters(ops.field, n, n - 1, 15)
+        py = aurora.aurora_snark_prover(ops, cs, primary, auxiliary, params).serialize()
+        assert hashlib.blake2b(py, digest_size=32).hexdigest() == want["transcript_blake2b"], "Python device prover's transcript differs from the oracle prover's"
