@@ -538,6 +538,13 @@ int iopx_comm_all_reduce_u64_dev(iopx_comm *comm, void *d_buf, size_t count, int
 int iopx_comm_broadcast_dev(iopx_comm *comm, void *d_buf, size_t bytes, int root);
 int iopx_comm_all_to_all_dev(iopx_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank);
 int iopx_comm_sendrecv_dev(iopx_comm *comm, const void *d_send, void *d_recv, size_t bytes, int peer);
+/* ONE additive transform as long as its domain, sharded across the N = 2^r ranks of `comm` (libiop_amd/csrc/fft_add_dist.hip): additive_FFT /
+ * additive_IFFT (libiop/algebra/fft.tcc:39-204) of 2^m coefficients over a 2^m-point affine subspace, every rank holding the contiguous block
+ * [rank 2^m / N, (rank + 1) 2^m / N) of the input and of the output (device memory, 2^m / N elements).  One all-to-all transposes the coefficients
+ * into the layout in which the Gao-Mateer recursion's top r levels are shard-local or whole-shard exchanges between peers, a complete local
+ * transform of 2^(m-r) points follows, and the last r butterfly levels exchange shards between peers.  m >= r + 1. */
+int iopx_add_fft_gf192_dist_dev(iopx_comm *comm, const uint64_t *d_block_coeffs, const uint64_t *basis, size_t m, const uint64_t *shift, uint64_t *d_block_out);
+int iopx_add_ifft_gf192_dist_dev(iopx_comm *comm, const uint64_t *d_block_evals, const uint64_t *basis, size_t m, const uint64_t *shift, uint64_t *d_block_out);
 /* While a communicator of N > 1 ranks is bound, every additive transform of the library splits its Gao-Mateer phase 1 (the twists and
  * Taylor expansions on the 2^d coefficients, fft.tcc:62-83 / :172-200) over the ranks when d >= 16: the first log2 N levels run on the
  * whole vector on every rank, from then on the sub-polynomials of different residues of the coefficient index mod N never mix, so rank

@@ -60,7 +60,7 @@ EXPORTED_SYMBOLS = [
     "iopx_fractal_index", "iopx_fractal_prove",
     "iopx_memcpy_d2h_deferrable", "iopx_comm_rccl_unique_id", "iopx_comm_create_rccl", "iopx_comm_create_callbacks", "iopx_comm_destroy", "iopx_comm_rank",
     "iopx_comm_all_gather_dev", "iopx_comm_all_reduce_u64_dev", "iopx_comm_broadcast_dev", "iopx_comm_all_to_all_dev", "iopx_comm_sendrecv_dev", "iopx_comm_stats", "iopx_comm_bind_transforms", "iopx_add_taylor_inv_gf192_dev", "iopx_add_combine_inv_gf192_dev",
-    "iopx_interleave_dev", "iopx_gather_rows_dev", "iopx_fri_snark_prove", "iopx_fri_snark_prove_dist", "iopx_aurora_prove_dist", "iopx_fractal_index_dist", "iopx_fractal_prove_dist",
+    "iopx_interleave_dev", "iopx_gather_rows_dev", "iopx_fri_snark_prove", "iopx_fri_snark_prove_dist", "iopx_add_fft_gf192_dist_dev", "iopx_add_ifft_gf192_dist_dev", "iopx_aurora_prove_dist", "iopx_fractal_index_dist", "iopx_fractal_prove_dist",
 ]
 
 
@@ -773,6 +773,13 @@ class Library:
         self._check(self.c.iopx_comm_create_callbacks(int(rank), int(world), ctypes.addressof(cbs), ctypes.byref(h)))
         self._comm_keepalive = getattr(self, "_comm_keepalive", []) + [(cbs, fns)]
         return h
+
+    def additive_FFT_dist_dev(self, comm, d_block, basis, shift, d_out, inverse=False):
+        """One transform as long as its domain across the ranks of `comm` (iopx_add_[i]fft_gf192_dist_dev): this rank's contiguous block in, its block out."""
+        basis, shift = _as_u64(basis), _as_u64(shift)
+        fn = self.c.iopx_add_ifft_gf192_dist_dev if inverse else self.c.iopx_add_fft_gf192_dist_dev
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, _u64p, _sz, _u64p, ctypes.c_void_p]
+        self._check(fn(comm, _vp(d_block), basis.ctypes.data_as(_u64p), basis.shape[0], shift.ctypes.data_as(_u64p), _vp(d_out)))
 
     def comm_destroy(self, comm):
         self.c.iopx_comm_destroy.argtypes = [ctypes.c_void_p]

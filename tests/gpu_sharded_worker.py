@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--protocol", choices=["aurora", "fractal"], required=True)
+    ap.add_argument("--protocol", choices=["aurora", "fractal", "fft"], required=True)
     ap.add_argument("--field", choices=["gf192", "edwards_Fr"], required=True)
     ap.add_argument("--impl", choices=["python", "native"], default="python")
     ap.add_argument("--log-n", type=int, required=True)
@@ -43,6 +43,31 @@ def main():
     n = 1 << a.log_n
     res = {"world": world, "impl": a.impl}
     try:
+        if a.protocol == "fft":
+            # one transform as long as its domain, block-distributed over the ranks (iopx_add_[i]fft_gf192_dist_dev), against the single-GPU transform
+            import numpy as np
+            m = a.log_n
+            basis = libiop_amd.standard_basis(m)
+            shift = np.array([1 << m, 0, 0], dtype=np.uint64)
+            coeffs = np.random.Generator(np.random.PCG64(a.seed)).integers(0, 2**64, size=(1 << m, 3), dtype=np.uint64)
+            d_all = torch.from_numpy(coeffs.view(np.int64)).to(dev)
+            d_full = torch.empty_like(d_all)
+            lib.additive_FFT_dev(d_all.data_ptr(), 1 << m, basis, shift, d_full.data_ptr())
+            comm = lib.comm_create_rccl_from_torch(dist, rank, world, dev)
+            per = (1 << m) // world
+            mine, back = torch.empty((per, 3), dtype=torch.int64, device=dev), torch.empty((per, 3), dtype=torch.int64, device=dev)
+            block = d_all[rank * per:(rank + 1) * per].contiguous()
+            lib.additive_FFT_dist_dev(comm, block.data_ptr(), basis, shift, mine.data_ptr())
+            lib.additive_FFT_dist_dev(comm, mine.data_ptr(), basis, shift, back.data_ptr(), inverse=True)
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(mine, d_full[rank * per:(rank + 1) * per]) and torch.equal(back, block))
+            flags = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(flags, torch.tensor([int(ok)], dtype=torch.int64, device=dev))
+            lib.comm_destroy(comm)
+            if rank == 0:
+                with open(a.out, "w") as f:
+                    json.dump({"world": world, "ranks_agree": True, "fft_ok": [int(x.item()) for x in flags]}, f)
+            return
         if a.impl == "python":
             ops = idist.sharded_ops(lib, torch, dev, field, idist.AuroraShard(dist, rank, world))
             res["ops"] = type(ops).__name__

@@ -548,3 +548,66 @@ def test_native_sharded_fri_snark_equals_oracle(world, field_code, dim):
     for r in range(world):
         assert ret[r][0] == ref, "rank %d" % r
         assert ret[r][2][0] > 0
+
+
+# ---- ONE transform as long as its domain across the ranks, natively (libiop_amd/csrc/fft_add_dist.hip behind iopx_add_[i]fft_gf192_dist_dev) ----
+def _native_fft_worker(rank, world, port, ret):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from emu_lib import emu
+        from helpers import rand_elems
+        lib = emu()
+        comm = lib.comm_create_torch_callbacks(dist, rank, world)
+        ok = []
+        for m, kind in ((6, "std"), (8, "general"), (11, "aurora")):
+            if kind == "std":
+                basis, shift = oracle.standard_basis(m, W), np.zeros(W, dtype=np.uint64)
+            elif kind == "aurora":
+                basis, shift = oracle.standard_basis(m, W), np.array([1 << m, 0, 0], dtype=np.uint64)
+            else:
+                basis, shift = rand_elems(70 + m, m, W), rand_elems(71 + m, 1, W)[0]
+            coeffs = rand_elems(72 + m, 1 << m, W)
+            full = oracle.additive_fft(coeffs, basis, shift)
+            per = (1 << m) // world
+            lo = rank * per
+            d_in, d_out, d_back = lib.malloc(per * 24), lib.malloc(per * 24), lib.malloc(per * 24)
+            try:
+                lib.h2d(d_in, np.ascontiguousarray(coeffs[lo:lo + per]))
+                lib.additive_FFT_dist_dev(comm, d_in, basis, shift, d_out)
+                got = np.empty((per, W), dtype=np.uint64)
+                lib.d2h(got, d_out)
+                ok.append(bool(np.array_equal(got, full[lo:lo + per])))
+                lib.additive_FFT_dist_dev(comm, d_out, basis, shift, d_back, inverse=True)           # back to the coefficients
+                lib.d2h(got, d_back)
+                ok.append(bool(np.array_equal(got, coeffs[lo:lo + per])))
+                evals = rand_elems(73 + m, 1 << m, W)                                               # independent evaluations against the oracle's IFFT
+                lib.h2d(d_in, np.ascontiguousarray(evals[lo:lo + per]))
+                lib.additive_FFT_dist_dev(comm, d_in, basis, shift, d_out, inverse=True)
+                lib.d2h(got, d_out)
+                ok.append(bool(np.array_equal(got, oracle.additive_ifft(evals, basis, shift)[lo:lo + per])))
+            finally:
+                for d in (d_in, d_out, d_back):
+                    lib.free(d)
+        ret[rank] = (ok, lib.comm_stats()[0])
+        lib.comm_destroy(comm)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_native_distributed_full_size_fft(world):
+    """additive_FFT / additive_IFFT of a polynomial as long as its domain, block-distributed: all-to-all transpose, top levels by shard exchanges, local
+    transform, cross-block butterflies — equal to the oracle's single-process transform on every rank."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_native_fft_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret[r][0] == [True] * 9, (r, ret[r])
+        assert ret[r][1] > 0

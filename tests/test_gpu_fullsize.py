@@ -337,3 +337,24 @@ def test_aurora_transcript_equals_the_oracle_provers_at_large_sizes(env, log_n):
         params = aurora.AuroraParameters(ops.field, n, n - 1, 15)
         py = aurora.aurora_snark_prover(ops, cs, primary, auxiliary, params).serialize()
         assert hashlib.blake2b(py, digest_size=32).hexdigest() == want["transcript_blake2b"], "Python device prover's transcript differs from the oracle prover's"
+
+
+@pytest.mark.parametrize("log_n", [16, 18])
+def test_fractal_transcript_equals_the_oracle_provers_at_large_sizes(env, log_n):
+    """The native Fractal indexer and prover over the 181-bit field against the oracle's recorded index root and transcript digest
+    (tests/golden/oracle_fractal_transcript_digests_large.json: 2^18 costs the oracle 7 minutes and 13 GB)."""
+    import json
+    import os
+    lib, torch, dev, _, _ = env
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_fractal_transcript_digests_large.json")) as f:
+        want = json.load(f)["digests"][str(log_n)]
+    n = 1 << log_n
+    inst = lib.aurora_example_instance(1, n, 0, n - 1, 0x2205)
+    try:
+        roots = lib.fractal_index(inst)
+        t = lib.fractal_prove(inst)
+    finally:
+        lib.aurora_instance_free(inst)
+    assert [r.hex() for r in roots] == want["index_roots"]
+    assert len(t) == want["argument_bytes"]
+    assert hashlib.blake2b(t, digest_size=32).hexdigest() == want["transcript_blake2b"], "native device transcript differs from the oracle prover's"

@@ -81,3 +81,11 @@ def test_native_sharded_aurora_2p16_equals_the_single_gpu_prover(tmp_path):
     for world in _worlds():
         res = _run(world, "aurora", "gf192", "native", 16, 15, 0x2204, tmp_path)
         assert res["equals_single_gpu_native_prover"], world
+
+
+def test_native_distributed_transform_under_rccl(tmp_path):
+    """iopx_add_fft_gf192_dist_dev / _ifft_: one 2^18-point transform block-distributed over the visible GPUs (all-to-all transpose + peer exchanges over
+    RCCL; with one GPU the call is the single-GPU transform) equals the single-GPU transform, and the inverse returns the coefficients."""
+    for world in _worlds():
+        res = _run(world, "fft", "gf192", "native", 18, 0, 0x2201, tmp_path)
+        assert res["fft_ok"] == [1] * world, (world, res)
