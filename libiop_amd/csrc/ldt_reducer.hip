@@ -76,6 +76,12 @@ struct LdtSlotParams {
     const int *slot_parent;         // per slot: parent slot or -1
     const int *oracle_slot;         // per oracle: slot or -1 (maximal)
     int num_slots;
+    // Degree gap 1 over a domain of one-word points (the standard-basis subspaces libiop builds: a point is a polynomial of degree < 32).  The
+    // oracles of that gap are summed first: sum_k (c_k + c'_k x) f_k = sum_k c_k f_k + x sum_k c'_k f_k — two comb products per oracle (the
+    // coefficients are wave-uniform) and ONE product by the one-word x for the group (six word products) instead of a comb and a general product
+    // per oracle.  In an Aurora proof three of the four sub-maximal oracles have gap 1 (h, g, the row check): 7 + 4 -> 10 + 1 + 1 products.
+    int small_slot;                 // the slot of exponent 1 handled that way, or -1
+    uint32_t small_shift, small_basis[32];      // x_j = small_shift + sum_{bit k of j} small_basis[k]
 };
 
 __global__ void __launch_bounds__(256) k_ldt_combine_add_slots(LdtSlotParams q)
@@ -106,7 +112,7 @@ __global__ void __launch_bounds__(256) k_ldt_combine_add_slots(LdtSlotParams q)
 #pragma unroll
                 for (int w = 0; w < 6; ++w) iopx_ldt_smem[(s * 6 + w) * 256 + lane] = v.w[w];
             }
-            gf192 acc = gf_zero();
+            gf192 acc = gf_zero(), gap1 = gf_zero();
             for (int o = 0; o < p.num_oracles; ++o) {
                 const gf192 f = gf_load(p.oracles[o], j);
                 gf192 c = gf_load(p.coef, 2 * o);
@@ -115,11 +121,21 @@ __global__ void __launch_bounds__(256) k_ldt_combine_add_slots(LdtSlotParams q)
                     gf_add_to(acc, gf_mul_uniform(f, c));
                     continue;
                 }
+                if (s == q.small_slot) {                     // gap 1, one-word points: both coefficients by the comb, x once for the group below
+                    gf_add_to(acc, gf_mul_uniform(f, c));
+                    gf_add_to(gap1, gf_mul_uniform(f, gf_load(p.coef, 2 * o + 1)));
+                    continue;
+                }
                 gf192 v;
 #pragma unroll
                 for (int w = 0; w < 6; ++w) v.w[w] = iopx_ldt_smem[(s * 6 + w) * 256 + lane];
                 gf_add_to(c, gf_mul_uniform(v, gf_load(p.coef, 2 * o + 1)));         // the coefficient is the same for every lane: comb product
                 gf_add_to(acc, gf_mul(c, f));
+            }
+            if (q.small_slot >= 0) {
+                uint32_t x = q.small_shift;
+                for (int k = 0; k < p.m; ++k) x ^= (0u - (uint32_t)((j >> k) & 1)) & q.small_basis[k];
+                gf_add_to(acc, gf_mul_small_over_xk(gap1, x, 0));
             }
             gf_store(p.out, j, acc);
         }
@@ -279,6 +295,22 @@ int iopx_ldt_combine_gf192_dev(const void *const *d_oracles, size_t num_oracles,
         if ((rc = upload(dparent.p, slot_parent.data(), ns * 4)) != IOPX_OK) return rc;
         if ((rc = upload(dslot.p, oracle_slot.data(), num_oracles * 4)) != IOPX_OK) return rc;
         LdtSlotParams q;
+        memset(&q, 0, sizeof(q));
+        q.small_slot = -1;
+        {
+            // the slot of exponent 1, when every point of the domain is a one-word polynomial (basis vectors and shift below 2^32) and the
+            // slot is a plain one (no parent, nobody's parent)
+            auto one_word = [](const uint64_t *w) { return w[1] == 0 && w[2] == 0 && (w[0] >> 32) == 0; };
+            const char *knob = getenv("IOPX_LDT_SMALL_GAP1");              // 0 switches the grouping off (A/B runs, tests of the general path)
+            bool small = (!knob || atoi(knob) != 0) && m <= 32 && one_word(shift);
+            for (size_t k = 0; small && k < m; ++k) small = one_word(basis + 3 * k);
+            if (small) {
+                for (size_t sidx = 0; sidx < slot_bits.size(); ++sidx)
+                    if (slot_bits[sidx] == 1 && slot_parent[sidx] < 0 && std::find(slot_parent.begin(), slot_parent.end(), (int)sidx) == slot_parent.end()) q.small_slot = (int)sidx;
+                q.small_shift = (uint32_t)shift[0];
+                for (size_t k = 0; k < m; ++k) q.small_basis[k] = (uint32_t)basis[3 * k];
+            }
+        }
         q.a = p;
         q.slot_bits = dbits.u64(); q.slot_parent = (const int *)dparent.p; q.oracle_slot = (const int *)dslot.p;
         q.num_slots = (int)(distinct.empty() ? 0 : ns);

@@ -46,6 +46,13 @@ def check_errors(lib):
         lib.ldt_combine([rand_elems(1, 8, W), rand_elems(1, 4, W)], [4, 4], rand_elems(2, 4, W), basis, shift)
 
 
+# degree gap 1 over one-word points (standard basis, one-word shift): the group takes two comb products per oracle and one one-word product
+# (k_ldt_combine_add_slots small_slot); gap-1 oracles alone, next to other gaps, next to maximal ones, and with a random basis (general path)
+GAP1 = [
+    (8, [100, 99], 31, "standard"), (9, [300, 299, 299, 299], 32, "standard"), (10, [512, 511, 496, 511, 512, 512, 511], 33, "standard"),
+    (7, [64, 63, 62, 63], 34, "standard"), (8, [200, 199, 199], 35, "random"), (12, [4096, 4095, 4080, 4096, 4096, 4096, 4095], 36, "standard"),
+]
+
 ADDITIVE = [
     (1, [1], 0, "random"), (3, [5, 5, 5], 1, "random"), (6, [40, 17, 40, 33], 2, "random"), (9, [300, 44, 1, 299, 300], 3, "standard"),
     (10, [1 << 9, (1 << 9) - 1, 7], 4, "standard"), (4, [3, 9], 5, "random"),

@@ -361,6 +361,11 @@ def test_ldt_combine_full_size_sampled(gpu):
     lc.check_additive_sampled(gpu, 22, [(1 << 21) - 1, 1 << 20, (1 << 20) + 2 * 41 - 1, (1 << 21) - 1], 11)
 
 
+@pytest.mark.parametrize("m,degrees,seed,kind", lc.GAP1)
+def test_ldt_combine_gap1_group(gpu, m, degrees, seed, kind):
+    lc.check_additive(gpu, m, degrees, seed, kind)
+
+
 def test_ldt_combine_errors(gpu):
     lc.check_errors(gpu)
 

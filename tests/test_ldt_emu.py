@@ -110,3 +110,8 @@ def test_sumcheck_g_multiplicative(log_n, slog, seed):
 @pytest.mark.parametrize("n,k,seed,prime", [(16, 3, 1, False), (300, 1, 2, False), (1024, 3, 3, True), (7, 2, 4, True)])
 def test_lincheck(n, k, seed, prime):
     lc.check_lincheck(emu(), n, k, seed, prime)
+
+
+@pytest.mark.parametrize("m,degrees,seed,kind", lc.GAP1)
+def test_ldt_combine_gap1_group(m, degrees, seed, kind):
+    lc.check_additive(emu(), m, degrees, seed, kind)
