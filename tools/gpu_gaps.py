@@ -9,6 +9,7 @@ ap.add_argument("path")
 ap.add_argument("--min-us", type=float, default=100.0)
 ap.add_argument("--context", type=int, default=0, help="also print this many kernels before and after each listed gap")
 ap.add_argument("--last-ms", type=float, default=120.0, help="look at the kernels of the last this-many milliseconds of the trace")
+ap.add_argument("--histogram", action="store_true", help="idle time by gap length, and by the kernel the GPU waited for (where the launch-bound time sits)")
 a = ap.parse_args()
 path = a.path if a.path.endswith(".db") else glob.glob(a.path + "/**/*.db", recursive=True)[0]
 c = sqlite3.connect(path)
@@ -23,6 +24,18 @@ short = lambda n: n.split("iopx")[-1][:40]
 gaps = [(rows[i + 1][0] - rows[i][1], short(rows[i][2]), short(rows[i + 1][2]), i) for i in range(len(rows) - 1)]
 print("window %.2f ms, kernels busy %.2f ms, idle %.2f ms in %d gaps (%d >= %.0f us)" % (span / 1e6, busy / 1e6, (span - busy) / 1e6, len(gaps),
       sum(1 for g in gaps if g[0] >= a.min_us * 1e3), a.min_us))
+if a.histogram:
+    buckets = [(0, 3), (3, 10), (10, 30), (30, 100), (100, 1e9)]
+    for lo, hi in buckets:
+        sel = [g for g in gaps if lo * 1e3 <= g[0] < hi * 1e3]
+        print("  gaps of %5.0f .. %-8s us: %5d, %.3f ms" % (lo, "%.0f" % hi if hi < 1e8 else "inf", len(sel), sum(g[0] for g in sel) / 1e6))
+    by_next = {}
+    for g in gaps:
+        k = g[2].split("E")[0][:36]
+        n, t = by_next.get(k, (0, 0))
+        by_next[k] = (n + 1, t + g[0])
+    for k, (n, t) in sorted(by_next.items(), key=lambda kv: -kv[1][1])[:12]:
+        print("  idle before %-38s %5d gaps, %.3f ms" % (k, n, t / 1e6))
 for g, before, after, i in sorted(gaps, reverse=True):
     if g < a.min_us * 1e3:
         break
