@@ -428,10 +428,18 @@ def main():
             "argument_bytes": len(tr5), "fri_query_repetitions": params5.fri_query_repetitions,
             "kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof5.items(), key=lambda kv: -kv[1][1])[:10]}}
         d5, (c5, ms5, b5) = max(prof5.items(), key=lambda kv: kv[1][1])
+        traffic5, traffic5_source = None, None
+        try:          # PMC passes of tools/fractal_bench.py at this size (tools/collect_profiles.sh), quoted only for the kernel sources they ran on
+            tj5 = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic_fractal.json")))
+            if tj5.get("log_n") == args.log_n and d5 in tj5.get("kernels", {}) and tj5.get("kernel_sources_sha256") == kernel_sources_digest():
+                traffic5 = tj5["kernels"][d5]["traffic_bytes_per_launch"]
+                traffic5_source = "profiles/r04_traffic_fractal.json (rocprofv3 --pmc passes of tools/fractal_bench.py --log-n %d, collected %s; averaged over the indexer's and the prover's launches)" % (args.log_n, tj5.get("collected", "?"))
+        except (OSError, ValueError):
+            pass
         out["config"]["secondary_fractal"]["roofline"] = {
             "bound": "hbm", "kernel": d5, "launches_per_proof": c5, "avg_launch_ms": ms5 / c5, "algorithmic_bytes_per_launch": b5 / c5 if b5 else None,
             "achieved": (b5 / (ms5 / 1e3) / 1e9) if b5 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (b5 / (ms5 / 1e3) / 1e9 / HBM_PEAK_GBS) if b5 else None,
-            "traffic": None, "binding": "integer VALU issue (29-bit-limb Montgomery products in v_mad_u64_u32 accumulators)"}
+            "traffic": traffic5, "traffic_source": traffic5_source, "binding": "integer VALU issue (29-bit-limb Montgomery products in v_mad_u64_u32 accumulators)"}
         del index5, tr5, tr5_py, cs5, d_z5
 
     if cpu is not None:

@@ -23,8 +23,8 @@ cd $R
 python3 tools/rocprof_summary.py $(find gpurun_out/${P}_prof -name "*.db" | head -1) > gpurun_out/${P}_rocprofv3_bench_aurora2p20.txt
 python3 tools/rocprof_summary.py $(find gpurun_out/${P}_fr_prof -name "*.db" | head -1) > gpurun_out/${P}_rocprofv3_fractal2p20.txt
 # GPU idle gaps inside the last proof of the traced run (under the tracer's own per-launch overhead: an upper bound on the unprofiled gaps)
-# (a 66 ms window that ends before the Python prover's cross-check proof and the proof under the library's own profiler: one timed native proof, phase unknown)
-python3 tools/gpu_gaps.py gpurun_out/${P}_prof --min-us 30 --last-ms 66 --end-offset-ms 160 --histogram > gpurun_out/${P}_gpu_gaps.txt
+# (one proof period of the timed loop: from the 4th proof's lincheck kernel to the 5th's)
+python3 tools/gpu_gaps.py gpurun_out/${P}_prof --min-us 30 --period-kernel k_lincheck_add --period-index 3 --histogram > gpurun_out/${P}_gpu_gaps.txt
 python3 tools/make_traffic_json.py gpurun_out/${P}_pmc_fetch gpurun_out/${P}_pmc_write 20 gpurun_out/${P}_traffic_aurora.json --bench-json gpurun_out/${P}_bench_under_rocprof.json --steps $((STEPS + WARM + 2)) > /dev/null
 python3 tools/make_traffic_json.py gpurun_out/${P}_fr_fetch gpurun_out/${P}_fr_write 20 gpurun_out/${P}_traffic_fractal.json --bench-json gpurun_out/${P}_fractal_2p20.json --steps 3 --min-ms 0.5 > /dev/null
 python3 tools/make_sq_json.py gpurun_out/${P}_pmc_sq gpurun_out/${P}_sq_aurora.json k_bfly_upperILb0 k_bfly_edgeILb0 k_bfly_edge_fwd_batch k_phase1 k_ldt_combine_add_slots k_merkle_leaves k_lincheck_add > /dev/null

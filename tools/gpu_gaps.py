@@ -10,6 +10,9 @@ ap.add_argument("--min-us", type=float, default=100.0)
 ap.add_argument("--context", type=int, default=0, help="also print this many kernels before and after each listed gap")
 ap.add_argument("--last-ms", type=float, default=120.0, help="look at the kernels of the last this-many milliseconds of the trace")
 ap.add_argument("--end-offset-ms", type=float, default=0.0, help="the window ends this many milliseconds before the last kernel (skip a tail that ran under other instrumentation)")
+ap.add_argument("--period-kernel", default=None, help="window = from the start of the I-th launch of this kernel (substring) to the start of the next one: for a kernel "
+                "that runs once per proof, exactly one proof period whatever the tracer's slowdown")
+ap.add_argument("--period-index", type=int, default=3)
 ap.add_argument("--histogram", action="store_true", help="idle time by gap length, and by the kernel the GPU waited for (where the launch-bound time sits)")
 a = ap.parse_args()
 path = a.path if a.path.endswith(".db") else glob.glob(a.path + "/**/*.db", recursive=True)[0]
@@ -17,8 +20,13 @@ c = sqlite3.connect(path)
 tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
 suf = [t for t in tabs if t.startswith("rocpd_metadata")][0][len("rocpd_metadata"):]
 rows = c.execute("select d.start, d.end, s.kernel_name from rocpd_kernel_dispatch%s d join rocpd_info_kernel_symbol%s s on d.kernel_id = s.id order by d.start" % (suf, suf)).fetchall()
-t_end = rows[-1][1] - a.end_offset_ms * 1e6
-rows = [r for r in rows if t_end - a.last_ms * 1e6 <= r[0] and r[1] <= t_end]
+if a.period_kernel:
+    marks = [r[0] for r in rows if a.period_kernel in r[2]]
+    lo_t, hi_t = marks[a.period_index], marks[a.period_index + 1]
+    rows = [r for r in rows if lo_t <= r[0] < hi_t]
+else:
+    t_end = rows[-1][1] - a.end_offset_ms * 1e6
+    rows = [r for r in rows if t_end - a.last_ms * 1e6 <= r[0] and r[1] <= t_end]
 busy = sum(r[1] - r[0] for r in rows)
 span = rows[-1][1] - rows[0][0]
 short = lambda n: n.split("iopx")[-1][:40]
