@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check the last transcript with the oracle verifier (needs oracle/liboracle.so)")
     ap.add_argument("--force-sharded", action="store_true", help="multi-GPU operator set with one rank (exercises the RCCL calls on a 1-GPU box)")
+    ap.add_argument("--native", action="store_true", help="also time the native prover (iopx_fractal_index / _prove; their _dist forms over an RCCL communicator "
+                    "when run under torch.distributed.run or with --force-sharded) and compare its transcript with the Python prover's")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     # one process per GPU under `python -m torch.distributed.run --nproc-per-node N tools/fractal_bench.py ...` (RCCL); alone otherwise
@@ -74,6 +76,31 @@ def main():
         res["runs"].append(run)
         if rank == 0:
             print(json.dumps(run)[:3000], flush=True)
+    if a.native:
+        comm = lib.comm_create_rccl_from_torch(dist, rank, world, dev) if (world > 1 or a.force_sharded) else None
+        inst = lib.aurora_example_instance(0 if field.additive else 1, n, k, n - 1, 0x2205)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        nroots = lib.fractal_index_dist(inst, comm) if comm is not None else lib.fractal_index(inst)
+        torch.cuda.synchronize()
+        res["native_indexer_s"] = time.time() - t0
+        times = []
+        for rep in range(max(a.reps, 3)):
+            torch.cuda.synchronize()
+            t0 = time.time()
+            nt = lib.fractal_prove_dist(inst, comm) if comm is not None else lib.fractal_prove(inst)
+            torch.cuda.synchronize()
+            times.append(time.time() - t0)
+        lib.comm_stats(reset=True)
+        (lib.fractal_prove_dist(inst, comm) if comm is not None else lib.fractal_prove(inst))
+        res["native"] = {"prover_s": times, "prover_s_min": min(times), "index_roots_equal": [bytes(r) for r in roots] == nroots, "transcript_equals_python": nt == tr.serialize(),
+                         "collectives_per_proof": lib.comm_stats()[0], "collective_bytes_per_proof_this_rank": lib.comm_stats()[1],
+                         "path": "iopx_fractal_prove_dist over an RCCL communicator of %d rank(s)" % world if comm is not None else "iopx_fractal_prove"}
+        lib.aurora_instance_free(inst)
+        if comm is not None:
+            lib.comm_destroy(comm)
+        if rank == 0:
+            print("native:", json.dumps(res["native"]), flush=True)
     if a.verify and rank == 0:
         import oracle
         code = oracle.FIELD_GF192 if field.additive else oracle.FIELD_EDWARDS
