@@ -140,9 +140,35 @@ struct StageChunk { void *p; size_t cap; hipEvent_t done; bool busy; };
 static std::vector<StageChunk> g_stage;
 static std::mutex g_stage_mu;
 
+// Per-call constants (shift terms, coefficient lists, pointer tables: a few hundred bytes each, ~140 of them per Aurora proof) are
+// delivered by a one-workgroup KERNEL whose argument block carries the bytes: an asynchronous copy makes the queue switch between the
+// compute and the copy path and leaves the GPU idle for several microseconds on both sides of it (profiles/r04_gpu_gaps.txt: the idle
+// time before the runtime's copy kernels was the largest share of the proof's launch gaps), a kernel launch is one more packet in the
+// compute queue.  The launch copies its arguments at enqueue time, so the caller's buffer is free on return, as with the staging path.
+#define IOPX_UPLOAD_WORDS 960                    // 3840 bytes of payload: the kernel argument block holds 4 KB
+struct UploadBlob { uint32_t w[IOPX_UPLOAD_WORDS]; };
+__global__ void k_upload_small(UploadBlob blob, uint32_t *dst, int words, int tail_bytes)
+{
+    for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = blob.w[i];
+    if (threadIdx.x == 0 && tail_bytes) {
+        uint8_t *d = (uint8_t *)(dst + words);
+        const uint32_t v = blob.w[words];
+        for (int b = 0; b < tail_bytes; ++b) d[b] = (uint8_t)(v >> (8 * b));
+    }
+}
+
 int upload(void *dst_dev, const void *src_host, size_t bytes)
 {
     if (bytes == 0) return IOPX_OK;
+    static const bool by_kernel = [] { const char *v = getenv("IOPX_UPLOAD_KERNEL"); return !v || atoi(v) != 0; }();
+    if (by_kernel && bytes <= sizeof(UploadBlob) && ((uintptr_t)dst_dev & 3) == 0) {
+        UploadBlob blob;
+        memcpy(blob.w, src_host, bytes);
+        g_bytes_h2d += bytes;
+        hipLaunchKernelGGL(k_upload_small, dim3(1), dim3(256), 0, g_stream, blob, (uint32_t *)dst_dev, (int)(bytes / 4), (int)(bytes % 4));
+        IOPX_HIP(hipGetLastError());
+        return IOPX_OK;
+    }
     std::lock_guard<std::mutex> lk(g_stage_mu);
     StageChunk *c = nullptr;
     for (auto &ch : g_stage) {
