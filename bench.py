@@ -346,6 +346,8 @@ def main():
                      "kernel_algorithmic_bytes_per_launch": {k: round(v[2] / v[0]) for k, v in prof.items() if v[2]},
                      # the profiled proof's kernel time (HIP events) against the timed loop's wall time per proof: launch gaps + host work + read-backs
                      "kernels_ms_total": round(sum(v[1] for v in prof.values()), 3),
+                     # idle time between consecutive launches of the profiled proof (HIP events; the longest gaps name the kernels on both sides)
+                     "launch_gaps": getattr(lib, "last_profile_gaps", None),
                      "host_gap_ms": round(prover_s * 1e3 - sum(v[1] for v in prof.values()), 3) if prof else None},
     }
 

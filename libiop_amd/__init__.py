@@ -1088,12 +1088,19 @@ class Library:
         reported (0 for kernels that do not) are kept in self.last_profile_products."""
         buf = ctypes.create_string_buffer(1 << 16)
         self._check(self.c.iopx_profile_report(buf, len(buf)))
-        out, products = {}, {}
+        out, products, gaps = {}, {}, {"idle_ms": None, "count": None, "longest": []}
         for line in buf.value.decode().splitlines():
             f = line.split()
+            if f[0] == "@idle":                      # idle time between consecutive profiled launches
+                gaps["idle_ms"], gaps["count"] = float(f[1]), int(f[2])
+                continue
+            if f[0] == "@gap":
+                gaps["longest"].append({"us": float(f[1]), "after": f[2], "before": f[3]})
+                continue
             out[f[0]] = (int(f[1]), float(f[2]), float(f[3]) if len(f) > 3 else 0.0)
             products[f[0]] = float(f[4]) if len(f) > 4 else 0.0
         self.last_profile_products = products
+        self.last_profile_gaps = gaps
         return out
 
     def gf192_mul_dev(self, d_a, d_b, d_out, count):

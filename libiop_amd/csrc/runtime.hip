@@ -1,5 +1,6 @@
 // libiop_amd runtime: device binding, stream, memory helpers, error strings (see include/libiop_amd.h).
 #include "runtime.h"
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -165,7 +166,7 @@ int upload(void *dst_dev, const void *src_host, size_t bytes)
         UploadBlob blob;
         memcpy(blob.w, src_host, bytes);
         g_bytes_h2d += bytes;
-        hipLaunchKernelGGL(k_upload_small, dim3(1), dim3(256), 0, g_stream, blob, (uint32_t *)dst_dev, (int)(bytes / 4), (int)(bytes % 4));
+        { ProfScope ps_("k_upload_small"); hipLaunchKernelGGL(k_upload_small, dim3(1), dim3(256), 0, g_stream, blob, (uint32_t *)dst_dev, (int)(bytes / 4), (int)(bytes % 4)); }
         IOPX_HIP(hipGetLastError());
         return IOPX_OK;
     }
@@ -321,9 +322,27 @@ int iopx_profile_report(char *buf, size_t cap)
             e.bytes += (double)r.bytes;
             e.products += (double)r.products;
         }
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
     }
+    // idle time between consecutive profiled launches (end event of one to start event of the next): where host work, read-backs and launch
+    // latency are exposed.  "@idle <total ms> <gaps>" and the twelve longest as "@gap <us> <after> <before>"
+    std::string gaps_out;
+    {
+        std::vector<std::pair<float, size_t>> gaps;
+        double idle = 0;
+        for (size_t i = 0; i + 1 < iopx::g_prof.size(); ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, iopx::g_prof[i].b, iopx::g_prof[i + 1].a) == hipSuccess && ms > 0) { gaps.emplace_back(ms, i); idle += ms; }
+        }
+        std::sort(gaps.begin(), gaps.end(), [](const std::pair<float, size_t> &x, const std::pair<float, size_t> &y) { return x.first > y.first; });
+        char line[256];
+        snprintf(line, sizeof(line), "@idle %.6f %zu\n", idle, gaps.size());
+        gaps_out += line;
+        for (size_t k = 0; k < gaps.size() && k < 12; ++k) {
+            snprintf(line, sizeof(line), "@gap %.1f %s %s\n", gaps[k].first * 1e3, iopx::g_prof[gaps[k].second].name, iopx::g_prof[gaps[k].second + 1].name);
+            gaps_out += line;
+        }
+    }
+    for (auto &r : iopx::g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     iopx::g_prof.clear();
     std::string out;
     for (auto &kv : agg) {
@@ -331,6 +350,7 @@ int iopx_profile_report(char *buf, size_t cap)
         snprintf(line, sizeof(line), "%s %zu %.6f %.0f %.0f\n", kv.first.c_str(), kv.second.launches, kv.second.ms, kv.second.bytes, kv.second.products);
         out += line;
     }
+    out += gaps_out;
     if (buf && cap) {
         const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
         memcpy(buf, out.data(), n);
