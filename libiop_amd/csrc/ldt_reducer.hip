@@ -13,7 +13,9 @@
 //     product (:104-128) yields.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 #include "gf192_dev.h"
 #include "gf192_host.h"
@@ -229,23 +231,40 @@ int iopx_ldt_combine_gf192_dev(const void *const *d_oracles, size_t num_oracles,
     }
     int nbits = 0;
     while (nbits < 64 && (all >> nbits)) ++nbits;
-    // basis[k]^(2^i), shift^(2^i) by repeated squaring (exponentiation.tcc:10-18)
-    std::vector<uint64_t> htab;                    // table i: x^(2^i) over the domain, in the subset-sum layout (entries + pre-summed levels)
-    std::vector<hgf192> cur;
-    cur.push_back(hgf192::from_words(shift));
-    for (size_t k = 0; k < m; ++k) cur.push_back(hgf192::from_words(basis + 3 * k));
-    for (int i = 0; i < (nbits ? nbits : 1); ++i) {
-        if ((all >> i) & 1) append_subset_table_with_ext(htab, cur);
-        else htab.resize(htab.size() + 3 * (m + 1) + SUBSET_TABLE_WORDS_EXTRA, 0);          // never read: no exponent has this bit
-        for (size_t k = 0; k <= m; ++k) cur[k] = cur[k].squared();
-    }
+    // basis[k]^(2^i), shift^(2^i) by repeated squaring (exponentiation.tcc:10-18).  The tables depend on the domain and on which exponent bits occur,
+    // not on the proof: kept on the device per (basis, shift, bit mask) — building them (m squarings and 1024 pre-summed entries per bit) and
+    // uploading ~25 KB per bit sat on the critical path between two rounds of every proof.
     TmpBuf dptrs, dtab, dcoef, dexpo;
+    {
+        static std::mutex mu;
+        static std::map<std::vector<uint64_t>, std::shared_ptr<DevBuf>> cache;
+        std::vector<uint64_t> key(basis, basis + 3 * m);
+        key.insert(key.end(), shift, shift + 3);
+        key.push_back(m); key.push_back(all);
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(key);
+        if (it == cache.end()) {
+            std::vector<uint64_t> htab;            // table i: x^(2^i) over the domain, in the subset-sum layout (entries + pre-summed levels)
+            std::vector<hgf192> cur;
+            cur.push_back(hgf192::from_words(shift));
+            for (size_t k = 0; k < m; ++k) cur.push_back(hgf192::from_words(basis + 3 * k));
+            for (int i = 0; i < (nbits ? nbits : 1); ++i) {
+                if ((all >> i) & 1) append_subset_table_with_ext(htab, cur);
+                else htab.resize(htab.size() + 3 * (m + 1) + SUBSET_TABLE_WORDS_EXTRA, 0);  // never read: no exponent has this bit
+                for (size_t k = 0; k <= m; ++k) cur[k] = cur[k].squared();
+            }
+            std::shared_ptr<DevBuf> buf(new DevBuf());
+            if ((rc = buf->alloc(htab.size() * 8)) != IOPX_OK) return rc;
+            if ((rc = upload(buf->p, htab.data(), htab.size() * 8)) != IOPX_OK) return rc;
+            if (cache.size() >= 32) cache.clear();                 // holders keep their entry alive through the shared_ptr
+            it = cache.emplace(key, buf).first;
+        }
+        dtab.borrow(it->second->p, it->second->bytes, it->second);
+    }
     if ((rc = dptrs.alloc(num_oracles * sizeof(void *))) != IOPX_OK) return rc;
-    if ((rc = dtab.alloc(htab.size() * 8)) != IOPX_OK) return rc;
     if ((rc = dcoef.alloc(hcoef.size() * 8)) != IOPX_OK) return rc;
     if ((rc = dexpo.alloc(num_oracles * 8)) != IOPX_OK) return rc;
     if ((rc = upload(dptrs.p, d_oracles, num_oracles * sizeof(void *))) != IOPX_OK) return rc;
-    if ((rc = upload(dtab.p, htab.data(), htab.size() * 8)) != IOPX_OK) return rc;
     if ((rc = upload(dcoef.p, hcoef.data(), hcoef.size() * 8)) != IOPX_OK) return rc;
     if ((rc = upload(dexpo.p, pl.expo.data(), num_oracles * 8)) != IOPX_OK) return rc;
     LdtAddParams p;
