@@ -1446,6 +1446,7 @@ int iopx_clear_plans(void)
     g_plans.clear();
     clear_mul_plans();
     clear_poseidon_sets();
+    clear_domain_tables();
     tmp_trim();
     return IOPX_OK;
 }

@@ -236,15 +236,10 @@ int iopx_ldt_combine_gf192_dev(const void *const *d_oracles, size_t num_oracles,
     // uploading ~25 KB per bit sat on the critical path between two rounds of every proof.
     TmpBuf dptrs, dtab, dcoef, dexpo;
     {
-        static std::mutex mu;
-        static std::map<std::vector<uint64_t>, std::shared_ptr<DevBuf>> cache;
         std::vector<uint64_t> key(basis, basis + 3 * m);
         key.insert(key.end(), shift, shift + 3);
-        key.push_back(m); key.push_back(all);
-        std::lock_guard<std::mutex> lk(mu);
-        auto it = cache.find(key);
-        if (it == cache.end()) {
-            std::vector<uint64_t> htab;            // table i: x^(2^i) over the domain, in the subset-sum layout (entries + pre-summed levels)
+        key.push_back(m); key.push_back(all); key.push_back(0x6c6474);      // "ldt"
+        rc = cached_domain_table(key, [&](std::vector<uint64_t> &htab) -> int {     // table i: x^(2^i) over the domain, in the subset-sum layout
             std::vector<hgf192> cur;
             cur.push_back(hgf192::from_words(shift));
             for (size_t k = 0; k < m; ++k) cur.push_back(hgf192::from_words(basis + 3 * k));
@@ -253,13 +248,9 @@ int iopx_ldt_combine_gf192_dev(const void *const *d_oracles, size_t num_oracles,
                 else htab.resize(htab.size() + 3 * (m + 1) + SUBSET_TABLE_WORDS_EXTRA, 0);  // never read: no exponent has this bit
                 for (size_t k = 0; k <= m; ++k) cur[k] = cur[k].squared();
             }
-            std::shared_ptr<DevBuf> buf(new DevBuf());
-            if ((rc = buf->alloc(htab.size() * 8)) != IOPX_OK) return rc;
-            if ((rc = upload(buf->p, htab.data(), htab.size() * 8)) != IOPX_OK) return rc;
-            if (cache.size() >= 32) cache.clear();                 // holders keep their entry alive through the shared_ptr
-            it = cache.emplace(key, buf).first;
-        }
-        dtab.borrow(it->second->p, it->second->bytes, it->second);
+            return IOPX_OK;
+        }, dtab);
+        if (rc != IOPX_OK) return rc;
     }
     if ((rc = dptrs.alloc(num_oracles * sizeof(void *))) != IOPX_OK) return rc;
     if ((rc = dcoef.alloc(hcoef.size() * 8)) != IOPX_OK) return rc;

@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
+#include <vector>
 #include <memory>
 #include <string>
 #include "../../include/libiop_amd.h"
@@ -122,6 +124,12 @@ struct TmpBuf {
     std::shared_ptr<DevBuf> keep;
     uint64_t *u64() const { return (uint64_t *)p; }
 };
+
+// Device-resident copies of host-built tables that depend on DOMAINS only (subset-sum tables of vanishing-polynomial values, inverse tables per coset,
+// power tables): a proof needs the same ones as the proof before it, and building + uploading them (25 KB per table) sat on the critical path
+// between rounds.  `build` fills the host words on a miss; the entry stays alive while a TmpBuf borrows it (TmpBuf::borrow's owner).
+int cached_domain_table(const std::vector<uint64_t> &key, const std::function<int(std::vector<uint64_t> &)> &build, TmpBuf &out);
+void clear_domain_tables();
 
 // Per-kernel timing with HIP events on the library's stream (iopx_profile_begin / iopx_profile_report).
 // Costs nothing when profiling is off.  Usage: { ProfScope ps("k_name"); hipLaunchKernelGGL(...); }

@@ -267,6 +267,34 @@ int defer_downloads_end()
     return IOPX_OK;
 }
 
+// ---- domain-dependent tables kept on the device ----------------------------------------------------
+static std::mutex g_dtab_mu;
+static std::map<std::vector<uint64_t>, std::shared_ptr<DevBuf>> g_dtabs;
+
+int cached_domain_table(const std::vector<uint64_t> &key, const std::function<int(std::vector<uint64_t> &)> &build, TmpBuf &out)
+{
+    std::lock_guard<std::mutex> lk(g_dtab_mu);
+    auto it = g_dtabs.find(key);
+    if (it == g_dtabs.end()) {
+        std::vector<uint64_t> words;
+        int rc = build(words);
+        if (rc != IOPX_OK) return rc;
+        std::shared_ptr<DevBuf> buf(new DevBuf());
+        if ((rc = buf->alloc(words.size() * 8)) != IOPX_OK) return rc;
+        if ((rc = upload(buf->p, words.data(), words.size() * 8)) != IOPX_OK) return rc;
+        if (g_dtabs.size() >= 64) g_dtabs.clear();          // borrowers keep their entries alive
+        it = g_dtabs.emplace(key, buf).first;
+    }
+    out.borrow(it->second->p, it->second->bytes, it->second);
+    return IOPX_OK;
+}
+
+void clear_domain_tables()
+{
+    std::lock_guard<std::mutex> lk(g_dtab_mu);
+    g_dtabs.clear();
+}
+
 // ---- per-kernel profiling -----------------------------------------------------------------------
 struct ProfRec { const char *name; hipEvent_t a, b; size_t bytes, products; };
 static bool g_prof_on = false;

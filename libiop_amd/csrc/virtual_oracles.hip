@@ -249,23 +249,30 @@ int iopx_rowcheck_gf192_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const ui
     const size_t h = constraint_dim, cosets = (size_t)1 << (m - h);
     // Z_H = prod_{v in H} (X - v): the subspace polynomial of span(basis[0..h)) built factor by factor, Z <- Z(X) (Z(X) + Z(b)),
     // shifted by its value at shift_H (vanishing_polynomial.tcc:373-395)
-    const std::shared_ptr<CachedSubspacePoly> lin_entry = cached_subspace_poly(basis, h);
-    CachedSubspacePoly &lin = *lin_entry;
-    auto eval = [&](const hgf192 &x) { return lin.eval(x); };
-    const hgf192 z_shift = eval(hgf192::from_words(constraint_shift));
-    std::vector<hgf192> z(cosets);
-    for (size_t c = 0; c < cosets; ++c) {
-        hgf192 x = hgf192::from_words(shift);               // first element of the coset: index c << h (utils.tcc:8-30)
-        for (size_t k = h; k < m; ++k) if ((c >> (k - h)) & 1) x += hgf192::from_words(basis + 3 * k);
-        z[c] = eval(x) + z_shift;
-        if (z[c].is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the codeword domain intersects the constraint domain");
-    }
-    host_batch_inverse(z);                                  // one field inversion for all cosets (this sits on the proof's critical path)
-    std::vector<uint64_t> zinv(3 * cosets);
-    for (size_t c = 0; c < cosets; ++c) memcpy(&zinv[3 * c], z[c].w, 24);
+    // 1 / Z_H on each coset of H inside the codeword domain: a function of the two domains only, kept on the device
+    std::vector<uint64_t> key(basis, basis + 3 * m);
+    key.insert(key.end(), shift, shift + 3);
+    key.insert(key.end(), constraint_shift, constraint_shift + 3);
+    key.push_back(m); key.push_back(h); key.push_back(0x726f77);            // "row"
     TmpBuf dz;
-    if ((rc = dz.alloc(zinv.size() * 8)) != IOPX_OK) return rc;
-    if ((rc = upload(dz.p, zinv.data(), zinv.size() * 8)) != IOPX_OK) return rc;
+    rc = cached_domain_table(key, [&](std::vector<uint64_t> &zinv) -> int {
+        const std::shared_ptr<CachedSubspacePoly> lin_entry = cached_subspace_poly(basis, h);
+        CachedSubspacePoly &lin = *lin_entry;
+        auto eval = [&](const hgf192 &x) { return lin.eval(x); };
+        const hgf192 z_shift = eval(hgf192::from_words(constraint_shift));
+        std::vector<hgf192> z(cosets);
+        for (size_t c = 0; c < cosets; ++c) {
+            hgf192 x = hgf192::from_words(shift);               // first element of the coset: index c << h (utils.tcc:8-30)
+            for (size_t k = h; k < m; ++k) if ((c >> (k - h)) & 1) x += hgf192::from_words(basis + 3 * k);
+            z[c] = eval(x) + z_shift;
+            if (z[c].is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the codeword domain intersects the constraint domain");
+        }
+        host_batch_inverse(z);                                  // one field inversion for all cosets
+        zinv.resize(3 * cosets);
+        for (size_t c = 0; c < cosets; ++c) memcpy(&zinv[3 * c], z[c].w, 24);
+        return IOPX_OK;
+    }, dz);
+    if (rc != IOPX_OK) return rc;
     const size_t n = (size_t)1 << m;
     { ProfScope ps_("k_rowcheck_add", 4 * n * 24); hipLaunchKernelGGL(k_rowcheck_add, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_Az, d_Bz, d_Cz, (const uint64_t *)dz.u64(), (int)h, n); }
     IOPX_HIP(hipGetLastError());
@@ -318,17 +325,24 @@ int iopx_fz_gf192_dev(const uint64_t *d_fw, const uint64_t *d_f1v, const uint64_
     if (!d_fw || !d_f1v || !d_out || (m > 0 && !basis) || !shift || (input_dim > 0 && !input_basis) || !input_shift)
         return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
     if (input_dim > m || m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "Codeword domain must be bigger than the input variable domain.");
-    const std::shared_ptr<CachedSubspacePoly> lin_entry = cached_subspace_poly(input_basis, input_dim);       // Z_I's linear part
-    CachedSubspacePoly &lin = *lin_entry;
-    auto eval = [&](const hgf192 &x) { return lin.eval(x); };
-    std::vector<hgf192> entries;
-    entries.push_back(eval(hgf192::from_words(shift)) + eval(hgf192::from_words(input_shift)));    // Z_I(shift) = lin(shift) + lin(shift_I)
-    for (size_t k = 0; k < m; ++k) entries.push_back(eval(hgf192::from_words(basis + 3 * k)));
-    std::vector<uint64_t> tab;
-    append_subset_table_with_ext(tab, entries);
+    // the subset-sum table of Z_I over the codeword domain: a function of the two domains only, kept on the device
+    std::vector<uint64_t> key(basis, basis + 3 * m);
+    key.insert(key.end(), shift, shift + 3);
+    key.insert(key.end(), input_basis, input_basis + 3 * input_dim);
+    key.insert(key.end(), input_shift, input_shift + 3);
+    key.push_back(m); key.push_back(input_dim); key.push_back(0x667a);      // "fz"
     TmpBuf dt;
-    if ((rc = dt.alloc(tab.size() * 8)) != IOPX_OK) return rc;
-    if ((rc = upload(dt.p, tab.data(), tab.size() * 8)) != IOPX_OK) return rc;
+    rc = cached_domain_table(key, [&](std::vector<uint64_t> &tab) -> int {
+        const std::shared_ptr<CachedSubspacePoly> lin_entry = cached_subspace_poly(input_basis, input_dim);       // Z_I's linear part
+        CachedSubspacePoly &lin = *lin_entry;
+        auto eval = [&](const hgf192 &x) { return lin.eval(x); };
+        std::vector<hgf192> entries;
+        entries.push_back(eval(hgf192::from_words(shift)) + eval(hgf192::from_words(input_shift)));    // Z_I(shift) = lin(shift) + lin(shift_I)
+        for (size_t k = 0; k < m; ++k) entries.push_back(eval(hgf192::from_words(basis + 3 * k)));
+        append_subset_table_with_ext(tab, entries);
+        return IOPX_OK;
+    }, dt);
+    if (rc != IOPX_OK) return rc;
     const size_t n = (size_t)1 << m;
     { ProfScope ps_("k_fz_add", 3 * n * 24); hipLaunchKernelGGL(k_fz_add, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_fw, d_f1v, (const uint64_t *)dt.u64(), (int)m, n); }
     IOPX_HIP(hipGetLastError());
@@ -372,28 +386,33 @@ int iopx_sumcheck_g_gf192_dev(const uint64_t *d_f, const uint64_t *d_h, const ui
     auto eval = [&](const hgf192 &x) { return lin_cached.eval(x); };
     if (lin.coeff[0].is_zero()) return fail(IOPX_ERR_INVALID_ARGUMENT, "the summation domain's basis is linearly dependent");
     const hgf192 c = lin.coeff[0].inverse() * hgf192::from_words(claimed_sum);   // eps^-1 mu (sumcheck.tcc:52-54)
-    std::vector<hgf192> xe, he, ze;
-    for (size_t k = 0; k <= m; ++k) {
-        const hgf192 v = hgf192::from_words(k == 0 ? shift : basis + 3 * (k - 1));
-        hgf192 vh = v;
-        for (size_t i = 0; i < summation_dim; ++i) vh = vh.squared();             // v^|H|
-        hgf192 vz = eval(v);
-        if (k == 0) vz += eval(hgf192::from_words(summation_shift));             // Z_H(shift) = lin(shift) + lin(shift_H)
-        xe.push_back(v); he.push_back(vh); ze.push_back(vz);
-    }
-    std::vector<uint64_t> xtab, htab, ztab;
-    append_subset_table_with_ext(xtab, xe);
-    append_subset_table_with_ext(htab, he);
-    append_subset_table_with_ext(ztab, ze);
-    TmpBuf dx, dh, dz, dc;
-    if ((rc = dx.alloc(xtab.size() * 8)) != IOPX_OK) return rc;
-    if ((rc = dh.alloc(htab.size() * 8)) != IOPX_OK) return rc;
-    if ((rc = dz.alloc(ztab.size() * 8)) != IOPX_OK) return rc;
+    // the subset-sum tables of x, x^|H| and Z_H(x) over the codeword domain: functions of the two domains only, kept on the device (one block)
+    std::vector<uint64_t> key(basis, basis + 3 * m);
+    key.insert(key.end(), shift, shift + 3);
+    key.insert(key.end(), summation_basis, summation_basis + 3 * summation_dim);
+    key.insert(key.end(), summation_shift, summation_shift + 3);
+    key.push_back(m); key.push_back(summation_dim); key.push_back(0x73756d);     // "sum"
+    const size_t table_words = 3 * (m + 1) + SUBSET_TABLE_WORDS_EXTRA;
+    TmpBuf dtabs, dc;
+    rc = cached_domain_table(key, [&](std::vector<uint64_t> &words) -> int {
+        std::vector<hgf192> xe, he, ze;
+        for (size_t k = 0; k <= m; ++k) {
+            const hgf192 v = hgf192::from_words(k == 0 ? shift : basis + 3 * (k - 1));
+            hgf192 vh = v;
+            for (size_t i = 0; i < summation_dim; ++i) vh = vh.squared();             // v^|H|
+            hgf192 vz = eval(v);
+            if (k == 0) vz += eval(hgf192::from_words(summation_shift));             // Z_H(shift) = lin(shift) + lin(shift_H)
+            xe.push_back(v); he.push_back(vh); ze.push_back(vz);
+        }
+        append_subset_table_with_ext(words, xe);
+        append_subset_table_with_ext(words, he);
+        append_subset_table_with_ext(words, ze);
+        return words.size() == 3 * table_words ? IOPX_OK : fail(IOPX_ERR_LOGIC, "subset table size");
+    }, dtabs);
+    if (rc != IOPX_OK) return rc;
     if ((rc = dc.alloc(24)) != IOPX_OK) return rc;
-    if ((rc = upload(dx.p, xtab.data(), xtab.size() * 8)) != IOPX_OK) return rc;
-    if ((rc = upload(dh.p, htab.data(), htab.size() * 8)) != IOPX_OK) return rc;
-    if ((rc = upload(dz.p, ztab.data(), ztab.size() * 8)) != IOPX_OK) return rc;
     if ((rc = upload(dc.p, c.w, 24)) != IOPX_OK) return rc;
+    struct { const uint64_t *p; const uint64_t *u64() const { return p; } } dx{ dtabs.u64() }, dh{ dtabs.u64() + table_words }, dz{ dtabs.u64() + 2 * table_words };
     SumcheckAddParams p;
     p.f = d_f; p.h = d_h; p.out = d_out;
     p.xtab = dx.u64(); p.htab = dh.u64(); p.ztab = dz.u64(); p.c = dc.u64();

@@ -2,6 +2,6 @@
 R=$PWD; export TMPDIR=/tmp; cd /tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/tg_prof -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2> $R/gpurun_out/tg.err
 cd $R
-python3 tools/gpu_gaps.py gpurun_out/tg_prof --min-us 25 --period-kernel k_lincheck_add --period-index 3 --histogram > gpurun_out/r04_gpu_gaps.txt
+python3 tools/gpu_gaps.py gpurun_out/tg_prof --min-us 60 --context 3 --period-kernel k_lincheck_add --period-index 3 --histogram > gpurun_out/r04_gpu_gaps.txt
 rm -rf gpurun_out/tg_prof
 cat gpurun_out/r04_gpu_gaps.txt | head -45
