@@ -14,7 +14,10 @@
 // the device operators of include/libiop_amd.h; nothing codeword-sized is ever in a std::vector.  Zero knowledge is out of scope
 // (masks and salts come from libsodium randomness: not reproducible).  Citations are relative to the reference tree.
 #pragma once
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "r1cs.hpp"
 
@@ -899,14 +902,25 @@ bcs_transformation_transcript<FieldT> aurora_snark_prover(const r1cs_constraint_
                                                           const r1cs_auxiliary_input<FieldT> &auxiliary_input, const aurora_snark_parameters<FieldT> &parameters,
                                                           const device_vector<FieldT> *d_assignment = nullptr)
 {
+    // IOPX_HOST_TIMING=1: wall-clock marks of the host-side phases on stderr (registration before the first kernel, the rounds, transcript extraction)
+    const bool timing = std::getenv("IOPX_HOST_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (timing) std::fprintf(stderr, "[iopx host] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    };
     bcs_prover<FieldT> IOP(parameters.pow_bits_);
     aurora_iop<FieldT> full_protocol(IOP, constraint_system, parameters);
     full_protocol.register_interactions();
     IOP.seal_interaction_registrations();
+    mark("interactions registered");
     full_protocol.register_queries();
     IOP.seal_query_registrations();
+    mark("queries registered");
     full_protocol.produce_proof(primary_input, auxiliary_input, d_assignment);
-    return IOP.get_transcript();
+    mark("rounds done (enqueued)");
+    bcs_transformation_transcript<FieldT> transcript = IOP.get_transcript();
+    mark("transcript extracted");
+    return transcript;
 }
 
 } // namespace libiop_amd
