@@ -895,12 +895,12 @@ public:
     }
 };
 
-// aurora_snark_prover (aurora_snark.tcc:119-146).  With d_assignment — the (1, primary, auxiliary) vector already in HBM — the
-// witness never crosses PCIe inside the call.
-template<typename FieldT>
-bcs_transformation_transcript<FieldT> aurora_snark_prover(const r1cs_constraint_system<FieldT> &constraint_system, const r1cs_primary_input<FieldT> &primary_input,
-                                                          const r1cs_auxiliary_input<FieldT> &auxiliary_input, const aurora_snark_parameters<FieldT> &parameters,
-                                                          const device_vector<FieldT> *d_assignment = nullptr)
+namespace detail {
+// registration, rounds, then `finish(IOP)`: the structured transcript or its canonical bytes
+template<typename FieldT, typename Finish>
+auto run_aurora_prover(const r1cs_constraint_system<FieldT> &constraint_system, const r1cs_primary_input<FieldT> &primary_input,
+                       const r1cs_auxiliary_input<FieldT> &auxiliary_input, const aurora_snark_parameters<FieldT> &parameters,
+                       const device_vector<FieldT> *d_assignment, Finish finish) -> decltype(finish(std::declval<bcs_prover<FieldT> &>()))
 {
     // IOPX_HOST_TIMING=1: wall-clock marks of the host-side phases on stderr (registration before the first kernel, the rounds, transcript extraction)
     const bool timing = std::getenv("IOPX_HOST_TIMING") != nullptr;
@@ -918,9 +918,31 @@ bcs_transformation_transcript<FieldT> aurora_snark_prover(const r1cs_constraint_
     mark("queries registered");
     full_protocol.produce_proof(primary_input, auxiliary_input, d_assignment);
     mark("rounds done (enqueued)");
-    bcs_transformation_transcript<FieldT> transcript = IOP.get_transcript();
+    auto result = finish(IOP);
     mark("transcript extracted");
-    return transcript;
+    return result;
+}
+} // namespace detail
+
+// aurora_snark_prover (aurora_snark.tcc:119-146).  With d_assignment — the (1, primary, auxiliary) vector already in HBM — the
+// witness never crosses PCIe inside the call.
+template<typename FieldT>
+bcs_transformation_transcript<FieldT> aurora_snark_prover(const r1cs_constraint_system<FieldT> &constraint_system, const r1cs_primary_input<FieldT> &primary_input,
+                                                          const r1cs_auxiliary_input<FieldT> &auxiliary_input, const aurora_snark_parameters<FieldT> &parameters,
+                                                          const device_vector<FieldT> *d_assignment = nullptr)
+{
+    return detail::run_aurora_prover<FieldT>(constraint_system, primary_input, auxiliary_input, parameters, d_assignment,
+                                             [](bcs_prover<FieldT> &IOP) { return IOP.get_transcript(); });
+}
+
+// ... returning aurora_snark_prover(...).serialize() without building the structured transcript (bcs_prover::get_transcript_bytes): what the C ABI hands out
+template<typename FieldT>
+std::string aurora_snark_prover_serialized(const r1cs_constraint_system<FieldT> &constraint_system, const r1cs_primary_input<FieldT> &primary_input,
+                                           const r1cs_auxiliary_input<FieldT> &auxiliary_input, const aurora_snark_parameters<FieldT> &parameters,
+                                           const device_vector<FieldT> *d_assignment = nullptr)
+{
+    return detail::run_aurora_prover<FieldT>(constraint_system, primary_input, auxiliary_input, parameters, d_assignment,
+                                             [](bcs_prover<FieldT> &IOP) { return IOP.get_transcript_bytes(); });
 }
 
 } // namespace libiop_amd

@@ -712,4 +712,21 @@ bcs_transformation_transcript<FieldT> fractal_snark_prover(const bcs_prover_inde
     return IOP.get_transcript();
 }
 
+// ... returning fractal_snark_prover(...).serialize() without building the structured transcript (bcs_prover::get_transcript_bytes)
+template<typename FieldT>
+std::string fractal_snark_prover_serialized(const bcs_prover_index<FieldT> &index, const r1cs_constraint_system<FieldT> &constraint_system,
+                                            const r1cs_primary_input<FieldT> &primary_input, const r1cs_auxiliary_input<FieldT> &auxiliary_input,
+                                            const fractal_snark_parameters<FieldT> &parameters, const device_vector<FieldT> *d_assignment = nullptr)
+{
+    constraint_system.prepare_device();
+    bcs_prover<FieldT> IOP(parameters.pow_bits_, &index);
+    fractal_iop<FieldT> full_protocol(IOP, constraint_system, parameters, &index.index_evals_over_K);
+    full_protocol.register_interactions();
+    IOP.seal_interaction_registrations();
+    full_protocol.register_queries();
+    IOP.seal_query_registrations();
+    full_protocol.produce_proof(primary_input, auxiliary_input, index, d_assignment);
+    return IOP.get_transcript_bytes();
+}
+
 } // namespace libiop_amd

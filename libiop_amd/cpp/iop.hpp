@@ -620,17 +620,23 @@ public:
     }
 
     // ---- transcript (bcs_prover.tcc:136-233) ----
-    bcs_transformation_transcript<FieldT> get_transcript()
+private:
+    // what both forms of the transcript are made of: per tree the sorted distinct query / leaf positions, the answers (position-major rows of
+    // `width` elements) and the authentication path bytes, read back through ONE drain of the stream
+    struct extracted {
+        std::vector<std::vector<std::size_t>> query_positions, leaf_positions;
+        std::vector<std::vector<FieldT>> flat_responses;
+        std::vector<std::vector<uint8_t>> proof_bytes;
+    };
+    extracted extract_queries()
     {
-        bcs_transformation_transcript<FieldT> t;
-        t.prover_messages_ = prover_messages_;
-        t.MT_roots_ = MT_roots_;
+        extracted x;
         std::map<std::size_t, std::size_t> random_cache, det_cache;
         std::vector<std::vector<std::size_t>> positions_by_oracle(oracle_regs_.size());
         for (auto &q : queries_) record(q.first, obtain_query_position(q.second, random_cache, det_cache), positions_by_oracle);   // registration order
         // the two small read-backs per tree are queued, not waited for one by one (iopx_defer_downloads_begin / _end)
-        std::vector<std::vector<FieldT>> flat_responses(MT_info_.size());
-        std::vector<std::vector<uint8_t>> proof_bytes(MT_info_.size());
+        x.flat_responses.resize(MT_info_.size());
+        x.proof_bytes.resize(MT_info_.size());
         check(iopx_defer_downloads_begin());
         bool deferring = true;
         struct end_on_unwind { bool &on; ~end_on_unwind() { if (on) (void)iopx_defer_downloads_end(); } } guard{ deferring };
@@ -646,14 +652,12 @@ public:
             for (std::size_t pos : qpos) lpos.push_back(cs == 1 ? pos : (domain.type() == affine_subspace_type ? pos / cs : pos % num_leaves));   // bcs_common.tcc:682-696
             std::sort(lpos.begin(), lpos.end());
             lpos.erase(std::unique(lpos.begin(), lpos.end()), lpos.end());
-            t.query_positions_.push_back(qpos);
-            t.MT_leaf_positions_.push_back(lpos);
-            flat_responses[mt].resize(qpos.size() * info.oracle_ids.size());
+            x.flat_responses[mt].resize(qpos.size() * info.oracle_ids.size());
             if (!qpos.empty()) {                                                             // bcs_prover.tcc:187-197
                 std::vector<const void *> ptrs;
                 for (std::size_t oid : info.oracle_ids) ptrs.push_back(oracles_[oid].data());
                 if (!domain.distributed()) {
-                    check(iopx_query_responses_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), domain.num_elements(), qpos.data(), qpos.size(), flat_responses[mt].data()));
+                    check(iopx_query_responses_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), domain.num_elements(), qpos.data(), qpos.size(), x.flat_responses[mt].data()));
                 } else {
                     // every rank writes the rows it owns into a zeroed (positions, oracles) device buffer; one all-reduce completes it everywhere
                     const dist::context &c = dist::ctx();
@@ -664,24 +668,37 @@ public:
                         const bool mine = domain.type() == affine_subspace_type ? p / block == c.rank : p % c.world == c.rank;
                         if (mine) { rows.push_back(row); local_index.push_back(domain.type() == affine_subspace_type ? p - c.rank * block : p / c.world); }
                     }
-                    const device_vector<FieldT> buf(flat_responses[mt].size());
+                    const device_vector<FieldT> buf(x.flat_responses[mt].size());
                     buf.fill_zero();
                     if (!rows.empty()) check(iopx_gather_rows_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), local_index.data(), rows.data(), rows.size(), buf.data()));
                     check(iopx_comm_all_reduce_u64_dev(c.comm, buf.data(), buf.size() * sizeof(FieldT) / 8, IOPX_COMM_SUM));
-                    check(iopx_memcpy_d2h_deferrable(flat_responses[mt].data(), buf.data(), buf.size() * sizeof(FieldT)));
+                    check(iopx_memcpy_d2h_deferrable(x.flat_responses[mt].data(), buf.data(), buf.size() * sizeof(FieldT)));
                 }
             }
-            proof_bytes[mt] = MT_trees_[mt].get_set_membership_proof_bytes(lpos);
+            x.proof_bytes[mt] = MT_trees_[mt].get_set_membership_proof_bytes(lpos);
+            x.query_positions.push_back(std::move(qpos));
+            x.leaf_positions.push_back(std::move(lpos));
         }
         check(iopx_defer_downloads_end());                                                   // one drain of the stream delivers every read-back queued above
         deferring = false;
+        return x;
+    }
+public:
+    bcs_transformation_transcript<FieldT> get_transcript()
+    {
+        bcs_transformation_transcript<FieldT> t;
+        t.prover_messages_ = prover_messages_;
+        t.MT_roots_ = MT_roots_;
+        extracted x = extract_queries();
+        t.query_positions_ = std::move(x.query_positions);
+        t.MT_leaf_positions_ = std::move(x.leaf_positions);
         for (std::size_t mt = 0; mt < MT_info_.size(); ++mt) {
             const std::size_t width = MT_info_[mt].oracle_ids.size(), count = t.query_positions_[mt].size();
             std::vector<std::vector<FieldT>> responses(count, std::vector<FieldT>(width));
             for (std::size_t p = 0; p < count; ++p)
-                for (std::size_t k = 0; k < width; ++k) responses[p][k] = flat_responses[mt][p * width + k];
+                for (std::size_t k = 0; k < width; ++k) responses[p][k] = x.flat_responses[mt][p * width + k];
             t.query_responses_.push_back(responses);
-            t.MT_set_membership_proofs_.push_back(device_merkle_tree::digests_of(proof_bytes[mt]));
+            t.MT_set_membership_proofs_.push_back(device_merkle_tree::digests_of(x.proof_bytes[mt]));
         }
         if (is_holographic_) {                                                               // remove_index_info_from_transcript (bcs_prover.tcc:119-134)
             t.prover_messages_.erase(t.prover_messages_.begin(), t.prover_messages_.begin() + num_prover_messages_at_end_of_round_[0]);
@@ -689,6 +706,35 @@ public:
         }
         t.proof_of_work_ = pow_answer_;
         return t;
+    }
+    // bcs_transformation_transcript::serialize() of get_transcript(), written straight from the read-back buffers: the structured form costs some
+    // five thousand small allocations per 2^20 proof (one std::string per authentication-path digest, one vector per answer row) — 0.5 ms at the
+    // end of every proof that a caller who wants the bytes (the C ABI) does not need to pay
+    std::string get_transcript_bytes()
+    {
+        const extracted x = extract_queries();
+        std::string out;
+        auto u64 = [&](uint64_t v) { out.append(reinterpret_cast<const char *>(&v), 8); };
+        const std::size_t first_message = is_holographic_ ? num_prover_messages_at_end_of_round_[0] : 0, first_root = is_holographic_ ? num_index_trees() : 0;
+        u64(prover_messages_.size() - first_message);
+        for (std::size_t m = first_message; m < prover_messages_.size(); ++m) {
+            u64(prover_messages_[m].size());
+            out.append(reinterpret_cast<const char *>(prover_messages_[m].data()), prover_messages_[m].size() * sizeof(FieldT));
+        }
+        u64(MT_roots_.size() - first_root);
+        for (std::size_t r = first_root; r < MT_roots_.size(); ++r) out.append(MT_roots_[r]);
+        for (std::size_t mt = 0; mt < MT_info_.size(); ++mt) {
+            u64(x.query_positions[mt].size());
+            for (std::size_t p : x.query_positions[mt]) u64(p);
+            u64(x.leaf_positions[mt].size());
+            for (std::size_t p : x.leaf_positions[mt]) u64(p);
+            u64(x.query_positions[mt].empty() ? 0 : MT_info_[mt].oracle_ids.size());
+            out.append(reinterpret_cast<const char *>(x.flat_responses[mt].data()), x.flat_responses[mt].size() * sizeof(FieldT));
+            u64(x.proof_bytes[mt].size() / 32);
+            out.append(reinterpret_cast<const char *>(x.proof_bytes[mt].data()), x.proof_bytes[mt].size());
+        }
+        out.append(pow_answer_);
+        return out;
     }
 };
 

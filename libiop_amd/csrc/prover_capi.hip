@@ -76,7 +76,7 @@ struct Instance : InstanceBase {
         if (!index || index_params[0] != security_parameter || index_params[1] != RS_extra_dimensions || index_params[2] != FRI_localization_parameter)
             throw std::logic_error("iopx_fractal_prove: no index for these parameters (call iopx_fractal_index first)");
         const fractal_snark_parameters<F> params(cs, security_parameter, RS_extra_dimensions, FRI_localization_parameter);
-        return fractal_snark_prover<F>(*index, cs, primary, auxiliary, params, &d_assignment).serialize();
+        return fractal_snark_prover_serialized<F>(*index, cs, primary, auxiliary, params, &d_assignment);
     }
     std::string prove(iopx_comm *comm, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter) override
     {
@@ -84,7 +84,7 @@ struct Instance : InstanceBase {
         const dist::scope bound(comm);
         const aurora_snark_parameters<F> params(cs.num_constraints(), cs.num_variables(), cs.num_inputs(), security_parameter, RS_extra_dimensions,
                                                 FRI_localization_parameter);
-        return aurora_snark_prover<F>(cs, primary, auxiliary, params, &d_assignment).serialize();
+        return aurora_snark_prover_serialized<F>(cs, primary, auxiliary, params, &d_assignment);
     }
 };
 
@@ -156,7 +156,7 @@ std::string fri_prove(iopx_comm *comm, const uint64_t *d_coeffs, size_t n_coeffs
     const dist::scope bound(comm);
     device_vector<F> coeffs(n_coeffs);
     if (n_coeffs) check(iopx_memcpy_d2d(coeffs.data(), d_coeffs, n_coeffs * 24));
-    return FRI_snark_prover<F>(coeffs, params).serialize();
+    return FRI_snark_prover_serialized<F>(coeffs, params);
 }
 
 } // namespace
