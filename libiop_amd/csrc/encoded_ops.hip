@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) k_spmv_fp3(SpmvParams p)
 struct PolyDivParams {
     const uint64_t *src;
     uint64_t *dst;
-    const uint64_t *consts;     // nterms elements (fp3: 2^203 form)
+    uint64_t consts[3 * PDIV_MAX_TERMS];     // nterms elements (fp3: 2^203 form), in the argument block: no upload launch per pass
     size_t off[PDIV_MAX_TERMS];
     size_t M;
     int nterms;
@@ -217,21 +217,17 @@ static int run_division(const uint64_t *d_high, size_t M, size_t min_offset, uin
         const std::vector<Term> terms = terms_of_pass(k);
         PolyDivParams p;
         memset(&p, 0, sizeof(p));
-        std::vector<uint64_t> consts;
         for (const Term &t : terms) {
             if (t.off >= M) continue;
+            memcpy(p.consts + 3 * p.nterms, t.c, 24);
             p.off[p.nterms++] = t.off;
-            consts.insert(consts.end(), t.c, t.c + 3);
         }
         if (p.nterms == 0) {        // nothing reaches back into the quotient: the factor is 1 on this range
             if (src != dst) IOPX_HIP(hipMemcpyAsync(dst, src, M * 24, hipMemcpyDeviceToDevice, stream()));
             src = dst;
             continue;
         }
-        TmpBuf dc;
-        if ((rc = dc.alloc(consts.size() * 8)) != IOPX_OK) return rc;
-        if ((rc = upload(dc.p, consts.data(), consts.size() * 8)) != IOPX_OK) return rc;
-        p.src = src; p.dst = dst; p.consts = dc.u64(); p.M = M;
+        p.src = src; p.dst = dst; p.M = M;
         if ((rc = launch(p)) != IOPX_OK) return rc;
         src = dst;
     }

@@ -81,8 +81,10 @@ __device__ __forceinline__ void b2b_init(uint64_t (&h)[8])
     h[0] ^= 0x01010000ull ^ 32ull;         // unkeyed, 32-byte digest
 }
 
+#define LEAF_INLINE_ORACLES 16
 struct LeafParams {
-    const uint64_t *const *oracles;     // device array of num_oracles device pointers
+    const uint64_t *const *oracles;     // device array of num_oracles device pointers, or null: then the pointers are inline_oracles
+    const uint64_t *inline_oracles[LEAF_INLINE_ORACLES];    // up to 16 oracles travel in the argument block (no upload launch per tree)
     const uint64_t *salts;              // nullptr or num_leaves * salt_words words
     uint64_t *nodes;                    // (2 L - 1) * 4 words
     size_t num_oracles, elem_words, n, coset_size, num_leaves;
@@ -94,6 +96,7 @@ __global__ void k_merkle_leaves(LeafParams p)
 {
     const size_t words_total = p.num_oracles * p.coset_size * p.elem_words;
     const size_t bytes_total = words_total * 8;
+    const uint64_t *const *oracles = p.oracles ? p.oracles : p.inline_oracles;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.num_leaves; i += (size_t)gridDim.x * blockDim.x) {
         uint64_t h[8];
         b2b_init(h);
@@ -101,7 +104,7 @@ __global__ void k_merkle_leaves(LeafParams p)
         // the serialisation cursor (oracle k, position j in the coset, word ww of the element) is the same for every lane: it
         // advances by counting, never by dividing (a 64-bit division costs about as much as a BLAKE2b round)
         uint32_t k = 0, j = 0, ww = 0;
-        const uint64_t *cur = p.oracles[0];
+        const uint64_t *cur = oracles[0];
         // position_by_coset_indices: subspace.tcc:86-91 / subgroup.tcc:191-197
         size_t pos = p.additive ? i * p.coset_size : i;
         const size_t pos_step = p.additive ? 1 : p.num_leaves;
@@ -118,7 +121,7 @@ __global__ void k_merkle_leaves(LeafParams p)
                         if (++j == p.coset_size) {
                             j = 0;
                             pos = p.additive ? i * p.coset_size : i;
-                            if (++k < p.num_oracles) cur = p.oracles[k];
+                            if (++k < p.num_oracles) cur = oracles[k];
                         }
                     }
                 }
@@ -189,7 +192,23 @@ __global__ void k_gather_nodes(uint64_t *out, const uint64_t *nodes, const uint6
     }
 }
 
-// out[(p * num_oracles + k) * elem_words + w] = oracle_k[pos[p]] word w
+// out[(p * num_oracles + k) * elem_words + w] = oracle_k[pos[p]] word w.  Up to 16 oracles and 256 positions (every tree of the shipped provers: 27 - 36
+// query repetitions of cosets of 2 - 4 positions) travel in the argument block; larger requests through device arrays.
+#define GATHER_INLINE_ORACLES 16
+#define GATHER_INLINE_POSITIONS 256
+struct GatherInline {
+    const uint64_t *oracles[GATHER_INLINE_ORACLES];
+    uint64_t pos[GATHER_INLINE_POSITIONS];
+};
+__global__ void k_gather_responses_inline(uint64_t *out, GatherInline g, size_t num_oracles, size_t elem_words, size_t count)
+{
+    const size_t total = count * num_oracles * elem_words;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t w = i % elem_words, k = (i / elem_words) % num_oracles, q = i / (elem_words * num_oracles);
+        out[i] = g.oracles[k][g.pos[q] * elem_words + w];
+    }
+}
+
 __global__ void k_gather_responses(uint64_t *out, const uint64_t *const *oracles, const uint64_t *pos, size_t num_oracles,
                                    size_t elem_words, size_t count)
 {
@@ -248,11 +267,15 @@ static int merkle_blake2b_impl(const void *const *d_oracles, size_t num_oracles,
     if (d_salts && salt_bytes > 96) return fail(IOPX_ERR_INVALID_ARGUMENT, "zk salt of %zu bytes does not fit one BLAKE2b block", salt_bytes);
 
     TmpBuf dptrs;
-    if ((rc = dptrs.alloc(num_oracles * sizeof(void *))) != IOPX_OK) return rc;
-    { int urc_ = upload(dptrs.p, d_oracles, num_oracles * sizeof(void *)); if (urc_ != IOPX_OK) return urc_; }
+    if (num_oracles > LEAF_INLINE_ORACLES) {
+        if ((rc = dptrs.alloc(num_oracles * sizeof(void *))) != IOPX_OK) return rc;
+        { int urc_ = upload(dptrs.p, d_oracles, num_oracles * sizeof(void *)); if (urc_ != IOPX_OK) return urc_; }
+    }
 
     LeafParams p;
-    p.oracles = (const uint64_t *const *)dptrs.p;
+    memset(&p, 0, sizeof(p));
+    p.oracles = (const uint64_t *const *)dptrs.p;                              // null when the pointers fit the argument block
+    if (num_oracles <= LEAF_INLINE_ORACLES) for (size_t k = 0; k < num_oracles; ++k) p.inline_oracles[k] = (const uint64_t *)d_oracles[k];
     p.salts = (const uint64_t *)d_salts;
     p.nodes = (uint64_t *)d_nodes;
     p.num_oracles = num_oracles; p.elem_words = elem_bytes / 8; p.n = n; p.coset_size = coset_size; p.num_leaves = L;
@@ -437,9 +460,21 @@ int iopx_query_responses_dev(const void *const *d_oracles, size_t num_oracles, s
     for (uint64_t v : pos) if (v >= n) return fail(IOPX_ERR_INVALID_ARGUMENT, "query position %llu outside the domain", (unsigned long long)v);
     const size_t words = elem_bytes / 8, total = num_positions * num_oracles * words;
     TmpBuf dptrs, dpos, dout;
+    if ((rc = dout.alloc(total * 8)) != IOPX_OK) return rc;
+    if (num_oracles <= GATHER_INLINE_ORACLES && num_positions <= GATHER_INLINE_POSITIONS) {
+        GatherInline g;
+        memset(&g, 0, sizeof(g));
+        for (size_t k = 0; k < num_oracles; ++k) g.oracles[k] = (const uint64_t *)d_oracles[k];
+        memcpy(g.pos, pos.data(), num_positions * 8);
+        { ProfScope ps_("k_gather_responses");
+          hipLaunchKernelGGL(k_gather_responses_inline, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, stream(), dout.u64(), g,
+                             num_oracles, words, num_positions); }
+        IOPX_HIP(hipGetLastError());
+        { int drc_ = download(values, dout.p, total * 8, /*deferrable=*/true); if (drc_ != IOPX_OK) return drc_; }
+        return IOPX_OK;
+    }
     if ((rc = dptrs.alloc(num_oracles * sizeof(void *))) != IOPX_OK) return rc;
     if ((rc = dpos.alloc(num_positions * 8)) != IOPX_OK) return rc;
-    if ((rc = dout.alloc(total * 8)) != IOPX_OK) return rc;
     if ((rc = upload(dptrs.p, d_oracles, num_oracles * sizeof(void *))) != IOPX_OK) return rc;
     if ((rc = upload(dpos.p, pos.data(), num_positions * 8)) != IOPX_OK) return rc;
     { ProfScope ps_("k_gather_responses");

@@ -385,6 +385,9 @@ def test_membership_proofs(gpu):
 
 def test_query_responses(gpu):
     tc.check_query_responses(gpu, 1 << 16, 4, 5)
+    tc.check_query_responses(gpu, 1 << 14, 2, 6, num_positions=400)
+    tc.check_query_responses(gpu, 1 << 10, 17, 7)
+    tc.check_wide_tree(gpu)
 
 
 # ---- FRI-only SNARK (config 3's shape): device transcript == the oracle prover's; the oracle's verifier accepts / rejects ----

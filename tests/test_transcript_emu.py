@@ -29,6 +29,12 @@ def test_large_odd_deferred_downloads():
 
 def test_query_responses():
     tc.check_query_responses(emu(), 256, 3, 5)
+    tc.check_query_responses(emu(), 4096, 2, 6, num_positions=400)          # more than 256 positions: device arrays
+    tc.check_query_responses(emu(), 128, 17, 7)                             # more than 16 oracles: device arrays
+
+
+def test_wide_tree():
+    tc.check_wide_tree(emu())
 
 
 @pytest.mark.parametrize("m,d,batch", [(6, 3, 1), (9, 5, 3), (8, 8, 2), (10, 1, 2), (12, 7, 2)])

@@ -136,13 +136,14 @@ def check_empty_and_errors(lib):
         lib.free(d)
 
 
-def check_query_responses(lib, n, r, seed):
+def check_query_responses(lib, n, r, seed, num_positions=37):
+    """r <= 16 oracles and <= 256 positions travel in the kernel's argument block, larger requests through device arrays: both are covered by the callers"""
     cols = [rand_elems(seed + k, n, 3) for k in range(r)]
     ds = [lib.malloc(c.nbytes) for c in cols]
     try:
         for dd, c in zip(ds, cols):
             lib.h2d(dd, c)
-        pos = sorted(set(int(v) for v in np.random.default_rng(seed).integers(0, n, size=37)))
+        pos = sorted(set(int(v) for v in np.random.default_rng(seed).integers(0, n, size=num_positions)))
         got = lib.query_responses_dev(ds, 24, n, pos)
         want = np.stack([np.stack([c[p] for c in cols]) for p in pos])
         assert np.array_equal(got, want)
@@ -151,6 +152,21 @@ def check_query_responses(lib, n, r, seed):
     finally:
         for dd in ds:
             lib.free(dd)
+
+
+def check_wide_tree(lib):
+    """A tree over 17 oracles (more than the 16 whose pointers fit the leaf kernel's argument block) and one over 16, against hashlib."""
+    import hashlib
+    for r in (16, 17):
+        L, cs = 8, 2
+        cols = [rand_elems(90 + k, L * cs, 3) for k in range(r)]
+        nodes = lib.merkle_tree(cols, cs)
+        leaf = [hashlib.blake2b(b"".join(c[cs * j:cs * (j + 1)].tobytes() for c in cols), digest_size=32).digest() for j in range(L)]
+        assert [bytes(nodes[L - 1 + j]) for j in range(L)] == leaf, r
+        lvl = leaf
+        while len(lvl) > 1:
+            lvl = [hashlib.blake2b(lvl[2 * i] + lvl[2 * i + 1], digest_size=32).digest() for i in range(len(lvl) // 2)]
+        assert bytes(nodes[0]) == lvl[0], r
 
 
 def test_hash_count_expectation():
