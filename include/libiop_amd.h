@@ -441,6 +441,12 @@ int iopx_upload_small(void *dst_dev, const void *src_host, size_t bytes);
  * r1cs_rs_iop.tcc:406-430 on multiplicative domains. */
 int iopx_gather_dev(const void *d_src, const uint64_t *d_index, size_t count, size_t elem_bytes, void *d_dst);
 int iopx_scatter_dev(const void *d_src, const uint64_t *d_index, size_t count, size_t elem_bytes, void *d_dst);
+/* d_dst[i] = d_src[i * stride] for i < count: the evaluations over the sub-coset of order |D| / stride inside a vector over a
+ * multiplicative coset D — the positions IFFT_of_known_degree reads (libiop/algebra/fft.tcc:435-456). */
+int iopx_gather_stride_dev(const void *d_src, size_t count, size_t stride, size_t elem_bytes, void *d_dst);
+/* *d_count += the number of 8-byte words at which the two device buffers differ (d_count: one uint64_t in device memory, zeroed by the
+ * caller).  The provers use it to confirm that a codeword computed by two routes is one codeword (libiop_amd/cpp/aurora.hpp, FRI_protocol). */
+int iopx_count_mismatch_dev(const void *d_a, const void *d_b, size_t bytes, uint64_t *d_count);
 /* Bytes moved by every host<->device copy the library has made (optionally reset): what a caller checks to assert that no
  * codeword-sized vector crossed PCIe during a proof. */
 int iopx_transfer_stats(uint64_t *h2d_bytes, uint64_t *d2h_bytes, int reset);

@@ -214,6 +214,20 @@ device_vector<FieldT> poly_div_vanishing(const device_vector<FieldT> &poly, std:
     return out;
 }
 
+// Virtual oracles whose POLYNOMIAL is wanted (the sumcheck's combined f, FRI's first oracle) are evaluated over the head of the codeword
+// domain only (dist::head_domain: as many points as the polynomial has coefficients) instead of over all of it, when that is at least 4x
+// fewer points and rank 0 holds them.  IOPX_HEAD_EVAL=0: the reference's schedule (every virtual oracle over the whole domain).
+inline bool head_evaluation_enabled()
+{
+    const char *e = std::getenv("IOPX_HEAD_EVAL");      // read per proof: tests prove the same instance both ways
+    return !(e && e[0] == '0');
+}
+template<typename FieldT>
+bool use_head(const field_subset<FieldT> &D, std::size_t count)
+{
+    return head_evaluation_enabled() && count * 4 <= D.num_elements() && D.num_elements() % count == 0 && dist::head_on_rank0(D, count);
+}
+
 template<typename FieldT>
 std::vector<const void *> pointers(const std::vector<device_vector<FieldT>> &v, std::size_t first = 0)
 {
@@ -305,13 +319,15 @@ public:
         primary_input_set_ = true;
     }
     const device_vector<FieldT> &f1v_coefficients() const { return f1v_coefficients_; }
-    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &constituents) const override
+    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &constituents) const override { return evaluated_contents_over(codeword_domain_, constituents); }
+    bool restrictable() const override { return true; }
+    device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &D, const std::vector<device_vector<FieldT>> &constituents) const override
     {
         if (constituents.size() != 1) throw std::invalid_argument("fz_virtual_oracle has one constituent oracle.");
         if (!primary_input_set_) throw std::logic_error("Evaluation requested before primary_input is set.");
         const field_subset<FieldT> &I = input_variable_domain_;
-        const device_vector<FieldT> f1v = dev::FFT<FieldT>(f1v_coefficients_, I.num_elements(), codeword_domain_);      // :211-212
-        const field_subset<FieldT> L = dist::local_domain(codeword_domain_);                  // pointwise: this rank's part is a domain of its own
+        const device_vector<FieldT> f1v = dev::FFT<FieldT>(f1v_coefficients_, I.num_elements(), D);                     // :211-212
+        const field_subset<FieldT> L = dist::local_domain(D);                                 // pointwise: this rank's part is a domain of its own
         device_vector<FieldT> out(L.num_elements());
         if (dev::additive(L))
             check(iopx_fz_gf192_dev(constituents[0].words(), f1v.words(), dev::basis_words(L), L.dimension(), dev::shift_words(L), dev::basis_words(I),
@@ -329,10 +345,12 @@ class rowcheck_ABC_virtual_oracle : public virtual_oracle<FieldT> {             
 public:
     rowcheck_ABC_virtual_oracle(const field_subset<FieldT> &codeword_domain, const field_subset<FieldT> &constraint_domain)
         : codeword_domain_(codeword_domain), constraint_domain_(constraint_domain) {}
-    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
+    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override { return evaluated_contents_over(codeword_domain_, c); }
+    bool restrictable() const override { return true; }
+    device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &D, const std::vector<device_vector<FieldT>> &c) const override
     {
         if (c.size() != 3) throw std::invalid_argument("rowcheck_ABC has three constituent oracles.");
-        const field_subset<FieldT> L = dist::local_domain(codeword_domain_);
+        const field_subset<FieldT> L = dist::local_domain(D);
         const field_subset<FieldT> &H = constraint_domain_;
         device_vector<FieldT> out(L.num_elements());
         if (dev::additive(L))
@@ -376,10 +394,12 @@ public:
         }
         for (std::size_t m = 0; m < matrices_T_->size(); ++m) (*matrices_T_)[m].times_vector(alpha_powers, abc, &r_Mz_[m], m > 0);     // :64-88
     }
-    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
+    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override { return evaluated_contents_over(codeword_domain_, c); }
+    bool restrictable() const override { return true; }
+    device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &D, const std::vector<device_vector<FieldT>> &c) const override
     {
         if (c.size() != matrices_T_->size() + 1) throw std::invalid_argument("multi_lincheck uses more constituent oracles than what was provided.");
-        const std::vector<device_vector<FieldT>> p = dev::reextend_packed<FieldT>(p_alpha_evals_, 2, summation_domain_, codeword_domain_);     // :94-98 + :112-118
+        const std::vector<device_vector<FieldT>> p = dev::reextend_packed<FieldT>(p_alpha_evals_, 2, summation_domain_, D);                    // :94-98 + :112-118
         const std::vector<const void *> Mz = dev::pointers(c, 1);
         device_vector<FieldT> out(c[0].size());
         auto fn = field_host<FieldT>::additive() ? iopx_lincheck_gf192_dev : iopx_lincheck_fp3_dev;
@@ -399,6 +419,8 @@ public:
         if (coefficients.size() != num_oracles_) throw std::invalid_argument("Random Linear Combination Oracle: Expected same number of random coefficients as oracles.");
         coefficients_ = coefficients;
     }
+    bool restrictable() const override { return true; }
+    device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &, const std::vector<device_vector<FieldT>> &c) const override { return evaluated_contents(c); }
     device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
     {
         if (c.size() != num_oracles_) throw std::invalid_argument("Random Linear Combination Oracle: Expected same number of evaluations as in registration.");
@@ -418,10 +440,12 @@ public:
     sumcheck_g_oracle(const field_subset<FieldT> &summation_domain, const field_subset<FieldT> &codeword_domain)
         : summation_domain_(summation_domain), codeword_domain_(codeword_domain), claimed_sum_(field_host<FieldT>::zero()) {}
     void set_claimed_sum(const FieldT &claimed_sum) { claimed_sum_ = claimed_sum; }
-    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
+    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override { return evaluated_contents_over(codeword_domain_, c); }
+    bool restrictable() const override { return true; }
+    device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &D, const std::vector<device_vector<FieldT>> &c) const override
     {
         if (c.size() != 2) throw std::invalid_argument("sumcheck_g_oracle has two constituent oracles");
-        const field_subset<FieldT> L = dist::local_domain(codeword_domain_);
+        const field_subset<FieldT> L = dist::local_domain(D);
         const field_subset<FieldT> &H = summation_domain_;
         device_vector<FieldT> out(L.num_elements());
         if (dev::additive(L))
@@ -448,10 +472,12 @@ public:
         if (coefficients.size() != 2 * degrees_.size()) throw std::invalid_argument("Expected the nunmber of random coefficients to be twice the number of oracles.");
         coefficients_ = coefficients;
     }
-    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
+    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override { return evaluated_contents_over(codeword_domain_, c); }
+    bool restrictable() const override { return true; }
+    device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &D, const std::vector<device_vector<FieldT>> &c) const override
     {
         if (c.size() != degrees_.size()) throw std::invalid_argument("Expected same number of evaluations as in registration.");
-        const field_subset<FieldT> L = dist::local_domain(codeword_domain_);
+        const field_subset<FieldT> L = dist::local_domain(D);
         const std::vector<const void *> ptrs = dev::pointers(c);
         device_vector<FieldT> out(L.num_elements());
         if (dev::additive(L))
@@ -506,12 +532,25 @@ public:
     {
         const std::vector<FieldT> challenge = IOP_.obtain_verifier_random_message(challenge_handle_);
         combined_f_oracle_->set_random_coefficients(challenge);
-        const device_vector<FieldT> evals = IOP_.get_oracle_evaluations(combined_f_handle_);
         FieldT combined_claimed_sum = field_host<FieldT>::zero();                            // :327-341
         for (std::size_t i = 0; i < challenge.size(); ++i)
             combined_claimed_sum = field_host<FieldT>::add(combined_claimed_sum, field_host<FieldT>::mul(challenge[i], claimed_sums_[i]));
         g_oracle_->set_claimed_sum(combined_claimed_sum);
-        const device_vector<FieldT> h = dev::interpolate_and_divide<FieldT>(evals, degree_bound_, L_, H_);                 // :351-354, :359-365
+        device_vector<FieldT> h;
+        const std::size_t count = (std::size_t)1 << detail::log2_ceil(degree_bound_);
+        if (degree_bound_ > H_.num_elements() && dev::use_head(L_, count) && IOP_.can_restrict(combined_f_handle_)) {
+            // the interpolant of :351-354 only reads the head of the codeword domain: evaluate the combined f there and nowhere else
+            h = device_vector<FieldT>(degree_bound_ - H_.num_elements());
+            if (!L_.distributed() || dist::ctx().rank == 0) {
+                const dist::one_rank_section alone;
+                const device_vector<FieldT> evals = IOP_.get_oracle_evaluations_over_head(combined_f_handle_, count);
+                h = dev::poly_div_vanishing<FieldT>(dev::IFFT<FieldT>(evals, dist::head_domain(L_, count)), degree_bound_, H_);
+            }
+            if (L_.distributed()) dist::broadcast<FieldT>(h, 0);
+        } else {
+            const device_vector<FieldT> evals = IOP_.get_oracle_evaluations(combined_f_handle_);
+            h = dev::interpolate_and_divide<FieldT>(evals, degree_bound_, L_, H_);                                         // :351-354, :359-365
+        }
         IOP_.submit_oracle(h_handle_, oracle<FieldT>(dev::FFT<FieldT>(h, h.size(), L_)));                                  // :384-387
     }
     std::vector<oracle_handle> get_all_oracle_handles() const { return { h_handle_, g_handle_ }; }
@@ -722,6 +761,57 @@ class FRI_protocol {                                                            
         }
         dist::mark_fri_domains(domains_, localization_);                                    // which L^(i) stay split over the ranks (dist.hpp)
     }
+    // f_1 without f_0 over all of L.  A virtual f_0 is only ever folded; its polynomial has at most `head` coefficients (2^ceil(log2 of the tested
+    // degree bound)), so f_1 = fold(f_0, x_0) has head / 2^eta_0 and is determined by its values on the head of L^(1) — which are the fold of f_0's
+    // values on the head of L (FRI's cosets of L, subspace.tcc:73-91 / subgroup.tcc:175-197, are cosets of the head too).  So: the virtual oracles
+    // over the head only (|L| / head times fewer evaluations), one fold there, interpolate, extend over L^(1): the same field elements as folding
+    // all of f_0 (:522-526) WHEN f_0 is that polynomial.  For an instance whose virtual oracles are not polynomials (an unsatisfied witness, a
+    // mismatched index: the reference still emits a transcript, which its verifier rejects) the two routes differ, so the result is confirmed on a
+    // second window of the same size next to the head — fold(f_0) there must be the extension's values — and on any difference this returns false
+    // and the caller takes the reference's route.  A rational function that is not the polynomial differs from it on all but boundedly many points,
+    // so a whole window of agreement does not happen by accident.
+    bool first_round_from_head(std::vector<std::vector<device_vector<FieldT>>> &by_interaction)
+    {
+        if (num_reductions_ < 2 || !dev::head_evaluation_enabled()) return false;
+        const field_subset<FieldT> &L0 = domains_[0], &L1 = domains_[1];
+        const std::size_t head = (std::size_t)1 << detail::log2_ceil(poly_degree_bound_), cs0 = (std::size_t)1 << localization_[0];
+        if (!dev::use_head(L0, head) || head / cs0 < 2) return false;
+        for (auto &h : poly_handles_) if (!h.is_virtual || !IOP_.can_restrict(h)) return false;
+        const dist::window h0 = dist::head_window(L0, head), h1 = dist::head_window(L1, head / cs0);
+        const dist::window c0 = dist::beside_head_window(L0, head), c1 = dist::beside_head_window(L1, head / cs0);      // c0 folds onto c1
+        const std::size_t me = dist::ctx().rank, checker = dist::window_owner(L0, c0);
+        if (checker == (std::size_t)-1 || (L1.distributed() && dist::window_owner(L1, c1) != checker)) return false;
+        const bool split = L0.distributed();
+        const field_subset<FieldT> D_h0 = dist::window_domain(L0, h0), D_h1 = dist::window_domain(L1, h1), D_c0 = dist::window_domain(L0, c0);
+        const device_array<uint64_t> d_differ(1);
+        check(iopx_memset_dev(d_differ.data(), 0, 8));
+        by_interaction.assign(interactive_repetitions_, std::vector<device_vector<FieldT>>(poly_handles_.size()));
+        for (std::size_t l = 0; l < poly_handles_.size(); ++l) {
+            device_vector<FieldT> f0;
+            if (!split || me == 0) { const dist::one_rank_section alone; f0 = IOP_.get_oracle_evaluations_over_window(poly_handles_[l], h0); }
+            for (std::size_t j = 0; j < interactive_repetitions_; ++j) {
+                const FieldT x_0 = IOP_.obtain_verifier_random_message(verifier_challenge_handles_[0][j])[0];
+                device_vector<FieldT> coeffs(head / cs0);
+                if (!split || me == 0) { const dist::one_rank_section alone; coeffs = dev::IFFT<FieldT>(dev::fold<FieldT>(f0, D_h0, cs0, x_0), D_h1); }
+                if (split) dist::broadcast<FieldT>(coeffs, 0);
+                by_interaction[j][l] = dev::FFT<FieldT>(coeffs, coeffs.size(), L1);
+            }
+            if (!split || me == checker) {
+                const dist::one_rank_section alone;
+                const device_vector<FieldT> f0c = IOP_.get_oracle_evaluations_over_window(poly_handles_[l], c0);
+                for (std::size_t j = 0; j < interactive_repetitions_; ++j) {
+                    const FieldT x_0 = IOP_.obtain_verifier_random_message(verifier_challenge_handles_[0][j])[0];
+                    const device_vector<FieldT> folded = dev::fold<FieldT>(f0c, D_c0, cs0, x_0), extended = dist::window_of<FieldT>(by_interaction[j][l], L1, c1);
+                    check(iopx_count_mismatch_dev(folded.data(), extended.data(), folded.size() * sizeof(FieldT), d_differ.data()));
+                }
+            }
+        }
+        if (split) check(iopx_comm_all_reduce_u64_dev(dist::ctx().comm, d_differ.data(), 1, IOPX_COMM_SUM));
+        uint64_t differ = 0;
+        check(iopx_memcpy_d2h(&differ, d_differ.data(), 8));
+        if (differ) by_interaction.clear();
+        return differ == 0;
+    }
 public:
     FRI_protocol(bcs_prover<FieldT> &IOP, const domain_handle &codeword_domain_handle, const std::vector<oracle_handle> &poly_handles,
                  const std::vector<std::size_t> &localization_parameters, std::size_t poly_degree_bound, std::size_t interactive_repetitions, std::size_t query_repetitions)
@@ -790,10 +880,15 @@ public:
     }
     void calculate_and_submit_proof()                                                        // :474-548
     {
-        std::vector<device_vector<FieldT>> first;
-        for (auto &h : poly_handles_) first.push_back(IOP_.get_oracle_evaluations(h));
-        std::vector<std::vector<device_vector<FieldT>>> by_interaction(interactive_repetitions_, first);
-        for (std::size_t i = 0; i < num_reductions_; ++i) {
+        std::vector<std::vector<device_vector<FieldT>>> by_interaction;
+        const bool from_head = first_round_from_head(by_interaction);
+        const std::size_t first_round = from_head ? 1 : 0;
+        if (!from_head) {
+            std::vector<device_vector<FieldT>> first;
+            for (auto &h : poly_handles_) first.push_back(IOP_.get_oracle_evaluations(h));
+            by_interaction.assign(interactive_repetitions_, first);
+        }
+        for (std::size_t i = first_round; i < num_reductions_; ++i) {
             const std::size_t cs = (std::size_t)1 << localization_[i];
             if (i > 0) {
                 for (std::size_t j = 0; j < interactive_repetitions_; ++j)

@@ -131,6 +131,100 @@ std::pair<std::size_t, std::size_t> coset_range(const field_subset<FieldT> &L, s
     return { c.rank * (cosets / c.world), cosets / c.world };
 }
 
+// ---- windows of a domain: `count` positions first + i * stride that form a domain of their own.  Subspaces: stride 1, `first` a multiple
+// of `count` (a power of two) — the coset of the span of the first log2(count) basis vectors through element `first`.  Cosets:
+// count * stride = |D|, first < stride — the coset of order `count` through element `first`.  The HEAD of a domain is the window at 0 whose
+// evaluations determine a polynomial of `count` coefficients: the positions IFFT_of_known_degree reads (fft.tcc:435-475). ----
+struct window {
+    std::size_t first, stride, count;
+    bool operator==(const window &o) const { return first == o.first && stride == o.stride && count == o.count; }
+};
+
+template<typename FieldT>
+window head_window(const field_subset<FieldT> &D, std::size_t count)
+{
+    if (count == 0 || count > D.num_elements() || D.num_elements() % count) throw std::invalid_argument("head_window: the count does not divide the domain");
+    return { 0, D.type() == affine_subspace_type ? 1 : D.num_elements() / count, count };
+}
+
+// the window next to the head inside the head of twice the size: positions [count, 2 count) of a subspace, the odd multiples of stride / 2 of a coset
+template<typename FieldT>
+window beside_head_window(const field_subset<FieldT> &D, std::size_t count)
+{
+    const window h = head_window(D, count);
+    if (2 * count > D.num_elements()) throw std::invalid_argument("beside_head_window: the domain is too small");
+    return D.type() == affine_subspace_type ? window{ count, 1, count } : window{ h.stride / 2, h.stride, count };
+}
+
+// the window as a domain (never distributed)
+template<typename FieldT>
+field_subset<FieldT> window_domain(const field_subset<FieldT> &D, const window &w)
+{
+    if (D.type() == affine_subspace_type) {
+        const std::size_t d = detail::log2_ceil(w.count);
+        if (w.stride != 1 || ((std::size_t)1 << d) != w.count || w.first % w.count || w.first + w.count > D.num_elements()) throw std::invalid_argument("not a window of this subspace");
+        uint64_t s[3];                                        // element_by_index(first) (subspace.tcc:56-71)
+        std::memcpy(s, detail::words(&D.shift()), 24);
+        for (std::size_t k = d; k < D.dimension(); ++k)
+            if ((w.first >> k) & 1) for (int i = 0; i < 3; ++i) s[i] ^= detail::words(&D.basis()[k])[i];
+        return field_subset<FieldT>(affine_subspace<FieldT>(std::vector<FieldT>(D.basis().begin(), D.basis().begin() + d), field_host<FieldT>::from_words(s)));
+    }
+    if (w.count * w.stride != D.num_elements() || w.first >= w.stride) throw std::invalid_argument("not a window of this coset");
+    return field_subset<FieldT>(w.count, field_host<FieldT>::mul(D.shift(), field_host<FieldT>::pow(D.generator(), w.first)));      // shift g^first
+}
+template<typename FieldT>
+field_subset<FieldT> head_domain(const field_subset<FieldT> &D, std::size_t count) { return window_domain(D, head_window(D, count)); }
+
+// the rank that holds every position of the window, or (std::size_t)-1 when they are spread over several (any rank when D is whole everywhere)
+template<typename FieldT>
+std::size_t window_owner(const field_subset<FieldT> &D, const window &w)
+{
+    if (!D.distributed()) return ctx().rank;
+    const std::size_t W = ctx().world;
+    if (D.type() == affine_subspace_type) {
+        const std::size_t per = D.num_elements() / W;
+        return w.first / per == (w.first + w.count - 1) / per ? w.first / per : (std::size_t)-1;
+    }
+    return w.stride % W == 0 ? w.first % W : (std::size_t)-1;
+}
+template<typename FieldT>
+bool head_on_rank0(const field_subset<FieldT> &D, std::size_t count) { return !D.distributed() || window_owner(D, head_window(D, count)) == 0; }
+
+// v: the owner's part of a vector over D (the whole vector when D is not distributed) -> the vector over the window
+template<typename FieldT>
+device_vector<FieldT> window_of(const device_vector<FieldT> &v, const field_subset<FieldT> &D, const window &w)
+{
+    if (window_owner(D, w) != ctx().rank) throw std::logic_error("window_of: this rank does not hold the window");
+    const std::size_t W = D.distributed() ? ctx().world : 1;
+    if (D.type() == affine_subspace_type) {
+        const std::size_t off = w.first % (D.num_elements() / W);
+        return off == 0 && w.count == v.size() ? v : v.slice(off, w.count);
+    }
+    const std::size_t off = w.first / W, stride = w.stride / W;
+    if (stride == 1) return v;
+    device_vector<FieldT> out(w.count);
+    check(iopx_gather_stride_dev(v.slice(off, v.size() - off).data(), w.count, stride, sizeof(FieldT), out.data()));
+    return out;
+}
+
+// `have`: a vector over the window `held` of D (not distributed: the holder has all of it) -> the vector over the window `want`, when every
+// position of `want` is one of `held` (false otherwise)
+template<typename FieldT>
+bool window_from_window(const device_vector<FieldT> &have, const window &held, const window &want, field_subset_type type, device_vector<FieldT> &out)
+{
+    if (type == affine_subspace_type) {
+        if (want.first < held.first || want.first + want.count > held.first + held.count) return false;
+        out = want == held ? have : have.slice(want.first - held.first, want.count);
+        return true;
+    }
+    if (want.first < held.first || (want.first - held.first) % held.stride || want.stride % held.stride || want.count > held.count) return false;
+    if (want == held) { out = have; return true; }
+    const std::size_t off = (want.first - held.first) / held.stride;
+    out = device_vector<FieldT>(want.count);
+    check(iopx_gather_stride_dev(have.slice(off, have.size() - off).data(), want.count, want.stride / held.stride, sizeof(FieldT), out.data()));
+    return true;
+}
+
 // ---- collectives on device vectors (enqueued on the library's stream) ------------------------------------------------------------
 template<typename T>
 device_array<T> all_gather(const device_array<T> &local)                                     // rank-major concatenation

@@ -173,10 +173,12 @@ public:
         alpha_ = alpha; r_Mz_ = r_Mz;
     }
     // p(alpha, x) sum_m r_m f_Mz(x) - f_z(x) t(x); constituents (fz, Mz..., t)
-    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
+    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override { return evaluated_contents_over(codeword_domain_, c); }
+    bool restrictable() const override { return true; }
+    device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &D, const std::vector<device_vector<FieldT>> &c) const override
     {
         if (c.size() != num_matrices_ + 2) throw std::invalid_argument("multi_lincheck uses more constituent oracles than what was provided.");
-        const device_vector<FieldT> p_alpha_prime = dev::lagrange_evals<FieldT>(alpha_, summation_domain_, codeword_domain_);       // :37-39
+        const device_vector<FieldT> p_alpha_prime = dev::lagrange_evals<FieldT>(alpha_, summation_domain_, D);                      // :37-39
         std::vector<const void *> Mz;
         for (std::size_t m = 0; m < num_matrices_; ++m) Mz.push_back(c[1 + m].data());
         device_vector<FieldT> out(c[0].size());
@@ -192,6 +194,8 @@ class single_matrix_denominator : public virtual_oracle<FieldT> {               
 public:
     single_matrix_denominator() : row_query_point_(field_host<FieldT>::zero()), column_query_point_(field_host<FieldT>::zero()) {}
     void set_challenge(const FieldT &row_query_point, const FieldT &column_query_point) { row_query_point_ = row_query_point; column_query_point_ = column_query_point; }
+    bool restrictable() const override { return true; }
+    device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &, const std::vector<device_vector<FieldT>> &c) const override { return evaluated_contents(c); }
     // (row - row_query)(col - col_query) from (row, col, row*col)
     device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
     {
@@ -224,6 +228,8 @@ class rational_linear_combination {
     };
     struct numerator_oracle : virtual_oracle<FieldT> {
         std::shared_ptr<shared_state> st;
+        bool restrictable() const override { return true; }
+        device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &, const std::vector<device_vector<FieldT>> &c) const override { return evaluated_contents(c); }
         device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
         {
             const std::size_t n = st->num_rationals;
@@ -233,6 +239,8 @@ class rational_linear_combination {
     };
     struct denominator_oracle : virtual_oracle<FieldT> {
         std::shared_ptr<shared_state> st;
+        bool restrictable() const override { return true; }
+        device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &, const std::vector<device_vector<FieldT>> &c) const override { return evaluated_contents(c); }
         device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
         {
             if (c.size() != st->num_rationals) throw std::invalid_argument("Expected same number of evaluations as in registration.");
@@ -291,13 +299,15 @@ class single_boundary_constraint : public virtual_oracle<FieldT> {              
 public:
     explicit single_boundary_constraint(const field_subset<FieldT> &L) : codeword_domain_(L), eval_point_(field_host<FieldT>::zero()), oracle_evaluation_(field_host<FieldT>::zero()) {}
     void set_evaluation_point_and_eval(const FieldT &eval_point, const FieldT &oracle_eval) { eval_point_ = eval_point; oracle_evaluation_ = oracle_eval; }
-    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
+    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override { return evaluated_contents_over(codeword_domain_, c); }
+    bool restrictable() const override { return true; }
+    device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &D, const std::vector<device_vector<FieldT>> &c) const override
     {
         typedef field_host<FieldT> H;
         if (c.size() != 1) throw std::invalid_argument("Single Boundary Constraint: Expected exactly 1 constituent oracle.");
         if (H::element_in_domain(codeword_domain_, eval_point_)) throw std::logic_error("the evaluation point lies in the codeword domain");
         const device_vector<FieldT> numerator = dev::lincomb_affine<FieldT>(c, { H::neg(H::one()) }, oracle_evaluation_);      // claimed - f
-        return dev::div<FieldT>(&numerator, dev::domain_offsets<FieldT>(codeword_domain_, eval_point_));                       // / (point - x)
+        return dev::div<FieldT>(&numerator, dev::domain_offsets<FieldT>(D, eval_point_));                                      // / (point - x)
     }
 };
 
@@ -308,10 +318,12 @@ class sumcheck_constraint_oracle : public virtual_oracle<FieldT> {              
 public:
     sumcheck_constraint_oracle(const field_subset<FieldT> &K, const field_subset<FieldT> &L) : summation_domain_(K), codeword_domain_(L), claimed_sum_(field_host<FieldT>::zero()) {}
     void set_claimed_sum(const FieldT &claimed_sum) { claimed_sum_ = claimed_sum; }
-    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override
+    device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override { return evaluated_contents_over(codeword_domain_, c); }
+    bool restrictable() const override { return true; }
+    device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &D, const std::vector<device_vector<FieldT>> &c) const override
     {
         if (c.size() != 3) throw std::invalid_argument("sumcheck_constraint_oracle has three constituent oracles");
-        const field_subset<FieldT> L = dist::local_domain(codeword_domain_);
+        const field_subset<FieldT> L = dist::local_domain(D);
         const field_subset<FieldT> &K = summation_domain_;
         device_vector<FieldT> out(L.num_elements());
         if (dev::additive(L)) {

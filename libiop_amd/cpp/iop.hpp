@@ -49,6 +49,13 @@ public:
     virtual ~virtual_oracle() {}
     // oracles.hpp:56-95: the prover side needs the whole-domain evaluation only
     virtual device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &constituent_oracle_evaluations) const = 0;
+    // The same pointwise map over a sub-domain D of the oracle's domain: D's evaluations of the constituents in, D's evaluations of the
+    // oracle out (bcs_prover::get_oracle_evaluations_over_head).  D is never distributed.
+    virtual bool restrictable() const { return false; }
+    virtual device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &, const std::vector<device_vector<FieldT>> &) const
+    {
+        throw std::logic_error("this virtual oracle is only evaluated over its whole domain");
+    }
 };
 
 // ---- handles (libiop/iop/iop.hpp:27-196) ----------------------------------------------------------------------------------------
@@ -334,6 +341,7 @@ private:
     std::vector<tree_info> MT_info_;
     std::map<std::size_t, std::vector<FieldT>> verifier_random_messages_;
     std::map<std::size_t, device_vector<FieldT>> virtual_contents_cache_;
+    std::map<std::size_t, std::vector<std::pair<dist::window, device_vector<FieldT>>>> window_cache_, real_window_cache_;
     hash_digest pow_answer_;
 
     void assert_can_register(std::size_t domain, std::size_t degree) const
@@ -617,6 +625,44 @@ public:
         device_vector<FieldT> result = reg.contents->evaluated_contents(constituents);
         if (reg.cache) virtual_contents_cache_[h.id] = result;
         return result;
+    }
+    // The oracle over a window of its domain D only (dist::window: a sub-domain in its own right) — above all the head of D, the `count`
+    // positions that determine a polynomial of `count` coefficients (the ones IFFT_of_known_degree reads, fft.tcc:435-475).  A virtual
+    // oracle is a pointwise map of its constituents, so its values on the window follow from the constituents' values there: |D| / count times
+    // less work than get_oracle_evaluations when only the oracle's polynomial is wanted.  Same field elements as the corresponding entries of
+    // get_oracle_evaluations(h).  Over a distributed domain: only on the rank that holds the window (dist::window_owner).
+    bool can_restrict(const oracle_handle &h) const
+    {
+        if (!h.is_virtual) return true;
+        const virtual_registration &reg = virtual_regs_[h.id];
+        if (!reg.contents->restrictable()) return false;
+        for (auto &c : reg.constituents) {
+            if ((c.is_virtual ? virtual_regs_[c.id].domain : oracle_regs_[c.id].domain) != reg.domain) return false;
+            if (!can_restrict(c)) return false;
+        }
+        return true;
+    }
+    device_vector<FieldT> get_oracle_evaluations_over_window(const oracle_handle &h, const dist::window &w)
+    {
+        const field_subset<FieldT> &D = domains_[h.is_virtual ? virtual_regs_[h.id].domain : oracle_regs_[h.id].domain];
+        auto &cache = h.is_virtual ? window_cache_[h.id] : real_window_cache_[h.id];
+        device_vector<FieldT> result;
+        for (auto &e : cache) if (dist::window_from_window<FieldT>(e.second, e.first, w, D.type(), result)) return result;
+        if (!h.is_virtual) {
+            result = dist::window_of<FieldT>(oracles_[h.id], D, w);
+            if (D.type() != affine_subspace_type) cache.emplace_back(w, result);              // a strided gather: once per oracle and window (subspaces: a view)
+            return result;
+        }
+        const virtual_registration &reg = virtual_regs_[h.id];
+        std::vector<device_vector<FieldT>> constituents;
+        for (auto &c : reg.constituents) constituents.push_back(get_oracle_evaluations_over_window(c, w));
+        result = reg.contents->evaluated_contents_over(dist::window_domain(D, w), constituents);
+        if (reg.cache) cache.emplace_back(w, result);
+        return result;
+    }
+    device_vector<FieldT> get_oracle_evaluations_over_head(const oracle_handle &h, std::size_t count)
+    {
+        return get_oracle_evaluations_over_window(h, dist::head_window(domains_[h.is_virtual ? virtual_regs_[h.id].domain : oracle_regs_[h.id].domain], count));
     }
 
     // ---- transcript (bcs_prover.tcc:136-233) ----

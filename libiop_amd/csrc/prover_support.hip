@@ -34,6 +34,24 @@ __global__ void __launch_bounds__(256) k_gather_words(const uint64_t *src, const
     }
 }
 
+// dst[i] = src[i * stride]: one lane per 8-byte word, so the writes are contiguous
+__global__ void __launch_bounds__(256) k_gather_stride_words(const uint64_t *src, size_t count, size_t stride, int words, uint64_t *dst)
+{
+    const size_t total = count * (size_t)words;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = t / (size_t)words, w = t % (size_t)words;
+        dst[t] = src[i * stride * (size_t)words + w];
+    }
+}
+
+// *count += the number of 8-byte words at which a and b differ (an atomic only from lanes that saw a difference: none, in the expected case)
+__global__ void __launch_bounds__(256) k_count_mismatch_words(const uint64_t *a, const uint64_t *b, size_t words, unsigned long long *count)
+{
+    unsigned long long mine = 0;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < words; t += (size_t)gridDim.x * blockDim.x) mine += a[t] != b[t];
+    if (mine) atomicAdd(count, mine);
+}
+
 __global__ void __launch_bounds__(256) k_scatter_words(const uint64_t *src, const uint64_t *index, size_t count, int words, uint64_t *dst)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
@@ -176,6 +194,30 @@ int iopx_gather_dev(const void *d_src, const uint64_t *d_index, size_t count, si
     if (elem_bytes == 0 || elem_bytes % 8) return fail(IOPX_ERR_INVALID_ARGUMENT, "gather: element size must be a multiple of 8 bytes");
     if (count == 0) return IOPX_OK;
     { ProfScope ps_("k_gather_words"); hipLaunchKernelGGL(k_gather_words, dim3(grid_of(count)), dim3(256), 0, stream(), (const uint64_t *)d_src, d_index, count, (int)(elem_bytes / 8), (uint64_t *)d_dst); }
+    return IOPX_OK;
+}
+
+int iopx_gather_stride_dev(const void *d_src, size_t count, size_t stride, size_t elem_bytes, void *d_dst)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (elem_bytes == 0 || elem_bytes % 8) return fail(IOPX_ERR_INVALID_ARGUMENT, "gather: element size must be a multiple of 8 bytes");
+    if (stride == 0) return fail(IOPX_ERR_INVALID_ARGUMENT, "gather: stride must be positive");
+    if (count == 0) return IOPX_OK;
+    if (!d_src || !d_dst) return fail(IOPX_ERR_INVALID_ARGUMENT, "gather: null argument");
+    const size_t words = elem_bytes / 8;
+    { ProfScope ps_("k_gather_stride_words", 2 * count * elem_bytes); hipLaunchKernelGGL(k_gather_stride_words, dim3(grid_of(count * words)), dim3(256), 0, stream(), (const uint64_t *)d_src, count, stride, (int)words, (uint64_t *)d_dst); }
+    return IOPX_OK;
+}
+
+int iopx_count_mismatch_dev(const void *d_a, const void *d_b, size_t bytes, uint64_t *d_count)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (bytes % 8) return fail(IOPX_ERR_INVALID_ARGUMENT, "count_mismatch: the byte count must be a multiple of 8");
+    if (bytes == 0) return IOPX_OK;
+    if (!d_a || !d_b || !d_count) return fail(IOPX_ERR_INVALID_ARGUMENT, "count_mismatch: null argument");
+    { ProfScope ps_("k_count_mismatch_words", 2 * bytes); hipLaunchKernelGGL(k_count_mismatch_words, dim3(grid_of(bytes / 8)), dim3(256), 0, stream(), (const uint64_t *)d_a, (const uint64_t *)d_b, bytes / 8, (unsigned long long *)d_count); }
     return IOPX_OK;
 }
 

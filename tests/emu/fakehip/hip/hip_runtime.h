@@ -35,6 +35,12 @@ static inline unsigned long long atomicMin(unsigned long long *p, unsigned long 
     if (v < old) *p = v;
     return old;
 }
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v)
+{
+    const unsigned long long old = *p;
+    *p = old + v;
+    return old;
+}
 static inline void __threadfence() {}
 static inline uint32_t __brev(uint32_t x)
 {
