@@ -321,6 +321,7 @@ public:
     const device_vector<FieldT> &f1v_coefficients() const { return f1v_coefficients_; }
     device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &constituents) const override { return evaluated_contents_over(codeword_domain_, constituents); }
     bool restrictable() const override { return true; }
+    std::size_t smallest_window() const override { return input_variable_domain_.num_elements(); }
     device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &D, const std::vector<device_vector<FieldT>> &constituents) const override
     {
         if (constituents.size() != 1) throw std::invalid_argument("fz_virtual_oracle has one constituent oracle.");
@@ -347,6 +348,7 @@ public:
         : codeword_domain_(codeword_domain), constraint_domain_(constraint_domain) {}
     device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override { return evaluated_contents_over(codeword_domain_, c); }
     bool restrictable() const override { return true; }
+    std::size_t smallest_window() const override { return constraint_domain_.num_elements(); }
     device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &D, const std::vector<device_vector<FieldT>> &c) const override
     {
         if (c.size() != 3) throw std::invalid_argument("rowcheck_ABC has three constituent oracles.");
@@ -396,6 +398,7 @@ public:
     }
     device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override { return evaluated_contents_over(codeword_domain_, c); }
     bool restrictable() const override { return true; }
+    std::size_t smallest_window() const override { return summation_domain_.num_elements(); }
     device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &D, const std::vector<device_vector<FieldT>> &c) const override
     {
         if (c.size() != matrices_T_->size() + 1) throw std::invalid_argument("multi_lincheck uses more constituent oracles than what was provided.");
@@ -442,6 +445,7 @@ public:
     void set_claimed_sum(const FieldT &claimed_sum) { claimed_sum_ = claimed_sum; }
     device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override { return evaluated_contents_over(codeword_domain_, c); }
     bool restrictable() const override { return true; }
+    std::size_t smallest_window() const override { return summation_domain_.num_elements(); }
     device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &D, const std::vector<device_vector<FieldT>> &c) const override
     {
         if (c.size() != 2) throw std::invalid_argument("sumcheck_g_oracle has two constituent oracles");
@@ -543,6 +547,8 @@ public:
             h = device_vector<FieldT>(degree_bound_ - H_.num_elements());
             if (!L_.distributed() || dist::ctx().rank == 0) {
                 const dist::one_rank_section alone;
+                const std::size_t later = IOP_.head_hint();         // the LDT reads the (cached) combined f over its own head: evaluate that one if it is larger
+                if (later > count && dev::use_head(L_, later)) (void)IOP_.get_oracle_evaluations_over_head(combined_f_handle_, later);
                 const device_vector<FieldT> evals = IOP_.get_oracle_evaluations_over_head(combined_f_handle_, count);
                 h = dev::poly_div_vanishing<FieldT>(dev::IFFT<FieldT>(evals, dist::head_domain(L_, count)), degree_bound_, H_);
             }
@@ -767,7 +773,7 @@ class FRI_protocol {                                                            
     // over the head only (|L| / head times fewer evaluations), one fold there, interpolate, extend over L^(1): the same field elements as folding
     // all of f_0 (:522-526) WHEN f_0 is that polynomial.  For an instance whose virtual oracles are not polynomials (an unsatisfied witness, a
     // mismatched index: the reference still emits a transcript, which its verifier rejects) the two routes differ, so the result is confirmed on a
-    // second window of the same size next to the head — fold(f_0) there must be the extension's values — and on any difference this returns false
+    // second window next to the head (as small as the virtual oracles can be evaluated over) — fold(f_0) there must be the extension's values — and on any difference this returns false
     // and the caller takes the reference's route.  A rational function that is not the polynomial differs from it on all but boundedly many points,
     // so a whole window of agreement does not happen by accident.
     bool first_round_from_head(std::vector<std::vector<device_vector<FieldT>>> &by_interaction)
@@ -778,7 +784,10 @@ class FRI_protocol {                                                            
         if (!dev::use_head(L0, head) || head / cs0 < 2) return false;
         for (auto &h : poly_handles_) if (!h.is_virtual || !IOP_.can_restrict(h)) return false;
         const dist::window h0 = dist::head_window(L0, head), h1 = dist::head_window(L1, head / cs0);
-        const dist::window c0 = dist::beside_head_window(L0, head), c1 = dist::beside_head_window(L1, head / cs0);      // c0 folds onto c1
+        std::size_t confirm = 2 * cs0;                                                        // the confirmation window: as small as the virtual oracles allow
+        for (auto &h : poly_handles_) confirm = std::max(confirm, IOP_.smallest_window(h));
+        confirm = std::min(head, (std::size_t)1 << detail::log2_ceil(confirm));
+        const dist::window c0 = dist::beside_head_window(L0, head, confirm), c1 = dist::beside_head_window(L1, head / cs0, confirm / cs0);  // c0 folds onto c1
         const std::size_t me = dist::ctx().rank, checker = dist::window_owner(L0, c0);
         if (checker == (std::size_t)-1 || (L1.distributed() && dist::window_owner(L1, c1) != checker)) return false;
         const bool split = L0.distributed();
@@ -935,6 +944,7 @@ public:
         for (std::size_t i = 0; i < num_output_LDT_instances_; ++i) combined_oracles_.push_back(std::make_shared<combined_LDT_device_oracle<FieldT>>(L, degrees));
         for (auto &o : combined_oracles_) combined_oracle_handles_.push_back(IOP_.register_virtual_oracle(codeword_domain_handle_, max_tested_degree_bound_, oracle_handles, o));
         for (std::size_t i = 0; i < num_output_LDT_instances_; ++i) random_coefficients_handles_.push_back(IOP_.register_verifier_random_message(2 * oracle_handles.size()));
+        IOP_.set_head_hint((std::size_t)1 << detail::log2_ceil(max_tested_degree_bound_));
         multi_LDT_ = std::make_shared<FRI_protocol<FieldT>>(IOP_, codeword_domain_handle_, combined_oracle_handles_, localization_parameters, max_tested_degree_bound_,
                                                             fri_interactive_repetitions, fri_query_repetitions);
         multi_LDT_->register_interactions();

@@ -147,13 +147,14 @@ window head_window(const field_subset<FieldT> &D, std::size_t count)
     return { 0, D.type() == affine_subspace_type ? 1 : D.num_elements() / count, count };
 }
 
-// the window next to the head inside the head of twice the size: positions [count, 2 count) of a subspace, the odd multiples of stride / 2 of a coset
+// a window of `count` <= head_count positions disjoint from the head of head_count: positions [head_count, head_count + count) of a subspace; the
+// coset of order `count` through element stride_head / 2 of a coset (the head holds the multiples of stride_head)
 template<typename FieldT>
-window beside_head_window(const field_subset<FieldT> &D, std::size_t count)
+window beside_head_window(const field_subset<FieldT> &D, std::size_t head_count, std::size_t count)
 {
-    const window h = head_window(D, count);
-    if (2 * count > D.num_elements()) throw std::invalid_argument("beside_head_window: the domain is too small");
-    return D.type() == affine_subspace_type ? window{ count, 1, count } : window{ h.stride / 2, h.stride, count };
+    const window h = head_window(D, head_count);
+    if (2 * head_count > D.num_elements() || count > head_count || head_count % count) throw std::invalid_argument("beside_head_window: no room next to the head");
+    return D.type() == affine_subspace_type ? window{ head_count, 1, count } : window{ h.stride / 2, D.num_elements() / count, count };
 }
 
 // the window as a domain (never distributed)

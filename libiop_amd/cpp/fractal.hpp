@@ -175,6 +175,7 @@ public:
     // p(alpha, x) sum_m r_m f_Mz(x) - f_z(x) t(x); constituents (fz, Mz..., t)
     device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override { return evaluated_contents_over(codeword_domain_, c); }
     bool restrictable() const override { return true; }
+    std::size_t smallest_window() const override { return summation_domain_.num_elements(); }
     device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &D, const std::vector<device_vector<FieldT>> &c) const override
     {
         if (c.size() != num_matrices_ + 2) throw std::invalid_argument("multi_lincheck uses more constituent oracles than what was provided.");
@@ -320,6 +321,7 @@ public:
     void set_claimed_sum(const FieldT &claimed_sum) { claimed_sum_ = claimed_sum; }
     device_vector<FieldT> evaluated_contents(const std::vector<device_vector<FieldT>> &c) const override { return evaluated_contents_over(codeword_domain_, c); }
     bool restrictable() const override { return true; }
+    std::size_t smallest_window() const override { return summation_domain_.num_elements(); }
     device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &D, const std::vector<device_vector<FieldT>> &c) const override
     {
         if (c.size() != 3) throw std::invalid_argument("sumcheck_constraint_oracle has three constituent oracles");

@@ -52,6 +52,7 @@ public:
     // The same pointwise map over a sub-domain D of the oracle's domain: D's evaluations of the constituents in, D's evaluations of the
     // oracle out (bcs_prover::get_oracle_evaluations_over_head).  D is never distributed.
     virtual bool restrictable() const { return false; }
+    virtual std::size_t smallest_window() const { return 2; }          // the fewest points of a window this oracle can be evaluated over
     virtual device_vector<FieldT> evaluated_contents_over(const field_subset<FieldT> &, const std::vector<device_vector<FieldT>> &) const
     {
         throw std::logic_error("this virtual oracle is only evaluated over its whole domain");
@@ -293,6 +294,8 @@ struct bcs_prover_index {
     std::vector<hash_digest> roots;
     std::vector<std::vector<FieldT>> prover_messages;
     std::vector<std::vector<device_vector<FieldT>>> index_evals_over_K;
+    // windows of the index oracles (bcs_prover::get_oracle_evaluations_over_window) that earlier proofs gathered: part of the index from then on
+    mutable std::map<std::size_t, std::vector<std::pair<dist::window, device_vector<FieldT>>>> oracle_windows;
 };
 struct bcs_verifier_index {                     // bcs_indexer::get_verifier_index (bcs_indexer.tcc:67-77)
     std::vector<hash_digest> index_MT_roots_;
@@ -341,6 +344,7 @@ private:
     std::vector<tree_info> MT_info_;
     std::map<std::size_t, std::vector<FieldT>> verifier_random_messages_;
     std::map<std::size_t, device_vector<FieldT>> virtual_contents_cache_;
+    std::size_t head_hint_ = 0;
     std::map<std::size_t, std::vector<std::pair<dist::window, device_vector<FieldT>>>> window_cache_, real_window_cache_;
     hash_digest pow_answer_;
 
@@ -642,10 +646,23 @@ public:
         }
         return true;
     }
+    // the head a later stage of the protocol will ask for (the LDT's): an earlier stage that needs a smaller head of a cached oracle evaluates
+    // the larger one once instead of both
+    void set_head_hint(std::size_t count) { head_hint_ = std::max(head_hint_, count); }
+    std::size_t head_hint() const { return head_hint_; }
+    std::size_t smallest_window(const oracle_handle &h) const
+    {
+        if (!h.is_virtual) return 1;
+        const virtual_registration &reg = virtual_regs_[h.id];
+        std::size_t m = reg.contents->smallest_window();
+        for (auto &c : reg.constituents) m = std::max(m, smallest_window(c));
+        return m;
+    }
     device_vector<FieldT> get_oracle_evaluations_over_window(const oracle_handle &h, const dist::window &w)
     {
         const field_subset<FieldT> &D = domains_[h.is_virtual ? virtual_regs_[h.id].domain : oracle_regs_[h.id].domain];
-        auto &cache = h.is_virtual ? window_cache_[h.id] : real_window_cache_[h.id];
+        const bool indexed = !h.is_virtual && index_ && is_holographic_ && !num_oracles_at_end_of_round_.empty() && h.id < num_oracles_at_end_of_round_[0];
+        auto &cache = h.is_virtual ? window_cache_[h.id] : (indexed ? index_->oracle_windows[h.id] : real_window_cache_[h.id]);
         device_vector<FieldT> result;
         for (auto &e : cache) if (dist::window_from_window<FieldT>(e.second, e.first, w, D.type(), result)) return result;
         if (!h.is_virtual) {

@@ -11,9 +11,9 @@
 //   iopx_rational_combine_*_dev             combined_numerator / combined_denominator::evaluated_contents (rational_linear_combination.tcc:13-108)
 //   iopx_rational_sumcheck_constraint_*_dev sumcheck_constraint_oracle::evaluated_contents (protocols/encoded/sumcheck/rational_sumcheck.tcc:58-112)
 //
-// Montgomery's trick runs per lane over the positions tid, tid + T, tid + 2T, ... (T = threads of the launch): the running
-// products are parked in the OUTPUT buffer on the way up and consumed on the way down, so a lane amortises one field inversion
-// over n / T elements (64 at the 2^25-element codeword size) with coalesced traffic and no LDS.
+// Montgomery's trick runs per lane over the positions tid, tid + T, tid + 2T, ... (T = lanes of the launch): the running
+// products are parked in the OUTPUT buffer on the way up and consumed on the way down (coalesced traffic), and the 256 lanes of a
+// workgroup combine their totals in an LDS tree so that the workgroup pays for one field inversion.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <vector>
@@ -40,67 +40,162 @@ struct DivParams {
     size_t n;
 };
 
+// The lanes of a workgroup share ONE field inversion: every lane parks its chain's total in an LDS tree (level 0: the 256 lane totals, level l:
+// products of pairs, 511 nodes), lane 0 inverts the root, and the inverses walk back down (a node's inverse times its sibling's product is its
+// other child's inverse).  A lane then pays 4 products per element plus ~26 for the tree, instead of an exponentiation of its own (~270
+// products over F_p): the inversion stops dominating when a lane's chain is short (n <= 2^22).  Written over logical lanes (lane = threadIdx.x,
+// + blockDim.x, ...) so that any block size runs the same arithmetic.
+static constexpr unsigned DIV_LANES = 256, DIV_TREE_NODES = 2 * DIV_LANES - 1;
+__device__ __forceinline__ unsigned div_level_base(int l) { return 2 * DIV_LANES - ((2 * DIV_LANES) >> l); }
+
 __global__ void __launch_bounds__(256) k_div_gf192(DivParams p)
 {
-    const size_t T = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
+    uint64_t *tree = iopx_smem;
+    const size_t T = (size_t)gridDim.x * DIV_LANES;
     gf192 one = gf_zero();
     one.w[0] = 1;
-    gf192 run = one;
-    size_t count = 0;
-    for (size_t j = tid; j < p.n; j += T, ++count) {
-        gf192 d = gf_load(p.den, j);
-        if (gf_is_zero(d)) d = one;
-        run = gf_mul(run, d);
-        gf_store(p.out, j, run);
+    for (unsigned lane = threadIdx.x; lane < DIV_LANES; lane += blockDim.x) {
+        gf192 run = one;
+        for (size_t j = (size_t)blockIdx.x * DIV_LANES + lane; j < p.n; j += T) {
+            gf192 d = gf_load(p.den, j);
+            if (gf_is_zero(d)) d = one;
+            run = gf_mul(run, d);
+            gf_store(p.out, j, run);
+        }
+        gf_store(tree, lane, run);
     }
-    if (count == 0) return;
-    gf192 inv = gf_inv(run);
-    for (size_t i = count; i-- > 0; ) {
-        const size_t j = tid + i * T;
-        gf192 d = gf_load(p.den, j);
-        const bool zero = gf_is_zero(d);
-        if (zero) d = one;
-        const gf192 before = i ? gf_load(p.out, j - T) : one;
-        gf192 q = gf_mul(before, inv);                      // 1 / d
-        inv = gf_mul(inv, d);
-        if (p.num) q = gf_mul(q, gf_load(p.num, j));
-        gf_store(p.out, j, zero ? gf_zero() : q);           // a zero denominator yields zero (utils.tcc:79-97)
+    __syncthreads();
+    for (int l = 1; (DIV_LANES >> l) >= 1; ++l) {
+        const unsigned cnt = DIV_LANES >> l, base = div_level_base(l), below = div_level_base(l - 1);
+        for (unsigned i = threadIdx.x; i < cnt; i += blockDim.x) gf_store(tree, base + i, gf_mul(gf_load(tree, below + 2 * i), gf_load(tree, below + 2 * i + 1)));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) gf_store(tree, DIV_TREE_NODES - 1, gf_inv(gf_load(tree, DIV_TREE_NODES - 1)));
+    __syncthreads();
+    for (int l = 8; l >= 1; --l) {
+        const unsigned cnt = DIV_LANES >> l, base = div_level_base(l), below = div_level_base(l - 1);
+        for (unsigned i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const gf192 inv = gf_load(tree, base + i), left = gf_load(tree, below + 2 * i), right = gf_load(tree, below + 2 * i + 1);
+            gf_store(tree, below + 2 * i, gf_mul(inv, right));
+            gf_store(tree, below + 2 * i + 1, gf_mul(inv, left));
+        }
+        __syncthreads();
+    }
+    for (unsigned lane = threadIdx.x; lane < DIV_LANES; lane += blockDim.x) {
+        const size_t tid = (size_t)blockIdx.x * DIV_LANES + lane;
+        const size_t count = tid < p.n ? (p.n - tid + T - 1) / T : 0;
+        gf192 inv = gf_load(tree, lane);
+        for (size_t i = count; i-- > 0; ) {
+            const size_t j = tid + i * T;
+            gf192 d = gf_load(p.den, j);
+            const bool zero = gf_is_zero(d);
+            if (zero) d = one;
+            const gf192 before = i ? gf_load(p.out, j - T) : one;
+            gf192 q = gf_mul(before, inv);                      // 1 / d
+            inv = gf_mul(inv, d);
+            if (p.num) q = gf_mul(q, gf_load(p.num, j));
+            gf_store(p.out, j, zero ? gf_zero() : q);           // a zero denominator yields zero (utils.tcc:79-97)
+        }
     }
 }
 
+// v^-1 mod p for 0 < v < p (plain integers, not Montgomery forms) by the binary extended Euclidean algorithm (HAC 14.61): at most ~2 * 181
+// halve-or-subtract steps on 192-bit integers — some 10^4 instructions against the 10^5 of the Fermat power (270 products) — for the ONE lane
+// of a workgroup that inverts the root of the tree; data-dependent control flow costs nothing with one lane active.
+__device__ inline fp3 fp_inv_binary(const fp3 &v)
+{
+    const uint64_t P0 = (uint64_t)FP3_P[0] | ((uint64_t)FP3_P[1] << 32), P1 = (uint64_t)FP3_P[2] | ((uint64_t)FP3_P[3] << 32), P2 = (uint64_t)FP3_P[4] | ((uint64_t)FP3_P[5] << 32);
+    uint64_t u0 = (uint64_t)v.w[0] | ((uint64_t)v.w[1] << 32), u1 = (uint64_t)v.w[2] | ((uint64_t)v.w[3] << 32), u2 = (uint64_t)v.w[4] | ((uint64_t)v.w[5] << 32);
+    uint64_t w0 = P0, w1 = P1, w2 = P2, a0 = 1, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;      // a u0 = u (mod p), b u0 = w (mod p) for the initial u0
+#define IOPX_HALVE(x0, x1, x2) { x0 = (x0 >> 1) | (x1 << 63); x1 = (x1 >> 1) | (x2 << 63); x2 >>= 1; }
+#define IOPX_ADD(x0, x1, x2, y0, y1, y2) { const uint64_t s0 = x0 + y0, c0 = s0 < x0, t1 = x1 + y1, c1 = t1 < x1, s1 = t1 + c0, c2 = s1 < t1; x0 = s0; x1 = s1; x2 = x2 + y2 + (c1 | c2); }
+#define IOPX_SUB(x0, x1, x2, y0, y1, y2) { const uint64_t d0 = x0 - y0, r0 = x0 < y0, t1 = x1 - y1, r1 = x1 < y1, d1 = t1 - r0, r2 = t1 < r0; x0 = d0; x1 = d1; x2 = x2 - y2 - (r1 | r2); }
+#define IOPX_GEQ(x0, x1, x2, y0, y1, y2) (x2 != y2 ? x2 > y2 : (x1 != y1 ? x1 > y1 : x0 >= y0))
+    while (!((u0 == 1 && (u1 | u2) == 0) || (w0 == 1 && (w1 | w2) == 0))) {
+        while (!(u0 & 1)) {
+            IOPX_HALVE(u0, u1, u2)
+            if (a0 & 1) IOPX_ADD(a0, a1, a2, P0, P1, P2)
+            IOPX_HALVE(a0, a1, a2)
+        }
+        while (!(w0 & 1)) {
+            IOPX_HALVE(w0, w1, w2)
+            if (b0 & 1) IOPX_ADD(b0, b1, b2, P0, P1, P2)
+            IOPX_HALVE(b0, b1, b2)
+        }
+        if (IOPX_GEQ(u0, u1, u2, w0, w1, w2)) {
+            IOPX_SUB(u0, u1, u2, w0, w1, w2)
+            if (!IOPX_GEQ(a0, a1, a2, b0, b1, b2)) IOPX_ADD(a0, a1, a2, P0, P1, P2)
+            IOPX_SUB(a0, a1, a2, b0, b1, b2)
+        } else {
+            IOPX_SUB(w0, w1, w2, u0, u1, u2)
+            if (!IOPX_GEQ(b0, b1, b2, a0, a1, a2)) IOPX_ADD(b0, b1, b2, P0, P1, P2)
+            IOPX_SUB(b0, b1, b2, a0, a1, a2)
+        }
+    }
+#undef IOPX_HALVE
+#undef IOPX_ADD
+#undef IOPX_SUB
+#undef IOPX_GEQ
+    const bool first = u0 == 1 && (u1 | u2) == 0;
+    const uint64_t r0 = first ? a0 : b0, r1 = first ? a1 : b1, r2 = first ? a2 : b2;
+    fp3 r;
+    r.w[0] = (uint32_t)r0; r.w[1] = (uint32_t)(r0 >> 32); r.w[2] = (uint32_t)r1; r.w[3] = (uint32_t)(r1 >> 32); r.w[4] = (uint32_t)r2; r.w[5] = (uint32_t)(r2 >> 32);
+    return r;
+}
+
 // F_p.  The device product is a b 2^-203 and stored values carry 2^192 (fp3_dev.h), so each product with a stored denominator
-// multiplies the running value by d 2^-11: starting from the 2^203 form of 1, run_i = 2^203 (prod_{j<=i} d_j) 2^(-11 i).  Its inverse
-// (x^(p-2), closed under the device product) times 2^-11 once per lane makes before * inv = 2^203 / d_i exactly, at every i — the
-// powers of 2^11 cancel step by step — so the denominators are never converted: 4 products per element plus the amortised inversion.
+// multiplies the running value by d 2^-11: starting from the 2^203 form of 1, run_i = 2^203 (prod_{j<=i} d_j) 2^(-11 i).  The lane totals,
+// their tree products and the inverses are all in the 2^203 form, which the device product keeps closed (x^(p-2) included); a lane's inverse
+// times 2^-11 once makes before * inv = 2^203 / d_i exactly, at every i — the powers of 2^11 cancel step by step — so the denominators are never
+// converted: 4 products per element plus the shared inversion.
 __global__ void __launch_bounds__(256) k_div_fp3(DivParams p)
 {
-    const size_t T = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
+    uint64_t *tree = iopx_smem;
+    const size_t T = (size_t)gridDim.x * DIV_LANES;
     const fp3 k192 = fp_load(p.consts, 1), one_t = fp_load(p.consts, 3), unscale_t = fp_load(p.consts, 4);
-    const uint64_t e0 = p.consts[6], e1 = p.consts[7], e2 = p.consts[8];
-    fp3 run = one_t;
-    size_t count = 0;
-    for (size_t j = tid; j < p.n; j += T, ++count) {
-        const fp3 d = fp_load(p.den, j);
-        const bool zero = (d.w[0] | d.w[1] | d.w[2] | d.w[3] | d.w[4] | d.w[5]) == 0;
-        run = fp_mul(run, zero ? k192 : d);                 // a zero denominator is stepped over as a stored 1
-        fp_store(p.out, j, run);
+    for (unsigned lane = threadIdx.x; lane < DIV_LANES; lane += blockDim.x) {
+        fp3 run = one_t;
+        for (size_t j = (size_t)blockIdx.x * DIV_LANES + lane; j < p.n; j += T) {
+            const fp3 d = fp_load(p.den, j);
+            const bool zero = (d.w[0] | d.w[1] | d.w[2] | d.w[3] | d.w[4] | d.w[5]) == 0;
+            run = fp_mul(run, zero ? k192 : d);                 // a zero denominator is stepped over as a stored 1
+            fp_store(p.out, j, run);
+        }
+        fp_store(tree, lane, run);
     }
-    if (count == 0) return;
-    fp3 inv = run;                                          // the exponent's top bit (bit 180) is set
-    for (int bit = 179; bit >= 0; --bit) {
-        inv = fp_mul(inv, inv);
-        const uint64_t w = bit >= 128 ? e2 : (bit >= 64 ? e1 : e0);
-        if ((w >> (bit & 63)) & 1) inv = fp_mul(inv, run);
+    __syncthreads();
+    for (int l = 1; (DIV_LANES >> l) >= 1; ++l) {
+        const unsigned cnt = DIV_LANES >> l, base = div_level_base(l), below = div_level_base(l - 1);
+        for (unsigned i = threadIdx.x; i < cnt; i += blockDim.x) fp_store(tree, base + i, fp_mul(fp_load(tree, below + 2 * i), fp_load(tree, below + 2 * i + 1)));
+        __syncthreads();
     }
-    inv = fp_mul(inv, unscale_t);
-    for (size_t i = count; i-- > 0; ) {
-        const size_t j = tid + i * T;
-        const fp3 d = fp_load(p.den, j);
-        const bool zero = (d.w[0] | d.w[1] | d.w[2] | d.w[3] | d.w[4] | d.w[5]) == 0;
-        const fp3 before = i ? fp_load(p.out, j - T) : one_t;
-        const fp3 q = fp_mul(before, inv);                  // (1 / d) 2^203
-        inv = fp_mul(inv, zero ? k192 : d);
-        fp_store(p.out, j, zero ? fp_zero() : fp_mul(p.num ? fp_load(p.num, j) : k192, q));
+    // the root is r 2^203 as an integer; its integer inverse times 2^609 through the device product is 2^203 / r: the 2^203 form of 1 / r
+    if (threadIdx.x == 0) fp_store(tree, DIV_TREE_NODES - 1, fp_mul(fp_inv_binary(fp_load(tree, DIV_TREE_NODES - 1)), fp_load(p.consts, 5)));
+    __syncthreads();
+    for (int l = 8; l >= 1; --l) {
+        const unsigned cnt = DIV_LANES >> l, base = div_level_base(l), below = div_level_base(l - 1);
+        for (unsigned i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const fp3 inv = fp_load(tree, base + i), left = fp_load(tree, below + 2 * i), right = fp_load(tree, below + 2 * i + 1);
+            fp_store(tree, below + 2 * i, fp_mul(inv, right));
+            fp_store(tree, below + 2 * i + 1, fp_mul(inv, left));
+        }
+        __syncthreads();
+    }
+    for (unsigned lane = threadIdx.x; lane < DIV_LANES; lane += blockDim.x) {
+        const size_t tid = (size_t)blockIdx.x * DIV_LANES + lane;
+        const size_t count = tid < p.n ? (p.n - tid + T - 1) / T : 0;
+        fp3 inv = fp_mul(fp_load(tree, lane), unscale_t);
+        for (size_t i = count; i-- > 0; ) {
+            const size_t j = tid + i * T;
+            const fp3 d = fp_load(p.den, j);
+            const bool zero = (d.w[0] | d.w[1] | d.w[2] | d.w[3] | d.w[4] | d.w[5]) == 0;
+            const fp3 before = i ? fp_load(p.out, j - T) : one_t;
+            const fp3 q = fp_mul(before, inv);                  // (1 / d) 2^203
+            inv = fp_mul(inv, zero ? k192 : d);
+            fp_store(p.out, j, zero ? fp_zero() : fp_mul(p.num ? fp_load(p.num, j) : k192, q));
+        }
     }
 }
 
@@ -228,8 +323,9 @@ __global__ void __launch_bounds__(256) k_sumcheck_constraint_fp3(uint64_t *out, 
     }
 }
 
-// slots of three words: 0: 2^214 (raw), 1: 2^192 = the stored 1, 2: p - 2, 3: 2^203 = the device form of 1, 4: the device form of 2^-11
-static void fo_fp_consts(uint64_t (&c)[15])
+// slots of three words: 0: 2^214 (raw), 1: 2^192 = the stored 1, 2: p - 2, 3: 2^203 = the device form of 1, 4: the device form of 2^-11,
+// 5: 2^609 (raw)
+static void fo_fp_consts(uint64_t (&c)[18])
 {
     const hfp3 k192 = hfp3::one(), k203 = k192.table_form(), k214 = k203.table_form();
     const hfp3 unscale_t = hfp3::from_uint(2048).inverse().table_form();
@@ -237,6 +333,8 @@ static void fo_fp_consts(uint64_t (&c)[15])
     c[6] = hfp3::P[0] - 2; c[7] = hfp3::P[1]; c[8] = hfp3::P[2];
     memcpy(c + 9, k203.w, 24);
     memcpy(c + 12, unscale_t.w, 24);
+    const hfp3 k609 = hfp3::from_uint(2).pow(417);              // stored words of 2^417: 2^417 2^192
+    memcpy(c + 15, k609.w, 24);
 }
 
 static int div_common(const uint64_t *d_num, const uint64_t *d_den, uint64_t *d_out, size_t n, bool prime_field)
@@ -250,16 +348,18 @@ static int div_common(const uint64_t *d_num, const uint64_t *d_den, uint64_t *d_
     p.num = d_num; p.den = d_den; p.out = d_out; p.consts = nullptr; p.n = n;
     TmpBuf dc;
     if (prime_field) {
-        uint64_t c[15];
-        fo_fp_consts(c);
-        if ((rc = dc.alloc(sizeof(c))) != IOPX_OK) return rc;
-        if ((rc = upload(dc.p, c, sizeof(c))) != IOPX_OK) return rc;
+        struct Consts { uint64_t c[18]; Consts() { fo_fp_consts(c); } };
+        static const Consts k;                                  // host-side field arithmetic: once per process
+        if ((rc = dc.alloc(sizeof(k.c))) != IOPX_OK) return rc;
+        if ((rc = upload(dc.p, k.c, sizeof(k.c))) != IOPX_OK) return rc;
         p.consts = dc.u64();
     }
-    const int grid = fo_grid(n, 2048);
-    const size_t bytes = n * 24 * (d_num ? 5 : 4);
-    if (prime_field) { ProfScope ps_("k_div_fp3", bytes); hipLaunchKernelGGL(k_div_fp3, dim3(grid), dim3(256), 0, stream(), p); }
-    else { ProfScope ps_("k_div_gf192", bytes); hipLaunchKernelGGL(k_div_gf192, dim3(grid), dim3(256), 0, stream(), p); }
+    // 16 elements per lane while that fills the GPU (the shared inversion is one lane's serial work per workgroup), 2048 workgroups at most
+    size_t grid = (n + DIV_LANES * 16 - 1) / (DIV_LANES * 16);
+    if (grid > 2048) grid = 2048;
+    const size_t bytes = n * 24 * (d_num ? 5 : 4), lds = (size_t)DIV_TREE_NODES * 24 + 8;
+    if (prime_field) { ProfScope ps_("k_div_fp3", bytes); hipLaunchKernelGGL(k_div_fp3, dim3((unsigned)grid), dim3(256), lds, stream(), p); }
+    else { ProfScope ps_("k_div_gf192", bytes); hipLaunchKernelGGL(k_div_gf192, dim3((unsigned)grid), dim3(256), lds, stream(), p); }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;
 }

@@ -110,7 +110,7 @@ def test_argument_checks():
 
 # ---- the kernels behind the holographic virtual oracles, one by one, against plain field arithmetic on the host ----
 @pytest.mark.parametrize("field_name", ["gf192", "edwards_Fr"])
-@pytest.mark.parametrize("n", [1, 7, 300, 2500])
+@pytest.mark.parametrize("n", [1, 7, 300, 2500, 9000])
 def test_div_kernel(field_name, n):
     fc.check_div_kernel(emu_lib.emu(), torch, CPU, field_name, n)
 

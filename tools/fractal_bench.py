@@ -92,10 +92,14 @@ def main():
             torch.cuda.synchronize()
             times.append(time.time() - t0)
         lib.comm_stats(reset=True)
+        lib.profile_begin()
         (lib.fractal_prove_dist(inst, comm) if comm is not None else lib.fractal_prove(inst))
+        nprof = lib.profile_report()
         res["native"] = {"prover_s": times, "prover_s_min": min(times), "index_roots_equal": [bytes(r) for r in roots] == nroots, "transcript_equals_python": nt == tr.serialize(),
                          "collectives_per_proof": lib.comm_stats()[0], "collective_bytes_per_proof_this_rank": lib.comm_stats()[1],
-                         "path": "iopx_fractal_prove_dist over an RCCL communicator of %d rank(s)" % world if comm is not None else "iopx_fractal_prove"}
+                         "path": "iopx_fractal_prove_dist over an RCCL communicator of %d rank(s)" % world if comm is not None else "iopx_fractal_prove",
+                         "kernels_ms_total": sum(v[1] for v in nprof.values()),
+                         "kernels": {kk: {"launches": v[0], "ms": round(v[1], 4), "bytes": v[2]} for kk, v in sorted(nprof.items(), key=lambda kv: -kv[1][1])}}
         lib.aurora_instance_free(inst)
         if comm is not None:
             lib.comm_destroy(comm)
