@@ -642,6 +642,26 @@ class Library:
         self._check(self.c.iopx_aurora_example_instance_create(int(field_code), int(num_constraints), int(num_inputs), int(num_variables), int(seed), ctypes.byref(h)))
         return h
 
+    def aurora_instance(self, field_code, matrices, num_variables, num_inputs, assignment):
+        """iopx_aurora_instance_create: an instance from the caller's own constraint system and variable assignment.  matrices = three
+        (row_ptr, col, coeff) triples in CSR form (A, B, C; coeff: (entries, 3) uint64 words; column 0 is the constant 1), assignment =
+        (num_variables, 3) words, primary inputs first.  Release with aurora_instance_free."""
+        class _R1CS(ctypes.Structure):
+            _fields_ = [("num_constraints", _sz), ("num_variables", _sz), ("num_inputs", _sz), ("row_ptr", _u64p * 3),
+                        ("col", ctypes.POINTER(ctypes.c_uint32) * 3), ("coeff", _u64p * 3)]
+        keep, r = [], _R1CS()
+        r.num_constraints, r.num_variables, r.num_inputs = len(matrices[0][0]) - 1, int(num_variables), int(num_inputs)
+        for q, (row_ptr, col, coeff) in enumerate(matrices):
+            rp, cl = np.ascontiguousarray(row_ptr, dtype=np.uint64), np.ascontiguousarray(col, dtype=np.uint32)
+            cf = np.ascontiguousarray(coeff, dtype=np.uint64).reshape(-1, 3)
+            keep += [rp, cl, cf]
+            r.row_ptr[q], r.col[q], r.coeff[q] = rp.ctypes.data_as(_u64p), cl.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), cf.ctypes.data_as(_u64p)
+        z = np.ascontiguousarray(assignment, dtype=np.uint64).reshape(-1, 3)
+        h = ctypes.c_void_p()
+        self.c.iopx_aurora_instance_create.argtypes = [ctypes.c_void_p, _u64p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        self._check(self.c.iopx_aurora_instance_create(ctypes.byref(r), z.ctypes.data_as(_u64p), int(field_code), ctypes.byref(h)))
+        return h
+
     def aurora_prove(self, instance, security_parameter=128, RS_extra_dimensions=5, FRI_localization_parameter=2):
         """aurora_snark_prover through the C ABI: the canonical transcript bytes."""
         buf, n = ctypes.c_void_p(), _sz(0)

@@ -1,0 +1,87 @@
+"""Shared cases for the native provers' two schedules (head of the codeword domain / whole domain): used by tests/test_head_eval_emu.py
+(kernel sources compiled for the CPU) and tests/test_gpu_head_eval.py (the real library on the MI355X)."""
+import numpy as np
+
+import aurora_cases as ac
+import oracle
+from libiop_amd import aurora, domains, r1cs
+
+
+def _code(field_name):
+    return 0 if field_name == "gf192" else 1
+
+
+def prove(lib, protocol, field_name, log_n, num_inputs, seed):
+    n = 1 << log_n
+    inst = lib.aurora_example_instance(_code(field_name), n, num_inputs, n - 1, seed)
+    try:
+        roots = lib.fractal_index(inst) if protocol == "fractal" else []
+        lib.profile_begin()
+        t = lib.fractal_prove(inst) if protocol == "fractal" else lib.aurora_prove(inst)
+        return t, roots, lib.profile_report()
+    finally:
+        lib.aurora_instance_free(inst)
+
+
+def ldt_bytes(prof):
+    return sum(v[2] for k, v in prof.items() if k.startswith("k_ldt_combine"))
+
+
+def check_both_schedules(lib, monkeypatch, protocol, field_name, log_n, num_inputs):
+    code = ac.FIELDS[field_name][0]
+    seed = 0x2204 if protocol == "aurora" else 0x2205
+    ref, ref_roots = (oracle.aurora_prove(code, log_n, num_inputs, seed), []) if protocol == "aurora" else oracle.fractal_prove(code, log_n, num_inputs, seed)
+    monkeypatch.delenv("IOPX_HEAD_EVAL", raising=False)
+    head, roots, head_prof = prove(lib, protocol, field_name, log_n, num_inputs, seed)
+    monkeypatch.setenv("IOPX_HEAD_EVAL", "0")
+    whole, roots0, whole_prof = prove(lib, protocol, field_name, log_n, num_inputs, seed)
+    assert head == ref and whole == ref and roots == ref_roots and roots0 == ref_roots
+    # the head schedule really ran: the LDT combination touched a fraction of the codeword domain, and the confirmation compared two windows
+    assert "k_count_mismatch_words" in head_prof and "k_count_mismatch_words" not in whole_prof
+    assert ldt_bytes(head_prof) * 4 <= ldt_bytes(whole_prof), (ldt_bytes(head_prof), ldt_bytes(whole_prof))
+
+
+def csr(ops, M):
+    return (M.row_ptr, M.col, ops.download(M.d_coeff))
+
+
+def check_unsatisfied_witness(lib, torch, device, monkeypatch, field_name, log_n=8):
+    """iopx_aurora_instance_create on the seeded constraint system with one auxiliary variable changed: Az * Bz != Cz, the rowcheck oracle is
+    not a polynomial.  The second prover (libiop_amd/aurora.py: every virtual oracle over the whole domain, the reference's schedule) defines the
+    bytes; the native prover must produce them with and without IOPX_HEAD_EVAL=0, and the oracle verifier rejects them."""
+    code, cls = ac.FIELDS[field_name]
+    field, k, seed = cls(), 15, 0x2204
+    n = 1 << log_n
+    ops = domains.DeviceOps(lib, torch, device, field)
+    cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, n, k, n - 1, seed)
+    params = aurora.AuroraParameters(field, n, n - 1, k)
+    mats = [csr(ops, M) for M in (cs.A, cs.B, cs.C)]
+    z = np.concatenate([np.asarray(primary, dtype=np.uint64).reshape(-1, 3), np.asarray(auxiliary, dtype=np.uint64).reshape(-1, 3)])
+
+    def native(assignment):
+        inst = lib.aurora_instance(_code(field_name), mats, n - 1, k, assignment)
+        try:
+            lib.profile_begin()
+            t = lib.aurora_prove(inst)
+            return t, lib.profile_report()
+        finally:
+            lib.aurora_instance_free(inst)
+
+    monkeypatch.delenv("IOPX_HEAD_EVAL", raising=False)
+    good, good_prof = native(z)
+    assert good == oracle.aurora_prove(code, log_n, k, seed)                    # the CSR route builds the seeded instance
+    assert good_prof["k_count_mismatch_words"][0] == 1
+
+    bad_z = z.copy()
+    bad_z[k + 5] = z[k + 6]                                                     # another valid field element in an auxiliary slot
+    assert not np.array_equal(bad_z, z)
+    expected = aurora.aurora_snark_prover(ops, cs, bad_z[:k], bad_z[k:], params).serialize()
+    assert expected != good
+    bad, bad_prof = native(bad_z)
+    assert bad == expected, "the head schedule changed the bytes of an unsatisfied instance's transcript"
+    assert not oracle.aurora_verify(code, log_n, k, seed, bad)
+    # head, confirmation window (differs), then the whole domain
+    launches = sum(v[0] for kk, v in bad_prof.items() if kk.startswith("k_ldt_combine"))
+    assert launches == 3 and bad_prof["k_count_mismatch_words"][0] == 1, bad_prof
+    monkeypatch.setenv("IOPX_HEAD_EVAL", "0")
+    assert native(bad_z)[0] == expected
