@@ -277,6 +277,11 @@ int iopx_ldt_combine_fp3_dev(const void *const *d_oracles, size_t num_oracles, c
  *          the reference assumes, :31-33)
  *   fp3:   H is the coset constraint_shift * <gen^(2^log_n / 2^constraint_log_order)> of order 2^constraint_log_order
  * Fails with IOPX_ERR_INVALID_ARGUMENT when the two domains intersect (Z_H vanishes on the codeword domain). */
+/* d_out[i] = d_in[i] / Z_S(x_i) over the domain span(basis[0..m)) + shift, S = span(basis[0..sub_dim)) + sub_shift: Z_S is constant on a coset
+ * of S, so this is one product per element with a per-coset inverse (the table rowcheck uses).  The pointwise form of
+ * polynomial_over_vanishing_polynomial (r1cs_rs_iop.tcc:563-565) on a domain that does not meet S, when the division is exact. */
+int iopx_div_by_vanishing_gf192_dev(const uint64_t *d_in, const uint64_t *basis, size_t m, const uint64_t *shift, size_t sub_dim, const uint64_t *sub_shift,
+                                    uint64_t *d_out);
 int iopx_rowcheck_gf192_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const uint64_t *d_Cz, const uint64_t *basis, size_t m,
                             const uint64_t *shift, size_t constraint_dim, const uint64_t *constraint_shift, uint64_t *d_out);
 int iopx_rowcheck_fp3_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const uint64_t *d_Cz, size_t log_n, const uint64_t *gen,

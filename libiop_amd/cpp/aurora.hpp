@@ -65,9 +65,10 @@ device_vector<FieldT> IFFT(const device_vector<FieldT> &evals, const field_subse
 
 // FFT_over_field_subset(IFFT_over_field_subset(v, H), L) for `batch` vectors stored back to back.  When H is spanned by the first basis
 // vectors of L the coefficient form is skipped (iopx_add_reextend_gf192_batch_dev); otherwise the two transforms run one after the other.
+// H_is_first_coset: H is the first coset of its span inside L (same shift), so the first |H| entries of each codeword are the input itself.
 template<typename FieldT>
 std::vector<device_vector<FieldT>> reextend_packed(const device_vector<FieldT> &packed, std::size_t batch, const field_subset<FieldT> &H,
-                                                   const field_subset<FieldT> &L)
+                                                   const field_subset<FieldT> &L, bool H_is_first_coset = false)
 {
     const std::size_t n = H.num_elements();
     std::vector<device_vector<FieldT>> outs;
@@ -75,8 +76,14 @@ std::vector<device_vector<FieldT>> reextend_packed(const device_vector<FieldT> &
     if (prefix) for (std::size_t i = 0; i < H.dimension(); ++i) prefix = prefix && std::memcmp(&H.basis()[i], &L.basis()[i], sizeof(FieldT)) == 0;
     if (prefix) {
         std::vector<uint64_t *> ptrs;
-        const auto range = dist::coset_range(L, H.dimension());
-        for (std::size_t k = 0; k < batch; ++k) { outs.emplace_back(range.second << H.dimension()); ptrs.push_back(outs.back().words()); }
+        auto range = dist::coset_range(L, H.dimension());
+        for (std::size_t k = 0; k < batch; ++k) outs.emplace_back(range.second << H.dimension());
+        const bool copy_first = H_is_first_coset && range.first == 0 && range.second > 1 && std::memcmp(&H.shift(), &L.shift(), sizeof(FieldT)) == 0;
+        for (std::size_t k = 0; k < batch; ++k) {
+            if (copy_first) outs[k].slice(0, n).copy_from(packed.slice(k * n, n));
+            ptrs.push_back(outs[k].words() + (copy_first ? 3 * n : 0));
+        }
+        if (copy_first) { range.first = 1; range.second -= 1; }
         check(iopx_add_reextend_gf192_batch_dev(packed.words(), batch, basis_words(L), L.dimension(), H.dimension(), shift_words(H), shift_words(L), range.first,
                                                 range.second, ptrs.data()));
         return outs;
@@ -217,6 +224,37 @@ device_vector<FieldT> poly_div_vanishing(const device_vector<FieldT> &poly, std:
 // Virtual oracles whose POLYNOMIAL is wanted (the sumcheck's combined f, FRI's first oracle) are evaluated over the head of the codeword
 // domain only (dist::head_domain: as many points as the polynomial has coefficients) instead of over all of it, when that is at least 4x
 // fewer points and rank 0 holds them.  IOPX_HEAD_EVAL=0: the reference's schedule (every virtual oracle over the whole domain).
+template<typename FieldT>
+device_vector<FieldT> div(const device_vector<FieldT> *num, const device_vector<FieldT> &den)        // batch_inverse(_and_mul), utils.tcc:57-118
+{
+    device_vector<FieldT> out(den.size());
+    auto fn = field_host<FieldT>::additive() ? iopx_gf192_div_dev : iopx_fp3_div_dev;
+    check(fn(num ? num->words() : nullptr, den.words(), out.words(), den.size()));
+    return out;
+}
+
+template<typename FieldT>
+device_vector<FieldT> vanishing_evals(const field_subset<FieldT> &S, const field_subset<FieldT> &D_in, const FieldT &constant)  // constant - Z_S(x) over D (this rank's part)
+{
+    const field_subset<FieldT> D = dist::local_domain(D_in);
+    device_vector<FieldT> out(D.num_elements());
+    if (additive(D))
+        check(iopx_vanishing_evals_gf192_dev(basis_words(D), D.dimension(), shift_words(D), basis_words(S), S.dimension(), shift_words(S), detail::words(&constant),
+                                             out.words()));
+    else
+        check(iopx_vanishing_evals_fp3_dev(D.dimension(), gen_words(D), shift_words(D), S.dimension(), shift_words(S), detail::words(&constant), out.words()));
+    return out;
+}
+
+// is H (a subspace) spanned by the first basis vectors of L?
+template<typename FieldT>
+bool spanned_by_prefix(const field_subset<FieldT> &H, const field_subset<FieldT> &L)
+{
+    if (!additive(H) || !additive(L) || H.dimension() > L.dimension()) return false;
+    for (std::size_t i = 0; i < H.dimension(); ++i) if (std::memcmp(&H.basis()[i], &L.basis()[i], sizeof(FieldT)) != 0) return false;
+    return true;
+}
+
 inline bool head_evaluation_enabled()
 {
     const char *e = std::getenv("IOPX_HEAD_EVAL");      // read per proof: tests prove the same instance both ways
@@ -545,14 +583,36 @@ public:
         if (degree_bound_ > H_.num_elements() && dev::use_head(L_, count) && IOP_.can_restrict(combined_f_handle_)) {
             // the interpolant of :351-354 only reads the head of the codeword domain: evaluate the combined f there and nowhere else
             h = device_vector<FieldT>(degree_bound_ - H_.num_elements());
+            // Subspaces, f over exactly two cosets C0, C1 of H (the usual case: deg f < 2 |H|): f = Z_H h + g with deg g, deg h < |H| and Z_H constant
+            // on a coset of H (z0, z1), so with R = the re-extension from one coset to the other (exact on polynomials of fewer than |H| coefficients)
+            // (C1 to C0 here) f|C0 - R(f|C1) = (z0 - z1) h|C0: h over C0 comes from one re-extension and one scaling, and its codeword from re-extending
+            // THAT (its first |H| entries are h over C0 itself) — no coefficient form, no division pass.  The quotient is unique, so these are :359-365's field elements.
+            const bool two_cosets = dev::additive(L_) && count == 2 * H_.num_elements() && dev::spanned_by_prefix(H_, L_);
+            if (two_cosets) h = device_vector<FieldT>(H_.num_elements());
             if (!L_.distributed() || dist::ctx().rank == 0) {
                 const dist::one_rank_section alone;
                 const std::size_t later = IOP_.head_hint();         // the LDT reads the (cached) combined f over its own head: evaluate that one if it is larger
                 if (later > count && dev::use_head(L_, later)) (void)IOP_.get_oracle_evaluations_over_head(combined_f_handle_, later);
                 const device_vector<FieldT> evals = IOP_.get_oracle_evaluations_over_head(combined_f_handle_, count);
-                h = dev::poly_div_vanishing<FieldT>(dev::IFFT<FieldT>(evals, dist::head_domain(L_, count)), degree_bound_, H_);
+                if (two_cosets) {
+                    const std::size_t n = H_.num_elements();
+                    const field_subset<FieldT> C0 = dist::window_domain(L_, dist::window{ 0, 1, n }), C1 = dist::window_domain(L_, dist::window{ n, 1, n });
+                    const device_vector<FieldT> moved = dev::reextend_packed<FieldT>(evals.slice(n, n), 1, C1, C0)[0];
+                    typedef field_host<FieldT> F;
+                    const FieldT scale = F::inverse(F::sub(F::vanishing_eval(H_, C0.shift()), F::vanishing_eval(H_, C1.shift())));
+                    const std::vector<device_vector<FieldT>> terms = { evals.slice(0, n), moved };
+                    const std::vector<const void *> ptrs = dev::pointers(terms);
+                    const FieldT coefficients[2] = { scale, F::neg(scale) };
+                    check(iopx_lincomb_gf192_dev(ptrs.data(), 2, detail::words(coefficients), n, h.words()));
+                } else {
+                    h = dev::poly_div_vanishing<FieldT>(dev::IFFT<FieldT>(evals, dist::head_domain(L_, count)), degree_bound_, H_);
+                }
             }
             if (L_.distributed()) dist::broadcast<FieldT>(h, 0);
+            if (two_cosets) {                                                                                               // h over C0 -> h over L
+                IOP_.submit_oracle(h_handle_, oracle<FieldT>(dev::reextend_packed<FieldT>(h, 1, dist::window_domain(L_, dist::window{ 0, 1, H_.num_elements() }), L_, true)[0]));
+                return;
+            }
         } else {
             const device_vector<FieldT> evals = IOP_.get_oracle_evaluations(combined_f_handle_);
             h = dev::interpolate_and_divide<FieldT>(evals, degree_bound_, L_, H_);                                         // :351-354, :359-365
@@ -707,14 +767,30 @@ public:
             check(iopx_gather_dev(d_z.data(), it->second.data(), V_.num_elements(), sizeof(FieldT), z_over_variable_domain.data()));
         }
         const device_vector<FieldT> fw_prime_evals = dev::sub<FieldT>(z_over_variable_domain, f1v_over_variable_domain);                     // :406-430
-        const device_vector<FieldT> fw_prime = dev::IFFT<FieldT>(fw_prime_evals, V_);                                                        // :551-555
         const std::size_t nC = C_.num_elements();
         const device_vector<FieldT> Mz(3 * nC);
         if (cs_.num_constraints() != nC) Mz.fill_zero();
         const sparse_matrix<FieldT> *M[3] = { &cs_.A, &cs_.B, &cs_.C };
         for (int q = 0; q < 3; ++q) M[q]->times_vector(d_z, Mz.slice(q * nC, cs_.num_constraints()));                                       // :586-592, r1cs.tcc:236-268
-        const device_vector<FieldT> fw = dev::poly_div_vanishing<FieldT>(fw_prime, V_.num_elements(), I_);                                   // :563-565
-        const std::vector<device_vector<FieldT>> codewords = dev::FFT_and_reextend_packed<FieldT>(fw, Mz, 3, C_, L_);                       // :567-568, :459-478
+        std::vector<device_vector<FieldT>> codewords;
+        if (dev::head_evaluation_enabled() && dev::spanned_by_prefix(V_, L_) && dev::spanned_by_prefix(I_, V_) && V_.dimension() < L_.dimension() && I_.num_elements() < V_.num_elements()) {
+            // f_w = f_w' / Z_I exactly (f_w' vanishes on the input positions by construction), deg f_w < |V|: so f_w over the first coset V0 of V inside L
+            // is f_w' there (one re-extension from V) divided by Z_I pointwise (V0 does not meet I), and its codeword is the re-extension of THAT —
+            // the coefficient form (:551-555), the division passes (:563-565) and both basis conversions drop out.  Same field elements.
+            field_subset<FieldT> whole = L_;
+            whole.set_distributed(false);
+            const field_subset<FieldT> V0 = dist::window_domain(whole, dist::window{ 0, 1, V_.num_elements() });
+            const device_vector<FieldT> fw_prime_V0 = dev::reextend_packed<FieldT>(fw_prime_evals, 1, V_, V0)[0];
+            const device_vector<FieldT> fw_V0(V0.num_elements());                            // Z_I is constant on the cosets of I: one product per element
+            check(iopx_div_by_vanishing_gf192_dev(fw_prime_V0.words(), dev::basis_words(V0), V0.dimension(), dev::shift_words(V0), I_.dimension(), dev::shift_words(I_),
+                                                  fw_V0.words()));
+            codewords.push_back(dev::reextend_packed<FieldT>(fw_V0, 1, V0, L_, true)[0]);
+            for (auto &cw : dev::reextend_packed<FieldT>(Mz, 3, C_, L_)) codewords.push_back(cw);
+        } else {
+            const device_vector<FieldT> fw_prime = dev::IFFT<FieldT>(fw_prime_evals, V_);                                                    // :551-555
+            const device_vector<FieldT> fw = dev::poly_div_vanishing<FieldT>(fw_prime, V_.num_elements(), I_);                               // :563-565
+            codewords = dev::FFT_and_reextend_packed<FieldT>(fw, Mz, 3, C_, L_);                                                             // :567-568, :459-478
+        }
         const oracle_handle handles[4] = { fw_handle_, fAz_handle_, fBz_handle_, fCz_handle_ };
         for (int q = 0; q < 4; ++q) IOP_.submit_oracle(handles[q], oracle<FieldT>(codewords[q]));                                           // :603-606
     }
@@ -800,10 +876,10 @@ class FRI_protocol {                                                            
             if (!split || me == 0) { const dist::one_rank_section alone; f0 = IOP_.get_oracle_evaluations_over_window(poly_handles_[l], h0); }
             for (std::size_t j = 0; j < interactive_repetitions_; ++j) {
                 const FieldT x_0 = IOP_.obtain_verifier_random_message(verifier_challenge_handles_[0][j])[0];
-                device_vector<FieldT> coeffs(head / cs0);
-                if (!split || me == 0) { const dist::one_rank_section alone; coeffs = dev::IFFT<FieldT>(dev::fold<FieldT>(f0, D_h0, cs0, x_0), D_h1); }
-                if (split) dist::broadcast<FieldT>(coeffs, 0);
-                by_interaction[j][l] = dev::FFT<FieldT>(coeffs, coeffs.size(), L1);
+                device_vector<FieldT> f1_head(head / cs0);                                         // f_1 over the head of L^(1)
+                if (!split || me == 0) { const dist::one_rank_section alone; f1_head = dev::fold<FieldT>(f0, D_h0, cs0, x_0); }
+                if (split) dist::broadcast<FieldT>(f1_head, 0);
+                by_interaction[j][l] = dev::reextend_packed<FieldT>(f1_head, 1, D_h1, L1)[0];     // subspaces: no coefficient form in between
             }
             if (!split || me == checker) {
                 const dist::one_rank_section alone;

@@ -19,15 +19,6 @@ namespace libiop_amd {
 namespace dev {
 
 template<typename FieldT>
-device_vector<FieldT> div(const device_vector<FieldT> *num, const device_vector<FieldT> &den)        // batch_inverse(_and_mul), utils.tcc:57-118
-{
-    device_vector<FieldT> out(den.size());
-    auto fn = field_host<FieldT>::additive() ? iopx_gf192_div_dev : iopx_fp3_div_dev;
-    check(fn(num ? num->words() : nullptr, den.words(), out.words(), den.size()));
-    return out;
-}
-
-template<typename FieldT>
 device_vector<FieldT> mul(const device_vector<FieldT> &a, const device_vector<FieldT> &b)
 {
     if (a.size() != b.size()) throw std::invalid_argument("mul: size mismatch");
@@ -52,19 +43,6 @@ device_vector<FieldT> domain_elements(const field_subset<FieldT> &D)            
 {
     if (additive(D)) return domain_offsets<FieldT>(D, field_host<FieldT>::zero());
     return pow_table<FieldT>(D.num_elements(), D.generator(), D.shift());
-}
-
-template<typename FieldT>
-device_vector<FieldT> vanishing_evals(const field_subset<FieldT> &S, const field_subset<FieldT> &D_in, const FieldT &constant)  // constant - Z_S(x) over D (this rank's part)
-{
-    const field_subset<FieldT> D = dist::local_domain(D_in);
-    device_vector<FieldT> out(D.num_elements());
-    if (additive(D))
-        check(iopx_vanishing_evals_gf192_dev(basis_words(D), D.dimension(), shift_words(D), basis_words(S), S.dimension(), shift_words(S), detail::words(&constant),
-                                             out.words()));
-    else
-        check(iopx_vanishing_evals_fp3_dev(D.dimension(), gen_words(D), shift_words(D), S.dimension(), shift_words(S), detail::words(&constant), out.words()));
-    return out;
 }
 
 // lagrange_polynomial(x, S, normalized = false).evaluations_over_field_subset(evaldomain) (lagrange_polynomial.tcc:66-136):

@@ -29,6 +29,15 @@ __global__ void __launch_bounds__(256) k_rowcheck_add(uint64_t *out, const uint6
     }
 }
 
+// out[j] = in[j] / Z_H(x_j): one product with the coset's inverse
+__global__ void __launch_bounds__(256) k_div_by_vanishing_add(uint64_t *out, const uint64_t *in, const uint64_t *zinv, int h, size_t n)
+{
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        const gf192 t = gf_load(in, j);
+        gf_store(out, j, h >= 6 ? gf_mul_uniform(t, gf_load(zinv, j >> h)) : gf_mul(t, gf_load(zinv, j >> h)));
+    }
+}
+
 // The field products of this library are data x table (fp3_dev.h): the product of two DATA values comes out as a b 2^181, so
 // Cz is brought to the same scale (times the stored 1 = 2^192) and the inverse table carries the missing 2^11 twice.
 __global__ void __launch_bounds__(256) k_rowcheck_fp(uint64_t *out, const uint64_t *az, const uint64_t *bz, const uint64_t *cz,
@@ -237,25 +246,17 @@ static void host_batch_inverse(std::vector<H> &v)
     v[0] = inv;
 }
 
-extern "C" {
-
-int iopx_rowcheck_gf192_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const uint64_t *d_Cz, const uint64_t *basis, size_t m,
-                            const uint64_t *shift, size_t constraint_dim, const uint64_t *constraint_shift, uint64_t *d_out)
+// 1 / Z_H on each coset of H = span(basis[0..h)) + constraint_shift inside the domain span(basis[0..m)) + shift: a function of the two domains
+// only, kept on the device.  Z_H = prod_{v in H} (X - v): the subspace polynomial of span(basis[0..h)) built factor by factor,
+// Z <- Z(X) (Z(X) + Z(b)), shifted by its value at shift_H (vanishing_polynomial.tcc:373-395).
+static int vanishing_inverse_table(const uint64_t *basis, size_t m, const uint64_t *shift, size_t h, const uint64_t *constraint_shift, TmpBuf &dz)
 {
-    int rc = ensure_device();
-    if (rc != IOPX_OK) return rc;
-    if (!d_Az || !d_Bz || !d_Cz || !d_out || (m > 0 && !basis) || !shift || !constraint_shift) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
-    if (constraint_dim > m || m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "the constraint domain must be a sub-domain of the codeword domain");
-    const size_t h = constraint_dim, cosets = (size_t)1 << (m - h);
-    // Z_H = prod_{v in H} (X - v): the subspace polynomial of span(basis[0..h)) built factor by factor, Z <- Z(X) (Z(X) + Z(b)),
-    // shifted by its value at shift_H (vanishing_polynomial.tcc:373-395)
-    // 1 / Z_H on each coset of H inside the codeword domain: a function of the two domains only, kept on the device
+    const size_t cosets = (size_t)1 << (m - h);
     std::vector<uint64_t> key(basis, basis + 3 * m);
     key.insert(key.end(), shift, shift + 3);
     key.insert(key.end(), constraint_shift, constraint_shift + 3);
     key.push_back(m); key.push_back(h); key.push_back(0x726f77);            // "row"
-    TmpBuf dz;
-    rc = cached_domain_table(key, [&](std::vector<uint64_t> &zinv) -> int {
+    return cached_domain_table(key, [&](std::vector<uint64_t> &zinv) -> int {
         const std::shared_ptr<CachedSubspacePoly> lin_entry = cached_subspace_poly(basis, h);
         CachedSubspacePoly &lin = *lin_entry;
         auto eval = [&](const hgf192 &x) { return lin.eval(x); };
@@ -272,7 +273,35 @@ int iopx_rowcheck_gf192_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const ui
         for (size_t c = 0; c < cosets; ++c) memcpy(&zinv[3 * c], z[c].w, 24);
         return IOPX_OK;
     }, dz);
+}
+
+extern "C" {
+
+int iopx_div_by_vanishing_gf192_dev(const uint64_t *d_in, const uint64_t *basis, size_t m, const uint64_t *shift, size_t sub_dim, const uint64_t *sub_shift,
+                                    uint64_t *d_out)
+{
+    int rc = ensure_device();
     if (rc != IOPX_OK) return rc;
+    if (!d_in || !d_out || (m > 0 && !basis) || !shift || !sub_shift) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (sub_dim > m || m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "the vanishing set must be spanned by a prefix of the domain's basis");
+    TmpBuf dz;
+    if ((rc = vanishing_inverse_table(basis, m, shift, sub_dim, sub_shift, dz)) != IOPX_OK) return rc;
+    const size_t n = (size_t)1 << m;
+    { ProfScope ps_("k_div_by_vanishing_add", 2 * n * 24); hipLaunchKernelGGL(k_div_by_vanishing_add, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_in, (const uint64_t *)dz.u64(), (int)sub_dim, n); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+int iopx_rowcheck_gf192_dev(const uint64_t *d_Az, const uint64_t *d_Bz, const uint64_t *d_Cz, const uint64_t *basis, size_t m,
+                            const uint64_t *shift, size_t constraint_dim, const uint64_t *constraint_shift, uint64_t *d_out)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!d_Az || !d_Bz || !d_Cz || !d_out || (m > 0 && !basis) || !shift || !constraint_shift) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (constraint_dim > m || m > 40) return fail(IOPX_ERR_INVALID_ARGUMENT, "the constraint domain must be a sub-domain of the codeword domain");
+    const size_t h = constraint_dim;
+    TmpBuf dz;
+    if ((rc = vanishing_inverse_table(basis, m, shift, h, constraint_shift, dz)) != IOPX_OK) return rc;
     const size_t n = (size_t)1 << m;
     { ProfScope ps_("k_rowcheck_add", 4 * n * 24); hipLaunchKernelGGL(k_rowcheck_add, dim3(vo_grid(n)), dim3(256), 0, stream(), d_out, d_Az, d_Bz, d_Cz, (const uint64_t *)dz.u64(), (int)h, n); }
     IOPX_HIP(hipGetLastError());

@@ -85,3 +85,31 @@ def check_unsatisfied_witness(lib, torch, device, monkeypatch, field_name, log_n
     assert launches == 3 and bad_prof["k_count_mismatch_words"][0] == 1, bad_prof
     monkeypatch.setenv("IOPX_HEAD_EVAL", "0")
     assert native(bad_z)[0] == expected
+
+
+def check_div_by_vanishing(lib, torch, device, m, sub_dim, seed):
+    """iopx_div_by_vanishing_gf192_dev against the general route (Z_S over the domain by iopx_vanishing_evals, then the batch-inversion division),
+    over a shifted standard-basis domain and over a general basis; a domain that meets S is refused."""
+    import ctypes
+    from helpers import rand_elems
+    field = domains.GF192()
+    ops = domains.DeviceOps(lib, torch, device, field)
+    lib.c.iopx_div_by_vanishing_gf192_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    for kind in ("standard", "general"):
+        basis = oracle.standard_basis(m, 3) if kind == "standard" else rand_elems(seed + 1, m, 3)
+        shift = np.array([1 << m, 0, 0], dtype=np.uint64) if kind == "standard" else rand_elems(seed + 2, 1, 3)[0]
+        sub_shift = np.zeros(3, dtype=np.uint64) if kind == "standard" else rand_elems(seed + 3, 1, 3)[0]
+        D = domains.Domain(field, domains.ADDITIVE, basis=basis, shift=shift)
+        S = domains.Domain(field, domains.ADDITIVE, basis=basis[:sub_dim].copy(), shift=sub_shift)
+        d_in = ops.upload(rand_elems(seed, 1 << m, 3))
+        expect = ops.download(ops.div(d_in, ops.vanishing_evals(S, D, np.zeros(3, dtype=np.uint64))))
+        out = ops.empty(1 << m)
+        b, s, ss = (np.ascontiguousarray(x, dtype=np.uint64) for x in (basis, shift, sub_shift))
+        lib._check(lib.c.iopx_div_by_vanishing_gf192_dev(d_in.data_ptr(), b.ctypes.data, m, s.ctypes.data, sub_dim, ss.ctypes.data, out.data_ptr()))
+        assert np.array_equal(ops.download(out), expect), (kind, m, sub_dim)
+    basis, zero = oracle.standard_basis(m, 3), np.zeros(3, dtype=np.uint64)
+    try:
+        lib._check(lib.c.iopx_div_by_vanishing_gf192_dev(d_in.data_ptr(), basis.ctypes.data, m, zero.ctypes.data, sub_dim, zero.ctypes.data, out.data_ptr()))
+    except ValueError:
+        return
+    raise AssertionError("a domain that contains S was accepted")

@@ -517,12 +517,16 @@ def test_phase1_split_over_the_ranks(world, monkeypatch):
 
 @pytest.mark.parametrize("world,protocol,field_code,log_n", [(2, "aurora", 0, 7), (8, "aurora", 0, 9), (4, "fractal", 0, 7)])
 def test_native_sharded_provers_with_phase1_split(world, protocol, field_code, log_n, monkeypatch):
-    """The native distributed provers with the phase-1 split active at test sizes (the 2^20 proof takes it by default, d >= 16)."""
+    """The native distributed provers with the phase-1 split active at test sizes (d >= 16 by default).  Aurora's default schedule re-extends its
+    codewords without a coefficient form, so no replicated basis conversion is left to split: its cases run the reference's schedule
+    (IOPX_HEAD_EVAL=0), which converts every oracle; Fractal keeps replicated conversions either way."""
     import oracle
     mgr = mp.Manager()
     plain, ret = mgr.dict(), mgr.dict()
     seed = 0x2204 if protocol == "aurora" else 0x2205
     args = (protocol, field_code, log_n, 15, seed, 5 if protocol == "aurora" else 3)
+    if protocol == "aurora":
+        monkeypatch.setenv("IOPX_HEAD_EVAL", "0")
     mp.spawn(_native_worker, args=(world, _free_port(), plain) + args, nprocs=world, join=True)       # default tuning: transforms stay whole at this size
     for k, v in P1_SHARD_ENV.items():
         monkeypatch.setenv(k, v)

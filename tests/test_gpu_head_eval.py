@@ -27,3 +27,8 @@ def test_both_schedules_give_the_oracle_transcript(gpu, protocol, field_name, lo
 @pytest.mark.parametrize("field_name", ["gf192", "edwards_Fr"])
 def test_unsatisfied_witness_is_proved_by_the_reference_schedule(gpu, field_name, monkeypatch):
     hc.check_unsatisfied_witness(gpu, torch, torch.device("cuda:0"), monkeypatch, field_name, log_n=10)
+
+
+@pytest.mark.parametrize("m,sub_dim", [(10, 4), (16, 4), (14, 9)])
+def test_div_by_vanishing(gpu, m, sub_dim):
+    hc.check_div_by_vanishing(gpu, torch, torch.device("cuda:0"), m, sub_dim, 60 + m)

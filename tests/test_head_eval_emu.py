@@ -27,6 +27,11 @@ def test_unsatisfied_witness_is_proved_by_the_reference_schedule(field_name, mon
     hc.check_unsatisfied_witness(emu_lib.emu(), torch, CPU, monkeypatch, field_name)
 
 
+@pytest.mark.parametrize("m,sub_dim", [(6, 2), (9, 4), (10, 7), (5, 5)])
+def test_div_by_vanishing(m, sub_dim):
+    hc.check_div_by_vanishing(emu_lib.emu(), torch, CPU, m, sub_dim, 40 + m)
+
+
 def test_instance_create_argument_checks():
     lib = emu_lib.emu()
     ops = domains.DeviceOps(lib, torch, CPU, domains.GF192())
