@@ -297,7 +297,8 @@ def main():
         "value": value,
         "unit": "field-ops/s",
         "unit_note": "numerator = the REFERENCE's operation count for the proof's transforms (eight zero-padded 2^25-point FFTs, ...: config.ref_fft_*), not "
-                     "the device's own work: the device evaluates the same codewords by cosets with far fewer products (config.device_field_products_per_proof)",
+                     "the device's own work: the device produces the same transcript bytes with far fewer products (config.device_field_products_per_proof) — the five "
+                     "committed codewords and FRI's f_1 by cosets, every virtual oracle over the head of the codeword domain only (config.schedule)",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -315,6 +316,9 @@ def main():
             "prover": ("native: iopx_aurora_prove (libiop_amd/cpp/aurora.hpp behind the C ABI); transcript equal to libiop_amd/aurora.py's" if comm is None else
                        "native: iopx_aurora_prove_dist (libiop_amd/cpp/aurora.hpp + dist.hpp behind the C ABI, RCCL communicator of %d rank(s)); transcript equal to "
                        "the single-GPU prover's" % world),
+            "schedule": ("reference's: every virtual oracle over the whole codeword domain (IOPX_HEAD_EVAL=0)" if os.environ.get("IOPX_HEAD_EVAL", "1")[:1] == "0" else
+                         "virtual oracles over the head of the codeword domain (as many points as their polynomial has coefficients), f_1 folded there and re-extended, "
+                         "confirmed on a second window; h, f_w and f_1 re-extended without coefficient forms (DESIGN.md section 4)"),
             "device_field_products_per_proof": device_products if world == 1 else None,
             "device_field_products_per_proof_this_rank": device_products,
             "device_products_per_s": device_products * world / prover_s if device_products else None,
