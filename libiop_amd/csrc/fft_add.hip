@@ -828,8 +828,12 @@ struct AddPlan {
     DevBuf ltab;                                // 2^d - 1 twiddles
     DevBuf pow_fwd, pow_inv;                    // 2^(d+1) - 2 entries each, built on first use
     bool have_fwd = false, have_inv = false;
-    DevBuf rs;                                  // per-call shift terms (stream ordered)
+    DevBuf rs;                                  // per-call shift terms (stream ordered) of a (shift, coset basis) the cache below does not hold
     size_t rs_cap = 0;
+    // The shift terms are a function of (shift, coset basis vectors) only, and a prover asks for the same few per domain in every proof: kept on the
+    // device per pair (host: (1 + nhi) d recursions; device: one constant-carrying launch — both off the path after the first proof).
+    std::map<std::vector<uint64_t>, std::unique_ptr<DevBuf>> rs_cache;
+    const uint64_t *rs_cur = nullptr;           // the terms the next launches read: a cache entry or `rs`
     // one-word basis ending in a power of x (the standard basis): numerators of the last level's twiddles, see BfParams::ltab_small
     DevBuf ltab_small;
     int small_k = -1;                           // basis[d-1] = x^small_k, or -1
@@ -1005,10 +1009,24 @@ static int upload_rs(AddPlan &pl, const hgf192 &shift, const uint64_t *hi_basis,
         }
         for (int v = 0; v <= nhi; ++v) pl.rs_small1[v] = recursed_numerator(pl.rs_small[v], pl.small_k);
     }
+    std::vector<uint64_t> key(shift.w, shift.w + 3);
+    key.push_back((uint64_t)nhi);
+    if (nhi) key.insert(key.end(), hi_basis, hi_basis + 3 * (size_t)nhi);
+    auto hit = pl.rs_cache.find(key);
+    if (hit != pl.rs_cache.end()) { pl.rs_cur = hit->second->u64(); return IOPX_OK; }
     std::vector<hgf192> rs((size_t)(1 + nhi) * d);
     pl.recursed_shifts(shift, rs.data());
     for (int v = 0; v < nhi; ++v) pl.recursed_shifts(hgf192::from_words(hi_basis + 3 * v), rs.data() + (size_t)(1 + v) * d);
     const size_t bytes = rs.size() * 24;
+    if (bytes && pl.rs_cache.size() < 64) {      // a prover's domains are few; anything beyond that takes the shared per-call buffer
+        std::unique_ptr<DevBuf> buf(new DevBuf());
+        int rc = buf->alloc(bytes);
+        if (rc != IOPX_OK) return rc;
+        if ((rc = upload(buf->p, rs.data(), bytes)) != IOPX_OK) return rc;
+        pl.rs_cur = buf->u64();
+        pl.rs_cache.emplace(std::move(key), std::move(buf));
+        return IOPX_OK;
+    }
     if (bytes > pl.rs_cap) {
         IOPX_HIP(hipStreamSynchronize(stream()));
         int rc = pl.rs.alloc(bytes);
@@ -1016,6 +1034,7 @@ static int upload_rs(AddPlan &pl, const hgf192 &shift, const uint64_t *hi_basis,
         pl.rs_cap = bytes;
     }
     if (bytes) { int urc_ = upload(pl.rs.p, rs.data(), bytes); if (urc_ != IOPX_OK) return urc_; }
+    pl.rs_cur = pl.rs.u64();
     return IOPX_OK;
 }
 
@@ -1222,7 +1241,7 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
     BfParams p;
     memset(&p, 0, sizeof(p));
     p.ltab = pl.ltab.u64();
-    p.rs = pl.rs.u64();
+    p.rs = pl.rs_cur;
     p.d = d; p.nhi = nhi;
     p.a_low = g.a_low; p.c_top = g.c_top;
     set_small_last(p, pl);
@@ -1236,7 +1255,7 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         int rcc = rs_comb.alloc(cosets * d * 24);
         if (rcc != IOPX_OK) return rcc;
         comb_base = coset_begin; comb_count = cosets;
-        { ProfScope ps_("k_rs_combine"); hipLaunchKernelGGL(k_rs_combine, dim3(grid_for(cosets * d, 256)), dim3(256), 0, stream(), rs_comb.u64(), (const uint64_t *)pl.rs.u64(), d, nhi, coset_begin, cosets * (size_t)d); }
+        { ProfScope ps_("k_rs_combine"); hipLaunchKernelGGL(k_rs_combine, dim3(grid_for(cosets * d, 256)), dim3(256), 0, stream(), rs_comb.u64(), pl.rs_cur, d, nhi, coset_begin, cosets * (size_t)d); }
         rs_comb_ptr = rs_comb.u64();
     }
     // too many cosets for that table (a short polynomial over a long domain: the prover's f_1v, 16 coefficients over 2^25 points): shift terms
@@ -1247,7 +1266,7 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         const size_t count = (size_t)groups * 256 * d;
         int rct = rs_tab.alloc(count * 24);
         if (rct != IOPX_OK) return rct;
-        { ProfScope ps_("k_rs_combine"); hipLaunchKernelGGL(k_rs_tables, dim3(grid_for(count, 256)), dim3(256), 0, stream(), rs_tab.u64(), (const uint64_t *)pl.rs.u64(), d, nhi, count); }
+        { ProfScope ps_("k_rs_combine"); hipLaunchKernelGGL(k_rs_tables, dim3(grid_for(count, 256)), dim3(256), 0, stream(), rs_tab.u64(), pl.rs_cur, d, nhi, count); }
         p.rs_tab = rs_tab.u64();
         p.rs_tab_groups = groups;
     }
@@ -1391,7 +1410,7 @@ static int run_phase2_fwd_batch(AddPlan &pl, const uint64_t *const *srcs, uint64
         const int rc = rs_comb.alloc(cosets * d * 24);
         if (rc != IOPX_OK) return rc;
         ProfScope ps_("k_rs_combine");
-        hipLaunchKernelGGL(k_rs_combine, dim3(grid_for(cosets * d, 256)), dim3(256), 0, stream(), rs_comb.u64(), (const uint64_t *)pl.rs.u64(), d, nhi, coset_begin, cosets * (size_t)d);
+        hipLaunchKernelGGL(k_rs_combine, dim3(grid_for(cosets * d, 256)), dim3(256), 0, stream(), rs_comb.u64(), pl.rs_cur, d, nhi, coset_begin, cosets * (size_t)d);
     }
     for (size_t c0 = 0; c0 < cosets; c0 += group) {
         const size_t nc = cosets - c0 < group ? cosets - c0 : group;
@@ -1403,7 +1422,7 @@ static int run_phase2_fwd_batch(AddPlan &pl, const uint64_t *const *srcs, uint64
         BfBatchParams q;
         memset(&q, 0, sizeof(q));
         BfParams &p = q.p;
-        p.ltab = pl.ltab.u64(); p.rs = pl.rs.u64(); p.d = d; p.nhi = nhi;
+        p.ltab = pl.ltab.u64(); p.rs = pl.rs_cur; p.d = d; p.nhi = nhi;
         p.a_low = g.a_low;
         set_small_last(p, pl);
         // 512 threads and batch * tile / 2 butterflies per level: whole trips for 2 and 3 tiles of 1024 (48 and 72 KB of LDS, two workgroups

@@ -252,16 +252,9 @@ int iopx_ldt_combine_gf192_dev(const void *const *d_oracles, size_t num_oracles,
         }, dtab);
         if (rc != IOPX_OK) return rc;
     }
-    if ((rc = dptrs.alloc(num_oracles * sizeof(void *))) != IOPX_OK) return rc;
-    if ((rc = dcoef.alloc(hcoef.size() * 8)) != IOPX_OK) return rc;
-    if ((rc = dexpo.alloc(num_oracles * 8)) != IOPX_OK) return rc;
-    if ((rc = upload(dptrs.p, d_oracles, num_oracles * sizeof(void *))) != IOPX_OK) return rc;
-    if ((rc = upload(dcoef.p, hcoef.data(), hcoef.size() * 8)) != IOPX_OK) return rc;
-    if ((rc = upload(dexpo.p, pl.expo.data(), num_oracles * 8)) != IOPX_OK) return rc;
     LdtAddParams p;
-    p.oracles = (const uint64_t *const *)dptrs.p;
     p.out = d_out;
-    p.tab = dtab.u64(); p.coef = dcoef.u64(); p.expo = dexpo.u64();
+    p.tab = dtab.u64();
     p.n = (size_t)1 << m; p.m = (int)m; p.num_oracles = (int)num_oracles;
     // slots: distinct exponents; those with >= 3 bits that all contain a common bit set hang off one slot holding that set
     std::vector<uint64_t> distinct;
@@ -290,20 +283,31 @@ int iopx_ldt_combine_gf192_dev(const void *const *d_oracles, size_t num_oracles,
         }
         for (size_t k = 0; k < num_oracles; ++k) if (pl.expo[k] == e) oracle_slot[k] = slot;
     }
-    if (slot_bits.size() > LDT_MAX_SLOTS) {
+    // the per-call tables travel in ONE block (one constant-carrying launch): oracle pointers, coefficient pairs, exponents, then the slot tables
+    const bool slots = slot_bits.size() <= LDT_MAX_SLOTS;
+    const size_t ns = slot_bits.size() ? slot_bits.size() : 1;
+    if (slots) { slot_bits.resize(ns, 0); slot_parent.resize(ns, -1); }
+    std::vector<uint64_t> meta;
+    const size_t off_ptrs = 0, off_coef = num_oracles, off_expo = off_coef + hcoef.size(), off_bits = off_expo + num_oracles,
+                 off_parent = off_bits + (slots ? ns : 0), off_slot = off_parent + (slots ? (ns + 1) / 2 : 0), total = off_slot + (slots ? (num_oracles + 1) / 2 : 0);
+    meta.resize(total, 0);
+    for (size_t k = 0; k < num_oracles; ++k) meta[off_ptrs + k] = (uint64_t)(uintptr_t)d_oracles[k];
+    std::memcpy(&meta[off_coef], hcoef.data(), hcoef.size() * 8);
+    std::memcpy(&meta[off_expo], pl.expo.data(), num_oracles * 8);
+    if (slots) {
+        std::memcpy(&meta[off_bits], slot_bits.data(), ns * 8);
+        std::memcpy(&meta[off_parent], slot_parent.data(), ns * 4);
+        std::memcpy(&meta[off_slot], oracle_slot.data(), num_oracles * 4);
+    }
+    if ((rc = dptrs.alloc(total * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(dptrs.p, meta.data(), total * 8)) != IOPX_OK) return rc;
+    const uint64_t *dmeta = dptrs.u64();
+    p.oracles = (const uint64_t *const *)(dmeta + off_ptrs);
+    p.coef = dmeta + off_coef; p.expo = dmeta + off_expo;
+    if (!slots) {
         ProfScope ps_("k_ldt_combine_add");
         hipLaunchKernelGGL(k_ldt_combine_add, dim3(ldt_grid(p.n)), dim3(256), 0, stream(), p);
     } else {
-        const size_t ns = slot_bits.size() ? slot_bits.size() : 1;
-        slot_bits.resize(ns, 0);
-        slot_parent.resize(ns, -1);
-        TmpBuf dbits, dparent, dslot;
-        if ((rc = dbits.alloc(ns * 8)) != IOPX_OK) return rc;
-        if ((rc = dparent.alloc(ns * 4)) != IOPX_OK) return rc;
-        if ((rc = dslot.alloc(num_oracles * 4)) != IOPX_OK) return rc;
-        if ((rc = upload(dbits.p, slot_bits.data(), ns * 8)) != IOPX_OK) return rc;
-        if ((rc = upload(dparent.p, slot_parent.data(), ns * 4)) != IOPX_OK) return rc;
-        if ((rc = upload(dslot.p, oracle_slot.data(), num_oracles * 4)) != IOPX_OK) return rc;
         LdtSlotParams q;
         memset(&q, 0, sizeof(q));
         q.small_slot = -1;
@@ -322,7 +326,7 @@ int iopx_ldt_combine_gf192_dev(const void *const *d_oracles, size_t num_oracles,
             }
         }
         q.a = p;
-        q.slot_bits = dbits.u64(); q.slot_parent = (const int *)dparent.p; q.oracle_slot = (const int *)dslot.p;
+        q.slot_bits = dmeta + off_bits; q.slot_parent = (const int *)(dmeta + off_parent); q.oracle_slot = (const int *)(dmeta + off_slot);
         q.num_slots = (int)(distinct.empty() ? 0 : ns);
         const size_t lds_bytes = ns * 6 * 256 * 4;           // 11..16 distinct degree gaps exceed the 64 KiB default
         if (lds_bytes > 64 * 1024)

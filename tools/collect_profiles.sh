@@ -8,25 +8,25 @@ R=$PWD
 export TMPDIR=/tmp
 cd /tmp
 STEPS=5; WARM=2
-BENCH="python3 $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-secondary"
+BENCH="python3 $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-secondary --no-cross-check"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${P}_prof -- $BENCH > $R/gpurun_out/${P}_bench_under_rocprof.json 2> $R/gpurun_out/${P}_prof.err
 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${P}_pmc_fetch -- $BENCH > /dev/null 2> $R/gpurun_out/${P}_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${P}_pmc_write -- $BENCH > /dev/null 2> $R/gpurun_out/${P}_pmc_write.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $R/gpurun_out/${P}_pmc_sq -- $BENCH > /dev/null 2> $R/gpurun_out/${P}_pmc_sq.err
-# the Fractal prover: 2 indexer runs + 3 proofs per command, the last one under the library's own profiler (algorithmic bytes per kernel)
-FR="python3 $R/tools/fractal_bench.py --log-n 20 --reps 3 --profile"
+# the native Fractal prover: 3 indexer runs + 4 proofs per command, the last one under the library's own profiler (algorithmic bytes per kernel)
+FR="python3 $R/tools/fractal_bench.py --log-n 20 --reps 3 --native --native-only"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${P}_fr_prof -- $FR --out $R/gpurun_out/${P}_fractal_2p20.json > /dev/null 2> $R/gpurun_out/${P}_fr_prof.err
 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${P}_fr_fetch -- $FR > /dev/null 2> $R/gpurun_out/${P}_fr_fetch.err
 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${P}_fr_write -- $FR > /dev/null 2> $R/gpurun_out/${P}_fr_write.err
 cd $R
-# bench.py also proves once more for its cross-check and once under its own profiler: STEPS + WARM + 2 proofs per command
+# bench.py also proves once more under its own profiler: STEPS + WARM + 1 proofs per command
 python3 tools/rocprof_summary.py $(find gpurun_out/${P}_prof -name "*.db" | head -1) > gpurun_out/${P}_rocprofv3_bench_aurora2p20.txt
 python3 tools/rocprof_summary.py $(find gpurun_out/${P}_fr_prof -name "*.db" | head -1) > gpurun_out/${P}_rocprofv3_fractal2p20.txt
 # GPU idle gaps inside the last proof of the traced run (under the tracer's own per-launch overhead: an upper bound on the unprofiled gaps)
 # (one proof period of the timed loop: from the 4th proof's lincheck kernel to the 5th's)
-python3 tools/gpu_gaps.py gpurun_out/${P}_prof --min-us 30 --period-kernel k_lincheck_add --period-index 3 --histogram > gpurun_out/${P}_gpu_gaps.txt
-python3 tools/make_traffic_json.py gpurun_out/${P}_pmc_fetch gpurun_out/${P}_pmc_write 20 gpurun_out/${P}_traffic_aurora.json --bench-json gpurun_out/${P}_bench_under_rocprof.json --steps $((STEPS + WARM + 2)) > /dev/null
-python3 tools/make_traffic_json.py gpurun_out/${P}_fr_fetch gpurun_out/${P}_fr_write 20 gpurun_out/${P}_traffic_fractal.json --bench-json gpurun_out/${P}_fractal_2p20.json --steps 3 --min-ms 0.5 > /dev/null
-python3 tools/make_sq_json.py gpurun_out/${P}_pmc_sq gpurun_out/${P}_sq_aurora.json k_bfly_upperILb0 k_bfly_edgeILb0 k_bfly_edge_fwd_batch k_phase1 k_ldt_combine_add_slots k_merkle_leaves k_lincheck_add > /dev/null
+python3 tools/gpu_gaps.py gpurun_out/${P}_prof --min-us 30 --period-kernel k_lincheck_add --period-index 4 --histogram > gpurun_out/${P}_gpu_gaps.txt
+python3 tools/make_traffic_json.py gpurun_out/${P}_pmc_fetch gpurun_out/${P}_pmc_write 20 gpurun_out/${P}_traffic_aurora.json --bench-json gpurun_out/${P}_bench_under_rocprof.json --steps $((STEPS + WARM + 1)) > /dev/null
+python3 tools/make_traffic_json.py gpurun_out/${P}_fr_fetch gpurun_out/${P}_fr_write 20 gpurun_out/${P}_traffic_fractal.json --bench-json gpurun_out/${P}_fractal_2p20.json --steps 4 --min-ms 0.2 > /dev/null
+python3 tools/make_sq_json.py gpurun_out/${P}_pmc_sq gpurun_out/${P}_sq_aurora.json k_bfly_upperILb0 k_bfly_edgeILb0 k_bfly_edge_fwd_batch k_bfly_upperILb1 k_ldt_combine_add_slots k_merkle_leaves k_merkle_level k_lincheck_add > /dev/null
 rm -rf gpurun_out/${P}_prof gpurun_out/${P}_pmc_fetch gpurun_out/${P}_pmc_write gpurun_out/${P}_pmc_sq gpurun_out/${P}_fr_prof gpurun_out/${P}_fr_fetch gpurun_out/${P}_fr_write
 head -14 gpurun_out/${P}_rocprofv3_bench_aurora2p20.txt

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="multi-GPU operator set with one rank (exercises the RCCL calls on a 1-GPU box)")
     ap.add_argument("--native", action="store_true", help="also time the native prover (iopx_fractal_index / _prove; their _dist forms over an RCCL communicator "
                     "when run under torch.distributed.run or with --force-sharded) and compare its transcript with the Python prover's")
+    ap.add_argument("--native-only", action="store_true", help="with --native: skip the Python prover (profiling runs); the indexer still runs once for the roots")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     # one process per GPU under `python -m torch.distributed.run --nproc-per-node N tools/fractal_bench.py ...` (RCCL); alone otherwise
@@ -48,7 +49,7 @@ def main():
     params = fractal.FractalParameters(field, cs)
     res = {"log_n": a.log_n, "field": a.field, "num_inputs": k, "n_gpus": world, "codeword_domain_dim": params.codeword_domain_dim,
            "fri_query_repetitions": params.fri_query_repetitions, "localization_parameters": params.localization_parameters, "runs": []}
-    for rep in range(2):
+    for rep in range(1 if a.native_only else 2):
         torch.cuda.synchronize()
         t0 = time.time()
         index, (roots, _) = fractal.fractal_snark_indexer(ops, cs, params)
@@ -57,7 +58,7 @@ def main():
     if rank == 0:
         print("indexer: %s s" % res["indexer_s"], flush=True)
     tr = None
-    for rep in range(a.reps):
+    for rep in range(0 if a.native_only else a.reps):
         marks = []
         torch.cuda.synchronize()
         if a.profile and rep == a.reps - 1:
@@ -95,7 +96,11 @@ def main():
         lib.profile_begin()
         (lib.fractal_prove_dist(inst, comm) if comm is not None else lib.fractal_prove(inst))
         nprof = lib.profile_report()
-        res["native"] = {"prover_s": times, "prover_s_min": min(times), "index_roots_equal": [bytes(r) for r in roots] == nroots, "transcript_equals_python": nt == tr.serialize(),
+        if a.native_only:             # the profiled proof in the place tools/make_traffic_json.py reads
+            res["runs"].append({"prover_s": min(times), "argument_bytes": len(nt), "prover": "native",
+                                "kernels": {kk: {"launches": v[0], "ms": v[1], "bytes": v[2]} for kk, v in sorted(nprof.items(), key=lambda kv: -kv[1][1])}})
+        res["native"] = {"prover_s": times, "prover_s_min": min(times), "index_roots_equal": [bytes(r) for r in roots] == nroots,
+                         "transcript_equals_python": (nt == tr.serialize()) if tr is not None else None,
                          "collectives_per_proof": lib.comm_stats()[0], "collective_bytes_per_proof_this_rank": lib.comm_stats()[1],
                          "path": "iopx_fractal_prove_dist over an RCCL communicator of %d rank(s)" % world if comm is not None else "iopx_fractal_prove",
                          "kernels_ms_total": sum(v[1] for v in nprof.values()),

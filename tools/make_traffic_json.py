@@ -22,10 +22,11 @@ def kernel_sources_digest():
     """The same digest bench.py computes: the figures are only quoted for the kernel sources they were collected on."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for dp, _, fs in sorted(os.walk(os.path.join(root, "libiop_amd", "csrc"))):
-        for f in sorted(fs):
-            if f.endswith((".hip", ".h")):
-                h.update(open(os.path.join(dp, f), "rb").read())
+    for sub in ("csrc", "cpp"):
+        for dp, _, fs in sorted(os.walk(os.path.join(root, "libiop_amd", sub))):
+            for f in sorted(fs):
+                if f.endswith((".hip", ".h", ".hpp")):
+                    h.update(open(os.path.join(dp, f), "rb").read())
     return h.hexdigest()
 
 
