@@ -60,6 +60,9 @@ class AuroraParameters:
         ceil_div = lambda bits, per: max(1, math.ceil(-bits / per))
         self.multi_lincheck_repetitions = ceil_div(self.interactive_soundness_error_bits, self.constraint_domain_dim - fbits)   # basic_lincheck.tcc:52-56
         codeword_size = 1 << self.codeword_domain_dim
+        if self.max_constraint_degree_bound + 1 >= codeword_size or self.max_tested_degree_bound + 1 >= codeword_size:
+            # the reference's unsigned subtraction wraps here (RS_extra_dimensions = 1): refused instead of deriving a query count from it
+            raise ValueError("the degree bounds leave no room in the codeword domain (RS_extra_dimensions too small)")
         self.absolute_proximity_parameter = min(codeword_size - self.max_constraint_degree_bound,
                                                 codeword_size - self.max_tested_degree_bound) - 1                              # ldt_reducer.tcc:34-42
         self.num_output_LDT_instances = ceil_div(self.interactive_soundness_error_bits, self.codeword_domain_dim - fbits)       # :53-56

@@ -322,6 +322,10 @@ struct aurora_snark_parameters {
         const double fbits = (double)field_host<FieldT>::soundness_bits();
         multi_lincheck_repetitions_ = repetitions((double)interactive_soundness_error_bits_, (double)constraint_domain_dim_ - fbits);     // basic_lincheck.tcc:52-56
         const std::size_t codeword_size = (std::size_t)1 << codeword_domain_dim_;
+        // The reference subtracts without looking (ldt_reducer.tcc:34-42): with RS_extra_dimensions = 1 the constraint degree bound reaches the codeword size,
+        // its proximity parameter wraps around and the query count that follows is meaningless.  Refused here.
+        if (max_constraint_degree_bound_ + 1 >= codeword_size || max_tested_degree_bound_ + 1 >= codeword_size)
+            throw std::invalid_argument("the degree bounds leave no room in the codeword domain (RS_extra_dimensions too small)");
         absolute_proximity_parameter_ = std::min(codeword_size - max_constraint_degree_bound_, codeword_size - max_tested_degree_bound_) - 1;   // ldt_reducer.tcc:34-42
         num_output_LDT_instances_ = repetitions((double)interactive_soundness_error_bits_, (double)codeword_domain_dim_ - fbits);         // :53-56
         std::size_t total_localization = 0;

@@ -110,6 +110,14 @@ def test_native_prover_argument_checks():
             lib.aurora_prove(inst)                                   # constraints not a power of two (aurora_iop.tcc:19-33)
     finally:
         lib.aurora_instance_free(inst)
+    inst = lib.aurora_example_instance(1, 128, 15, 127, 1)
+    try:
+        with pytest.raises(ValueError):
+            lib.aurora_prove(inst, RS_extra_dimensions=1)            # the constraint degree bound reaches the codeword size: the reference's proximity parameter wraps
+        with pytest.raises(ValueError):
+            aurora.AuroraParameters(domains.EdwardsFr(), 128, 127, 15, RS_extra_dimensions=1)
+    finally:
+        lib.aurora_instance_free(inst)
     with pytest.raises(ValueError):
         lib.aurora_example_instance(0, 128, 200, 127, 1)         # more inputs than variables (r1cs_examples.tcc:29-32)
     with pytest.raises(ValueError):
