@@ -276,12 +276,13 @@ static int fp_build_pow(uint64_t *out, const hfp3 &base, const hfp3 &init, int n
     hfp3 x = base;
     for (int k = 0; k < nb; ++k) { const hfp3 t = x.table_form(); sq.insert(sq.end(), t.w, t.w + 3); x = x.squared(); }
     const hfp3 init_t = init.table_form();
-    TmpBuf dsq, dinit;
+    const size_t init_at = sq.size();                       // one block: the squarings, then the initial value (one constant-carrying launch)
+    sq.insert(sq.end(), init_t.w, init_t.w + 3);
+    TmpBuf dsq;
     int rc;
-    if ((rc = dsq.alloc(sq.size() * 8 + 8)) != IOPX_OK) return rc;
-    if ((rc = dinit.alloc(24)) != IOPX_OK) return rc;
-    if (!sq.empty()) { int urc_ = upload(dsq.p, sq.data(), sq.size() * 8); if (urc_ != IOPX_OK) return urc_; }
-    { int urc_ = upload(dinit.p, init_t.w, 24); if (urc_ != IOPX_OK) return urc_; }
+    if ((rc = dsq.alloc(sq.size() * 8)) != IOPX_OK) return rc;
+    { int urc_ = upload(dsq.p, sq.data(), sq.size() * 8); if (urc_ != IOPX_OK) return urc_; }
+    struct { const uint64_t *p; const uint64_t *u64() const { return p; } } dinit = { dsq.u64() + init_at };
     const size_t count = (size_t)1 << nb;
     if (nb <= 14) {         // up to 14 products per entry: one launch beats the three of the expansion scheme for the small per-call tables
         { ProfScope ps_("k_fp_pow_direct"); hipLaunchKernelGGL(k_fp_pow_direct, dim3(mgrid(count, 256)), dim3(256), 0, stream(), out, (const uint64_t *)dsq.u64(), (const uint64_t *)dinit.u64(), nb, count); }

@@ -348,10 +348,9 @@ static int div_common(const uint64_t *d_num, const uint64_t *d_den, uint64_t *d_
     p.num = d_num; p.den = d_den; p.out = d_out; p.consts = nullptr; p.n = n;
     TmpBuf dc;
     if (prime_field) {
-        struct Consts { uint64_t c[18]; Consts() { fo_fp_consts(c); } };
-        static const Consts k;                                  // host-side field arithmetic: once per process
-        if ((rc = dc.alloc(sizeof(k.c))) != IOPX_OK) return rc;
-        if ((rc = upload(dc.p, k.c, sizeof(k.c))) != IOPX_OK) return rc;
+        // the field's own constants: computed once per process, kept on the device
+        rc = cached_domain_table({ 0x646976 /* "div" */ }, [](std::vector<uint64_t> &w) -> int { uint64_t c[18]; fo_fp_consts(c); w.assign(c, c + 18); return IOPX_OK; }, dc);
+        if (rc != IOPX_OK) return rc;
         p.consts = dc.u64();
     }
     // 16 elements per lane while that fills the GPU (the shared inversion is one lane's serial work per workgroup), 2048 workgroups at most

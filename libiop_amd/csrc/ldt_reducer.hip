@@ -368,21 +368,23 @@ int iopx_ldt_combine_fp3_dev(const void *const *d_oracles, size_t num_oracles, c
         hhi[k] = hi.u64();
         hlo[k] = lo.u64();
     }
-    TmpBuf dptrs, dhi, dlo, dcoef;
-    if ((rc = dptrs.alloc(num_oracles * sizeof(void *))) != IOPX_OK) return rc;
-    if ((rc = dhi.alloc(num_oracles * sizeof(void *))) != IOPX_OK) return rc;
-    if ((rc = dlo.alloc(num_oracles * sizeof(void *))) != IOPX_OK) return rc;
-    if ((rc = dcoef.alloc(hcoef.size() * 8)) != IOPX_OK) return rc;
-    if ((rc = upload(dptrs.p, d_oracles, num_oracles * sizeof(void *))) != IOPX_OK) return rc;
-    if ((rc = upload(dhi.p, hhi.data(), num_oracles * sizeof(void *))) != IOPX_OK) return rc;
-    if ((rc = upload(dlo.p, hlo.data(), num_oracles * sizeof(void *))) != IOPX_OK) return rc;
-    if ((rc = upload(dcoef.p, hcoef.data(), hcoef.size() * 8)) != IOPX_OK) return rc;
+    // one block for the four per-call tables (one constant-carrying launch): oracle pointers, the two table-pointer lists, the coefficients
+    std::vector<uint64_t> meta(3 * num_oracles + hcoef.size());
+    for (size_t k = 0; k < num_oracles; ++k) {
+        meta[k] = (uint64_t)(uintptr_t)d_oracles[k];
+        meta[num_oracles + k] = (uint64_t)(uintptr_t)hhi[k];
+        meta[2 * num_oracles + k] = (uint64_t)(uintptr_t)hlo[k];
+    }
+    std::memcpy(&meta[3 * num_oracles], hcoef.data(), hcoef.size() * 8);
+    TmpBuf dmeta;
+    if ((rc = dmeta.alloc(meta.size() * 8)) != IOPX_OK) return rc;
+    if ((rc = upload(dmeta.p, meta.data(), meta.size() * 8)) != IOPX_OK) return rc;
     LdtFpParams p;
-    p.oracles = (const uint64_t *const *)dptrs.p;
-    p.hi = (const uint64_t *const *)dhi.p;
-    p.lo = (const uint64_t *const *)dlo.p;
+    p.oracles = (const uint64_t *const *)dmeta.u64();
+    p.hi = (const uint64_t *const *)(dmeta.u64() + num_oracles);
+    p.lo = (const uint64_t *const *)(dmeta.u64() + 2 * num_oracles);
     p.out = d_out;
-    p.coef = dcoef.u64();
+    p.coef = dmeta.u64() + 3 * num_oracles;
     p.n = (size_t)1 << log_n; p.num_oracles = (int)num_oracles;
     { ProfScope ps_("k_ldt_combine_fp", (num_oracles + 1) * p.n * 24); hipLaunchKernelGGL(k_ldt_combine_fp, dim3(ldt_grid(p.n)), dim3(256), 0, stream(), p); }
     IOPX_HIP(hipGetLastError());
