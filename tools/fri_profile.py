@@ -1,5 +1,6 @@
-import sys, time, json
-sys.path.insert(0, '/root/repo')
+"""Per-kernel profile of the FRI-only SNARK (BASELINE configs[2]: degree 2^20 on the 2^22-point domain over GF(2^192)) through iopx_fri_snark_prove on cuda:0."""
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np, libiop_amd
 from libiop_amd import domains, r1cs
 lib = libiop_amd.lib(); lib.init(0); lib.set_stream(torch.cuda.current_stream().cuda_stream)
