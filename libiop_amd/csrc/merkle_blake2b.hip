@@ -363,11 +363,14 @@ static int merkle_blake2b_impl(const void *const *d_oracles, size_t num_oracles,
     size_t grid = (L + 255) / 256;
     if (grid > 65536) grid = 65536;
     {
-        ProfScope ps_("k_merkle_leaves", num_oracles * n * elem_bytes + L * 32);
         // the fixed-shape kernel where it applies (IOPX_MERKLE_FIXED=0: the general one everywhere, for A/B runs and tests of the general path)
         static const bool fixed_ok = [] { const char *e = getenv("IOPX_MERKLE_FIXED"); return !(e && e[0] == '0'); }();
-        bool fixed = fixed_ok && elem_bytes == 24 && !d_salts && num_oracles <= 4 && ((uintptr_t)d_nodes & 15) == 0;
+        bool fixed = fixed_ok && elem_bytes == 24 && !d_salts && num_oracles <= 4 && (coset_size == 2 || coset_size == 4) && ((uintptr_t)d_nodes & 15) == 0;
         for (size_t k = 0; fixed && p.additive && k < num_oracles; ++k) fixed = ((uintptr_t)d_oracles[k] & 15) == 0;
+        // profile names per shape (oracles x coset size), as tools/make_traffic_json.py derives them from the kernel symbols
+        static const char *const shape_names[4][2] = { { "k_merkle_leaves_1x2", "k_merkle_leaves_1x4" }, { "k_merkle_leaves_2x2", "k_merkle_leaves_2x4" },
+                                                      { "k_merkle_leaves_3x2", "k_merkle_leaves_3x4" }, { "k_merkle_leaves_4x2", "k_merkle_leaves_4x4" } };
+        ProfScope ps_(fixed ? shape_names[num_oracles - 1][coset_size == 4] : "k_merkle_leaves", num_oracles * n * elem_bytes + L * 32);
         if (fixed) {
             switch (num_oracles) {
                 case 1: fixed = launch_leaves_sub24<1>(p, coset_size, (unsigned)grid); break;

@@ -65,6 +65,10 @@ def profile_name(symbol):
         first = "1" if targ in ("true", "1", "(bool)1") else ("0" if targ in ("false", "0", "(bool)0") else None)
     if name in ("k_bfly_upper", "k_bfly_edge", "k_phase1"):
         return name + ("_inv" if first == "1" else "_fwd")
+    if name == "k_merkle_leaves_sub24":                                        # template arguments: oracles, coset size (, position map)
+        m = re.search(r"k_merkle_leaves_sub24ILi(\d+)ELi(\d+)E", sym) or re.search(r"k_merkle_leaves_sub24<(\d+),\s*(\d+)", sym)
+        if m:
+            return "k_merkle_leaves_%sx%s" % (m.group(1), m.group(2))
     if name in ("k_fri_fold_fused", "k_fri_fold_fused_mul"):                  # template argument: the localization parameter
         m = re.search(r"%sILi(\d+)E" % name, sym) or re.search(r"%s<(\d+)>" % name, sym)
         if m:
