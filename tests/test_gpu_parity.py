@@ -135,7 +135,7 @@ def test_fri_chain_cfg3_shape_small(gpu):
 
 
 @pytest.mark.parametrize("additive", [True, False])
-@pytest.mark.parametrize("r,cs,L", [(1, 1, 2), (1, 2, 16), (4, 2, 64), (1, 4, 32), (12, 2, 8), (2, 8, 4), (4, 2, 1 << 15), (1, 2, 1 << 17)])
+@pytest.mark.parametrize("r,cs,L", [(1, 1, 2), (1, 2, 16), (4, 2, 64), (1, 4, 32), (12, 2, 8), (2, 8, 4), (4, 2, 1 << 15), (1, 2, 1 << 17), (2, 2, 128), (2, 4, 1 << 12), (3, 4, 32), (4, 4, 256), (3, 2, 1 << 14), (5, 2, 16)])
 def test_merkle(gpu, additive, r, cs, L):
     n = L * cs
     oracles = [rand_elems(700 + k, n, W) for k in range(r)]

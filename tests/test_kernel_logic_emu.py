@@ -117,7 +117,7 @@ def test_fri_fold_x_in_domain():
 
 
 @pytest.mark.parametrize("additive", [True, False])
-@pytest.mark.parametrize("r,cs,L", [(1, 1, 2), (1, 2, 16), (4, 2, 64), (1, 4, 32), (12, 2, 8), (2, 8, 4), (3, 2, 4096)])
+@pytest.mark.parametrize("r,cs,L", [(1, 1, 2), (1, 2, 16), (4, 2, 64), (1, 4, 32), (12, 2, 8), (2, 8, 4), (3, 2, 4096), (2, 2, 128), (2, 4, 64), (3, 4, 32), (4, 4, 256), (5, 2, 16)])
 def test_merkle(additive, r, cs, L):
     n = L * cs
     oracles = [rand_elems(700 + k, n, W) for k in range(r)]
