@@ -45,6 +45,42 @@ struct DivParams {
 // other child's inverse).  A lane then pays 4 products per element plus ~26 for the tree, instead of an exponentiation of its own (~270
 // products over F_p): the inversion stops dominating when a lane's chain is short (n <= 2^22).  Written over logical lanes (lane = threadIdx.x,
 // + blockDim.x, ...) so that any block size runs the same arithmetic.
+// a^-1 in GF(2)[x] / (x^192 + x^7 + x^2 + x + 1) for a != 0 by the binary extended Euclidean algorithm on polynomials (u, v, g1, g2 with
+// g1 a = u, g2 a = v mod f; the higher-degree one absorbs a shifted copy of the other until u = 1): at most 2 * 192 shift-and-XOR steps on
+// four-word values — for the ONE lane that inverts a workgroup's root, instead of the 191 squarings + 13 products of gf_inv.
+__device__ inline gf192 gf_inv_euclid(const gf192 &a)
+{
+    uint64_t u[4] = { (uint64_t)a.w[0] | ((uint64_t)a.w[1] << 32), (uint64_t)a.w[2] | ((uint64_t)a.w[3] << 32), (uint64_t)a.w[4] | ((uint64_t)a.w[5] << 32), 0 };
+    uint64_t v[4] = { 0x87, 0, 0, 1 }, g1[4] = { 1, 0, 0, 0 }, g2[4] = { 0, 0, 0, 0 };
+    auto degree = [](const uint64_t (&x)[4]) -> int {
+        for (int k = 3; k >= 0; --k) if (x[k]) return 64 * k + 63 - __builtin_clzll(x[k]);
+        return -1;
+    };
+    auto xor_shifted = [](uint64_t (&x)[4], const uint64_t (&y)[4], int j) {          // x ^= y << j
+        const int ws = j >> 6, bs = j & 63;
+        for (int k = 3; k >= ws; --k) {
+            uint64_t t = y[k - ws] << bs;
+            if (bs && k - ws - 1 >= 0) t |= y[k - ws - 1] >> (64 - bs);
+            x[k] ^= t;
+        }
+    };
+    int du = degree(u), dv = 192;
+    while (du > 0) {
+        int j = du - dv;
+        if (j < 0) {
+            for (int k = 0; k < 4; ++k) { const uint64_t t = u[k]; u[k] = v[k]; v[k] = t; const uint64_t s = g1[k]; g1[k] = g2[k]; g2[k] = s; }
+            const int t = du; du = dv; dv = t;
+            j = -j;
+        }
+        xor_shifted(u, v, j);
+        xor_shifted(g1, g2, j);
+        du = degree(u);
+    }
+    gf192 r;
+    r.w[0] = (uint32_t)g1[0]; r.w[1] = (uint32_t)(g1[0] >> 32); r.w[2] = (uint32_t)g1[1]; r.w[3] = (uint32_t)(g1[1] >> 32); r.w[4] = (uint32_t)g1[2]; r.w[5] = (uint32_t)(g1[2] >> 32);
+    return r;
+}
+
 static constexpr unsigned DIV_LANES = 256, DIV_TREE_NODES = 2 * DIV_LANES - 1;
 __device__ __forceinline__ unsigned div_level_base(int l) { return 2 * DIV_LANES - ((2 * DIV_LANES) >> l); }
 
@@ -71,7 +107,7 @@ __global__ void __launch_bounds__(256) k_div_gf192(DivParams p)
         for (unsigned i = threadIdx.x; i < cnt; i += blockDim.x) gf_store(tree, base + i, gf_mul(gf_load(tree, below + 2 * i), gf_load(tree, below + 2 * i + 1)));
         __syncthreads();
     }
-    if (threadIdx.x == 0) gf_store(tree, DIV_TREE_NODES - 1, gf_inv(gf_load(tree, DIV_TREE_NODES - 1)));
+    if (threadIdx.x == 0) gf_store(tree, DIV_TREE_NODES - 1, gf_inv_euclid(gf_load(tree, DIV_TREE_NODES - 1)));
     __syncthreads();
     for (int l = 8; l >= 1; --l) {
         const unsigned cnt = DIV_LANES >> l, base = div_level_base(l), below = div_level_base(l - 1);
