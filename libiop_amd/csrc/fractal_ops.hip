@@ -50,34 +50,38 @@ struct DivParams {
 // four-word values — for the ONE lane that inverts a workgroup's root, instead of the 191 squarings + 13 products of gf_inv.
 __device__ inline gf192 gf_inv_euclid(const gf192 &a)
 {
-    uint64_t u[4] = { (uint64_t)a.w[0] | ((uint64_t)a.w[1] << 32), (uint64_t)a.w[2] | ((uint64_t)a.w[3] << 32), (uint64_t)a.w[4] | ((uint64_t)a.w[5] << 32), 0 };
-    uint64_t v[4] = { 0x87, 0, 0, 1 }, g1[4] = { 1, 0, 0, 0 }, g2[4] = { 0, 0, 0, 0 };
-    auto degree = [](const uint64_t (&x)[4]) -> int {
-        for (int k = 3; k >= 0; --k) if (x[k]) return 64 * k + 63 - __builtin_clzll(x[k]);
-        return -1;
-    };
-    auto xor_shifted = [](uint64_t (&x)[4], const uint64_t (&y)[4], int j) {          // x ^= y << j
-        const int ws = j >> 6, bs = j & 63;
-        for (int k = 3; k >= ws; --k) {
-            uint64_t t = y[k - ws] << bs;
-            if (bs && k - ws - 1 >= 0) t |= y[k - ws - 1] >> (64 - bs);
-            x[k] ^= t;
-        }
-    };
-    int du = degree(u), dv = 192;
+    // scalars, not arrays: a dynamically indexed local array would live in scratch memory
+    uint64_t u0 = (uint64_t)a.w[0] | ((uint64_t)a.w[1] << 32), u1 = (uint64_t)a.w[2] | ((uint64_t)a.w[3] << 32), u2 = (uint64_t)a.w[4] | ((uint64_t)a.w[5] << 32), u3 = 0;
+    uint64_t v0 = 0x87, v1 = 0, v2 = 0, v3 = 1, g0 = 1, g1 = 0, g2 = 0, g3 = 0, h0 = 0, h1 = 0, h2 = 0, h3 = 0;      // g a = u, h a = v (mod f)
+#define IOPX_DEG(x0, x1, x2, x3) ((x3) ? 255 - __builtin_clzll(x3) : ((x2) ? 191 - __builtin_clzll(x2) : ((x1) ? 127 - __builtin_clzll(x1) : ((x0) ? 63 - __builtin_clzll(x0) : -1))))
+#define IOPX_XOR_SHIFTED(x0, x1, x2, x3, y0, y1, y2, y3, j)                                                     \
+    {                                                                                                           \
+        const int bs_ = (j) & 63, ws_ = (j) >> 6;                                                               \
+        uint64_t t0_ = y0, t1_ = y1, t2_ = y2, t3_ = y3;                                                        \
+        if (bs_) { t3_ = (y3 << bs_) | (y2 >> (64 - bs_)); t2_ = (y2 << bs_) | (y1 >> (64 - bs_)); t1_ = (y1 << bs_) | (y0 >> (64 - bs_)); t0_ = y0 << bs_; } \
+        if (ws_ == 0) { x0 ^= t0_; x1 ^= t1_; x2 ^= t2_; x3 ^= t3_; }                                           \
+        else if (ws_ == 1) { x1 ^= t0_; x2 ^= t1_; x3 ^= t2_; }                                                 \
+        else if (ws_ == 2) { x2 ^= t0_; x3 ^= t1_; }                                                            \
+        else { x3 ^= t0_; }                                                                                     \
+    }
+    int du = IOPX_DEG(u0, u1, u2, u3), dv = 192;
     while (du > 0) {
         int j = du - dv;
         if (j < 0) {
-            for (int k = 0; k < 4; ++k) { const uint64_t t = u[k]; u[k] = v[k]; v[k] = t; const uint64_t s = g1[k]; g1[k] = g2[k]; g2[k] = s; }
-            const int t = du; du = dv; dv = t;
+            uint64_t t;
+            t = u0; u0 = v0; v0 = t; t = u1; u1 = v1; v1 = t; t = u2; u2 = v2; v2 = t; t = u3; u3 = v3; v3 = t;
+            t = g0; g0 = h0; h0 = t; t = g1; g1 = h1; h1 = t; t = g2; g2 = h2; h2 = t; t = g3; g3 = h3; h3 = t;
+            const int d = du; du = dv; dv = d;
             j = -j;
         }
-        xor_shifted(u, v, j);
-        xor_shifted(g1, g2, j);
-        du = degree(u);
+        IOPX_XOR_SHIFTED(u0, u1, u2, u3, v0, v1, v2, v3, j)
+        IOPX_XOR_SHIFTED(g0, g1, g2, g3, h0, h1, h2, h3, j)
+        du = IOPX_DEG(u0, u1, u2, u3);
     }
+#undef IOPX_DEG
+#undef IOPX_XOR_SHIFTED
     gf192 r;
-    r.w[0] = (uint32_t)g1[0]; r.w[1] = (uint32_t)(g1[0] >> 32); r.w[2] = (uint32_t)g1[1]; r.w[3] = (uint32_t)(g1[1] >> 32); r.w[4] = (uint32_t)g1[2]; r.w[5] = (uint32_t)(g1[2] >> 32);
+    r.w[0] = (uint32_t)g0; r.w[1] = (uint32_t)(g0 >> 32); r.w[2] = (uint32_t)g1; r.w[3] = (uint32_t)(g1 >> 32); r.w[4] = (uint32_t)g2; r.w[5] = (uint32_t)(g2 >> 32);
     return r;
 }
 
