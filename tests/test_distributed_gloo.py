@@ -457,6 +457,70 @@ def test_native_sharded_fractal_prover_equals_oracle(world, field_code, log_n, n
         assert ret[r][0] == ref, "rank %d" % r
 
 
+def _bad_witness_instance(lib, field_code, log_n, k, seed):
+    """The seeded constraint system with one auxiliary variable changed (Az * Bz != Cz): an instance handle built through iopx_aurora_instance_create."""
+    import torch
+    import head_cases as hc
+    from libiop_amd import domains, r1cs
+    field = domains.GF192() if field_code == 0 else domains.EdwardsFr()
+    ops = domains.DeviceOps(lib, torch, torch.device("cpu"), field)
+    n = 1 << log_n
+    cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, n, k, n - 1, seed)
+    z = np.concatenate([np.asarray(primary, dtype=np.uint64).reshape(-1, 3), np.asarray(auxiliary, dtype=np.uint64).reshape(-1, 3)])
+    z[k + 5] = z[k + 6]
+    return lib.aurora_instance(field_code, [hc.csr(ops, M) for M in (cs.A, cs.B, cs.C)], n - 1, k, z)
+
+
+def _bad_witness_worker(rank, world, port, ret, field_code, log_n):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from emu_lib import emu
+        lib = emu()
+        comm = lib.comm_create_torch_callbacks(dist, rank, world)
+        inst = _bad_witness_instance(lib, field_code, log_n, 15, 0x2204)
+        try:
+            lib.profile_begin()
+            t = lib.aurora_prove_dist(inst, comm, 128, 5, 2)
+            prof = lib.profile_report()
+            ret[rank] = (t, sum(v[0] for k, v in prof.items() if k.startswith("k_ldt_combine")))
+        finally:
+            lib.aurora_instance_free(inst)
+            lib.comm_destroy(comm)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,field_code,log_n", [(2, 0, 8), (4, 0, 9), (2, 1, 9)])
+def test_native_sharded_unsatisfied_witness_takes_the_reference_schedule_on_every_rank(world, field_code, log_n, monkeypatch):
+    """An unsatisfied witness over the ranks: the confirmation window's mismatch count is all-reduced, so EVERY rank discards the head schedule's f_1 and
+    proves by the reference's schedule — the bytes of the single-process prover run with IOPX_HEAD_EVAL=0."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    from emu_lib import emu
+    lib = emu()
+    monkeypatch.setenv("IOPX_HEAD_EVAL", "0")
+    inst = _bad_witness_instance(lib, field_code, log_n, 15, 0x2204)
+    try:
+        expected = lib.aurora_prove(inst)
+    finally:
+        lib.aurora_instance_free(inst)
+    monkeypatch.delenv("IOPX_HEAD_EVAL")
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bad_witness_worker, args=(world, _free_port(), ret, field_code, log_n), nprocs=world, join=True)
+    for r in range(world):
+        assert ret[r][0] == expected, "rank %d" % r
+    # the whole-domain combination ran on every rank after the head (rank 0) and the confirmation window (its owner)
+    assert all(ret[r][1] >= 1 for r in range(world)) and sum(ret[r][1] for r in range(world)) == world + 2, dict((r, ret[r][1]) for r in range(world))
+
+
 # ---- phase 1 of the replicated transforms split over the ranks (iopx_comm_bind_transforms; fft_add.hip run_phase1) ----
 P1_SHARD_ENV = {"IOPX_P1_SHARD_MIN_D": "6", "IOPX_TILE_BITS": "5", "IOPX_P1_COLS": "2", "IOPX_P2_COLS": "2", "IOPX_P2_TOP": "2"}
 
