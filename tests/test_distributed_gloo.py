@@ -433,7 +433,7 @@ def test_native_sharded_aurora_prover_equals_oracle(world, log_n, rs_extra):
         assert ret[r][2][0] > 0, "no collective was issued"
 
 
-@pytest.mark.parametrize("world,log_n", [(2, 9), (4, 10)])
+@pytest.mark.parametrize("world,log_n", [(2, 9), (4, 10), (8, 9)])
 def test_native_sharded_aurora_prover_over_the_prime_field_equals_oracle(world, log_n):
     """181-bit field, residue classes (leaf digests exchanged by all-to-all)."""
     import oracle
@@ -445,7 +445,7 @@ def test_native_sharded_aurora_prover_over_the_prime_field_equals_oracle(world, 
         assert ret[r][0] == ref, "rank %d" % r
 
 
-@pytest.mark.parametrize("world,field_code,log_n,num_inputs", [(2, 0, 6, 15), (4, 0, 7, 15), (8, 0, 7, 15), (2, 1, 7, 0), (4, 1, 8, 15)])
+@pytest.mark.parametrize("world,field_code,log_n,num_inputs", [(2, 0, 6, 15), (4, 0, 7, 15), (8, 0, 7, 15), (2, 1, 7, 0), (4, 1, 8, 15), (8, 1, 8, 0)])
 def test_native_sharded_fractal_prover_equals_oracle(world, field_code, log_n, num_inputs):
     import oracle
     mgr = mp.Manager()
