@@ -115,6 +115,13 @@ int iopx_add_reextend_lde_gf192_batch_dev(const uint64_t *d_evals, size_t batch,
                                           const uint64_t *basis, size_t m, size_t d_dim, const uint64_t *eval_shift, const uint64_t *shift,
                                           size_t coset_begin, size_t coset_count, uint64_t *const *d_outs);
 
+/* Two groups of evaluation vectors over cosets of span(basis[0..d_dim)) with different shifts, re-extended in one batch (group a's codewords first
+ * in d_outs, then group b's): what iopx_add_reextend_gf192_batch_dev does per group, with the forward passes — and the last pass up to four vectors share —
+ * run over all of them.  The Aurora prover's round 1: f_Az, f_Bz, f_Cz over H together with f_w over the first coset of V inside L. */
+int iopx_add_reextend2_gf192_batch_dev(const uint64_t *d_evals_a, size_t batch_a, const uint64_t *eval_shift_a, const uint64_t *d_evals_b, size_t batch_b,
+                                       const uint64_t *eval_shift_b, const uint64_t *basis, size_t m, size_t d_dim, const uint64_t *shift,
+                                       size_t coset_begin, size_t coset_count, uint64_t *const *d_outs);
+
 /* Building blocks of ONE transform sharded across GPUs (libiop_amd/dist.py).  The top log2(N) levels of
  * additive_FFT touch index bits that live on different GPUs; dist.py runs them with these calls plus peer exchanges.
  *   iopx_add_taylor_gf192_dev   in place: S[i] *= d_twist[i] (optional), then the Taylor-expansion network of one

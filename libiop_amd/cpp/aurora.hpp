@@ -92,6 +92,29 @@ std::vector<device_vector<FieldT>> reextend_packed(const device_vector<FieldT> &
     return outs;
 }
 
+// reextend_packed(a, batch_a, Ha, L) followed by reextend_packed(b, batch_b, Hb, L) in one call, when Ha and Hb are cosets of the same span of L's first
+// basis vectors (iopx_add_reextend2_gf192_batch_dev: the forward passes and the shared last pass run over all the vectors); the separate calls otherwise.
+template<typename FieldT>
+std::vector<device_vector<FieldT>> reextend2_packed(const device_vector<FieldT> &a, std::size_t batch_a, const field_subset<FieldT> &Ha, const device_vector<FieldT> &b,
+                                                    std::size_t batch_b, const field_subset<FieldT> &Hb, const field_subset<FieldT> &L)
+{
+    std::vector<device_vector<FieldT>> outs;
+    bool together = additive(L) && additive(Ha) && additive(Hb) && Ha.dimension() == Hb.dimension() && Ha.dimension() > 0 && Ha.dimension() <= L.dimension();
+    for (std::size_t i = 0; together && i < Ha.dimension(); ++i)
+        together = std::memcmp(&Ha.basis()[i], &L.basis()[i], sizeof(FieldT)) == 0 && std::memcmp(&Hb.basis()[i], &L.basis()[i], sizeof(FieldT)) == 0;
+    if (!together) {
+        outs = reextend_packed<FieldT>(a, batch_a, Ha, L);
+        for (auto &cw : reextend_packed<FieldT>(b, batch_b, Hb, L)) outs.push_back(cw);
+        return outs;
+    }
+    const auto range = dist::coset_range(L, Ha.dimension());
+    std::vector<uint64_t *> ptrs;
+    for (std::size_t k = 0; k < batch_a + batch_b; ++k) { outs.emplace_back(range.second << Ha.dimension()); ptrs.push_back(outs.back().words()); }
+    check(iopx_add_reextend2_gf192_batch_dev(a.words(), batch_a, shift_words(Ha), b.words(), batch_b, shift_words(Hb), basis_words(L), L.dimension(), Ha.dimension(),
+                                             shift_words(L), range.first, range.second, ptrs.data()));
+    return outs;
+}
+
 // { FFT_over_field_subset(poly, L) } followed by reextend_packed(packed, batch, H, L): one call when H is spanned by the first basis vectors
 // of L and the polynomial has at most |H| coefficients (iopx_add_reextend_lde_gf192_batch_dev: the transforms share their last passes),
 // the separate calls otherwise.  Same field elements either way.
@@ -788,8 +811,14 @@ public:
             const device_vector<FieldT> fw_V0(V0.num_elements());                            // Z_I is constant on the cosets of I: one product per element
             check(iopx_div_by_vanishing_gf192_dev(fw_prime_V0.words(), dev::basis_words(V0), V0.dimension(), dev::shift_words(V0), I_.dimension(), dev::shift_words(I_),
                                                   fw_V0.words()));
-            codewords.push_back(dev::reextend_packed<FieldT>(fw_V0, 1, V0, L_, true)[0]);
-            for (auto &cw : dev::reextend_packed<FieldT>(Mz, 3, C_, L_)) codewords.push_back(cw);
+            if (V0.dimension() == C_.dimension() && std::getenv("IOPX_FW_SEPARATE") == nullptr) {
+                // one batch of four: at the pair bits where three polynomials leave a wavefront a quarter empty, four fill it
+                const std::vector<device_vector<FieldT>> four = dev::reextend2_packed<FieldT>(Mz, 3, C_, fw_V0, 1, V0, L_);
+                codewords = { four[3], four[0], four[1], four[2] };
+            } else {
+                codewords.push_back(dev::reextend_packed<FieldT>(fw_V0, 1, V0, L_, true)[0]);
+                for (auto &cw : dev::reextend_packed<FieldT>(Mz, 3, C_, L_)) codewords.push_back(cw);
+            }
         } else {
             const device_vector<FieldT> fw_prime = dev::IFFT<FieldT>(fw_prime_evals, V_);                                                    // :551-555
             const device_vector<FieldT> fw = dev::poly_div_vanishing<FieldT>(fw_prime, V_.num_elements(), I_);                               // :563-565

@@ -1712,6 +1712,53 @@ int iopx_add_reextend_lde_gf192_batch_dev(const uint64_t *d_evals, size_t batch,
     return IOPX_OK;
 }
 
+// Two groups of evaluation vectors over cosets of the same span with different shifts (f_Az, f_Bz, f_Cz over H and f_w over the first coset of
+// V inside L), re-extended in ONE batch: each group's butterflies are undone with its own shift terms, the forward passes — and the last pass that up
+// to four vectors share — run over all of them.  Outputs: group a's codewords first, then group b's; bit for bit the separate calls'.
+int iopx_add_reextend2_gf192_batch_dev(const uint64_t *d_evals_a, size_t batch_a, const uint64_t *eval_shift_a, const uint64_t *d_evals_b, size_t batch_b,
+                                       const uint64_t *eval_shift_b, const uint64_t *basis, size_t m, size_t d_dim, const uint64_t *shift,
+                                       size_t coset_begin, size_t coset_count, uint64_t *const *d_outs)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    rc = check_basis_args(basis, m, shift);
+    if (rc != IOPX_OK) return rc;
+    if (!d_evals_a || !d_evals_b || !d_outs || !eval_shift_a || !eval_shift_b) return fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
+    if (batch_a == 0 || batch_b == 0 || batch_a + batch_b > 65535) return fail(IOPX_ERR_INVALID_ARGUMENT, "batch sizes %zu + %zu outside 1..65535", batch_a, batch_b);
+    if (d_dim == 0 || d_dim > m) return fail(IOPX_ERR_INVALID_ARGUMENT, "the evaluation domains must be spanned by the first basis vectors of the codeword domain");
+    const size_t total = batch_a + batch_b;
+    for (size_t k = 0; k < total; ++k) if (!d_outs[k]) return fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
+    const int d = (int)d_dim, nhi = (int)m - d;
+    const size_t all_cosets = (size_t)1 << nhi, nd = (size_t)1 << d;
+    if (coset_count == 0 || coset_begin >= all_cosets || coset_count > all_cosets - coset_begin)
+        return fail(IOPX_ERR_INVALID_ARGUMENT, "coset range [%zu, +%zu) outside the %zu cosets of the transform", coset_begin, coset_count, all_cosets);
+    AddPlan *pl = nullptr;
+    rc = get_plan(basis, d, &pl);
+    if (rc != IOPX_OK) return rc;
+    TmpBuf work;
+    rc = work.alloc(total * nd * 24);
+    if (rc != IOPX_OK) return rc;
+    rc = upload_rs(*pl, hgf192::from_words(eval_shift_a), nullptr, 0);
+    if (rc != IOPX_OK) return rc;
+    rc = run_phase2<true>(*pl, d_evals_a, work.u64(), 0, 0, batch_a);
+    if (rc != IOPX_OK) return rc;
+    rc = upload_rs(*pl, hgf192::from_words(eval_shift_b), nullptr, 0);            // stream-ordered (or another cached table): after group a's inverse passes
+    if (rc != IOPX_OK) return rc;
+    rc = run_phase2<true>(*pl, d_evals_b, work.u64() + 3 * batch_a * nd, 0, 0, batch_b);
+    if (rc != IOPX_OK) return rc;
+    rc = upload_rs(*pl, hgf192::from_words(shift), basis + 3 * (size_t)d, nhi);
+    if (rc != IOPX_OK) return rc;
+    for (size_t k0 = 0; k0 < total; k0 += 4) {               // groups of up to four share the last pass
+        const size_t nb = total - k0 < 4 ? total - k0 : 4;
+        const uint64_t *srcs[4];
+        uint64_t *dsts[4];
+        for (size_t k = 0; k < nb; ++k) { srcs[k] = work.u64() + 3 * (k0 + k) * nd; dsts[k] = d_outs[k0 + k]; }
+        rc = run_phase2_fwd_batch(*pl, srcs, dsts, nb, nhi, coset_begin, coset_count);
+        if (rc != IOPX_OK) return rc;
+    }
+    return IOPX_OK;
+}
+
 int iopx_add_fft_gf192(const uint64_t *coeffs, size_t n_coeffs, const uint64_t *basis, size_t m,
                        const uint64_t *shift, uint64_t *out)
 {
