@@ -908,6 +908,16 @@ class Library:
         self._check(self.c.iopx_add_reextend_gf192_batch_dev(_vp(d_evals), int(batch), basis.ctypes.data_as(_u64p), basis.shape[0], int(d_dim),
                                                              es.ctypes.data_as(_u64p), shift.ctypes.data_as(_u64p), int(coset_begin), int(coset_count), cout))
 
+    def additive_reextend2_batch_dev(self, d_evals_a, batch_a, eval_shift_a, d_evals_b, batch_b, eval_shift_b, basis, d_dim, shift, coset_begin, coset_count, d_outs):
+        """additive_reextend_batch_dev for two groups of vectors over cosets of the same span with different shifts, in one batch: d_outs holds
+        group a's codewords first, then group b's."""
+        basis, shift, ea, eb = _as_u64(basis), _as_u64(shift), _as_u64(eval_shift_a), _as_u64(eval_shift_b)
+        self.c.iopx_add_reextend2_gf192_batch_dev.argtypes = [_vp, _sz, _u64p, _vp, _sz, _u64p, _u64p, _sz, _sz, _u64p, _sz, _sz, ctypes.POINTER(_vp)]
+        cout = (_vp * len(d_outs))(*d_outs)
+        self._check(self.c.iopx_add_reextend2_gf192_batch_dev(_vp(d_evals_a), int(batch_a), ea.ctypes.data_as(_u64p), _vp(d_evals_b), int(batch_b), eb.ctypes.data_as(_u64p),
+                                                              basis.ctypes.data_as(_u64p), basis.shape[0], int(d_dim), shift.ctypes.data_as(_u64p), int(coset_begin),
+                                                              int(coset_count), cout))
+
     def additive_reextend_lde_batch_dev(self, d_evals, batch, d_coeffs, n_coeffs, basis, d_dim, eval_shift, shift, coset_begin, coset_count, d_outs):
         """additive_reextend_batch_dev plus, in the same batch, the codewords of the polynomials at device pointers d_coeffs (n_coeffs
         coefficients each, at most 2^d_dim): d_outs holds the `batch` re-extensions first, then one codeword per polynomial."""

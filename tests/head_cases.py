@@ -113,3 +113,25 @@ def check_div_by_vanishing(lib, torch, device, m, sub_dim, seed):
     except ValueError:
         return
     raise AssertionError("a domain that contains S was accepted")
+
+
+def check_reextend2(lib, torch, device, m, d, batch_a, batch_b, seed, general=False):
+    """iopx_add_reextend2_gf192_batch_dev against the oracle's IFFT over each group's own coset followed by the FFT over the codeword domain, on a
+    coset range, for the standard basis (the prover's) and a random one."""
+    from helpers import rand_elems
+    field = domains.GF192()
+    ops = domains.DeviceOps(lib, torch, device, field)
+    basis = rand_elems(seed + 1, m, 3) if general else oracle.standard_basis(m, 3)
+    shift = rand_elems(seed + 2, 1, 3)[0] if general else np.array([1 << m, 0, 0], dtype=np.uint64)
+    shift_a, shift_b = np.zeros(3, dtype=np.uint64), shift.copy()                  # H itself and the first coset of its span inside L
+    nd, cosets = 1 << d, 1 << (m - d)
+    ev_a, ev_b = rand_elems(seed + 3, batch_a * nd, 3), rand_elems(seed + 4, batch_b * nd, 3)
+    first, count = (1, cosets - 1) if cosets > 2 else (0, cosets)
+    d_a, d_b = ops.upload(ev_a), ops.upload(ev_b)
+    outs = [ops.empty(count * nd) for _ in range(batch_a + batch_b)]
+    lib.additive_reextend2_batch_dev(d_a.data_ptr(), batch_a, shift_a, d_b.data_ptr(), batch_b, shift_b, basis, d, shift, first, count, [o.data_ptr() for o in outs])
+    for k in range(batch_a + batch_b):
+        ev, sh = (ev_a[k * nd:(k + 1) * nd], shift_a) if k < batch_a else (ev_b[(k - batch_a) * nd:(k - batch_a + 1) * nd], shift_b)
+        coeffs = oracle.additive_ifft(ev, basis[:d], sh)
+        full = oracle.additive_fft(coeffs, basis, shift)
+        assert np.array_equal(ops.download(outs[k]), full[first * nd:(first + count) * nd]), (m, d, k, general)

@@ -32,3 +32,8 @@ def test_unsatisfied_witness_is_proved_by_the_reference_schedule(gpu, field_name
 @pytest.mark.parametrize("m,sub_dim", [(10, 4), (16, 4), (14, 9)])
 def test_div_by_vanishing(gpu, m, sub_dim):
     hc.check_div_by_vanishing(gpu, torch, torch.device("cuda:0"), m, sub_dim, 60 + m)
+
+
+@pytest.mark.parametrize("m,d,batch_a,batch_b,general", [(16, 11, 3, 1, False), (17, 12, 3, 1, False), (13, 10, 2, 3, False), (14, 11, 3, 1, True)])
+def test_reextend_two_groups_in_one_batch(gpu, m, d, batch_a, batch_b, general):
+    hc.check_reextend2(gpu, torch, torch.device("cuda:0"), m, d, batch_a, batch_b, 70 + m, general)

@@ -32,6 +32,11 @@ def test_div_by_vanishing(m, sub_dim):
     hc.check_div_by_vanishing(emu_lib.emu(), torch, CPU, m, sub_dim, 40 + m)
 
 
+@pytest.mark.parametrize("m,d,batch_a,batch_b,general", [(8, 5, 3, 1, False), (9, 6, 1, 1, False), (7, 6, 2, 3, False), (8, 4, 3, 1, True)])
+def test_reextend_two_groups_in_one_batch(m, d, batch_a, batch_b, general):
+    hc.check_reextend2(emu_lib.emu(), torch, CPU, m, d, batch_a, batch_b, 90 + m, general)
+
+
 def test_instance_create_argument_checks():
     lib = emu_lib.emu()
     ops = domains.DeviceOps(lib, torch, CPU, domains.GF192())
