@@ -416,6 +416,11 @@ int iopx_pow_solve_blake2b(const uint8_t *challenge, size_t pow_bitlen, uint8_t 
  * with its last word set to i - 1; *found receives the smallest passing index in [first, first + count) or UINT64_MAX.
  * iopx_pow_candidate_blake2b writes the 32-byte answer of a candidate index (host only). */
 int iopx_pow_search_blake2b(const uint8_t *challenge, size_t pow_bitlen, uint64_t first, uint64_t count, uint64_t *found);
+/* ... in two halves: _begin enqueues the batch on the library's stream and returns, _end waits for it and reads the result.  Between the two the
+ * caller may do host work and enqueue further launches behind the grind — the BCS prover derives, gathers and reads back its query answers there
+ * (they do not depend on the proof-of-work answer, bcs_prover.tcc:52-59).  One pending search at a time. */
+int iopx_pow_search_blake2b_begin(const uint8_t *challenge, size_t pow_bitlen, uint64_t first, uint64_t count);
+int iopx_pow_search_blake2b_end(uint64_t *found);
 int iopx_pow_candidate_blake2b(const uint8_t *challenge, uint64_t index, uint8_t *pow);
 /* pow<FieldT, FieldT>::solve_pow (pow.tcc:73-84,129-141) with the Poseidon two-to-one hash over alt_bn128 Fr: the
  * smallest k >= 0 such that word 0 of two_to_one(challenge, FieldT(k)) (canonical integer) has its low pow_bitlen bits

@@ -22,6 +22,9 @@
 // dist::scope binds a communicator (iopx_comm, include/libiop_amd.h) for the calls of this host thread; without one the same code is the
 // single-GPU prover (rank 0 of 1, nothing marked).
 #pragma once
+#include <cstdlib>
+#include <algorithm>
+#include <functional>
 #include "device.hpp"
 
 namespace libiop_amd {
@@ -287,14 +290,38 @@ inline std::vector<std::size_t> membership_proof_node_indices(std::size_t num_le
 // pow::solve_pow (bcs/pow.tcc:67-103) split by candidate range: in super-batch s rank r searches candidates [(s N + r) B_s, (s N + r + 1) B_s);
 // a min all-reduce of the hits ends the search at the first super-batch that has one, and the minimum is the reference's first hit (the
 // candidates of earlier super-batches all failed).  32-byte challenge -> 32-byte answer.
-inline std::string solve_pow(const std::string &challenge, std::size_t pow_bitlen)
+// `behind_the_grind`: host work (and launches) that does not depend on the answer; on one GPU it runs between the enqueueing of the first long batch
+// and the wait for it, so the GPU grinds while the host prepares — and afterwards in every other case.
+inline std::string solve_pow(const std::string &challenge, std::size_t pow_bitlen, const std::function<void()> &behind_the_grind = nullptr)
 {
     const context &c = ctx();
     uint8_t answer[32];
+    const uint8_t *ch = reinterpret_cast<const uint8_t *>(challenge.data());
     if (!c.active() || c.world == 1) {
-        check(iopx_pow_solve_blake2b(reinterpret_cast<const uint8_t *>(challenge.data()), pow_bitlen, answer));
+        // iopx_pow_solve_blake2b's batches (2^16 candidates, then 16 x as many each time): the short ones are waited for as before
+        uint64_t found = ~(uint64_t)0, first = 0, batch = (uint64_t)1 << 16;
+        bool ran = false;
+        const char *knob = std::getenv("IOPX_POW_BEHIND_LOG2");         // batches of at least 2^this candidates take the work behind them (tests: 0)
+        const uint64_t long_batch = (uint64_t)1 << (knob ? std::min(40, std::max(0, std::atoi(knob))) : 22);
+        while (found == ~(uint64_t)0) {
+            if (behind_the_grind && !ran && batch >= long_batch) {
+                check(iopx_pow_search_blake2b_begin(ch, pow_bitlen, first, batch));
+                struct finish { bool armed = true; ~finish() { uint64_t ignored; if (armed) (void)iopx_pow_search_blake2b_end(&ignored); } } guard;
+                behind_the_grind();
+                ran = true;
+                guard.armed = false;
+                check(iopx_pow_search_blake2b_end(&found));
+            } else {
+                check(iopx_pow_search_blake2b(ch, pow_bitlen, first, batch, &found));
+            }
+            first += batch;
+            if (batch < ((uint64_t)1 << 28)) batch <<= 4;
+        }
+        if (behind_the_grind && !ran) behind_the_grind();
+        check(iopx_pow_candidate_blake2b(ch, found, answer));
         return std::string(reinterpret_cast<const char *>(answer), 32);
     }
+    if (behind_the_grind) behind_the_grind();
     const uint64_t none = ~(uint64_t)0;
     uint64_t first = 0, batch = (uint64_t)1 << 14;
     const device_array<uint64_t> d_hit(1);

@@ -606,7 +606,10 @@ private:
         run_hashchain_for_round(ended, num_roots);
         // bcs_prover.tcc:52-59; the indexer's one-round protocol registers no proof of work (bcs_common.tcc:426-431)
         if (num_prover_rounds_done_ == num_interaction_rounds_ && !(is_holographic_ && num_interaction_rounds_ == 1)) {
-            pow_answer_ = dist::solve_pow(hashchain_.squeeze_root_type(), pow_bitlen_);      // split by candidate range over the ranks
+            // The query phase (positions from the hashchain, gathers, one drain) does not depend on the answer: on one GPU it runs behind the grind's
+            // first long batch.  The challenge is squeezed first, the query positions after it: the hashchain's order is the reference's either way.
+            const std::string challenge = hashchain_.squeeze_root_type();
+            pow_answer_ = dist::solve_pow(challenge, pow_bitlen_, [this] { extracted_ = extract_queries(); have_extracted_ = true; });   // split by candidate range over the ranks
         }
     }
 public:
@@ -746,13 +749,22 @@ private:
         deferring = false;
         return x;
     }
+    extracted extracted_;
+    bool have_extracted_ = false;
+    // the query phase's results: computed behind the proof-of-work grind when the protocol has one, here otherwise (and again for a second transcript)
+    extracted take_extracted()
+    {
+        if (!have_extracted_) return extract_queries();
+        have_extracted_ = false;
+        return std::move(extracted_);
+    }
 public:
     bcs_transformation_transcript<FieldT> get_transcript()
     {
         bcs_transformation_transcript<FieldT> t;
         t.prover_messages_ = prover_messages_;
         t.MT_roots_ = MT_roots_;
-        extracted x = extract_queries();
+        extracted x = take_extracted();
         t.query_positions_ = std::move(x.query_positions);
         t.MT_leaf_positions_ = std::move(x.leaf_positions);
         for (std::size_t mt = 0; mt < MT_info_.size(); ++mt) {
@@ -775,7 +787,7 @@ public:
     // end of every proof that a caller who wants the bytes (the C ABI) does not need to pay
     std::string get_transcript_bytes()
     {
-        const extracted x = extract_queries();
+        const extracted x = take_extracted();
         std::string out;
         auto u64 = [&](uint64_t v) { out.append(reinterpret_cast<const char *>(&v), 8); };
         const std::size_t first_message = is_holographic_ ? num_prover_messages_at_end_of_round_[0] : 0, first_root = is_holographic_ ? num_index_trees() : 0;

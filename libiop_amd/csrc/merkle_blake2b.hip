@@ -461,30 +461,54 @@ int iopx_merkle_blake2b(const void *const *oracles, size_t num_oracles, size_t e
     return IOPX_OK;
 }
 
+// The search in two halves, so that the caller can put host work (and further launches) behind a long batch: _begin enqueues the batch on the
+// library's stream and returns, _end reads the result back (one pending search per host thread's library state).
+static TmpBuf g_pow_best;
+static bool g_pow_pending = false;
+
+int iopx_pow_search_blake2b_begin(const uint8_t *challenge, size_t pow_bitlen, uint64_t first, uint64_t count)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (!challenge) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (pow_bitlen > 30) return fail(IOPX_ERR_INVALID_ARGUMENT, "pow_bitlen %zu: the reference's `1 << pow_bitlen` is an int shift", pow_bitlen);
+    if (g_pow_pending) return fail(IOPX_ERR_LOGIC, "a proof-of-work search is already pending");
+    PowChallenge c;
+    memcpy(c.w, challenge, 32);
+    const uint64_t mask = ((uint64_t)1 << pow_bitlen) - 1;
+    if ((rc = g_pow_best.alloc(8)) != IOPX_OK) return rc;
+    const unsigned long long none = ~0ull;
+    if ((rc = upload(g_pow_best.p, &none, 8)) != IOPX_OK) return rc;
+    if (count) {
+        ProfScope ps_("k_pow_blake2b");
+        hipLaunchKernelGGL(k_pow_blake2b, dim3((unsigned)((count + 255) / 256 > 1536 ? 1536 : (count + 255) / 256)), dim3(256), 0, stream(),   // <= one resident set of workgroups (256 CUs x 6): the grid advances through the candidates together
+                           c, first, count, mask, (unsigned long long *)g_pow_best.p);
+    }
+    g_pow_pending = true;
+    return IOPX_OK;
+}
+
+int iopx_pow_search_blake2b_end(uint64_t *found)
+{
+    if (!found) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (!g_pow_pending) return fail(IOPX_ERR_LOGIC, "no proof-of-work search is pending");
+    g_pow_pending = false;
+    unsigned long long hit = ~0ull;
+    const int rc = download(&hit, g_pow_best.p, 8);
+    g_pow_best.release();
+    if (rc != IOPX_OK) return rc;
+    *found = hit;
+    return IOPX_OK;
+}
+
 // Candidates in the reference's order (pow.tcc:86-112): index 0 is the challenge itself, index i >= 1 the challenge with its last
 // 8-byte word set to i - 1.  Searches [first, first + count) and reports the smallest passing index, or ~0.
 int iopx_pow_search_blake2b(const uint8_t *challenge, size_t pow_bitlen, uint64_t first, uint64_t count, uint64_t *found)
 {
-    int rc = ensure_device();
+    if (!found) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    const int rc = iopx_pow_search_blake2b_begin(challenge, pow_bitlen, first, count);
     if (rc != IOPX_OK) return rc;
-    if (!challenge || !found) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
-    if (pow_bitlen > 30) return fail(IOPX_ERR_INVALID_ARGUMENT, "pow_bitlen %zu: the reference's `1 << pow_bitlen` is an int shift", pow_bitlen);
-    PowChallenge c;
-    memcpy(c.w, challenge, 32);
-    const uint64_t mask = ((uint64_t)1 << pow_bitlen) - 1;
-    TmpBuf best;
-    if ((rc = best.alloc(8)) != IOPX_OK) return rc;
-    const unsigned long long none = ~0ull;
-    if ((rc = upload(best.p, &none, 8)) != IOPX_OK) return rc;
-    unsigned long long hit = none;
-    if (count) {
-        { ProfScope ps_("k_pow_blake2b");
-          hipLaunchKernelGGL(k_pow_blake2b, dim3((unsigned)((count + 255) / 256 > 1536 ? 1536 : (count + 255) / 256)), dim3(256), 0, stream(),   // <= one resident set of workgroups (256 CUs x 6): the grid advances through the candidates together
-                             c, first, count, mask, (unsigned long long *)best.p); }
-        { int drc_ = download(&hit, best.p, 8); if (drc_ != IOPX_OK) return drc_; }
-    }
-    *found = hit;
-    return IOPX_OK;
+    return iopx_pow_search_blake2b_end(found);
 }
 
 // the 32-byte answer of candidate `index` (see iopx_pow_search_blake2b)

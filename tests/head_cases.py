@@ -135,3 +135,14 @@ def check_reextend2(lib, torch, device, m, d, batch_a, batch_b, seed, general=Fa
         coeffs = oracle.additive_ifft(ev, basis[:d], sh)
         full = oracle.additive_fft(coeffs, basis, shift)
         assert np.array_equal(ops.download(outs[k]), full[first * nd:(first + count) * nd]), (m, d, k, general)
+
+
+def check_query_phase_behind_the_grind(lib, monkeypatch, protocol, field_name, log_n, num_inputs):
+    code = ac.FIELDS[field_name][0]
+    seed = 0x2204 if protocol == "aurora" else 0x2205
+    ref = oracle.aurora_prove(code, log_n, num_inputs, seed) if protocol == "aurora" else oracle.fractal_prove(code, log_n, num_inputs, seed)[0]
+    monkeypatch.setenv("IOPX_POW_BEHIND_LOG2", "0")
+    behind = prove(lib, protocol, field_name, log_n, num_inputs, seed)[0]
+    monkeypatch.setenv("IOPX_POW_BEHIND_LOG2", "40")
+    after = prove(lib, protocol, field_name, log_n, num_inputs, seed)[0]
+    assert behind == ref and after == ref

@@ -37,3 +37,8 @@ def test_div_by_vanishing(gpu, m, sub_dim):
 @pytest.mark.parametrize("m,d,batch_a,batch_b,general", [(16, 11, 3, 1, False), (17, 12, 3, 1, False), (13, 10, 2, 3, False), (14, 11, 3, 1, True)])
 def test_reextend_two_groups_in_one_batch(gpu, m, d, batch_a, batch_b, general):
     hc.check_reextend2(gpu, torch, torch.device("cuda:0"), m, d, batch_a, batch_b, 70 + m, general)
+
+
+@pytest.mark.parametrize("protocol,field_name,log_n,num_inputs", [("aurora", "gf192", 12, 15), ("fractal", "edwards_Fr", 10, 0)])
+def test_query_phase_behind_the_grind(gpu, protocol, field_name, log_n, num_inputs, monkeypatch):
+    hc.check_query_phase_behind_the_grind(gpu, monkeypatch, protocol, field_name, log_n, num_inputs)

@@ -37,6 +37,13 @@ def test_reextend_two_groups_in_one_batch(m, d, batch_a, batch_b, general):
     hc.check_reextend2(emu_lib.emu(), torch, CPU, m, d, batch_a, batch_b, 90 + m, general)
 
 
+@pytest.mark.parametrize("protocol,field_name,log_n,num_inputs", [("aurora", "gf192", 8, 15), ("fractal", "edwards_Fr", 7, 0)])
+def test_query_phase_behind_the_grind(protocol, field_name, log_n, num_inputs, monkeypatch):
+    """The query phase enqueued behind the proof-of-work batch (IOPX_POW_BEHIND_LOG2=0: behind the very first batch, as the 2^20 proof does behind its
+    2^24-candidate batch) and after the grind (the default at test sizes, whose grinds end within the short batches): the same bytes."""
+    hc.check_query_phase_behind_the_grind(emu_lib.emu(), monkeypatch, protocol, field_name, log_n, num_inputs)
+
+
 def test_instance_create_argument_checks():
     lib = emu_lib.emu()
     ops = domains.DeviceOps(lib, torch, CPU, domains.GF192())
