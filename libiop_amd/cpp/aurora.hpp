@@ -1099,9 +1099,17 @@ public:
                                             params_.fri_query_repetitions_);
     }
     void register_queries() { LDT_reducer_->register_queries(); }
-    void produce_proof(const std::vector<FieldT> &primary_input, const std::vector<FieldT> &auxiliary_input, const device_vector<FieldT> *d_assignment = nullptr)   // :334-344
+    bool witness_submitted_ = false;
+    // produce_proof in two halves: the witness oracles' kernels are enqueued by the first (no host synchronisation), so that a caller may finish host-side
+    // set-up that the first round does not need — the query registrations — while the GPU works
+    void submit_witness(const std::vector<FieldT> &primary_input, const std::vector<FieldT> &auxiliary_input, const device_vector<FieldT> *d_assignment = nullptr)
     {
         protocol_->submit_witness_oracles(primary_input, auxiliary_input, d_assignment);
+        witness_submitted_ = true;
+    }
+    void produce_proof(const std::vector<FieldT> &primary_input, const std::vector<FieldT> &auxiliary_input, const device_vector<FieldT> *d_assignment = nullptr)   // :334-344
+    {
+        if (!witness_submitted_) protocol_->submit_witness_oracles(primary_input, auxiliary_input, d_assignment);
         IOP_.signal_prover_round_done();
         protocol_->calculate_and_submit_proof();
         IOP_.signal_prover_round_done();
@@ -1127,6 +1135,8 @@ auto run_aurora_prover(const r1cs_constraint_system<FieldT> &constraint_system, 
     full_protocol.register_interactions();
     IOP.seal_interaction_registrations();
     mark("interactions registered");
+    full_protocol.submit_witness(primary_input, auxiliary_input, d_assignment);     // round 1's kernels are in flight while the queries are registered
+    mark("witness oracles enqueued");
     full_protocol.register_queries();
     IOP.seal_query_registrations();
     mark("queries registered");

@@ -656,11 +656,19 @@ public:
         IOP_.signal_index_submissions_done();
         return over_K;
     }
-    void produce_proof(const std::vector<FieldT> &primary_input, const std::vector<FieldT> &auxiliary_input, const bcs_prover_index<FieldT> &index,
-                       const device_vector<FieldT> *d_assignment = nullptr)                  // :316-329, r1cs_rs_iop.tcc:618-627
+    // produce_proof in two halves (as aurora_iop's): the index and the witness oracles' kernels first, the query registrations while the GPU works
+    bool witness_submitted_ = false;
+    void submit_witness(const std::vector<FieldT> &primary_input, const std::vector<FieldT> &auxiliary_input, const bcs_prover_index<FieldT> &index,
+                        const device_vector<FieldT> *d_assignment = nullptr)
     {
         IOP_.submit_prover_index(index);
         protocol_->submit_witness_oracles(primary_input, auxiliary_input, d_assignment);
+        witness_submitted_ = true;
+    }
+    void produce_proof(const std::vector<FieldT> &primary_input, const std::vector<FieldT> &auxiliary_input, const bcs_prover_index<FieldT> &index,
+                       const device_vector<FieldT> *d_assignment = nullptr)                  // :316-329, r1cs_rs_iop.tcc:618-627
+    {
+        if (!witness_submitted_) submit_witness(primary_input, auxiliary_input, index, d_assignment);
         IOP_.signal_prover_round_done();
         lincheck_->calculate_response_alpha();
         IOP_.signal_prover_round_done();
@@ -715,6 +723,7 @@ std::string fractal_snark_prover_serialized(const bcs_prover_index<FieldT> &inde
     fractal_iop<FieldT> full_protocol(IOP, constraint_system, parameters, &index.index_evals_over_K);
     full_protocol.register_interactions();
     IOP.seal_interaction_registrations();
+    full_protocol.submit_witness(primary_input, auxiliary_input, index, d_assignment);      // round 1's kernels are in flight while the queries are registered
     full_protocol.register_queries();
     IOP.seal_query_registrations();
     full_protocol.produce_proof(primary_input, auxiliary_input, index, d_assignment);
