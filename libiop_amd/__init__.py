@@ -867,6 +867,18 @@ class Library:
         self._check(self.c.iopx_pow_search_blake2b(ctypes.addressof(ch), int(pow_bitlen), int(first), int(count), ctypes.byref(found)))
         return None if found.value == 0xFFFFFFFFFFFFFFFF else int(found.value)
 
+    def pow_search_begin(self, challenge, pow_bitlen, first, count):
+        """pow_search in two halves: enqueues the batch on the library's stream and returns; pow_search_end waits and reads the result."""
+        ch = (ctypes.c_uint8 * 32).from_buffer_copy(bytes(challenge))
+        self.c.iopx_pow_search_blake2b_begin.argtypes = [_vp, _sz, ctypes.c_uint64, ctypes.c_uint64]
+        self._check(self.c.iopx_pow_search_blake2b_begin(ctypes.addressof(ch), int(pow_bitlen), int(first), int(count)))
+
+    def pow_search_end(self):
+        found = ctypes.c_uint64(0)
+        self.c.iopx_pow_search_blake2b_end.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+        self._check(self.c.iopx_pow_search_blake2b_end(ctypes.byref(found)))
+        return None if found.value == 0xFFFFFFFFFFFFFFFF else int(found.value)
+
     def pow_candidate(self, challenge, index):
         ch = (ctypes.c_uint8 * 32).from_buffer_copy(bytes(challenge))
         out = (ctypes.c_uint8 * 32)()

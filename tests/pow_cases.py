@@ -54,3 +54,18 @@ def test_bitlen_rule():
     assert oracle.pow_bitlen(20, 200) == 13          # test_pow.cpp:41-44: floor(log2 200) = 7
     assert oracle.pow_bitlen(20 + 3 + 7, 128) == 23  # dim_h = 20, algebraic hash
     assert oracle.pow_bitlen(20 + 3 + 0, 1) == 23    # dim_h = 20, BLAKE2b
+
+
+def check_search_in_two_halves(lib):
+    """iopx_pow_search_blake2b_begin / _end: the same answer as the one-call search; misuse (a second begin, an end without a begin) is refused."""
+    import pytest
+    ch = bytes(range(32))
+    whole = lib.pow_search(ch, 9, 0, 1 << 14)
+    lib.pow_search_begin(ch, 9, 0, 1 << 14)
+    with pytest.raises(AssertionError):
+        lib.pow_search_begin(ch, 9, 0, 16)          # IOPX_ERR_LOGIC: one pending search at a time
+    assert lib.pow_search_end() == whole and whole is not None
+    with pytest.raises(AssertionError):
+        lib.pow_search_end()
+    lib.pow_search_begin(ch, 30, 5, 0)               # an empty range: nothing found
+    assert lib.pow_search_end() is None

@@ -342,6 +342,10 @@ def test_pow_errors(gpu):
     pw.check_errors(gpu)
 
 
+def test_pow_search_in_two_halves(gpu):
+    pw.check_search_in_two_halves(gpu)
+
+
 # ---- LDT reducer (ldt_reducer_aux.tcc:39-131) -----------------------------------------------------------------
 import ldt_cases as lc
 

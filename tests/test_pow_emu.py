@@ -24,3 +24,7 @@ def test_poseidon():
 
 def test_errors():
     pw.check_errors(emu())
+
+
+def test_search_in_two_halves():
+    pw.check_search_in_two_halves(emu())
