@@ -763,3 +763,93 @@ def fractal_index_oracle(field, log_constraints, num_inputs, seed, matrix, which
     if rc != 0:
         raise RuntimeError("oracle_fractal_index_oracle failed (%d)" % rc)
     return out
+
+
+# ---- general instances: CSR triples + the full assignment in, transcript out (oracle_capi.cpp "general instances") ----
+def _csr_args(field, matrices, num_variables, num_inputs):
+    """matrices: three (row_ptr, col, coeff) triples — A, B, C; coeff is (entries, words) uint64.  Returns (ctypes arguments, keep-alive list)."""
+    keep, rp, cl, cf = [], (_u64p * 3)(), (ctypes.POINTER(ctypes.c_uint32) * 3)(), (_u64p * 3)()
+    words = {FIELD_EDWARDS: 3, FIELD_GF64: 1, FIELD_GF192: 3}[field]
+    for q, (row_ptr, col, coeff) in enumerate(matrices):
+        a, b = np.ascontiguousarray(row_ptr, dtype=np.uint64), np.ascontiguousarray(col, dtype=np.uint32)
+        c = np.ascontiguousarray(coeff, dtype=np.uint64).reshape(-1, words)
+        assert c.shape[0] == b.shape[0] == int(a[-1]), "CSR arrays disagree"
+        keep += [a, b, c]
+        rp[q], cl[q], cf[q] = _p(a), b.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), _p(c)
+    sz = ctypes.c_size_t
+    n = len(matrices[0][0]) - 1
+    return [ctypes.c_int(field), sz(n), sz(num_variables), sz(num_inputs), rp, cl, cf], keep
+
+
+def aurora_prove_csr(field, matrices, num_variables, num_inputs, assignment, security=128, rs_extra=5, localization=2):
+    """Serialized transcript of aurora_snark_prover on the caller's constraint system; assignment = (num_variables, words), primary inputs first."""
+    l = lib()
+    l.oracle_aurora_prove_csr.restype = ctypes.c_long
+    args, keep = _csr_args(field, matrices, num_variables, num_inputs)
+    z = _c(assignment)
+    sz = ctypes.c_size_t
+    n = l.oracle_aurora_prove_csr(*args, _p(z), sz(security), sz(rs_extra), sz(localization))
+    if n < 0:
+        raise RuntimeError("oracle_aurora_prove_csr failed (%d)" % n)
+    buf = (ctypes.c_uint8 * n)()
+    l.oracle_aurora_fetch(buf)
+    return bytes(buf)
+
+
+def aurora_verify_csr(field, matrices, num_variables, num_inputs, primary_input, transcript, security=128, rs_extra=5, localization=2):
+    args, keep = _csr_args(field, matrices, num_variables, num_inputs)
+    prim = _c(primary_input) if num_inputs else np.zeros((1, 3), dtype=np.uint64)
+    buf = (ctypes.c_uint8 * len(transcript)).from_buffer_copy(bytes(transcript))
+    sz = ctypes.c_size_t
+    rc = lib().oracle_aurora_verify_csr(*args, _p(prim), sz(security), sz(rs_extra), sz(localization), buf, sz(len(transcript)))
+    if rc < 0:
+        raise RuntimeError("oracle_aurora_verify_csr failed (%d)" % rc)
+    return bool(rc)
+
+
+def fractal_prove_csr(field, matrices, num_variables, num_inputs, assignment, security=128, rs_extra=3, localization=2):
+    """(serialized transcript, index Merkle roots) of fractal_snark_indexer + fractal_snark_prover on the caller's constraint system."""
+    l = lib()
+    l.oracle_fractal_prove_csr.restype = ctypes.c_long
+    l.oracle_fractal_index_roots.restype = ctypes.c_long
+    args, keep = _csr_args(field, matrices, num_variables, num_inputs)
+    z = _c(assignment)
+    sz = ctypes.c_size_t
+    n = l.oracle_fractal_prove_csr(*args, _p(z), sz(security), sz(rs_extra), sz(localization))
+    if n < 0:
+        raise RuntimeError("oracle_fractal_prove_csr failed (%d)" % n)
+    buf = (ctypes.c_uint8 * n)()
+    l.oracle_aurora_fetch(buf)
+    k = l.oracle_fractal_index_roots(None)
+    roots = (ctypes.c_uint8 * (32 * k))()
+    l.oracle_fractal_index_roots(roots)
+    return bytes(buf), [bytes(roots[32 * i:32 * i + 32]) for i in range(k)]
+
+
+def fractal_verify_csr(field, matrices, num_variables, num_inputs, primary_input, transcript, index_roots, security=128, rs_extra=3, localization=2):
+    args, keep = _csr_args(field, matrices, num_variables, num_inputs)
+    prim = _c(primary_input) if num_inputs else np.zeros((1, 3), dtype=np.uint64)
+    buf = (ctypes.c_uint8 * len(transcript)).from_buffer_copy(bytes(transcript))
+    flat = b"".join(index_roots)
+    rbuf = (ctypes.c_uint8 * max(1, len(flat))).from_buffer_copy(flat if flat else b"\0")
+    sz = ctypes.c_size_t
+    rc = lib().oracle_fractal_verify_csr(*args, _p(prim), sz(security), sz(rs_extra), sz(localization), buf, sz(len(transcript)), rbuf, sz(len(index_roots)))
+    if rc < 0:
+        raise RuntimeError("oracle_fractal_verify_csr failed (%d)" % rc)
+    return bool(rc)
+
+
+def r1cs_check_csr(field, matrices, num_variables, num_inputs, assignment):
+    """(number of violated constraints, Az, Bz, Cz) for z = (1, assignment): r1cs_constraint_system::is_satisfied and
+    create_Az_Bz_Cz_from_variable_assignment."""
+    l = lib()
+    l.oracle_r1cs_check_csr.restype = ctypes.c_long
+    args, keep = _csr_args(field, matrices, num_variables, num_inputs)
+    words = {FIELD_EDWARDS: 3, FIELD_GF64: 1, FIELD_GF192: 3}[field]
+    n = len(matrices[0][0]) - 1
+    z = _c(assignment)
+    out = np.zeros((3, n, words), dtype=np.uint64)
+    bad = l.oracle_r1cs_check_csr(*args, _p(z), _p(out))
+    if bad < 0:
+        raise RuntimeError("oracle_r1cs_check_csr failed (%d)" % bad)
+    return int(bad), out[0], out[1], out[2]

@@ -737,6 +737,158 @@ int oracle_fractal_index_oracle(int field, size_t log_constraints, size_t num_in
     return -1;
 }
 
+} // extern "C"
+
+// ---- general instances: the constraint system as CSR triples (what a caller builds through r1cs_constraint_system::add_constraint,
+// relations/r1cs.tcc:151-160: a row is the linear combination's term LIST — repeated indices and index 0, the constant 1, allowed,
+// relations/variable.tcc:196-230) and the full variable assignment (primary inputs first).  Entry t of row i of matrix q is
+// (col[q][t], coeff[q][t * words]) for row_ptr[q][i] <= t < row_ptr[q][i + 1]. ----
+namespace {
+struct csr_view {
+    size_t num_constraints, num_variables, num_inputs;
+    const uint64_t *const *row_ptr;
+    const uint32_t *const *col;
+    const uint64_t *const *coeff;
+};
+template<typename F>
+r1cs_system<F> system_from_csr(const csr_view &v)
+{
+    r1cs_system<F> cs;
+    cs.num_inputs = v.num_inputs;
+    cs.num_variables = v.num_variables;
+    std::vector<typename r1cs_system<F>::row> *M[3] = { &cs.A, &cs.B, &cs.C };
+    for (int q = 0; q < 3; ++q) {
+        M[q]->resize(v.num_constraints);
+        for (size_t i = 0; i < v.num_constraints; ++i)
+            for (uint64_t t = v.row_ptr[q][i]; t < v.row_ptr[q][i + 1]; ++t) {
+                if (v.col[q][t] > v.num_variables) throw std::invalid_argument("column index exceeds the number of variables");
+                F c;
+                memcpy((void *)&c, (const uint8_t *)v.coeff[q] + t * sizeof(F), sizeof(F));
+                (*M[q])[i].push_back({ (size_t)v.col[q][t], c });
+            }
+    }
+    return cs;
+}
+template<typename F>
+std::vector<F> load_elements(const uint64_t *src, size_t count)
+{
+    std::vector<F> out(count);
+    if (count) memcpy((void *)out.data(), src, count * sizeof(F));
+    return out;
+}
+template<typename F>
+long aurora_prove_csr_impl(const csr_view &v, const uint64_t *assignment, size_t security, size_t rs_extra, size_t localization)
+{
+    const r1cs_system<F> cs = system_from_csr<F>(v);
+    const std::vector<F> z = load_elements<F>(assignment, v.num_variables);
+    const std::vector<F> primary(z.begin(), z.begin() + v.num_inputs), auxiliary(z.begin() + v.num_inputs, z.end());
+    const aurora_parameters<F> params(security, rs_extra, localization, v.num_constraints, v.num_variables, v.num_inputs);
+    g_last_transcript = aurora_snark_prover<F>(cs, primary, auxiliary, params).serialize();
+    return (long)g_last_transcript.size();
+}
+template<typename F>
+int aurora_verify_csr_impl(const csr_view &v, const uint64_t *primary_input, size_t security, size_t rs_extra, size_t localization, const uint8_t *bytes, size_t len)
+{
+    const r1cs_system<F> cs = system_from_csr<F>(v);
+    const std::vector<F> primary = load_elements<F>(primary_input, v.num_inputs);
+    const aurora_parameters<F> params(security, rs_extra, localization, v.num_constraints, v.num_variables, v.num_inputs);
+    bcs_transcript<F> t;
+    try { t = bcs_transcript<F>::deserialize(bytes, len); } catch (const std::exception &) { return 0; }
+    return aurora_snark_verifier<F>(cs, primary, t, params) ? 1 : 0;
+}
+template<typename F>
+long fractal_prove_csr_impl(const csr_view &v, const uint64_t *assignment, size_t security, size_t rs_extra, size_t localization)
+{
+    const r1cs_system<F> cs = system_from_csr<F>(v);
+    const std::vector<F> z = load_elements<F>(assignment, v.num_variables);
+    const std::vector<F> primary(z.begin(), z.begin() + v.num_inputs), auxiliary(z.begin() + v.num_inputs, z.end());
+    const fractal_parameters<F> params(security, rs_extra, localization, cs);
+    const fractal_index<F> index = fractal_snark_indexer<F>(cs, params);
+    g_last_index_roots.clear();
+    for (auto &r : index.MT_roots) g_last_index_roots.insert(g_last_index_roots.end(), r.begin(), r.end());
+    g_last_transcript = fractal_snark_prover<F>(index, cs, primary, auxiliary, params).serialize();
+    return (long)g_last_transcript.size();
+}
+template<typename F>
+int fractal_verify_csr_impl(const csr_view &v, const uint64_t *primary_input, size_t security, size_t rs_extra, size_t localization, const uint8_t *bytes, size_t len,
+                            const uint8_t *roots, size_t num_roots)
+{
+    const r1cs_system<F> cs = system_from_csr<F>(v);
+    const std::vector<F> primary = load_elements<F>(primary_input, v.num_inputs);
+    const fractal_parameters<F> params(security, rs_extra, localization, cs);
+    std::vector<digest_t> index_roots;
+    for (size_t i = 0; i < num_roots; ++i) index_roots.push_back(digest_t(roots + i * DIGEST_LEN, roots + (i + 1) * DIGEST_LEN));
+    bcs_transcript<F> t;
+    try { t = bcs_transcript<F>::deserialize(bytes, len, num_roots); } catch (const std::exception &) { return 0; }
+    return fractal_snark_verifier<F>(index_roots, cs, primary, t, params) ? 1 : 0;
+}
+// r1cs_constraint_system::is_satisfied (relations/r1cs.tcc:112-147): <A_i, z> * <B_i, z> = <C_i, z> for every row, z = (1, assignment).
+// Returns the number of violated rows; Mz_out (nullable): Az, Bz, Cz one after the other (create_Az_Bz_Cz_from_variable_assignment, :236-268).
+template<typename F>
+long r1cs_check_csr_impl(const csr_view &v, const uint64_t *assignment, uint64_t *Mz_out)
+{
+    const r1cs_system<F> cs = system_from_csr<F>(v);
+    std::vector<F> z(1, F::one());
+    const std::vector<F> rest = load_elements<F>(assignment, v.num_variables);
+    z.insert(z.end(), rest.begin(), rest.end());
+    const std::vector<F> Az = sparse_times_vector<F>(cs.A, z), Bz = sparse_times_vector<F>(cs.B, z), Cz = sparse_times_vector<F>(cs.C, z);
+    long violated = 0;
+    for (size_t i = 0; i < v.num_constraints; ++i) if (!(Az[i] * Bz[i] == Cz[i])) ++violated;
+    if (Mz_out) {
+        const std::vector<F> *three[3] = { &Az, &Bz, &Cz };
+        for (int q = 0; q < 3; ++q) memcpy((uint8_t *)Mz_out + q * v.num_constraints * sizeof(F), (const void *)three[q]->data(), v.num_constraints * sizeof(F));
+    }
+    return violated;
+}
+} // namespace
+
+extern "C" {
+
+#define CSR_VIEW const csr_view v = { num_constraints, num_variables, num_inputs, row_ptr, col, coeff }
+long oracle_aurora_prove_csr(int field, size_t num_constraints, size_t num_variables, size_t num_inputs, const uint64_t *const *row_ptr, const uint32_t *const *col,
+                             const uint64_t *const *coeff, const uint64_t *assignment, size_t security, size_t rs_extra, size_t localization)
+{
+    CSR_VIEW;
+    try { AURORA_DISPATCH(field, return aurora_prove_csr_impl<F>(v, assignment, security, rs_extra, localization)); }
+    catch (const std::exception &e) { fprintf(stderr, "oracle_aurora_prove_csr: %s\n", e.what()); return -2; }
+    return -1;
+}
+int oracle_aurora_verify_csr(int field, size_t num_constraints, size_t num_variables, size_t num_inputs, const uint64_t *const *row_ptr, const uint32_t *const *col,
+                             const uint64_t *const *coeff, const uint64_t *primary_input, size_t security, size_t rs_extra, size_t localization,
+                             const uint8_t *transcript, size_t len)
+{
+    CSR_VIEW;
+    try { AURORA_DISPATCH(field, return aurora_verify_csr_impl<F>(v, primary_input, security, rs_extra, localization, transcript, len)); }
+    catch (const std::exception &e) { fprintf(stderr, "oracle_aurora_verify_csr: %s\n", e.what()); return -2; }
+    return -1;
+}
+long oracle_fractal_prove_csr(int field, size_t num_constraints, size_t num_variables, size_t num_inputs, const uint64_t *const *row_ptr, const uint32_t *const *col,
+                              const uint64_t *const *coeff, const uint64_t *assignment, size_t security, size_t rs_extra, size_t localization)
+{
+    CSR_VIEW;
+    try { AURORA_DISPATCH(field, return fractal_prove_csr_impl<F>(v, assignment, security, rs_extra, localization)); }
+    catch (const std::exception &e) { fprintf(stderr, "oracle_fractal_prove_csr: %s\n", e.what()); return -2; }
+    return -1;
+}
+int oracle_fractal_verify_csr(int field, size_t num_constraints, size_t num_variables, size_t num_inputs, const uint64_t *const *row_ptr, const uint32_t *const *col,
+                              const uint64_t *const *coeff, const uint64_t *primary_input, size_t security, size_t rs_extra, size_t localization,
+                              const uint8_t *transcript, size_t len, const uint8_t *roots, size_t num_roots)
+{
+    CSR_VIEW;
+    try { AURORA_DISPATCH(field, return fractal_verify_csr_impl<F>(v, primary_input, security, rs_extra, localization, transcript, len, roots, num_roots)); }
+    catch (const std::exception &e) { fprintf(stderr, "oracle_fractal_verify_csr: %s\n", e.what()); return -2; }
+    return -1;
+}
+long oracle_r1cs_check_csr(int field, size_t num_constraints, size_t num_variables, size_t num_inputs, const uint64_t *const *row_ptr, const uint32_t *const *col,
+                           const uint64_t *const *coeff, const uint64_t *assignment, uint64_t *Mz_out)
+{
+    CSR_VIEW;
+    try { AURORA_DISPATCH(field, return r1cs_check_csr_impl<F>(v, assignment, Mz_out)); }
+    catch (const std::exception &e) { fprintf(stderr, "oracle_r1cs_check_csr: %s\n", e.what()); return -2; }
+    return -1;
+}
+#undef CSR_VIEW
+
 // FRI-only SNARK (aurora.hpp FRI_snark_*): the polynomial's coefficients are seeded_element(seed, i), i < 2^(dim - rs_extra)
 } // extern "C"
 

@@ -4,6 +4,7 @@
 // oracle's gf192 (same 24-byte layout as libff::gf192) and the oracle as the checker.
 //   test_shim nodevice : every operator must throw std::runtime_error on a host without a GPU
 //   test_shim gpu      : parity on a real MI355X
+//   test_shim aurora|fractal|general N : the C++ provers against the oracle provers, sizes up to 2^N
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -389,9 +390,128 @@ static int run_fractal(size_t max_log_n)
     return 0;
 }
 
+// ---- general constraint systems, built row by row through r1cs_constraint_system::add_constraint (relations/r1cs.tcc:151-160) the way a
+// circuit front end does: a row is a term list (variable.tcc:196-230) of zero to five terms, index 0 = the constant 1, an index may repeat,
+// arbitrary coefficients in all three matrices, two columns hit by a quarter of the rows.  generate_r1cs_example's rows (one unit term in A
+// and B) exercise none of that.  max_nnz bounds the entries per matrix for Fractal (at most |H|, holographic_lincheck.tcc:72-90). ----
+template<typename F>
+struct general_instance {
+    oracle::r1cs_system<F> ocs;
+    libiop_amd::r1cs_constraint_system<F> cs;
+    std::vector<F> primary, auxiliary;
+};
+template<typename F>
+static general_instance<F> make_general(size_t n, size_t num_variables, size_t num_inputs, uint64_t seed, size_t max_nnz, int violate)
+{
+    typedef typename oracle::r1cs_system<F>::row row;
+    general_instance<F> g;
+    std::mt19937_64 r(seed);
+    std::vector<F> z(1, F::one());
+    for (size_t i = 0; i < num_variables; ++i) z.push_back(oracle::seeded_element(seed, i, (const F *)nullptr));
+    const size_t hot[2] = { 1 + (size_t)(r() % std::max<size_t>(1, num_inputs)), std::min(num_variables, num_inputs + 1 + (size_t)(r() % std::max<size_t>(1, num_variables - num_inputs))) };
+    size_t used[3] = { 0, 0, 0 };
+    auto count = [&](int q, size_t at_least) {
+        static const size_t dense[8] = { 0, 1, 1, 2, 2, 3, 4, 5 }, sparse[8] = { 0, 0, 0, 1, 1, 1, 2, 3 };
+        const size_t k = std::max(at_least, (max_nnz ? sparse : dense)[r() % 8]);
+        return max_nnz ? std::min(k, max_nnz - used[q]) : k;
+    };
+    auto terms = [&](size_t k) {
+        row out;
+        for (size_t t = 0; t < k; ++t) {
+            const unsigned u = r() % 100;
+            size_t col = u < 8 && !out.empty() ? out[r() % out.size()].first : u < 30 ? hot[r() % 2] : u < 40 ? 0 : 1 + (size_t)(r() % num_variables);
+            F c = oracle::seeded_element(seed ^ 0xC0EFF, r() % 100000, (const F *)nullptr);
+            if (r() % 5 == 0) c = F::one() + F::one() + F::one();
+            out.push_back({ col, c });
+        }
+        return out;
+    };
+    auto dot = [&](const row &rw) { F acc = F::zero(); for (auto &t : rw) acc += z[t.first] * t.second; return acc; };
+    g.cs.primary_input_size_ = num_inputs;
+    g.cs.auxiliary_input_size_ = num_variables - num_inputs;
+    g.ocs.num_inputs = num_inputs;
+    g.ocs.num_variables = num_variables;
+    for (size_t i = 0; i < n; ++i) {
+        const bool c_full = max_nnz && used[2] == max_nnz;
+        const row a = c_full ? row() : terms(count(0, 0)), b = terms(count(1, 0));
+        const F target = dot(a) * dot(b);
+        const size_t kc = count(2, target.is_zero() ? 0 : 1);
+        row c = terms(kc ? kc - 1 : 0);
+        if (kc) {
+            size_t col = r() % 3 ? 1 + (size_t)(r() % num_variables) : 0;
+            if (z[col].is_zero()) col = 0;
+            c.push_back({ col, (target - dot(c)) * z[col].inverse() });
+        }
+        if (violate == 1 && i == n / 3 && !c.empty()) c.back().second += F::one();            // one violated constraint
+        used[0] += a.size(); used[1] += b.size(); used[2] += c.size();
+        g.ocs.A.push_back(a); g.ocs.B.push_back(b); g.ocs.C.push_back(c);
+        g.cs.add_constraint({ to_lc<F>(a), to_lc<F>(b), to_lc<F>(c) });
+    }
+    if (violate == 2) z[hot[0]] += F::one();                                                  // one wrong primary input: a column many rows read
+    g.primary.assign(z.begin() + 1, z.begin() + 1 + num_inputs);
+    g.auxiliary.assign(z.begin() + 1 + num_inputs, z.end());
+    return g;
+}
+
+template<typename F>
+static int run_general_aurora(size_t n, size_t num_variables, size_t num_inputs, uint64_t seed, int violate)
+{
+    const general_instance<F> g = make_general<F>(n, num_variables, num_inputs, seed, 0, violate);
+    const libiop_amd::aurora_snark_parameters<F> params(n, num_variables, num_inputs);
+    const oracle::aurora_parameters<F> oparams(128, 5, 2, n, num_variables, num_inputs);
+    const std::string mine = libiop_amd::aurora_snark_prover<F>(g.cs, g.primary, g.auxiliary, params).serialize();
+    const oracle::bcs_transcript<F> oproof = oracle::aurora_snark_prover<F>(g.ocs, g.primary, g.auxiliary, oparams);
+    const std::vector<uint8_t> ref = oproof.serialize();
+    CHECK(mine.size() == ref.size() && memcmp(mine.data(), ref.data(), ref.size()) == 0);
+    CHECK(oracle::aurora_snark_verifier<F>(g.ocs, g.primary, oproof, oparams) == (violate == 0));
+    printf("general aurora %s %zu x %zu, k = %zu%s: %zu transcript bytes equal the oracle prover's\n", libiop_amd::field_host<F>::additive() ? "gf192" : "edwards_Fr", n,
+           num_variables + 1, num_inputs, violate == 1 ? ", one violated constraint" : violate == 2 ? ", one wrong input" : "", ref.size());
+    return 0;
+}
+
+template<typename F>
+static int run_general_fractal(size_t n, size_t num_inputs, uint64_t seed, size_t max_nnz, int violate)
+{
+    const general_instance<F> g = make_general<F>(n, n - 1, num_inputs, seed, max_nnz, violate);
+    const libiop_amd::fractal_snark_parameters<F> params(g.cs);
+    const oracle::fractal_parameters<F> oparams(128, 3, 2, g.ocs);
+    const auto index = libiop_amd::fractal_snark_indexer<F>(g.cs, params);
+    const oracle::fractal_index<F> oindex = oracle::fractal_snark_indexer<F>(g.ocs, oparams);
+    CHECK(index.second.index_MT_roots_.size() == oindex.MT_roots.size());
+    for (size_t i = 0; i < oindex.MT_roots.size(); ++i) CHECK(memcmp(index.second.index_MT_roots_[i].data(), oindex.MT_roots[i].data(), 32) == 0);
+    const oracle::bcs_transcript<F> oproof = oracle::fractal_snark_prover<F>(oindex, g.ocs, g.primary, g.auxiliary, oparams);
+    const std::vector<uint8_t> ref = oproof.serialize();
+    const std::string mine = libiop_amd::fractal_snark_prover<F>(index.first, g.cs, g.primary, g.auxiliary, params).serialize();
+    CHECK(mine.size() == ref.size() && memcmp(mine.data(), ref.data(), ref.size()) == 0);
+    CHECK(oracle::fractal_snark_verifier<F>(oindex.MT_roots, g.ocs, g.primary, oproof, oparams) == (violate == 0));
+    printf("general fractal %s 2^%zu, k = %zu, <= %zu entries per matrix%s: index root and %zu transcript bytes equal the oracle's\n",
+           libiop_amd::field_host<F>::additive() ? "gf192" : "edwards_Fr", (size_t)oracle::ceil_log2(n), num_inputs, max_nnz, violate ? ", unsatisfied" : "", ref.size());
+    return 0;
+}
+
+static int run_general(size_t max_log_n)
+{
+    for (size_t log_n = 7; log_n <= max_log_n; ++log_n) {
+        const size_t n = (size_t)1 << log_n;
+        if (run_general_aurora<FieldT>(n, n - 1, 15, 100 + log_n, 0) || run_general_aurora<Fr>(n, n - 1, 15, 100 + log_n, 0)) return 1;
+        if (run_general_fractal<FieldT>(n, 15, 200 + log_n, n, 0) || run_general_fractal<Fr>(n, 15, 200 + log_n, n, 0)) return 1;
+    }
+    // more variables than constraints and the other way round (aurora_iop.tcc:37-43: the summation domain is the larger of the two)
+    if (run_general_aurora<FieldT>(128, 511, 7, 301, 0) || run_general_aurora<Fr>(512, 127, 31, 302, 0) || run_general_aurora<Fr>(128, 127, 0, 303, 0)) return 1;
+    if (run_general_fractal<Fr>(256, 0, 304, 100, 0) || run_general_fractal<FieldT>(128, 31, 305, 128, 0)) return 1;
+    // unsatisfied: the reference emits a transcript all the same, the oracle prover defines its bytes, its verifier rejects them
+    for (int violate = 1; violate <= 2; ++violate) {
+        if (run_general_aurora<FieldT>(256, 255, 15, 400 + violate, violate) || run_general_aurora<Fr>(256, 255, 15, 410 + violate, violate)) return 1;
+        if (run_general_fractal<FieldT>(128, 15, 420 + violate, 128, violate) || run_general_fractal<Fr>(128, 15, 430 + violate, 128, violate)) return 1;
+    }
+    printf("general ok\n");
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     const std::string mode = argc > 1 ? argv[1] : "nodevice";
+    if (mode == "general") return run_general(argc > 2 ? (size_t)atoi(argv[2]) : 8);
     if (mode == "fractal") return run_fractal(argc > 2 ? (size_t)atoi(argv[2]) : 8);
     if (mode == "aurora") return run_aurora(argc > 2 ? (size_t)atoi(argv[2]) : 10);
     return mode == "gpu" ? run_gpu() : run_nodevice();

@@ -47,8 +47,9 @@ def csr(ops, M):
 
 def check_unsatisfied_witness(lib, torch, device, monkeypatch, field_name, log_n=8):
     """iopx_aurora_instance_create on the seeded constraint system with one auxiliary variable changed: Az * Bz != Cz, the rowcheck oracle is
-    not a polynomial.  The second prover (libiop_amd/aurora.py: every virtual oracle over the whole domain, the reference's schedule) defines the
-    bytes; the native prover must produce them with and without IOPX_HEAD_EVAL=0, and the oracle verifier rejects them."""
+    not a polynomial.  The oracle prover on the same CSR triples and assignment (oracle.aurora_prove_csr) defines the bytes; the second prover
+    (libiop_amd/aurora.py: the reference's schedule) and the native prover with and without IOPX_HEAD_EVAL=0 must produce them, and the oracle
+    verifier rejects them."""
     code, cls = ac.FIELDS[field_name]
     field, k, seed = cls(), 15, 0x2204
     n = 1 << log_n
@@ -75,8 +76,9 @@ def check_unsatisfied_witness(lib, torch, device, monkeypatch, field_name, log_n
     bad_z = z.copy()
     bad_z[k + 5] = z[k + 6]                                                     # another valid field element in an auxiliary slot
     assert not np.array_equal(bad_z, z)
-    expected = aurora.aurora_snark_prover(ops, cs, bad_z[:k], bad_z[k:], params).serialize()
+    expected = oracle.aurora_prove_csr(code, mats, n - 1, k, bad_z)             # the ORACLE prover defines the bytes of the unsatisfied instance
     assert expected != good
+    assert aurora.aurora_snark_prover(ops, cs, bad_z[:k], bad_z[k:], params).serialize() == expected
     bad, bad_prof = native(bad_z)
     assert bad == expected, "the head schedule changed the bytes of an unsatisfied instance's transcript"
     assert not oracle.aurora_verify(code, log_n, k, seed, bad)

@@ -71,6 +71,25 @@ def test_cpp_fractal_prover_on_cpu_emulation():
     assert r.returncode == 0 and "fractal ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_cpp_provers_on_general_constraint_systems_on_cpu_emulation():
+    """Instances built row by row through r1cs_constraint_system::add_constraint — multi-term rows, constant-column terms, repeated and hot
+    columns, empty rows, non-square systems, unsatisfied variants — proved by the C++ Aurora and Fractal provers: bytes equal the oracle's."""
+    from emu_lib import emu
+    emu()
+    exe = os.path.join(ROOT, "tests", "cpp", "test_shim_emu")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(os.path.join(ROOT, "tests", "cpp", "test_shim.cpp")):
+        test_cpp_aurora_prover_on_cpu_emulation()
+    r = subprocess.run([exe, "general", "7"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "general ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_provers_on_general_constraint_systems_on_gpu():
+    exe = _build()
+    r = subprocess.run([exe, "general", "11"], capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0 and "general ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_cpp_fractal_prover_on_gpu():
     exe = _build()

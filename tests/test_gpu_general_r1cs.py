@@ -1,0 +1,54 @@
+"""General constraint systems through iopx_aurora_instance_create on the MI355X, 2^8 - 2^12 constraints, both fields, native and Python provers,
+byte-equal to the oracle provers fed the same CSR triples; the unsatisfied variants' bytes are the oracle's too (tests/general_cases.py; the
+CPU-compiled run is tests/test_general_r1cs_emu.py)."""
+import pytest
+import torch
+
+import general_cases as gc
+
+pytestmark = pytest.mark.gpu
+BOTH = ["gf192", "edwards_Fr"]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import libiop_amd
+    lib = libiop_amd.lib()
+    lib.init(0)
+    lib.set_stream(torch.cuda.current_stream().cuda_stream)      # DeviceOps (the second prover) shares torch's stream
+    return lib
+
+
+DEV = torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("field_name", BOTH)
+@pytest.mark.parametrize("num_constraints,num_variables", [(4096, 4095), (1024, 8191)])
+def test_spmv_against_the_oracle(gpu, field_name, num_constraints, num_variables):
+    gc.check_spmv(gpu, torch, DEV, field_name, num_constraints, num_variables, 6)
+
+
+@pytest.mark.parametrize("field_name", BOTH)
+@pytest.mark.parametrize("num_constraints,num_variables,num_inputs", [(256, 255, 15), (4096, 4095, 15), (1024, 4095, 31), (2048, 511, 7), (512, 511, 0)])
+def test_aurora_on_general_instances(gpu, field_name, num_constraints, num_variables, num_inputs, monkeypatch):
+    gc.check_aurora(gpu, torch, DEV, monkeypatch, field_name, num_constraints, num_variables, num_inputs, 50 + num_inputs)
+
+
+@pytest.mark.parametrize("field_name", BOTH)
+@pytest.mark.parametrize("kind", ["constraint", "primary", "auxiliary"])
+@pytest.mark.parametrize("log_n", [8, 11])
+def test_aurora_unsatisfied_bytes_are_the_oracles(gpu, field_name, kind, log_n, monkeypatch):
+    n = 1 << log_n
+    gc.check_aurora_unsatisfied(gpu, torch, DEV, monkeypatch, field_name, n, n - 1, 15, 60 + log_n, kind)
+
+
+@pytest.mark.parametrize("field_name,num_constraints,num_inputs,max_nnz", [("gf192", 256, 15, None), ("gf192", 1024, 15, 700), ("edwards_Fr", 4096, 15, None),
+                                                                           ("edwards_Fr", 2048, 0, None), ("edwards_Fr", 1024, 31, 400)])
+def test_fractal_on_general_instances(gpu, field_name, num_constraints, num_inputs, max_nnz, monkeypatch):
+    gc.check_fractal(gpu, torch, DEV, monkeypatch, field_name, num_constraints, num_inputs, 70 + num_inputs, max_nnz=max_nnz)
+
+
+@pytest.mark.parametrize("field_name,num_constraints", [("gf192", 256), ("edwards_Fr", 2048)])
+@pytest.mark.parametrize("kind", ["constraint", "primary", "auxiliary"])
+def test_fractal_unsatisfied_bytes_are_the_oracles(gpu, field_name, num_constraints, kind, monkeypatch):
+    gc.check_fractal(gpu, torch, DEV, monkeypatch, field_name, num_constraints, 15, 80, kind=kind)
