@@ -565,7 +565,8 @@ int iopx_comm_sendrecv_dev(iopx_comm *comm, const void *d_send, void *d_recv, si
  * additive_IFFT (libiop/algebra/fft.tcc:39-204) of 2^m coefficients over a 2^m-point affine subspace, every rank holding the contiguous block
  * [rank 2^m / N, (rank + 1) 2^m / N) of the input and of the output (device memory, 2^m / N elements).  One all-to-all transposes the coefficients
  * into the layout in which the Gao-Mateer recursion's top r levels are shard-local or whole-shard exchanges between peers, a complete local
- * transform of 2^(m-r) points follows, and the last r butterfly levels exchange shards between peers.  m >= r + 1. */
+ * transform of 2^(m-r) points follows, and the last r butterfly levels exchange shards between peers.  m >= 2 r (the transpose moves 2^(m-2r)
+ * elements between every pair of ranks); shorter transforms are refused with IOPX_ERR_INVALID_ARGUMENT. */
 int iopx_add_fft_gf192_dist_dev(iopx_comm *comm, const uint64_t *d_block_coeffs, const uint64_t *basis, size_t m, const uint64_t *shift, uint64_t *d_block_out);
 int iopx_add_ifft_gf192_dist_dev(iopx_comm *comm, const uint64_t *d_block_evals, const uint64_t *basis, size_t m, const uint64_t *shift, uint64_t *d_block_out);
 /* While a communicator of N > 1 ranks is bound, every additive transform of the library splits its Gao-Mateer phase 1 (the twists and
@@ -573,7 +574,9 @@ int iopx_add_ifft_gf192_dist_dev(iopx_comm *comm, const uint64_t *d_block_evals,
  * whole vector on every rank, from then on the sub-polynomials of different residues of the coefficient index mod N never mix, so rank
  * r runs the remaining levels on the residue class r (a contiguous copy) and one all-gather reassembles the vector.  REQUIRES that every
  * rank issues the same sequence of transforms on the same (replicated) inputs — what the distributed provers do for everything over
- * the <= 2^21-element domains; a section that only one rank executes must unbind first.  NULL unbinds. */
+ * the <= 2^21-element domains; a section that only one rank executes must unbind first.  NULL unbinds.  The binding belongs to the calling
+ * host thread (transforms issued from other threads are not affected); the library's stream is one per process all the same, so the prover
+ * entry points of one process are meant to be driven from one thread at a time. */
 int iopx_comm_bind_transforms(iopx_comm *comm);
 /* collectives issued and payload bytes sent by this rank through any communicator since the last reset (reset != 0 clears them) */
 int iopx_comm_stats(uint64_t *num_collectives, uint64_t *bytes, int reset);

@@ -97,7 +97,9 @@ struct iopx_comm {
 };
 
 namespace iopx {
-static iopx_comm *g_transform_comm = nullptr;
+// per host thread, like the distribution context of libiop_amd/cpp/dist.hpp (dist::ctx()) whose scopes bind and unbind it: a transform on
+// another thread never joins a collective this thread's peers did not issue
+static thread_local iopx_comm *g_transform_comm = nullptr;
 CommInfo transform_comm()
 {
     CommInfo ci{ g_transform_comm, 0, 1 };

@@ -1464,6 +1464,7 @@ int iopx_clear_plans(void)
     (void)hipDeviceSynchronize();
     g_plans.clear();
     clear_mul_plans();
+    clear_dist_plans();
     clear_poseidon_sets();
     clear_domain_tables();
     tmp_trim();

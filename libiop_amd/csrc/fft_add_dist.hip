@@ -73,7 +73,9 @@ struct DistPlan {
 };
 
 std::mutex g_dplan_mu;
-std::map<std::vector<uint64_t>, std::unique_ptr<DistPlan>> g_dplans;
+std::map<std::vector<uint64_t>, std::shared_ptr<DistPlan>> g_dplans;      // shared: a caller keeps its plan alive across an eviction
+size_t g_dplan_bytes = 0;                                                  // device bytes of the cached plans' twist tables
+const size_t DPLAN_CACHE_BYTES = (size_t)4 << 30;
 
 hgf192 hpow(hgf192 base, size_t e)
 {
@@ -82,16 +84,15 @@ hgf192 hpow(hgf192 base, size_t e)
     return r;
 }
 
-int get_dist_plan(const uint64_t *basis, int m, const uint64_t *shift, size_t rank, size_t world, DistPlan **out)
+int get_dist_plan(const uint64_t *basis, int m, const uint64_t *shift, size_t rank, size_t world, std::shared_ptr<DistPlan> *out)
 {
     std::vector<uint64_t> key(basis, basis + 3 * (size_t)m);
     key.insert(key.end(), shift, shift + 3);
     key.push_back((uint64_t)m); key.push_back(rank); key.push_back(world);
     std::lock_guard<std::mutex> lk(g_dplan_mu);
     auto it = g_dplans.find(key);
-    if (it != g_dplans.end()) { *out = it->second.get(); return IOPX_OK; }
-    if (g_dplans.size() >= 16) g_dplans.clear();
-    std::unique_ptr<DistPlan> pl(new DistPlan());
+    if (it != g_dplans.end()) { *out = it->second; return IOPX_OK; }
+    std::shared_ptr<DistPlan> pl(new DistPlan());
     int r = 0;
     while (((size_t)1 << r) < world) ++r;
     pl->m = m; pl->r = r; pl->rank = rank; pl->world = world; pl->s = rev_bits(rank, r); pl->n_loc = (size_t)1 << (m - r);
@@ -129,7 +130,10 @@ int get_dist_plan(const uint64_t *basis, int m, const uint64_t *shift, size_t ra
     }
     pl->local_basis = b;
     pl->local_shift = sh;
-    *out = pl.get();
+    const size_t plan_bytes = 2 * (size_t)r * pl->n_loc * 24;
+    if (g_dplans.size() >= 16 || g_dplan_bytes + plan_bytes > DPLAN_CACHE_BYTES) { g_dplans.clear(); g_dplan_bytes = 0; }
+    g_dplan_bytes += plan_bytes;
+    *out = pl;
     g_dplans[key] = std::move(pl);
     return IOPX_OK;
 }
@@ -207,10 +211,12 @@ int dist_transform(iopx_comm *comm, const uint64_t *d_block, const uint64_t *bas
     iopx_comm_rank(comm, &rank, &world);
     int r = 0;
     while ((1 << r) < world) ++r;
-    if (m > 40 || (size_t)r + 1 > m) return fail(IOPX_ERR_INVALID_ARGUMENT, "a %zu-dimensional domain cannot be split over %d ranks", m, world);
+    // the transpose moves 2^(m - 2r) elements between every pair of ranks: a shorter transform has nothing to put in a chunk
+    if (m > 40 || (world > 1 && m < 2 * (size_t)r)) return fail(IOPX_ERR_INVALID_ARGUMENT, "a %zu-dimensional domain cannot be split over %d ranks (needs m >= %d)", m, world, 2 * r);
     if (world == 1) return inverse ? iopx_add_ifft_gf192_dev(d_block, basis, m, shift, d_out) : iopx_add_fft_gf192_dev(d_block, (size_t)1 << m, basis, m, shift, d_out);
-    DistPlan *pl = nullptr;
-    if ((rc = get_dist_plan(basis, (int)m, shift, (size_t)rank, (size_t)world, &pl)) != IOPX_OK) return rc;
+    std::shared_ptr<DistPlan> held;
+    if ((rc = get_dist_plan(basis, (int)m, shift, (size_t)rank, (size_t)world, &held)) != IOPX_OK) return rc;
+    DistPlan *pl = held.get();
     const Ctx c{ comm, pl };
     const size_t n_loc = pl->n_loc, cnt = n_loc / (size_t)world, bytes = n_loc * 24;
     const int lm = (int)m - r;
@@ -280,6 +286,13 @@ int dist_transform(iopx_comm *comm, const uint64_t *d_block, const uint64_t *bas
 }
 
 } // namespace
+
+void clear_dist_plans()
+{
+    std::lock_guard<std::mutex> lk(g_dplan_mu);
+    g_dplans.clear();
+    g_dplan_bytes = 0;
+}
 } // namespace iopx
 
 extern "C" {

@@ -463,8 +463,8 @@ int iopx_merkle_blake2b(const void *const *oracles, size_t num_oracles, size_t e
 
 // The search in two halves, so that the caller can put host work (and further launches) behind a long batch: _begin enqueues the batch on the
 // library's stream and returns, _end reads the result back (one pending search per host thread's library state).
-static TmpBuf g_pow_best;
-static bool g_pow_pending = false;
+static thread_local TmpBuf g_pow_best;
+static thread_local bool g_pow_pending = false;
 
 int iopx_pow_search_blake2b_begin(const uint8_t *challenge, size_t pow_bitlen, uint64_t first, uint64_t count)
 {
@@ -478,7 +478,7 @@ int iopx_pow_search_blake2b_begin(const uint8_t *challenge, size_t pow_bitlen, u
     const uint64_t mask = ((uint64_t)1 << pow_bitlen) - 1;
     if ((rc = g_pow_best.alloc(8)) != IOPX_OK) return rc;
     const unsigned long long none = ~0ull;
-    if ((rc = upload(g_pow_best.p, &none, 8)) != IOPX_OK) return rc;
+    if ((rc = upload(g_pow_best.p, &none, 8)) != IOPX_OK) { g_pow_best.release(); return rc; }
     if (count) {
         ProfScope ps_("k_pow_blake2b");
         hipLaunchKernelGGL(k_pow_blake2b, dim3((unsigned)((count + 255) / 256 > 1536 ? 1536 : (count + 255) / 256)), dim3(256), 0, stream(),   // <= one resident set of workgroups (256 CUs x 6): the grid advances through the candidates together

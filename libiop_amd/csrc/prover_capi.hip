@@ -61,10 +61,12 @@ struct Instance : InstanceBase {
     {
         require_supported_security(security_parameter);
         const dist::scope bound(comm);
-        index_comm = comm;
         const fractal_snark_parameters<F> params(cs, security_parameter, RS_extra_dimensions, FRI_localization_parameter);
+        index.reset();                                           // a failed indexer leaves no index behind, rather than the previous one under a new label
+        index_params[0] = index_params[1] = index_params[2] = 0;
         auto made = fractal_snark_indexer<F>(cs, params);
         index.reset(new bcs_prover_index<F>(std::move(made.first)));
+        index_comm = comm;
         index_params[0] = security_parameter; index_params[1] = RS_extra_dimensions; index_params[2] = FRI_localization_parameter;
         return made.second.index_MT_roots_;
     }

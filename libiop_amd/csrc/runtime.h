@@ -150,6 +150,7 @@ int build_two_level(const hfp3 &base, const hfp3 &init, int logc, TmpBuf &hi, Tm
 
 // Per-module plan caches dropped by iopx_clear_plans() (the caller has synchronised the device).
 void clear_mul_plans();
+void clear_dist_plans();           // fft_add_dist.hip: the sharded transforms' per-rank twist tables
 void clear_poseidon_sets();
 
 // comm.hip: the communicator bound for transforms (iopx_comm_bind_transforms), or null; its rank / world; collectives for library-internal

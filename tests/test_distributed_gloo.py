@@ -663,7 +663,21 @@ def _native_fft_worker(rank, world, port, ret):
             finally:
                 for d in (d_in, d_out, d_back):
                     lib.free(d)
-        ret[rank] = (ok, lib.comm_stats()[0])
+        before = lib.comm_stats()[0]
+        if world > 2:                                        # m = 2 log2(world) - 1: nothing to put in a transpose chunk — refused, no collective issued
+            m = 2 * (world.bit_length() - 1) - 1
+            per = max(1, (1 << m) // world)
+            d_a, d_b = lib.malloc(per * 24), lib.malloc(per * 24)
+            for inverse in (False, True):
+                try:
+                    lib.additive_FFT_dist_dev(comm, d_a, oracle.standard_basis(m, W), np.zeros(W, dtype=np.uint64), d_b, inverse=inverse)
+                    ok.append(False)
+                except ValueError:
+                    ok.append(True)
+            lib.free(d_a)
+            lib.free(d_b)
+            ok.append(lib.comm_stats()[0] == before)
+        ret[rank] = (ok, before)
         lib.comm_destroy(comm)
     finally:
         dist.destroy_process_group()
@@ -677,5 +691,5 @@ def test_native_distributed_full_size_fft(world):
     ret = mgr.dict()
     mp.spawn(_native_fft_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     for r in range(world):
-        assert ret[r][0] == [True] * 9, (r, ret[r])
+        assert ret[r][0] == [True] * (9 if world == 2 else 12), (r, ret[r])
         assert ret[r][1] > 0
