@@ -339,10 +339,11 @@ def test_aurora_transcript_equals_the_oracle_provers_at_large_sizes(env, log_n):
         assert hashlib.blake2b(py, digest_size=32).hexdigest() == want["transcript_blake2b"], "Python device prover's transcript differs from the oracle prover's"
 
 
-@pytest.mark.parametrize("log_n", [16, 18])
+@pytest.mark.parametrize("log_n", [16, 18, 20])
 def test_fractal_transcript_equals_the_oracle_provers_at_large_sizes(env, log_n):
     """The native Fractal indexer and prover over the 181-bit field against the oracle's recorded index root and transcript digest
-    (tests/golden/oracle_fractal_transcript_digests_large.json: 2^18 costs the oracle 7 minutes and 13 GB)."""
+    (tests/golden/oracle_fractal_transcript_digests_large.json: 2^18 costs the oracle 7 minutes and 13 GB, 2^20 — BASELINE configs[4]'s own
+    size, what bench.py times as secondary_fractal — 15 minutes and 47 GB)."""
     import json
     import os
     lib, torch, dev, _, _ = env
