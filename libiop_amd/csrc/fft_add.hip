@@ -35,7 +35,7 @@ namespace iopx {
 // Tile geometry.  Defaults: 2048-element phase-2 tiles (48 KiB of LDS per workgroup), 1024-element phase-1 and edge tiles.  The IOPX_TILE_BITS /
 // IOPX_P1_COLS / IOPX_P2_COLS / IOPX_P2_TOP environment variables override them (read once): used for
 // tuning, and by the tests to exercise the multi-pass schedules at small transform sizes.
-struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last, scratch_mb, p1_comb, rs_comb_cap_log2, p2_radix4; };
+struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last, scratch_mb, p1_comb, rs_comb_cap_log2, p2_radix4, edge_lean; };
 static int env_int(const char *name, int dflt, int lo, int hi)
 {
     const char *v = getenv(name);
@@ -74,6 +74,11 @@ static const Tuning &tuning()
         // 25.0 ms at 5 waves without spills (profiles/r04_ab_radix4*.txt): the LDS round trip and the per-level barrier are not what separates
         // the kernel from its VALU ceiling.  Kept as an experiment, off by default.
         u.p2_radix4 = env_int("IOPX_P2_RADIX4", 0, 0, 1);
+        // The general product in its 54-register form (gf_mul_lean), the kernel at six wavefronts per SIMD instead of four.  Bit 0: the batched last
+        // pass (k_bfly_edge_fwd_batch 8.35 -> 7.75 ms per proof: its two comb levels want the sixth wave, 1743 -> 1591 cycles per wave-product);
+        // bit 1: the single-polynomial edge passes, where it LOSES (3.63 -> 3.72 ms: all of their upper levels are general products, which run
+        // at the same rate from four waves up — 3209 cycles, the lean form 3342 — profiles/r05_mul_rates.txt, r05_ab_edge_lean_wl.txt)
+        u.edge_lean = env_int("IOPX_EDGE_LEAN", 1, 0, 3);
         return u;
     }();
     return t;
@@ -446,16 +451,17 @@ __global__ void k_rs_tables(uint64_t *out, const uint64_t *rs, int d, int nhi, s
     }
 }
 
-template<bool INV, bool COMB>
+// LEAN: the general product in its small-register form (gf_mul_lean), for the kernels built to run six wavefronts per SIMD
+template<bool INV, bool COMB, bool LEAN = false>
 __device__ __forceinline__ void bf_apply(uint64_t *s, int E, int ia, int ib, const gf192 &tw, bool uniform)
 {
     gf192 a = lds_get(s, E, ia), b = lds_get(s, E, ib);
     if (!INV) {
-        gf_add_to(a, (COMB && uniform) ? gf_mul_uniform(b, tw) : gf_mul(b, tw));  // S[a] += S[b] * t ; S[b] += S[a]  (fft.tcc:116-117)
+        gf_add_to(a, (COMB && uniform) ? gf_mul_uniform(b, tw) : (LEAN ? gf_mul_lean(b, tw) : gf_mul(b, tw)));  // S[a] += S[b] * t ; S[b] += S[a]  (fft.tcc:116-117)
         gf_add_to(b, a);
     } else {
         gf_add_to(b, a);                    // S[b] += S[a] ; S[a] += S[b] * t     (fft.tcc:164-165)
-        gf_add_to(a, (COMB && uniform) ? gf_mul_uniform(b, tw) : gf_mul(b, tw));
+        gf_add_to(a, (COMB && uniform) ? gf_mul_uniform(b, tw) : (LEAN ? gf_mul_lean(b, tw) : gf_mul(b, tw)));
     }
     lds_put(s, E, ia, a);
     lds_put(s, E, ib, b);
@@ -598,8 +604,10 @@ __global__ void __launch_bounds__(COMB ? 512 : 1024, COMB ? (R4 ? 5 : 6) : 1) k_
 
 // Forward: last pass — pair bits a_low-1 .. 0, then natural-order (bit-reversed) store.
 // Inverse: first pass — natural-order load, pair bits 0 .. a_low-1, block-order store.
-template<bool INV, bool COMB>
-__global__ void __launch_bounds__(COMB ? 512 : 1024) k_bfly_edge(BfParams p)
+// LEAN (round 5): the general product in its 53-register form and a register budget of 80, so that six wavefronts per SIMD are resident
+// instead of four (launched with at most 256 threads).
+template<bool INV, bool COMB, bool LEAN>
+__global__ void __launch_bounds__(LEAN ? 256 : (COMB ? 512 : 1024), LEAN ? 6 : 1) k_bfly_edge(BfParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
     uint64_t *s = iopx_smem;
@@ -673,7 +681,7 @@ __global__ void __launch_bounds__(COMB ? 512 : 1024) k_bfly_edge(BfParams p)
             const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
             const int li = ia & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
             const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
-            bf_apply<INV, COMB>(s, E, ia, ib, bf_twiddle(p, coset, u, pbit), pbit >= 6);
+            bf_apply<INV, COMB, LEAN>(s, E, ia, ib, bf_twiddle(p, coset, u, pbit), pbit >= 6);
         }
         __syncthreads();
     }
@@ -715,7 +723,8 @@ struct BfBatchParams {
     int batch;
 };
 
-__global__ void __launch_bounds__(512) k_bfly_edge_fwd_batch(BfBatchParams q)
+template<bool LEAN>
+__global__ void __launch_bounds__(512, LEAN ? 6 : 1) k_bfly_edge_fwd_batch(BfBatchParams q)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
     const BfParams &p = q.p;
@@ -739,11 +748,12 @@ __global__ void __launch_bounds__(512) k_bfly_edge_fwd_batch(BfBatchParams q)
     }
     __syncthreads();
 
+    const int half = E >> 1;
     for (int t = 0; t < p.a_low; ++t) {
         const int pbit = p.a_low - 1 - t;
         const int G = 1 << pbit;                        // butterflies that share a twiddle, per polynomial
         if (pbit >= 4 && q.batch * G >= 48) {
-            const int groups = (E >> 1) >> pbit, chunks = (q.batch * G + 63) >> 6;
+            const int groups = half >> pbit, chunks = (q.batch * G + 63) >> 6;
             // a strided loop over (work item, lane) like every other loop here; the block size is a multiple of 64, so x >> 6 is the
             // same in all lanes of a wavefront
             for (int x = tid; x < groups * chunks * 64; x += nt) {
@@ -763,7 +773,6 @@ __global__ void __launch_bounds__(512) k_bfly_edge_fwd_batch(BfBatchParams q)
                 }
             }
         } else if (pbit == 0 && p.ltab_small) {
-            const int half = E >> 1;
             for (int x = tid; x < q.batch * half; x += nt) {
                 const int b = x / half, ia = (x - b * half) << 1;
                 const size_t unit = unit0 + (size_t)(ia >> tb);
@@ -774,7 +783,6 @@ __global__ void __launch_bounds__(512) k_bfly_edge_fwd_batch(BfBatchParams q)
                 bf_apply_small<false>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | 1, bf_twiddle_small(p, coset, u), p.small_k);
             }
         } else if (pbit == 1 && p.ltab_small1) {
-            const int half = E >> 1;
             for (int x = tid; x < q.batch * half; x += nt) {
                 const int b = x / half, bf = x - b * half;
                 const int ia = ((bf >> 1) << 2) | (bf & 1);
@@ -786,7 +794,6 @@ __global__ void __launch_bounds__(512) k_bfly_edge_fwd_batch(BfBatchParams q)
                 bf_apply_small1<false>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | 2, bf_twiddle_small1(p, coset, u), p.small1_k1, p.small1_k2);
             }
         } else {
-            const int half = E >> 1;
             for (int x = tid; x < q.batch * half; x += nt) {
                 const int b = x / half, bf = x - b * half;
                 const int low = bf & (G - 1), high = bf >> pbit;
@@ -796,7 +803,7 @@ __global__ void __launch_bounds__(512) k_bfly_edge_fwd_batch(BfBatchParams q)
                 const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
                 const int li = ia & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
                 const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
-                bf_apply<false, false>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | G, bf_twiddle(p, coset, u, pbit), false);
+                bf_apply<false, false, LEAN>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | G, bf_twiddle(p, coset, u, pbit), false);
             }
         }
         __syncthreads();
@@ -1299,8 +1306,13 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         p.g_bits = g_bits; p.total_units = units; p.coset_base = cbase;
         p.rs_comb = comb_count ? rs_comb_ptr + 3 * (cbase - comb_base) * d : nullptr;
         int rc;
-        if ((rc = set_lds(k_bfly_edge<INV, false>, lds)) != IOPX_OK) return rc;
-        { ProfScope ps_(INV ? "k_bfly_edge_inv" : "k_bfly_edge_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)p.a_low); hipLaunchKernelGGL((k_bfly_edge<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        if ((tuning().edge_lean & 2) && threads <= 256) {
+            if ((rc = set_lds(k_bfly_edge<INV, false, true>, lds)) != IOPX_OK) return rc;
+            { ProfScope ps_(INV ? "k_bfly_edge_inv" : "k_bfly_edge_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)p.a_low); hipLaunchKernelGGL((k_bfly_edge<INV, false, true>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+            return IOPX_OK;
+        }
+        if ((rc = set_lds(k_bfly_edge<INV, false, false>, lds)) != IOPX_OK) return rc;
+        { ProfScope ps_(INV ? "k_bfly_edge_inv" : "k_bfly_edge_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)p.a_low); hipLaunchKernelGGL((k_bfly_edge<INV, false, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         return IOPX_OK;
     };
     auto launch_upper = [&](const Up &u, const uint64_t *s, uint64_t *dd, int shared, size_t ncos, size_t cbase) -> int {
@@ -1361,6 +1373,7 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         size_t group = SCRATCH_BYTES / (nd * 24);
         if (group < 1) group = 1;
         if (group > cosets) group = cosets;
+        group = (cosets + (cosets + group - 1) / group - 1) / ((cosets + group - 1) / group);     // even groups: 31 cosets go as 8, 8, 8, 7, not 10, 10, 10, 1 (a one-coset launch leaves most CUs idle in its tail)
         TmpBuf scratch;
         rc = scratch.alloc(group * nd * 24);
         if (rc != IOPX_OK) return rc;
@@ -1399,6 +1412,7 @@ static int run_phase2_fwd_batch(AddPlan &pl, const uint64_t *const *srcs, uint64
     size_t group = SCRATCH_BYTES / (nd * 24);
     if (group < 1) group = 1;
     if (group > cosets) group = cosets;
+    group = (cosets + (cosets + group - 1) / group - 1) / ((cosets + group - 1) / group);         // even groups (see run_phase2)
     std::vector<std::unique_ptr<TmpBuf>> scratch;
     for (size_t k = 0; k < batch; ++k) {
         scratch.emplace_back(new TmpBuf());
@@ -1414,7 +1428,10 @@ static int run_phase2_fwd_batch(AddPlan &pl, const uint64_t *const *srcs, uint64
     }
     for (size_t c0 = 0; c0 < cosets; c0 += group) {
         const size_t nc = cosets - c0 < group ? cosets - c0 : group;
-        for (size_t k = 0; k < batch; ++k) {                    // upper passes only: the scratch holds the block-order input of the last pass
+        // upper passes only: the scratch holds the block-order input of the last pass.  (One launch per pass for all polynomials of the batch —
+        // four times the workgroups, a quarter of the launch tails — was measured in round 5: k_bfly_upper unchanged, the last pass 0.4 ms slower,
+        // its input no longer in the Infinity Cache: profiles/r05_ab_upper_batch.txt.)
+        for (size_t k = 0; k < batch; ++k) {
             const int rc = run_phase2<false>(pl, srcs[k], scratch[k]->u64(), nhi, coset_begin + c0, nc, /*upper_only=*/true, rs_comb.u64() + 3 * c0 * d);
             if (rc != IOPX_OK) return rc;
         }
@@ -1437,9 +1454,15 @@ static int run_phase2_fwd_batch(AddPlan &pl, const uint64_t *const *srcs, uint64
         q.batch = (int)batch;
         for (size_t k = 0; k < batch; ++k) { q.srcs[k] = scratch[k]->u64(); q.dsts[k] = dsts[k] + 3 * c0 * nd; }
         const size_t lds = (((size_t)24) << tb) * batch;
-        if ((rc = set_lds(k_bfly_edge_fwd_batch, lds)) != IOPX_OK) return rc;
-        { ProfScope ps_("k_bfly_edge_fwd_batch", batch * (nc << d) * 48, batch * ((nc << d) >> 1) * (size_t)p.a_low);
-          hipLaunchKernelGGL(k_bfly_edge_fwd_batch, dim3((unsigned)p.total_units), dim3(512), lds, stream(), q); }
+        if (tuning().edge_lean & 1) {
+            if ((rc = set_lds(k_bfly_edge_fwd_batch<true>, lds)) != IOPX_OK) return rc;
+            ProfScope ps_("k_bfly_edge_fwd_batch", batch * (nc << d) * 48, batch * ((nc << d) >> 1) * (size_t)p.a_low);
+            hipLaunchKernelGGL(k_bfly_edge_fwd_batch<true>, dim3((unsigned)p.total_units), dim3(512), lds, stream(), q);
+        } else {
+            if ((rc = set_lds(k_bfly_edge_fwd_batch<false>, lds)) != IOPX_OK) return rc;
+            ProfScope ps_("k_bfly_edge_fwd_batch", batch * (nc << d) * 48, batch * ((nc << d) >> 1) * (size_t)p.a_low);
+            hipLaunchKernelGGL(k_bfly_edge_fwd_batch<false>, dim3((unsigned)p.total_units), dim3(512), lds, stream(), q);
+        }
     }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;

@@ -199,6 +199,56 @@ __device__ __forceinline__ gf192 gf_mul(const gf192 &a, const gf192 &b)
     return gf_reduce(c);
 }
 
+// The same product with a small register footprint (round 5).  gf_mul splits all twelve input words into their hole forms up front and
+// forms the Karatsuba sums on the split words: 72 VGPRs before the first multiply, 114 - 118 for a kernel built around it, i.e. four
+// wavefronts per SIMD.  Here the Karatsuba sums are formed on the WORDS and every word product splits its own two operands — each split
+// form is used by exactly one product, and (x0 ^ x1) & m is one three-input op — so the instruction count stays (937 against 931 VALU ops)
+// while the product needs 54 VGPRs: the edge kernels fit 80 registers and run six wavefronts per SIMD.
+__device__ __forceinline__ void clmul32_words(uint32_t x, uint32_t y, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t xs[4] = { x & 0x11111111u, x & 0x22222222u, x & 0x44444444u, x & 0x88888888u };
+    const uint32_t ys[4] = { y & 0x11111111u, y & 0x22222222u, y & 0x44444444u, y & 0x88888888u };
+    uint32_t zl[4], zh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint64_t a = (uint64_t)xs[0] * ys[k], b = (uint64_t)xs[1] * ys[(k + 3) & 3], c = (uint64_t)xs[2] * ys[(k + 2) & 3], d = (uint64_t)xs[3] * ys[(k + 1) & 3];
+        zl[k] = xor3((uint32_t)a, (uint32_t)b, (uint32_t)c) ^ (uint32_t)d;
+        zh[k] = xor3((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32)) ^ (uint32_t)(d >> 32);
+    }
+    lo = bsel(bsel(zl[0], zl[1], 0x55555555u), bsel(zl[2], zl[3], 0x55555555u), 0x33333333u);
+    hi = bsel(bsel(zh[0], zh[1], 0x55555555u), bsel(zh[2], zh[3], 0x55555555u), 0x33333333u);
+}
+
+// (a0 + a1 X + a2 X^2)(b0 + b1 X + b2 X^2), X = x^32: Karatsuba with six word products (the formula of clmul96)
+__device__ __forceinline__ void clmul96_words(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t (&c)[6])
+{
+    uint32_t d0l, d0h, d1l, d1h, d2l, d2h, e01l, e01h, e02l, e02h, e12l, e12h;
+    clmul32_words(a0, b0, d0l, d0h);
+    clmul32_words(a1, b1, d1l, d1h);
+    clmul32_words(a2, b2, d2l, d2h);
+    clmul32_words(a0 ^ a1, b0 ^ b1, e01l, e01h);
+    clmul32_words(a0 ^ a2, b0 ^ b2, e02l, e02h);
+    clmul32_words(a1 ^ a2, b1 ^ b2, e12l, e12h);
+    const uint32_t m1l = xor3(e01l, d0l, d1l), m1h = xor3(e01h, d0h, d1h);
+    const uint32_t m2l = xor3(e02l, d0l, d2l) ^ d1l, m2h = xor3(e02h, d0h, d2h) ^ d1h;
+    const uint32_t m3l = xor3(e12l, d1l, d2l), m3h = xor3(e12h, d1h, d2h);
+    c[0] = d0l; c[1] = d0h ^ m1l; c[2] = m1h ^ m2l; c[3] = m2h ^ m3l; c[4] = m3h ^ d2l; c[5] = d2h;
+}
+
+__device__ __forceinline__ gf192 gf_mul_lean(const gf192 &a, const gf192 &b)
+{
+    uint32_t p0[6], p1[6], p2[6];
+    clmul96_words(a.w[0], a.w[1], a.w[2], b.w[0], b.w[1], b.w[2], p0);
+    clmul96_words(a.w[3], a.w[4], a.w[5], b.w[3], b.w[4], b.w[5], p2);
+    clmul96_words(a.w[0] ^ a.w[3], a.w[1] ^ a.w[4], a.w[2] ^ a.w[5], b.w[0] ^ b.w[3], b.w[1] ^ b.w[4], b.w[2] ^ b.w[5], p1);
+    uint32_t c[12];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { c[i] = p0[i]; c[6 + i] = p2[i]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c[3 + i] ^= xor3(p1[i], p0[i], p2[i]);
+    return gf_reduce(c);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Product by  y / x^k  for a one-word y and 0 <= k < 32.
 //

@@ -853,3 +853,18 @@ def r1cs_check_csr(field, matrices, num_variables, num_inputs, assignment):
     if bad < 0:
         raise RuntimeError("oracle_r1cs_check_csr failed (%d)" % bad)
     return int(bad), out[0], out[1], out[2]
+
+
+def block_times(reset=True):
+    """{block name: (inclusive seconds, calls)} of the oracle provers since the last reset, under the reference's libff::enter_block names
+    ("Construct Merkle tree", "pow", "evaluating next FRI codeword", "Call to additive_FFT_wrapper", ...: oracle/field.hpp)."""
+    l = lib()
+    l.oracle_block_times.restype = ctypes.c_size_t
+    need = l.oracle_block_times(None, ctypes.c_size_t(0), ctypes.c_int(0))
+    buf = ctypes.create_string_buffer(need + 16)
+    l.oracle_block_times(buf, ctypes.c_size_t(need + 16), ctypes.c_int(1 if reset else 0))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, sec, calls = line.split("\t")
+        out[name] = (float(sec), int(calls))
+    return out

@@ -590,10 +590,12 @@ template<typename F> std::vector<mult_coset<F>> fri_domains(const mult_coset<F> 
 }
 template<typename F> std::vector<F> fri_fold(const std::vector<F> &f, const affine_subspace<F> &d, size_t cs, const F &x)
 {
+    timed_block tb("evaluating next FRI codeword");                                                   // fri_ldt.tcc:519
     return additive_evaluate_next_f_i_over_entire_domain<F>(f, d, cs, x);
 }
 template<typename F> std::vector<F> fri_fold(const std::vector<F> &f, const mult_coset<F> &d, size_t cs, const F &x)
 {
+    timed_block tb("evaluating next FRI codeword");
     return multiplicative_evaluate_next_f_i_over_entire_domain<F>(f, d, cs, x);
 }
 // evaluate_next_f_i_at_coset (fri_aux.tcc:251-349): `shift` is the queried coset's first element
@@ -846,6 +848,7 @@ template<typename F>
 bcs_transcript<F> aurora_snark_prover(const r1cs_system<F> &cs, const std::vector<F> &primary_input, const std::vector<F> &auxiliary_input,
                                       const aurora_parameters<F> &params)
 {
+    timed_block tb("Aurora SNARK prover");                                                            // aurora_snark.tcc:126
     bcs_protocol<F> IOP(params.pow_bits);
     aurora_iop<F> full_protocol(IOP, cs, params);
     full_protocol.register_interactions();
@@ -853,6 +856,7 @@ bcs_transcript<F> aurora_snark_prover(const r1cs_system<F> &cs, const std::vecto
     full_protocol.register_queries();
     IOP.seal_query_registrations();
     full_protocol.produce_proof(primary_input, auxiliary_input);
+    timed_block tb_transcript("Obtain transcript");                                                   // aurora_snark.tcc:138
     return IOP.get_transcript();
 }
 

@@ -16,15 +16,36 @@
 // tests/test_oracle_field.py; byte-identity with libff itself is NOT checkable in this image
 // ("parity unpinned" for the libff constants).
 #pragma once
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <cstddef>
+#include <map>
+#include <string>
 
 #if defined(__PCLMUL__)
 #include <immintrin.h>
 #endif
 
 namespace oracle {
+
+// ---- block timers under the reference's own block names (libff::enter_block / leave_block: bcs/bcs_prover.tcc:26,43,52,
+// protocols/ldt/fri/fri_ldt.tcc:519, algebra/fft.tcc:210,222,382,394, snark/aurora_snark.tcc:126,138): inclusive wall-clock seconds and call
+// counts per name, read by bench.py's cpu_baseline leg through oracle_block_times.  Off the hot loops: one clock read at each end of a block. ----
+struct block_times {
+    static std::map<std::string, std::pair<double, size_t>> &table() { static std::map<std::string, std::pair<double, size_t>> t; return t; }
+};
+struct timed_block {
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    explicit timed_block(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
+    ~timed_block()
+    {
+        auto &e = block_times::table()[name];
+        e.first += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        e.second += 1;
+    }
+};
 
 // ---- carry-less 64x64 -> 128 -------------------------------------------------------------
 static inline void clmul64_portable(uint64_t a, uint64_t b, uint64_t &lo, uint64_t &hi)

@@ -268,6 +268,7 @@ public:
     void signal_prover_round_done()
     {
         if (num_prover_rounds_done_ >= num_interaction_rounds_) throw std::logic_error("attempting to signal end of a round after protocol already finished");
+        timed_block tb_round("Finish prover round");                                                 // bcs_prover.tcc:26
         const size_t ended_round = num_prover_rounds_done_;
         for (size_t id = min_oracle_id(ended_round); id < max_oracle_id(ended_round); ++id)
             if (!oracles_present_[id]) throw std::logic_error("signaling end of round without submitting all oracles in the round");
@@ -288,6 +289,7 @@ public:
             const size_t n = dom_size(domains_[kv.first]);
             std::vector<uint8_t> &nodes = MT_nodes_[processed_MTs_];
             nodes.resize((2 * (n / cs) - 1) * DIGEST_LEN);
+            timed_block tb_tree("Construct Merkle tree");                                             // bcs_prover.tcc:43
             merkle_build(ptrs.data(), ptrs.size(), sizeof(F), n, cs, dom_additive(domains_[kv.first]), nullptr, 0, nodes.data());
             roots.push_back(digest_t(nodes.begin(), nodes.begin() + DIGEST_LEN));
             ++processed_MTs_;
@@ -297,6 +299,7 @@ public:
         if (num_prover_rounds_done_ == num_interaction_rounds_ && !(is_holographic_ && num_interaction_rounds_ == 1)) {
             const digest_t challenge = squeeze_root_type();
             pow_answer_.resize(DIGEST_LEN);
+            timed_block tb_pow("pow");                                                                // bcs_prover.tcc:52
             pow_solve_blake2b(challenge.data(), pow_bitlen_, pow_answer_.data());
         }
     }

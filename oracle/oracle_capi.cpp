@@ -889,6 +889,20 @@ long oracle_r1cs_check_csr(int field, size_t num_constraints, size_t num_variabl
 }
 #undef CSR_VIEW
 
+// the block timers of field.hpp: "name\tseconds\tcalls\n" per block into buf (returns the length needed); reset != 0 clears them afterwards
+size_t oracle_block_times(char *buf, size_t cap, int reset)
+{
+    std::string out;
+    for (auto &kv : block_times::table()) {
+        char line[256];
+        snprintf(line, sizeof line, "%s\t%.9f\t%zu\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        out += line;
+    }
+    if (buf && cap) { const size_t n = out.size() < cap - 1 ? out.size() : cap - 1; memcpy(buf, out.data(), n); buf[n] = 0; }
+    if (reset) block_times::table().clear();
+    return out.size() + 1;
+}
+
 // FRI-only SNARK (aurora.hpp FRI_snark_*): the polynomial's coefficients are seeded_element(seed, i), i < 2^(dim - rs_extra)
 } // extern "C"
 

@@ -1,4 +1,8 @@
-// Micro-benchmark: in-register throughput of the GF(2^192) products (no memory traffic in the loop).
+// Micro-benchmark: in-register throughput of the GF(2^192) products (no memory traffic in the loop) against the number of wavefronts per
+// SIMD.  A workgroup is 256 threads (one wavefront per SIMD of its CU) and asks for 160 KB / k of LDS, so exactly k workgroups — k waves per
+// SIMD — are resident, whatever the kernel's register count allows beyond that.  Round 5: general = gf_mul (114 VGPRs: at most 4 waves),
+// lean = gf_mul_lean (53 VGPRs), uniform = the comb product.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I libiop_amd/csrc/include -mllvm -pragma-unroll-threshold=1000000 tools/ubench/mul_rates.hip -o tools/ubench/mul_rates
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "../../libiop_amd/csrc/gf192_dev.h"
@@ -7,33 +11,40 @@
 template<int MODE>
 __global__ void __launch_bounds__(256) k(const uint64_t *in, uint64_t *out)
 {
+    extern __shared__ uint64_t lds[];
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     gf192 x = gf_load(in, i), y = gf_load(in, (i * 7 + 3) & 0xffff);
     const gf192 u = gf_load(in, 5);
+    if (in == out) lds[threadIdx.x] = x.w[0];            // never true: keeps the allocation
     for (int r = 0; r < CHAIN; ++r) {
         if (MODE == 0) x = gf_mul(x, y);
+        else if (MODE == 2) x = gf_mul_lean(x, y);
         else x = gf_mul_uniform(x, u);
     }
     gf_store(out, i, x);
 }
 
-template<int MODE> void run(const char *name, const uint64_t *in, uint64_t *out, int blocks)
+template<int MODE> void run(const char *name, const uint64_t *in, uint64_t *out, int waves)
 {
+    const int blocks = 256 * waves * 8;
+    const size_t lds = (160 * 1024) / waves - 256;
+    hipFuncSetAttribute((const void *)k<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, in, out);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), lds, 0, in, out);
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, in, out);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), lds, 0, in, out);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("%-10s blocks=%5d  %8.3f ms  %.3e mult/s\n", name, blocks, ms, (double)blocks * 256 * CHAIN / ms * 1e3);
+    const double rate = (double)blocks * 256 * CHAIN / ms * 1e3;
+    printf("%-8s %d waves/SIMD (asked)  %8.3f ms  %.3e products/s  %.0f cycles per wave-product per SIMD\n", name, waves, ms, rate, 1024.0 * 2.4e9 * 64 / rate);
 }
 
 int main()
 {
-    const int maxb = 256 * 16;
     uint64_t *in, *out;
-    hipMalloc(&in, (size_t)maxb * 256 * 24); hipMalloc(&out, (size_t)maxb * 256 * 24);
-    hipMemset(in, 0x5a, (size_t)maxb * 256 * 24);
-    for (int b : {256 * 2, 256 * 4, 256 * 8, 256 * 16}) { run<0>("general", in, out, b); run<1>("uniform", in, out, b); }
+    const size_t n = (size_t)256 * 8 * 8 * 256;
+    hipMalloc(&in, n * 24); hipMalloc(&out, n * 24);
+    hipMemset(in, 0x5a, n * 24);
+    for (int w : {2, 3, 4, 5, 6, 8}) { run<0>("general", in, out, w); run<2>("lean", in, out, w); run<1>("uniform", in, out, w); }
     return 0;
 }

@@ -12,6 +12,7 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed)
     uint32_t a[8];
     for (int i = 0; i < 8; ++i) a[i] = seed * (threadIdx.x + 1) + i;
     uint32_t b = seed ^ 0x9e3779b9u, c = seed + 77, sc = 0;
+    uint32_t d2[4] = { seed, 0x3ff00000u | (seed & 0xfffff), seed * 3u, 0x3fe00000u | (seed & 0xffff) };
     for (int r = 0; r < REP; ++r) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -39,6 +40,16 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, uint32_t seed)
             if (OP == 21) asm volatile("v_readfirstlane_b32 %1, %0\n\tv_xor_b32 %0, %1, %0" : "+v"(a[i]), "=s"(sc) : );
             if (OP == 22) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a[i]) : "s"(seed));
             if (OP == 23) asm volatile("v_and_b32 %0, 0x55555555, %0" : "+v"(a[i]));
+            // round 5: the double-precision pipe (a 181-bit Montgomery product on FMA limbs) and the other integer multiplies
+            if (OP == 24) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(*(double *)&a[i & 6]) : "v"(*(double *)&d2[0]), "v"(*(double *)&d2[2]));
+            if (OP == 25) asm volatile("v_add_f64 %0, %0, %1" : "+v"(*(double *)&a[i & 6]) : "v"(*(double *)&d2[0]));
+            if (OP == 26) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(*(double *)&a[i & 6]) : "v"(*(double *)&d2[0]));
+            if (OP == 27) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            if (OP == 28) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+            if (OP == 29) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(*(double *)&a[i & 6]) : "v"(b));
+            if (OP == 30) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(*(uint64_t *)&a[i & 6]) : "v"(b), "v"(c) : "vcc");
+            if (OP == 31) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(*(uint64_t *)&a[i & 6]) : "v"(*(uint64_t *)&d2[0]), "v"(*(uint64_t *)&d2[2]));
+            if (OP == 32) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));
         }
     }
     uint32_t s = 0;
@@ -87,5 +98,14 @@ int main()
     run<22>("v_xor_b32 (VOP2, sgpr src0)", d);
     run<23>("v_and_b32 (VOP2, literal)", d);
     run<21>("v_readfirstlane + v_xor pair", d);
+    run<24>("v_fma_f64", d);
+    run<25>("v_add_f64", d);
+    run<26>("v_mul_f64", d);
+    run<29>("v_cvt_f64_u32", d);
+    run<27>("v_mul_hi_u32", d);
+    run<28>("v_mad_u32_u24", d);
+    run<30>("v_mad_i64_i32", d);
+    run<32>("v_fma_f32", d);
+    run<31>("v_pk_fma_f32 (2 lanes of f32 per op)", d);
     return 0;
 }
