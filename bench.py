@@ -105,10 +105,11 @@ def _oracle_prove(k):
 def cpu_baseline_leg(k, all_cores):
     """Times the oracle prover (test infrastructure: used here as the reported CPU baseline only) on the 2^k-constraint sample."""
     import oracle
+    oracle.block_times()                 # reset
     t0 = time.perf_counter()
     ref = oracle.aurora_prove(oracle.FIELD_GF192, k, 15, SEED)
     cpu_s = time.perf_counter() - t0
-    out = {"transcript": ref, "seconds": cpu_s, "log_n": k, "host": host_description()}
+    out = {"transcript": ref, "seconds": cpu_s, "log_n": k, "host": host_description(), "blocks": oracle.block_times()}
     if all_cores:
         # not in the reference (it is single-threaded): one independent proof per logical core, all at once — a throughput figure
         import multiprocessing as mp
@@ -134,6 +135,43 @@ def alu_model():
         return None
 
 
+# The reference's own profiling blocks (libff::enter_block) and the device kernels that do their work: per-stage time on both legs under one
+# vocabulary.  Device side = HIP-event time of the kernels inside one proof; CPU side = the oracle's timers under the same names (oracle/field.hpp).
+REFERENCE_BLOCKS = [
+    ("Call to additive_FFT_wrapper", "libiop/algebra/fft.tcc:210", ("k_bfly_upper_fwd", "k_bfly_edge_fwd", "k_phase1_fwd", "k_rs_combine", "k_pad_copy", "k_pow_direct", "k_pow_expand", "k_fill")),
+    ("Call to additive_IFFT_wrapper", "libiop/algebra/fft.tcc:222", ("k_bfly_upper_inv", "k_bfly_edge_inv", "k_phase1_inv")),
+    ("Construct Merkle tree", "libiop/bcs/bcs_prover.tcc:43", ("k_merkle_",)),
+    ("evaluating next FRI codeword", "libiop/protocols/ldt/fri/fri_ldt.tcc:519", ("k_fri_fold",)),
+    ("pow", "libiop/bcs/bcs_prover.tcc:52", ("k_pow_blake2b",)),
+    ("Obtain transcript", "libiop/snark/aurora_snark.tcc:138", ("k_gather_nodes", "k_gather_responses")),
+]
+
+
+def device_stages(prof):
+    """Kernel time of one proof (HIP events) grouped under the reference's block names; what no block of the reference times on its own — the
+    virtual oracles' evaluated_contents, the sparse products, constant uploads — is 'other (virtual oracles, sparse products, uploads)'."""
+    out, used = {}, set()
+    for name, where, prefixes in REFERENCE_BLOCKS:
+        members = [k for k in prof if k.startswith(prefixes)]
+        used.update(members)
+        out[name] = {"ms": round(sum(prof[k][1] for k in members), 4), "launches": sum(prof[k][0] for k in members), "reference_block": where}
+    rest = [k for k in prof if k not in used]
+    out["other (virtual oracles, sparse products, uploads)"] = {"ms": round(sum(prof[k][1] for k in rest), 4), "launches": sum(prof[k][0] for k in rest)}
+    return out
+
+
+def headline_cpu_figure():
+    """The oracle prover at the HEADLINE size, measured once on the GPU box's host (tools/cpu_baseline_sizes.py, hours of one core: not repeated per run):
+    profiles/r04_cpu_baseline_sizes.json, with the transcript digest its time was accepted on — the digest the device prover's transcript must hash to."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_baseline_sizes.json")))
+        e = next(x for x in j["sizes"] if x["log_n"] == 20)
+        return {"log_n": 20, "prover_seconds": e["prover_seconds"], "field_ops_per_s": e["field_ops_per_s"], "cores": j["cores"], "kind": j["kind"],
+                "host": j["host"], "transcript_blake2b": e["transcript_blake2b"], "source": "profiles/r04_cpu_baseline_sizes.json (tools/cpu_baseline_sizes.py --log-n 20)"}
+    except (OSError, ValueError, KeyError, StopIteration):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,8 +184,8 @@ def main():
                     help="skip the second prover's proof after the timed loop (profiling runs: its reference-schedule launches would mix into the per-kernel counters)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the multi-GPU operator set even with one rank (exercises the RCCL calls on a 1-GPU box; run under torch.distributed.run)")
-    ap.add_argument("--cpu-log-n", type=int, default=13, help="size of the CPU-baseline sample (oracle prover); 2^13: about 20 s on one core")
-    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-host-cores variant of the CPU baseline (one independent oracle proof per core)")
+    ap.add_argument("--cpu-log-n", type=int, default=12, help="size of the CPU-baseline sample (oracle prover); 2^12: about 8 s on one core, 2^13: 17 s")
+    ap.add_argument("--cpu-all-cores", action="store_true", help="also time one independent oracle proof per host core at once (not in the reference, which is single-threaded)")
     args = ap.parse_args()
 
     # RCCL prints a version banner on STDOUT at NCCL_DEBUG=VERSION/INFO (seen on the GPU box: five lines ahead of the JSON line);
@@ -168,7 +206,7 @@ def main():
     # device prover's for that instance further down, before the number is reported.
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline_leg(args.cpu_log_n, not args.no_cpu_all_cores)
+        cpu = cpu_baseline_leg(args.cpu_log_n, args.cpu_all_cores)
 
     import torch
     import torch.distributed as dist
@@ -218,8 +256,17 @@ def main():
 
     transcript = None
     import gc
+    # the very first proof of this process on this instance, timed on its own: it builds what the later ones find cached — per-domain plans
+    # and twiddle tables, the transposed lincheck matrices, subspace-polynomial tables, the buffer pool (reported, never part of `value`)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    first = step()
+    torch.cuda.synchronize()
+    first_proof_s = time.perf_counter() - t0
     for _ in range(args.warmup):
         transcript = step()
+    if transcript is None:
+        transcript = first
     gc.collect()
     gc.freeze()             # the instance, the plans and the modules are long-lived: keep them out of the collector's generations
     torch.cuda.synchronize()
@@ -268,11 +315,22 @@ def main():
         assert t_ref.serialize() == transcript.serialize(), "the two schedules produced different transcripts"
         reference_schedule = {"ms_per_step": ref_s * 1e3, "steps": 5, "transcript_equal": True}
 
-    # per-kernel durations of one more proof, live, with HIP events on the stream the kernels are launched on
+    # per-kernel durations of one more proof, live, with HIP events on the stream the kernels are launched on.  The timed loop builds every round's
+    # Merkle tree on the library's side stream, beside the next round's transforms; for THIS proof the trees stay on the main stream
+    # (IOPX_MERKLE_STREAM=0, read per round), so that every kernel is timed running alone and the durations add up
     lib.comm_stats(reset=True)
-    lib.profile_begin()
-    step()
-    prof = lib.profile_report()
+    os.environ["IOPX_MERKLE_STREAM"] = "0"
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        serial_proof_s = time.perf_counter() - t0
+        lib.profile_begin()
+        step()
+        prof = lib.profile_report()
+    finally:
+        del os.environ["IOPX_MERKLE_STREAM"]
     comm_calls, comm_bytes = lib.comm_stats()
     dom_name, (dom_cnt, dom_ms, dom_bytes) = max(prof.items(), key=lambda kv: kv[1][1])
     dom_avg_s = dom_ms / dom_cnt / 1e3
@@ -334,6 +392,8 @@ def main():
                         "security 128, RS_extra_dimensions 5, FRI localization 2, non-zk, BLAKE2b: one complete proof per step, "
                         "instance and witness resident in HBM" % (args.log_n, SEED),
             "log_n": args.log_n, "field": "gf192", "prover_s": prover_s,
+            "first_proof_ms": first_proof_s * 1e3,          # cold: this process's first proof of the instance (plans, tables, caches built), before the warm-up
+            "stages_ms": device_stages(prof),                # kernel time of one proof under the reference's profiling block names
             "prover": ("native: iopx_aurora_prove (libiop_amd/cpp/aurora.hpp behind the C ABI); transcript equal to libiop_amd/aurora.py's" if comm is None else
                        "native: iopx_aurora_prove_dist (libiop_amd/cpp/aurora.hpp + dist.hpp behind the C ABI, RCCL communicator of %d rank(s)); transcript equal to "
                        "the single-GPU prover's" % world),
@@ -374,7 +434,10 @@ def main():
                      "kernels_ms_total": round(sum(v[1] for v in prof.values()), 3),
                      # idle time between consecutive launches of the profiled proof (HIP events; the longest gaps name the kernels on both sides)
                      "launch_gaps": getattr(lib, "last_profile_gaps", None),
-                     "host_gap_ms": round(prover_s * 1e3 - sum(v[1] for v in prof.values()), 3) if prof else None},
+                     "host_gap_ms": round(prover_s * 1e3 - sum(v[1] for v in prof.values()), 3) if prof else None,
+                     "host_gap_note": "timed loop's ms per proof minus the profiled proof's kernel sum; negative since round 5: the loop overlaps each round's Merkle tree with the "
+                                      "next round's kernels on a second stream, the profiled proof (ms_per_proof_trees_on_main_stream) does not",
+                     "ms_per_proof_trees_on_main_stream": round(serial_proof_s * 1e3, 3)},
     }
 
     if reference_schedule:
@@ -486,8 +549,12 @@ def main():
         ops_k = sum(sum(ref_fft_ops(m)) for _, m in inv_k)
         out["cpu_baseline"] = {"value": ops_k / cpu["seconds"], "unit": "field-ops/s", "cores": 1, "kind": "port",
                                "sample": "the same prover on a 2^%d-constraint instance (same protocol, rate 1/32, seed): %.2f s on one core, run before the "
-                                         "GPU loop; its transcript equals the device prover's byte for byte" % (k, cpu["seconds"]),
-                               "seconds": cpu["seconds"], "sample_log_n": k, "host": cpu["host"]}
+                                         "GPU loop; its transcript equals the device prover's byte for byte (headline_size: the 2^20 instance itself, measured once)" % (k, cpu["seconds"]),
+                               "seconds": cpu["seconds"], "sample_log_n": k, "host": cpu["host"],
+                               # inclusive seconds / calls of the sample under the reference's block names (nested: the FFT wrappers run inside other blocks)
+                               "stages_s": {name: {"seconds": round(v[0], 6), "calls": v[1]} for name, v in sorted(cpu["blocks"].items())},
+                               # the same prover at the headline size, measured once on this pool's host (not re-run here: 42 minutes of one core)
+                               "headline_size": headline_cpu_figure()}
         if "all_cores" in cpu:
             ac = cpu["all_cores"]
             inv_a = aurora_transform_inventory(ac["log_n"], params_k.RS_extra_dimensions, ac["log_n"] + params_k.RS_extra_dimensions - sum(

@@ -59,6 +59,15 @@ int         iopx_malloc(void **dptr, size_t bytes);
 int         iopx_free(void *dptr);
 int         iopx_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int         iopx_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+/* A second stream for work nothing later in the caller's sequence waits for (the provers put each round's Merkle tree there: its root is
+ * needed by the transcript only — reference quirk F8, bcs/hashing/blake2b.tcc:51-66 — while the next round's transforms go on on the main
+ * stream).  _begin: the side stream waits for everything enqueued so far and becomes the library's current stream (kernels, copies, pool
+ * allocations); _end: back to the main stream, the side work still in flight; _join: the main stream waits for the side stream (no host
+ * wait) and buffers freed inside the section become reusable.  iopx_synchronize and iopx_set_stream join first.  Sections do not nest; one
+ * host thread per process drives them.  Collectives of a communicator stay on the main stream (the provers do not fork when distributed). */
+int         iopx_side_stream_begin(void);
+int         iopx_side_stream_end(void);
+int         iopx_side_stream_join(void);
 /* iopx_memcpy_d2h that takes part in an iopx_defer_downloads window (below): queued there, delivered by iopx_defer_downloads_end */
 int         iopx_memcpy_d2h_deferrable(void *dst_host, const void *src_dev, size_t bytes);
 /* Transcript extraction reads back two small results per Merkle tree (iopx_query_responses_dev, iopx_merkle_membership_proof_dev).  Between

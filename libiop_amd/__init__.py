@@ -56,6 +56,7 @@ EXPORTED_SYMBOLS = [
     "iopx_pool_alloc", "iopx_pool_free", "iopx_memcpy_d2d", "iopx_memset_dev", "iopx_upload_small", "iopx_gather_dev", "iopx_scatter_dev", "iopx_gather_stride_dev", "iopx_count_mismatch_dev", "iopx_div_by_vanishing_gf192_dev", "iopx_add_reextend2_gf192_batch_dev",
     "iopx_transfer_stats", "iopx_blake2b_host", "iopx_gf192_host_mul", "iopx_fp3_host_add", "iopx_fp3_host_sub", "iopx_fp3_host_inverse",
     "iopx_fp3_from_uint", "iopx_fp3_modulus", "iopx_pow_search_blake2b", "iopx_pow_search_blake2b_begin", "iopx_pow_search_blake2b_end", "iopx_pow_candidate_blake2b",
+    "iopx_side_stream_begin", "iopx_side_stream_end", "iopx_side_stream_join",
     "iopx_aurora_instance_create", "iopx_aurora_example_instance_create", "iopx_aurora_prove", "iopx_aurora_instance_free", "iopx_host_free",
     "iopx_fractal_index", "iopx_fractal_prove",
     "iopx_memcpy_d2h_deferrable", "iopx_comm_rccl_unique_id", "iopx_comm_create_rccl", "iopx_comm_create_callbacks", "iopx_comm_destroy", "iopx_comm_rank",

@@ -188,6 +188,8 @@ public:
         check(iopx_memcpy_d2h(d, distributed_ ? top_nodes_.data() : nodes_.data(), 32));
         return hash_digest(reinterpret_cast<const char *>(d), 32);
     }
+    // the same read-back queued into dst (32 bytes that outlive the window) inside an iopx_defer_downloads window, immediate outside one
+    void get_root_into(uint8_t *dst) const { check(iopx_memcpy_d2h_deferrable(dst, distributed_ ? top_nodes_.data() : nodes_.data(), 32)); }
     // the auxiliary hashes of the pruned multi-membership proof as raw bytes (32 each); inside an iopx_defer_downloads window the buffer is
     // filled by iopx_defer_downloads_end
     std::vector<uint8_t> get_set_membership_proof_bytes(const std::vector<std::size_t> &leaf_positions) const
@@ -422,6 +424,7 @@ private:
 
 public:
     explicit bcs_prover(std::size_t pow_work_parameter, const bcs_prover_index<FieldT> *index = nullptr) : pow_bitlen_(pow_work_parameter), index_(index) {}
+    ~bcs_prover() { (void)iopx_side_stream_join(); }            // trees still being built beside the rounds read this object's oracles (an unwinding proof)
 
     // ---- registration ----
     domain_handle register_domain(const field_subset<FieldT> &S) { domains_.push_back(S); return domain_handle{ domains_.size() - 1 }; }
@@ -498,6 +501,8 @@ public:
                 MT_trees_.emplace_back();
                 MT_roots_.emplace_back();
             }
+        root_pending_.assign(MT_roots_.size(), 0);
+        root_bytes_.assign(MT_roots_.size() * 32, 0);
     }
     query_position_handle register_random_query_position(const domain_handle &domain)
     {
@@ -555,8 +560,9 @@ public:
         finish_round(index_ == nullptr);
     }
     std::size_t num_index_trees() const { return oracles_in_round_by_domain(0).size(); }
-    bcs_prover_index<FieldT> get_prover_index() const                                        // bcs_indexer::get_bcs_prover_index (bcs_indexer.tcc:80-103)
+    bcs_prover_index<FieldT> get_prover_index()                                              // bcs_indexer::get_bcs_prover_index (bcs_indexer.tcc:80-103)
     {
+        resolve_roots();
         bcs_prover_index<FieldT> idx;
         const std::size_t k = num_index_trees(), count = num_oracles_at_end_of_round_[0];
         idx.oracles.assign(oracles_.begin(), oracles_.begin() + count);
@@ -565,14 +571,47 @@ public:
         idx.prover_messages.assign(prover_messages_.begin(), prover_messages_.begin() + num_prover_messages_at_end_of_round_[0]);
         return idx;
     }
-    bcs_verifier_index get_verifier_index() const
+    bcs_verifier_index get_verifier_index()
     {
+        resolve_roots();
         bcs_verifier_index v;
         v.index_MT_roots_.assign(MT_roots_.begin(), MT_roots_.begin() + num_index_trees());
         return v;
     }
     void signal_prover_round_done() { finish_round(true); }
 private:
+    std::vector<char> root_pending_;            // trees whose root has not been read back yet
+    std::vector<uint8_t> root_bytes_;           // 32 bytes per tree: the target of the queued read-backs
+    static bool merkle_aside()                  // read per round (a profiling run measures its kernels one at a time with IOPX_MERKLE_STREAM=0)
+    {
+        const char *e = std::getenv("IOPX_MERKLE_STREAM");
+        return !(e && e[0] == '0');
+    }
+    static bool defer_roots()
+    {
+        static const bool on = [] { const char *e = std::getenv("IOPX_DEFER_ROOTS"); return !(e && e[0] == '0'); }();
+        return on;
+    }
+    // queues the read-back of every pending root (inside a defer window: delivered by its end); finish_pending_roots turns the bytes into digests
+    void queue_pending_roots()
+    {
+        for (std::size_t mt = 0; mt < root_pending_.size(); ++mt)
+            if (root_pending_[mt]) MT_trees_[mt].get_root_into(root_bytes_.data() + 32 * mt);
+    }
+    void finish_pending_roots()
+    {
+        for (std::size_t mt = 0; mt < root_pending_.size(); ++mt)
+            if (root_pending_[mt]) { MT_roots_[mt] = hash_digest(reinterpret_cast<const char *>(root_bytes_.data() + 32 * mt), 32); root_pending_[mt] = 0; }
+    }
+    void resolve_roots()
+    {
+        bool any = false;
+        for (char c : root_pending_) any = any || c;
+        if (!any) return;
+        check(iopx_side_stream_join());
+        queue_pending_roots();                  // outside a window: immediate copies
+        finish_pending_roots();
+    }
     void finish_round(bool build_trees)
     {
         if (num_prover_rounds_done_ >= num_interaction_rounds_) throw std::logic_error("attempting to signal end of a round after protocol already finished");
@@ -594,8 +633,19 @@ private:
             if (build_trees) {
                 std::vector<device_vector<FieldT>> round_oracles;
                 for (std::size_t oid : kv.second) round_oracles.push_back(oracles_[oid]);
+                // ... and nothing else in the next round reads the tree, so its kernels (leaves, levels and the single-workgroup top: 5.7 ms of a
+                // 2^20 proof, 0.9 ms of it latency-bound) go to the library's side stream and run beside the next round's transforms; the query
+                // phase joins.  Not when distributed: the tree's collectives stay in the communicator's one stream order.  IOPX_MERKLE_STREAM=0: main stream.
+                const bool aside = defer_roots() && merkle_aside() && !dist::ctx().active();
+                if (aside) check(iopx_side_stream_begin());
+                struct back_to_main { bool on; ~back_to_main() { if (on) (void)iopx_side_stream_end(); } } section{ aside };
                 MT_trees_[processed_MTs_] = device_merkle_tree(round_oracles, domains_[kv.first], cs);
-                MT_roots_[processed_MTs_] = MT_trees_[processed_MTs_].get_root();
+                // The root is needed on the host for the TRANSCRIPT only: blake2b_hashchain::absorb never mixes its input in (reference quirk F8,
+                // bcs/hashing/blake2b.tcc:51-66), so every challenge is a function of the round structure and the prover may go on enqueuing the
+                // next round without waiting for this tree.  The read-back is queued with the query phase's (one drain of the stream for all of
+                // them); IOPX_DEFER_ROOTS=0 reads each root at its round end, as round 4 did (11 drains of about 40 us per 2^20 proof).
+                if (defer_roots()) root_pending_[processed_MTs_] = 1;
+                else MT_roots_[processed_MTs_] = MT_trees_[processed_MTs_].get_root();
             } else {                                                                         // "The Merkle trees are already filled in by the preprocessor."
                 MT_trees_[processed_MTs_] = index_->trees[processed_MTs_];
                 MT_roots_[processed_MTs_] = index_->roots[processed_MTs_];
@@ -697,6 +747,7 @@ private:
     extracted extract_queries()
     {
         extracted x;
+        check(iopx_side_stream_join());                                                      // the trees built beside the rounds: the gathers below read them
         std::map<std::size_t, std::size_t> random_cache, det_cache;
         std::vector<std::vector<std::size_t>> positions_by_oracle(oracle_regs_.size());
         for (auto &q : queries_) record(q.first, obtain_query_position(q.second, random_cache, det_cache), positions_by_oracle);   // registration order
@@ -745,8 +796,10 @@ private:
             x.query_positions.push_back(std::move(qpos));
             x.leaf_positions.push_back(std::move(lpos));
         }
+        queue_pending_roots();                                                               // the roots travel with the answers and the paths
         check(iopx_defer_downloads_end());                                                   // one drain of the stream delivers every read-back queued above
         deferring = false;
+        finish_pending_roots();
         return x;
     }
     extracted extracted_;
@@ -763,8 +816,9 @@ public:
     {
         bcs_transformation_transcript<FieldT> t;
         t.prover_messages_ = prover_messages_;
-        t.MT_roots_ = MT_roots_;
         extracted x = take_extracted();
+        resolve_roots();
+        t.MT_roots_ = MT_roots_;
         t.query_positions_ = std::move(x.query_positions);
         t.MT_leaf_positions_ = std::move(x.leaf_positions);
         for (std::size_t mt = 0; mt < MT_info_.size(); ++mt) {
@@ -788,6 +842,7 @@ public:
     std::string get_transcript_bytes()
     {
         const extracted x = take_extracted();
+        resolve_roots();
         std::string out;
         auto u64 = [&](uint64_t v) { out.append(reinterpret_cast<const char *>(&v), 8); };
         const std::size_t first_message = is_holographic_ ? num_prover_messages_at_end_of_round_[0] : 0, first_root = is_holographic_ ? num_index_trees() : 0;

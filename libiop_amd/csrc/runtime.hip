@@ -36,7 +36,17 @@ int fail(int code, const char *fmt, ...)
 
 const char *last_error() { return g_err; }
 
-hipStream_t stream() { std::lock_guard<std::mutex> lk(g_mu); return g_stream; }
+// ---- the side stream (round 5): work that nothing later in the round waits for — a round's Merkle tree, whose root only the transcript
+// needs (bcs_prover::finish_round) — is enqueued there while the main stream goes on with the next round.  One fork: the side stream waits for
+// everything the main stream held at that moment; one join: the main stream waits for the side stream, and the temporaries freed on the side
+// are released for reuse.  Single host thread per process, like the rest of the prover entry points. ----
+static hipStream_t g_side_stream = nullptr;
+static hipEvent_t g_fork_event = nullptr, g_join_event = nullptr;
+static bool g_on_side = false;              // launches and copies go to the side stream
+static bool g_side_dirty = false;           // the side stream holds work the main stream has not waited for
+static inline hipStream_t active_stream() { return g_on_side ? g_side_stream : g_stream; }
+
+hipStream_t stream() { std::lock_guard<std::mutex> lk(g_mu); return active_stream(); }
 int bound_device();
 
 int ensure_device()
@@ -80,6 +90,7 @@ int set_stream(void *s, bool own)
     // switch under the lock, so a concurrent iopx_set_stream / iopx_use_own_stream from another host thread cannot make this
     // call drain a stream that is no longer (or not yet) the current one
     std::lock_guard<std::mutex> lk(g_mu);
+    if (g_side_dirty) (void)hipStreamSynchronize(g_side_stream);
     (void)hipStreamSynchronize(g_stream);
     g_caller_stream = !own;
     g_stream = own ? g_own_stream : (hipStream_t)s;
@@ -122,14 +133,55 @@ void *tmp_alloc(size_t bytes, size_t *cap)
     return p;
 }
 
+static std::vector<TmpBlock> g_tmp_quarantine;     // freed while the side stream was current: reusable once the main stream has joined it
+
 void tmp_free(void *p, size_t cap)
 {
     std::lock_guard<std::mutex> lk(g_tmp_mu);
-    g_tmp_free.push_back({p, cap});
+    (g_on_side ? g_tmp_quarantine : g_tmp_free).push_back({p, cap});
+}
+
+int side_stream_begin()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_on_side) return fail(IOPX_ERR_LOGIC, "iopx_side_stream_begin: already on the side stream");
+    if (!g_side_stream) {
+        IOPX_HIP(hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking));
+        IOPX_HIP(hipEventCreateWithFlags(&g_fork_event, hipEventDisableTiming));
+        IOPX_HIP(hipEventCreateWithFlags(&g_join_event, hipEventDisableTiming));
+    }
+    IOPX_HIP(hipEventRecord(g_fork_event, g_stream));
+    IOPX_HIP(hipStreamWaitEvent(g_side_stream, g_fork_event, 0));
+    g_on_side = true;
+    g_side_dirty = true;
+    return IOPX_OK;
+}
+
+int side_stream_end()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_on_side) return fail(IOPX_ERR_LOGIC, "iopx_side_stream_end without begin");
+    g_on_side = false;
+    return IOPX_OK;
+}
+
+int side_stream_join()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_on_side) return fail(IOPX_ERR_LOGIC, "iopx_side_stream_join inside a side-stream section");
+    if (!g_side_dirty) return IOPX_OK;
+    IOPX_HIP(hipEventRecord(g_join_event, g_side_stream));
+    IOPX_HIP(hipStreamWaitEvent(g_stream, g_join_event, 0));
+    g_side_dirty = false;
+    std::lock_guard<std::mutex> lt(g_tmp_mu);
+    g_tmp_free.insert(g_tmp_free.end(), g_tmp_quarantine.begin(), g_tmp_quarantine.end());
+    g_tmp_quarantine.clear();
+    return IOPX_OK;
 }
 
 void tmp_trim()
 {
+    if (g_side_dirty) (void)hipStreamSynchronize(g_side_stream);
     (void)hipStreamSynchronize(g_stream);
     std::lock_guard<std::mutex> lk(g_tmp_mu);
     for (auto &b : g_tmp_free) (void)hipFree(b.p);
@@ -166,7 +218,7 @@ int upload(void *dst_dev, const void *src_host, size_t bytes)
         UploadBlob blob;
         memcpy(blob.w, src_host, bytes);
         g_bytes_h2d += bytes;
-        { ProfScope ps_("k_upload_small"); hipLaunchKernelGGL(k_upload_small, dim3(1), dim3(256), 0, g_stream, blob, (uint32_t *)dst_dev, (int)(bytes / 4), (int)(bytes % 4)); }
+        { ProfScope ps_("k_upload_small"); hipLaunchKernelGGL(k_upload_small, dim3(1), dim3(256), 0, active_stream(), blob, (uint32_t *)dst_dev, (int)(bytes / 4), (int)(bytes % 4)); }
         IOPX_HIP(hipGetLastError());
         return IOPX_OK;
     }
@@ -188,8 +240,8 @@ int upload(void *dst_dev, const void *src_host, size_t bytes)
         c = &g_stage.back();
     }
     memcpy(c->p, src_host, bytes);
-    IOPX_HIP(copy_h2d(dst_dev, c->p, bytes, g_stream));
-    IOPX_HIP(hipEventRecord(c->done, g_stream));
+    IOPX_HIP(copy_h2d(dst_dev, c->p, bytes, active_stream()));
+    IOPX_HIP(hipEventRecord(c->done, active_stream()));
     c->busy = true;
     return IOPX_OK;
 }
@@ -222,14 +274,14 @@ int download(void *dst_host, const void *src_dev, size_t bytes, bool deferrable)
         }
         char *slot = c->p + c->used;
         c->used += need;
-        IOPX_HIP(copy_d2h(slot, src_dev, bytes, g_stream));
+        IOPX_HIP(copy_d2h(slot, src_dev, bytes, active_stream()));
         g_defer_items.push_back({dst_host, slot, bytes});
         return IOPX_OK;
     }
     if (bytes > ((size_t)4 << 20)) {                    // large read-backs (test helpers): the plain path
         lk.unlock();
-        IOPX_HIP(copy_d2h(dst_host, src_dev, bytes, g_stream));
-        IOPX_HIP(hipStreamSynchronize(g_stream));
+        IOPX_HIP(copy_d2h(dst_host, src_dev, bytes, active_stream()));
+        IOPX_HIP(hipStreamSynchronize(active_stream()));
         return IOPX_OK;
     }
     if (bytes > g_bounce_cap) {
@@ -240,8 +292,8 @@ int download(void *dst_host, const void *src_dev, size_t bytes, bool deferrable)
         if (e != hipSuccess) return fail(IOPX_ERR_RUNTIME, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
         g_bounce_cap = cap;
     }
-    IOPX_HIP(copy_d2h(g_bounce, src_dev, bytes, g_stream));
-    IOPX_HIP(hipStreamSynchronize(g_stream));
+    IOPX_HIP(copy_d2h(g_bounce, src_dev, bytes, active_stream()));
+    IOPX_HIP(hipStreamSynchronize(active_stream()));
     memcpy(dst_host, g_bounce, bytes);
     return IOPX_OK;
 }
@@ -308,14 +360,14 @@ ProfScope::ProfScope(const char *name, size_t work_bytes, size_t work_products) 
     r.bytes = work_bytes;
     r.products = work_products;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-    (void)hipEventRecord(r.a, g_stream);
+    (void)hipEventRecord(r.a, active_stream());
     slot = (int)g_prof.size();
     g_prof.push_back(r);
 }
 
 ProfScope::~ProfScope()
 {
-    if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, g_stream);
+    if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, active_stream());
 }
 
 } // namespace iopx
@@ -418,8 +470,26 @@ int iopx_synchronize(void)
 {
     int rc = iopx::ensure_device();
     if (rc != IOPX_OK) return rc;
+    rc = iopx::side_stream_join();              // the main stream waits for the side stream; draining the main one then covers both
+    if (rc != IOPX_OK) return rc;
     IOPX_HIP(hipStreamSynchronize(iopx::stream()));
     return IOPX_OK;
+}
+
+int iopx_side_stream_begin(void)
+{
+    int rc = iopx::ensure_device();
+    if (rc != IOPX_OK) return rc;
+    return iopx::side_stream_begin();
+}
+
+int iopx_side_stream_end(void) { return iopx::side_stream_end(); }
+
+int iopx_side_stream_join(void)
+{
+    int rc = iopx::ensure_device();
+    if (rc != IOPX_OK) return rc;
+    return iopx::side_stream_join();
 }
 
 int iopx_malloc(void **dptr, size_t bytes)

@@ -116,6 +116,7 @@ static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 
 // LDS: one static buffer, the size of a CU's LDS

@@ -8,6 +8,8 @@ against the oracle in a CHILD process with the environment that takes the branch
   IOPX_SMALL_LAST=0         general product at the last two levels (no one- / two-word numerators)
   IOPX_COMB=0               general product everywhere (fft.tcc:39-124 has one multiplier; every branch must agree with it)
   IOPX_P2_RADIX4=1          two butterfly levels per LDS round trip in the upper passes (an experiment that measured slower; kept correct)
+  IOPX_EDGE_LEAN=0 / 3      the edge passes' general product in its 114- / 54-register form in both edge kernels (default 1: the batched one only)
+  IOPX_DEFER_ROOTS=0        (provers) every Merkle root read back at its round end instead of with the query phase's read-backs
 
 and, with the default environment, the exact f_1v shape (16 coefficients over the 2^25-point codeword domain) sampled against
 oracle.poly_eval."""
@@ -128,10 +130,34 @@ def _run(script, extra_env, timeout=1500):
 
 
 @pytest.mark.parametrize("env", [{"IOPX_RS_COMB_CAP_LOG2": "3"}, {"IOPX_P1_COMB": "0"}, {"IOPX_EDGE_BATCH": "0"}, {"IOPX_SMALL_LAST": "0"},
-                                 {"IOPX_COMB": "0"}, {"IOPX_RS_COMB_CAP_LOG2": "3", "IOPX_SMALL_LAST": "0"}, {"IOPX_P2_RADIX4": "1"}],
+                                 {"IOPX_COMB": "0"}, {"IOPX_RS_COMB_CAP_LOG2": "3", "IOPX_SMALL_LAST": "0"}, {"IOPX_P2_RADIX4": "1"}, {"IOPX_EDGE_LEAN": "0"},
+                                 {"IOPX_EDGE_LEAN": "3"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_env_gated_branches_equal_the_oracle(env):
     _run(SHAPES, env)
+
+
+PROVERS = r"""
+import oracle
+import libiop_amd
+lib = libiop_amd.lib()
+lib.init(0)
+for field, code, log_n in ((0, oracle.FIELD_GF192, 11), (1, oracle.FIELD_EDWARDS, 12)):
+    n = 1 << log_n
+    inst = lib.aurora_example_instance(field, n, 15, n - 1, 0x2204)
+    assert lib.aurora_prove(inst) == oracle.aurora_prove(code, log_n, 15, 0x2204)
+    lib.aurora_instance_free(inst)
+inst = lib.aurora_example_instance(1, 1024, 0, 1023, 0x2205)
+ref, ref_roots = oracle.fractal_prove(oracle.FIELD_EDWARDS, 10, 0, 0x2205)
+assert lib.fractal_index(inst) == ref_roots and lib.fractal_prove(inst) == ref and lib.fractal_prove(inst) == ref
+lib.aurora_instance_free(inst)
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("env", [{"IOPX_DEFER_ROOTS": "0"}, {"IOPX_DEFER_ROOTS": "1"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_provers_with_roots_read_at_round_ends_or_with_the_queries(env):
+    _run(PROVERS, env)
 
 
 def test_f1v_shape_16_coefficients_over_2p25_points():
