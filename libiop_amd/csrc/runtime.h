@@ -149,9 +149,11 @@ struct hfp3;
 int build_two_level(const hfp3 &base, const hfp3 &init, int logc, TmpBuf &hi, TmpBuf &lo, bool cache_hi = true);
 
 // Per-module plan caches dropped by iopx_clear_plans() (the caller has synchronised the device).
-int side_stream_begin();
-int side_stream_end();
-int side_stream_join();
+// the side stream (runtime.hip): the provers' Merkle trees (C ABI iopx_side_stream_*)
+int side_stream_fork(int k);
+int side_stream_select(int k);      // -1: back to the main stream
+int side_stream_join(int k);
+int side_stream_current();
 void clear_mul_plans();
 void clear_dist_plans();           // fft_add_dist.hip: the sharded transforms' per-rank twist tables
 void clear_poseidon_sets();

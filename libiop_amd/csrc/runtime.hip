@@ -36,15 +36,19 @@ int fail(int code, const char *fmt, ...)
 
 const char *last_error() { return g_err; }
 
-// ---- the side stream (round 5): work that nothing later in the round waits for — a round's Merkle tree, whose root only the transcript
-// needs (bcs_prover::finish_round) — is enqueued there while the main stream goes on with the next round.  One fork: the side stream waits for
-// everything the main stream held at that moment; one join: the main stream waits for the side stream, and the temporaries freed on the side
-// are released for reuse.  Single host thread per process, like the rest of the prover entry points. ----
-static hipStream_t g_side_stream = nullptr;
-static hipEvent_t g_fork_event = nullptr, g_join_event = nullptr;
-static bool g_on_side = false;              // launches and copies go to the side stream
-static bool g_side_dirty = false;           // the side stream holds work the main stream has not waited for
-static inline hipStream_t active_stream() { return g_on_side ? g_side_stream : g_stream; }
+// ---- the side stream (round 5): work that the next launches on the main stream do not wait for runs beside them — a round's Merkle tree,
+// whose root only the transcript needs (bcs_prover::finish_round).  (A second one, for every other coset group of a low-degree extension, was
+// tried: independent chains of launches, each filling the other's launch tails — 1893 -> 1704 cycles per wave-butterfly in tools/ubench/bfly_loop,
+// nothing in the prover, 37.98 -> 38.3 ms: profiles/r05_ab_fft_streams.txt.)
+// fork: the side stream waits for everything the main stream holds at that moment; select: which stream the library's launches, copies and
+// pool frees go to; join: the main stream waits for the side stream (no host wait) and the blocks freed on it become reusable.  One host
+// thread per process drives them, like the rest of the prover entry points. ----
+#define IOPX_SIDE_STREAMS 1
+static hipStream_t g_side_stream[IOPX_SIDE_STREAMS] = { nullptr };
+static hipEvent_t g_fork_event[IOPX_SIDE_STREAMS], g_join_event[IOPX_SIDE_STREAMS];
+static int g_cur_side = -1;                 // -1: the main stream is current
+static bool g_side_dirty[IOPX_SIDE_STREAMS] = { false };      // the side stream holds work the main stream has not waited for
+static inline hipStream_t active_stream() { return g_cur_side >= 0 ? g_side_stream[g_cur_side] : g_stream; }
 
 hipStream_t stream() { std::lock_guard<std::mutex> lk(g_mu); return active_stream(); }
 int bound_device();
@@ -90,7 +94,7 @@ int set_stream(void *s, bool own)
     // switch under the lock, so a concurrent iopx_set_stream / iopx_use_own_stream from another host thread cannot make this
     // call drain a stream that is no longer (or not yet) the current one
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_side_dirty) (void)hipStreamSynchronize(g_side_stream);
+    for (int k = 0; k < IOPX_SIDE_STREAMS; ++k) if (g_side_dirty[k]) (void)hipStreamSynchronize(g_side_stream[k]);
     (void)hipStreamSynchronize(g_stream);
     g_caller_stream = !own;
     g_stream = own ? g_own_stream : (hipStream_t)s;
@@ -133,55 +137,59 @@ void *tmp_alloc(size_t bytes, size_t *cap)
     return p;
 }
 
-static std::vector<TmpBlock> g_tmp_quarantine;     // freed while the side stream was current: reusable once the main stream has joined it
+static std::vector<TmpBlock> g_tmp_quarantine[IOPX_SIDE_STREAMS];     // freed while a side stream was current: reusable once the main stream has joined it
 
 void tmp_free(void *p, size_t cap)
 {
     std::lock_guard<std::mutex> lk(g_tmp_mu);
-    (g_on_side ? g_tmp_quarantine : g_tmp_free).push_back({p, cap});
+    (g_cur_side >= 0 ? g_tmp_quarantine[g_cur_side] : g_tmp_free).push_back({p, cap});
 }
 
-int side_stream_begin()
+int side_stream_fork(int k)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_on_side) return fail(IOPX_ERR_LOGIC, "iopx_side_stream_begin: already on the side stream");
-    if (!g_side_stream) {
-        IOPX_HIP(hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking));
-        IOPX_HIP(hipEventCreateWithFlags(&g_fork_event, hipEventDisableTiming));
-        IOPX_HIP(hipEventCreateWithFlags(&g_join_event, hipEventDisableTiming));
+    if (k < 0 || k >= IOPX_SIDE_STREAMS) return fail(IOPX_ERR_INVALID_ARGUMENT, "side stream %d", k);
+    if (g_cur_side >= 0) return fail(IOPX_ERR_LOGIC, "side_stream_fork inside a side-stream section");
+    if (!g_side_stream[k]) {
+        IOPX_HIP(hipStreamCreateWithFlags(&g_side_stream[k], hipStreamNonBlocking));
+        IOPX_HIP(hipEventCreateWithFlags(&g_fork_event[k], hipEventDisableTiming));
+        IOPX_HIP(hipEventCreateWithFlags(&g_join_event[k], hipEventDisableTiming));
     }
-    IOPX_HIP(hipEventRecord(g_fork_event, g_stream));
-    IOPX_HIP(hipStreamWaitEvent(g_side_stream, g_fork_event, 0));
-    g_on_side = true;
-    g_side_dirty = true;
+    IOPX_HIP(hipEventRecord(g_fork_event[k], g_stream));
+    IOPX_HIP(hipStreamWaitEvent(g_side_stream[k], g_fork_event[k], 0));
+    g_side_dirty[k] = true;
     return IOPX_OK;
 }
 
-int side_stream_end()
+// k = -1: the main stream.  A side stream must have been forked since its last join.
+int side_stream_select(int k)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_on_side) return fail(IOPX_ERR_LOGIC, "iopx_side_stream_end without begin");
-    g_on_side = false;
+    if (k >= IOPX_SIDE_STREAMS || (k >= 0 && !g_side_dirty[k])) return fail(IOPX_ERR_LOGIC, "side_stream_select(%d) without a fork", k);
+    g_cur_side = k < 0 ? -1 : k;
     return IOPX_OK;
 }
 
-int side_stream_join()
+int side_stream_current() { return g_cur_side; }
+
+int side_stream_join(int k)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_on_side) return fail(IOPX_ERR_LOGIC, "iopx_side_stream_join inside a side-stream section");
-    if (!g_side_dirty) return IOPX_OK;
-    IOPX_HIP(hipEventRecord(g_join_event, g_side_stream));
-    IOPX_HIP(hipStreamWaitEvent(g_stream, g_join_event, 0));
-    g_side_dirty = false;
+    if (k < 0 || k >= IOPX_SIDE_STREAMS) return fail(IOPX_ERR_INVALID_ARGUMENT, "side stream %d", k);
+    if (g_cur_side >= 0) return fail(IOPX_ERR_LOGIC, "side_stream_join inside a side-stream section");
+    if (!g_side_dirty[k]) return IOPX_OK;
+    IOPX_HIP(hipEventRecord(g_join_event[k], g_side_stream[k]));
+    IOPX_HIP(hipStreamWaitEvent(g_stream, g_join_event[k], 0));
+    g_side_dirty[k] = false;
     std::lock_guard<std::mutex> lt(g_tmp_mu);
-    g_tmp_free.insert(g_tmp_free.end(), g_tmp_quarantine.begin(), g_tmp_quarantine.end());
-    g_tmp_quarantine.clear();
+    g_tmp_free.insert(g_tmp_free.end(), g_tmp_quarantine[k].begin(), g_tmp_quarantine[k].end());
+    g_tmp_quarantine[k].clear();
     return IOPX_OK;
 }
 
 void tmp_trim()
 {
-    if (g_side_dirty) (void)hipStreamSynchronize(g_side_stream);
+    for (int k = 0; k < IOPX_SIDE_STREAMS; ++k) if (g_side_dirty[k]) (void)hipStreamSynchronize(g_side_stream[k]);
     (void)hipStreamSynchronize(g_stream);
     std::lock_guard<std::mutex> lk(g_tmp_mu);
     for (auto &b : g_tmp_free) (void)hipFree(b.p);
@@ -470,8 +478,8 @@ int iopx_synchronize(void)
 {
     int rc = iopx::ensure_device();
     if (rc != IOPX_OK) return rc;
-    rc = iopx::side_stream_join();              // the main stream waits for the side stream; draining the main one then covers both
-    if (rc != IOPX_OK) return rc;
+    for (int k = 0; k < IOPX_SIDE_STREAMS; ++k) // the main stream waits for the side stream; draining it then covers both
+        if ((rc = iopx::side_stream_join(k)) != IOPX_OK) return rc;
     IOPX_HIP(hipStreamSynchronize(iopx::stream()));
     return IOPX_OK;
 }
@@ -480,16 +488,21 @@ int iopx_side_stream_begin(void)
 {
     int rc = iopx::ensure_device();
     if (rc != IOPX_OK) return rc;
-    return iopx::side_stream_begin();
+    if ((rc = iopx::side_stream_fork(0)) != IOPX_OK) return rc;
+    return iopx::side_stream_select(0);
 }
 
-int iopx_side_stream_end(void) { return iopx::side_stream_end(); }
+int iopx_side_stream_end(void)
+{
+    if (iopx::side_stream_current() != 0) return iopx::fail(IOPX_ERR_LOGIC, "iopx_side_stream_end without begin");
+    return iopx::side_stream_select(-1);
+}
 
 int iopx_side_stream_join(void)
 {
     int rc = iopx::ensure_device();
     if (rc != IOPX_OK) return rc;
-    return iopx::side_stream_join();
+    return iopx::side_stream_join(0);
 }
 
 int iopx_malloc(void **dptr, size_t bytes)

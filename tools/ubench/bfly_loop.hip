@@ -162,5 +162,31 @@ int main()
                    butterflies / ms * 1e3, ms * 1e-3 * 2.4e9 * 1024 / (butterflies / 64), clk[1] ? (double)clk[0] / ((double)clk[1] * 10.0) : 0.0);
         }
     }
+    // launch tails: the same 64 launches of 4096 tiles (k_bfly_upper's typical launch) on ONE stream, and alternating between TWO streams — does the
+    // second stream's work fill the CUs that the tail of a launch leaves idle?
+    {
+        hipStream_t st[2];
+        CK(hipStreamCreateWithFlags(&st[0], hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&st[1], hipStreamNonBlocking));
+        hipEvent_t e0, e1, j; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreateWithFlags(&j, hipEventDisableTiming));
+        const size_t lds = 48 * 1024;
+        for (int tiles : {4096, 2048, 1024}) {
+            for (int streams = 1; streams <= 2; ++streams) {
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int launches = 64;
+                    CK(hipDeviceSynchronize());
+                    CK(hipEventRecord(e0, st[0]));
+                    if (streams == 2) { CK(hipEventRecord(j, st[0])); CK(hipStreamWaitEvent(st[1], j, 0)); }
+                    for (int i = 0; i < launches; ++i)
+                        hipLaunchKernelGGL(k_loop<6>, dim3(tiles), dim3(512), lds, st[streams == 2 ? (i & 1) : 0], table, entries - 1, shift, out, g_tiles_in, g_tiles_out, g_clk);
+                    if (streams == 2) { CK(hipEventRecord(j, st[1])); CK(hipStreamWaitEvent(st[0], j, 0)); }
+                    CK(hipEventRecord(e1, st[0])); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                    const double butterflies = (double)launches * tiles * 1024 * LEVELS;
+                    if (pass) printf("%d launches of %5d tiles on %d stream(s): %8.3f ms  %.3e butterflies/s  %6.0f cycles per wave-butterfly per SIMD at 2.4 GHz\n", launches, tiles, streams, ms,
+                                     butterflies / ms * 1e3, ms * 1e-3 * 2.4e9 * 1024 / (butterflies / 64));
+                }
+            }
+        }
+    }
     return 0;
 }
