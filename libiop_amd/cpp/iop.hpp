@@ -224,6 +224,24 @@ private:
         const std::vector<std::size_t> idx = dist::membership_proof_node_indices(global_leaves_, leaf_positions);
         std::vector<uint8_t> aux(32 * idx.size());
         if (idx.empty()) return aux;
+        const device_array<uint8_t> buf(aux.size());
+        buf.fill_zero();
+        gather_owned_proof_nodes(idx, buf.data());
+        check(iopx_comm_all_reduce_u64_dev(c.comm, buf.data(), aux.size() / 8, IOPX_COMM_SUM));
+        check(iopx_memcpy_d2h_deferrable(aux.data(), buf.data(), aux.size()));
+        return aux;
+    }
+public:
+    bool distributed() const { return distributed_; }
+    // the two halves of the above for a caller that completes the rows of SEVERAL trees with one all-reduce (bcs_prover::extract_queries): the
+    // heap indices of the auxiliary nodes (the same on every rank), and this rank's nodes written into a zeroed (indices, 32) device buffer
+    std::vector<std::size_t> distributed_proof_nodes(const std::vector<std::size_t> &leaf_positions) const
+    {
+        return dist::membership_proof_node_indices(global_leaves_, leaf_positions);
+    }
+    void gather_owned_proof_nodes(const std::vector<std::size_t> &idx, uint8_t *d_rows) const
+    {
+        const dist::context &c = dist::ctx();
         std::vector<uint64_t> rows, local_nodes, top_rows, top_nodes;
         for (std::size_t row = 0; row < idx.size(); ++row) {
             const std::size_t node = idx[row];
@@ -239,14 +257,9 @@ private:
                 local_nodes.push_back((((std::size_t)1 << loc_depth) - 1) + (j & (((std::size_t)1 << loc_depth) - 1)));
             }
         }
-        const device_array<uint8_t> buf(aux.size());
-        buf.fill_zero();
         const void *src = nodes_.data(), *top = top_nodes_.data();
-        if (!rows.empty()) check(iopx_gather_rows_dev(&src, 1, 32, local_nodes.data(), rows.data(), rows.size(), buf.data()));
-        if (!top_rows.empty()) check(iopx_gather_rows_dev(&top, 1, 32, top_nodes.data(), top_rows.data(), top_rows.size(), buf.data()));
-        check(iopx_comm_all_reduce_u64_dev(c.comm, buf.data(), aux.size() / 8, IOPX_COMM_SUM));
-        check(iopx_memcpy_d2h_deferrable(aux.data(), buf.data(), aux.size()));
-        return aux;
+        if (!rows.empty()) check(iopx_gather_rows_dev(&src, 1, 32, local_nodes.data(), rows.data(), rows.size(), d_rows));
+        if (!top_rows.empty()) check(iopx_gather_rows_dev(&top, 1, 32, top_nodes.data(), top_rows.data(), top_rows.size(), d_rows));
     }
 };
 
@@ -754,15 +767,18 @@ private:
         // the two small read-backs per tree are queued, not waited for one by one (iopx_defer_downloads_begin / _end)
         x.flat_responses.resize(MT_info_.size());
         x.proof_bytes.resize(MT_info_.size());
-        check(iopx_defer_downloads_begin());
-        bool deferring = true;
-        struct end_on_unwind { bool &on; ~end_on_unwind() { if (on) (void)iopx_defer_downloads_end(); } } guard{ deferring };
+        // Distributed trees: every queried row (an answer row, an authentication-path node) has exactly one owner.  All trees' rows go into ONE zeroed
+        // device buffer — the arena — each rank writes the rows it owns, and a single all-reduce completes it everywhere: one collective per proof
+        // for the whole query phase instead of two per tree (22 for Aurora's eleven trees).  First the positions and the arena's layout ...
+        struct plan { std::vector<std::size_t> qpos, lpos, proof_nodes; std::size_t answers_at = 0, proof_at = 0; };
+        std::vector<plan> plans(MT_info_.size());
+        std::size_t arena_bytes = 0;
         for (std::size_t mt = 0; mt < MT_info_.size(); ++mt) {
             const tree_info &info = MT_info_[mt];
             const std::size_t cs = get_round_parameters(info.round);
             const field_subset<FieldT> &domain = domains_[info.domain];
             const std::size_t num_leaves = domain.num_elements() / cs;
-            std::vector<std::size_t> qpos, lpos;                                             // sorted and distinct, as the reference's sets are
+            std::vector<std::size_t> &qpos = plans[mt].qpos, &lpos = plans[mt].lpos;         // sorted and distinct, as the reference's sets are
             for (std::size_t oid : info.oracle_ids) qpos.insert(qpos.end(), positions_by_oracle[oid].begin(), positions_by_oracle[oid].end());
             std::sort(qpos.begin(), qpos.end());
             qpos.erase(std::unique(qpos.begin(), qpos.end()), qpos.end());
@@ -770,13 +786,30 @@ private:
             std::sort(lpos.begin(), lpos.end());
             lpos.erase(std::unique(lpos.begin(), lpos.end()), lpos.end());
             x.flat_responses[mt].resize(qpos.size() * info.oracle_ids.size());
+            if (domain.distributed() && !qpos.empty()) { plans[mt].answers_at = arena_bytes; arena_bytes += x.flat_responses[mt].size() * sizeof(FieldT); }
+            if (MT_trees_[mt].distributed() && !lpos.empty()) {
+                plans[mt].proof_nodes = MT_trees_[mt].distributed_proof_nodes(lpos);
+                x.proof_bytes[mt].resize(32 * plans[mt].proof_nodes.size());
+                plans[mt].proof_at = arena_bytes;
+                arena_bytes += x.proof_bytes[mt].size();
+            }
+        }
+        const device_array<uint8_t> arena(arena_bytes ? arena_bytes : 8);
+        if (arena_bytes) arena.fill_zero();
+        check(iopx_defer_downloads_begin());
+        bool deferring = true;
+        struct end_on_unwind { bool &on; ~end_on_unwind() { if (on) (void)iopx_defer_downloads_end(); } } guard{ deferring };
+        // ... then every tree's gathers (no collective) ...
+        for (std::size_t mt = 0; mt < MT_info_.size(); ++mt) {
+            const tree_info &info = MT_info_[mt];
+            const field_subset<FieldT> &domain = domains_[info.domain];
+            const std::vector<std::size_t> &qpos = plans[mt].qpos, &lpos = plans[mt].lpos;
             if (!qpos.empty()) {                                                             // bcs_prover.tcc:187-197
                 std::vector<const void *> ptrs;
                 for (std::size_t oid : info.oracle_ids) ptrs.push_back(oracles_[oid].data());
                 if (!domain.distributed()) {
                     check(iopx_query_responses_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), domain.num_elements(), qpos.data(), qpos.size(), x.flat_responses[mt].data()));
                 } else {
-                    // every rank writes the rows it owns into a zeroed (positions, oracles) device buffer; one all-reduce completes it everywhere
                     const dist::context &c = dist::ctx();
                     const std::size_t block = domain.num_elements() / c.world;
                     std::vector<uint64_t> rows, local_index;
@@ -785,16 +818,28 @@ private:
                         const bool mine = domain.type() == affine_subspace_type ? p / block == c.rank : p % c.world == c.rank;
                         if (mine) { rows.push_back(row); local_index.push_back(domain.type() == affine_subspace_type ? p - c.rank * block : p / c.world); }
                     }
-                    const device_vector<FieldT> buf(x.flat_responses[mt].size());
-                    buf.fill_zero();
-                    if (!rows.empty()) check(iopx_gather_rows_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), local_index.data(), rows.data(), rows.size(), buf.data()));
-                    check(iopx_comm_all_reduce_u64_dev(c.comm, buf.data(), buf.size() * sizeof(FieldT) / 8, IOPX_COMM_SUM));
-                    check(iopx_memcpy_d2h_deferrable(x.flat_responses[mt].data(), buf.data(), buf.size() * sizeof(FieldT)));
+                    if (!rows.empty()) check(iopx_gather_rows_dev(ptrs.data(), ptrs.size(), sizeof(FieldT), local_index.data(), rows.data(), rows.size(), arena.data() + plans[mt].answers_at));
                 }
             }
-            x.proof_bytes[mt] = MT_trees_[mt].get_set_membership_proof_bytes(lpos);
-            x.query_positions.push_back(std::move(qpos));
-            x.leaf_positions.push_back(std::move(lpos));
+            if (MT_trees_[mt].distributed()) {
+                if (!plans[mt].proof_nodes.empty()) MT_trees_[mt].gather_owned_proof_nodes(plans[mt].proof_nodes, arena.data() + plans[mt].proof_at);
+            } else {
+                x.proof_bytes[mt] = MT_trees_[mt].get_set_membership_proof_bytes(lpos);
+            }
+        }
+        // ... one all-reduce, and the read-backs of its parts
+        if (arena_bytes) {
+            check(iopx_comm_all_reduce_u64_dev(dist::ctx().comm, arena.data(), arena_bytes / 8, IOPX_COMM_SUM));
+            for (std::size_t mt = 0; mt < MT_info_.size(); ++mt) {
+                if (domains_[MT_info_[mt].domain].distributed() && !plans[mt].qpos.empty())
+                    check(iopx_memcpy_d2h_deferrable(x.flat_responses[mt].data(), arena.data() + plans[mt].answers_at, x.flat_responses[mt].size() * sizeof(FieldT)));
+                if (!plans[mt].proof_nodes.empty())
+                    check(iopx_memcpy_d2h_deferrable(x.proof_bytes[mt].data(), arena.data() + plans[mt].proof_at, x.proof_bytes[mt].size()));
+            }
+        }
+        for (std::size_t mt = 0; mt < MT_info_.size(); ++mt) {
+            x.query_positions.push_back(std::move(plans[mt].qpos));
+            x.leaf_positions.push_back(std::move(plans[mt].lpos));
         }
         queue_pending_roots();                                                               // the roots travel with the answers and the paths
         check(iopx_defer_downloads_end());                                                   // one drain of the stream delivers every read-back queued above
