@@ -342,10 +342,10 @@ def main():
     # committed PMC run of the same kernels and labelled with its file; null when that run covered other kernel sources
     traffic, traffic_source = None, None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic_aurora.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r05_traffic_aurora.json")))
         if tj.get("log_n") == args.log_n and dom_name in tj.get("kernels", {}) and tj.get("kernel_sources_sha256") == kernel_sources_digest():
             traffic = tj["kernels"][dom_name]["traffic_bytes_per_launch"]
-            traffic_source = "profiles/r04_traffic_aurora.json (rocprofv3 --pmc passes of this command, collected %s)" % tj.get("collected", "?")
+            traffic_source = "profiles/r05_traffic_aurora.json (rocprofv3 --pmc passes of this command, collected %s)" % tj.get("collected", "?")
     except (OSError, ValueError):
         pass
     # ALU ceiling: the rate measured live in this run (field products of the launches / their HIP-event time) against the VALU-issue
@@ -530,10 +530,10 @@ def main():
         d5, (c5, ms5, b5) = max(prof5.items(), key=lambda kv: kv[1][1])
         traffic5, traffic5_source = None, None
         try:          # PMC passes of tools/fractal_bench.py at this size (tools/collect_profiles.sh), quoted only for the kernel sources they ran on
-            tj5 = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic_fractal.json")))
+            tj5 = json.load(open(os.path.join(ROOT, "profiles", "r05_traffic_fractal.json")))
             if tj5.get("log_n") == args.log_n and d5 in tj5.get("kernels", {}) and tj5.get("kernel_sources_sha256") == kernel_sources_digest():
                 traffic5 = tj5["kernels"][d5]["traffic_bytes_per_launch"]
-                traffic5_source = "profiles/r04_traffic_fractal.json (rocprofv3 --pmc passes of tools/fractal_bench.py --log-n %d, collected %s; averaged over the indexer's and the prover's launches)" % (args.log_n, tj5.get("collected", "?"))
+                traffic5_source = "profiles/r05_traffic_fractal.json (rocprofv3 --pmc passes of tools/fractal_bench.py --log-n %d, collected %s; averaged over the indexer's and the prover's launches)" % (args.log_n, tj5.get("collected", "?"))
         except (OSError, ValueError):
             pass
         out["config"]["secondary_fractal"]["roofline"] = {
