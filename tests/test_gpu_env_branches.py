@@ -10,6 +10,7 @@ against the oracle in a CHILD process with the environment that takes the branch
   IOPX_P2_RADIX4=1          two butterfly levels per LDS round trip in the upper passes (an experiment that measured slower; kept correct)
   IOPX_EDGE_LEAN=0 / 3      the edge passes' general product in its 114- / 54-register form in both edge kernels (default 1: the batched one only)
   IOPX_DEFER_ROOTS=0        (provers) every Merkle root read back at its round end instead of with the query phase's read-backs
+  IOPX_MERKLE_STREAM=0      (provers) no side stream: every round's Merkle tree on the main stream
 
 and, with the default environment, the exact f_1v shape (16 coefficients over the 2^25-point codeword domain) sampled against
 oracle.poly_eval."""
@@ -155,7 +156,7 @@ print("ok")
 """
 
 
-@pytest.mark.parametrize("env", [{"IOPX_DEFER_ROOTS": "0"}, {"IOPX_DEFER_ROOTS": "1"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+@pytest.mark.parametrize("env", [{"IOPX_DEFER_ROOTS": "0"}, {"IOPX_DEFER_ROOTS": "1"}, {"IOPX_MERKLE_STREAM": "0"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_provers_with_roots_read_at_round_ends_or_with_the_queries(env):
     _run(PROVERS, env)
 

@@ -1,5 +1,6 @@
 """Round-5 switches on the CPU-compiled kernels, each in a child process (the values are read once per process):
   IOPX_DEFER_ROOTS=0   every Merkle root read back at its round end (round 4's schedule) instead of with the query phase's read-backs
+  IOPX_MERKLE_STREAM=0 no side stream: every round's Merkle tree on the main stream
   IOPX_EDGE_LEAN=0/2/3 the edge passes' general product in its 114- or 54-register form (batched last pass / single-polynomial passes)
 The provers must give the oracle's bytes and the transforms the oracle's values on every branch."""
 import os
@@ -59,6 +60,10 @@ def _run(script, extra_env):
 
 def test_roots_read_at_every_round_end():
     _run(PROVERS, {"IOPX_DEFER_ROOTS": "0"})
+
+
+def test_trees_on_the_main_stream():
+    _run(PROVERS, {"IOPX_MERKLE_STREAM": "0"})
 
 
 @pytest.mark.parametrize("lean", ["0", "3"])
