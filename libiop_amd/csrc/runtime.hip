@@ -125,9 +125,10 @@ void *tmp_alloc(size_t bytes, size_t *cap)
     void *p = nullptr;
     const size_t c = (bytes + 255) & ~(size_t)255;
     if (hipMalloc(&p, c) != hipSuccess) {
-        // out of memory: drop the cache (after draining the stream) and retry once
+        // out of memory: drop the cache (after draining the streams) and retry once
         (void)hipGetLastError();
-        (void)hipStreamSynchronize(stream());
+        for (int k = 0; k < IOPX_SIDE_STREAMS; ++k) if (g_side_dirty[k]) (void)hipStreamSynchronize(g_side_stream[k]);
+        (void)hipStreamSynchronize(g_stream);
         std::lock_guard<std::mutex> lk(g_tmp_mu);
         for (auto &b : g_tmp_free) (void)hipFree(b.p);
         g_tmp_free.clear();
