@@ -22,6 +22,27 @@ def _build():
     return EXE
 
 
+def _build_emu():
+    """tests/cpp/test_shim.cpp against the CPU build of the kernel sources (tests/emu): compiled once, again only when a source, a header of
+    libiop_amd/cpp or oracle/, or the emulation library is newer (the compile is 40 s of a 60 s test)."""
+    from emu_lib import emu
+    emu()
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    exe = os.path.join(ROOT, "tests", "cpp", "test_shim_emu")
+    src = os.path.join(ROOT, "tests", "cpp", "test_shim.cpp")
+    deps = [src, os.path.join(emu_dir, "libiopx_emu.so"), os.path.join(ROOT, "include", "libiop_amd.h")]
+    for d in ("libiop_amd/cpp", "oracle"):
+        deps += [os.path.join(ROOT, d, h) for h in os.listdir(os.path.join(ROOT, d)) if h.endswith((".hpp", ".h"))]
+    import fcntl
+    with open(os.path.join(emu_dir, ".build.lock"), "w") as lock:               # xdist workers may arrive together: one build at a time
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-mpclmul", "-msse4.1", src, "-o", exe + ".tmp", os.path.join(emu_dir, "libiopx_emu.so"),
+                                   "-Wl,-rpath," + emu_dir])
+            os.replace(exe + ".tmp", exe)
+    return exe
+
+
 def test_cpp_shim_without_device():
     import libiop_amd
     exe = _build()
@@ -33,13 +54,7 @@ def test_cpp_shim_without_device():
 
 def test_cpp_shim_parity_on_cpu_emulation():
     """The same parity half, linked against the CPU build of the kernel sources (tests/emu): host-side logic of the shim."""
-    from emu_lib import emu
-    emu()
-    emu_dir = os.path.join(ROOT, "tests", "emu")
-    exe = os.path.join(ROOT, "tests", "cpp", "test_shim_emu")
-    src = os.path.join(ROOT, "tests", "cpp", "test_shim.cpp")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-mpclmul", "-msse4.1", src, "-o", exe, os.path.join(emu_dir, "libiopx_emu.so"),
-                           "-Wl,-rpath," + emu_dir])
+    exe = _build_emu()
     r = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "gpu ok" in r.stdout, r.stdout + r.stderr
 
@@ -48,13 +63,7 @@ def test_cpp_aurora_prover_on_cpu_emulation():
     """VERDICT r2 row (b'): the C++ prover surface — libiop_amd/cpp/{iop,r1cs,aurora}.hpp, aurora_snark_prover<FieldT>(cs, primary,
     auxiliary, params) with device-resident oracles — proves 2^7..2^10 instances over both fields; transcript bytes equal the oracle
     prover's, and the PCIe byte counters stay far below one codeword.  Here against the CPU build of the kernel sources."""
-    from emu_lib import emu
-    emu()
-    emu_dir = os.path.join(ROOT, "tests", "emu")
-    exe = os.path.join(ROOT, "tests", "cpp", "test_shim_emu")
-    src = os.path.join(ROOT, "tests", "cpp", "test_shim.cpp")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-mpclmul", "-msse4.1", src, "-o", exe, os.path.join(emu_dir, "libiopx_emu.so"),
-                           "-Wl,-rpath," + emu_dir])
+    exe = _build_emu()
     r = subprocess.run([exe, "aurora", "10"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "aurora ok" in r.stdout, r.stdout + r.stderr
 
@@ -62,11 +71,7 @@ def test_cpp_aurora_prover_on_cpu_emulation():
 def test_cpp_fractal_prover_on_cpu_emulation():
     """libiop_amd/cpp/fractal.hpp: fractal_snark_indexer / fractal_snark_prover<FieldT> — index root and transcript bytes equal the oracle's,
     both fields, k = 0 / 15 / 1 (reference quirk F15), one index serving two proofs."""
-    from emu_lib import emu
-    emu()
-    exe = os.path.join(ROOT, "tests", "cpp", "test_shim_emu")
-    if not os.path.exists(exe):
-        test_cpp_aurora_prover_on_cpu_emulation()
+    exe = _build_emu()
     r = subprocess.run([exe, "fractal", "7"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "fractal ok" in r.stdout, r.stdout + r.stderr
 
@@ -74,11 +79,7 @@ def test_cpp_fractal_prover_on_cpu_emulation():
 def test_cpp_provers_on_general_constraint_systems_on_cpu_emulation():
     """Instances built row by row through r1cs_constraint_system::add_constraint — multi-term rows, constant-column terms, repeated and hot
     columns, empty rows, non-square systems, unsatisfied variants — proved by the C++ Aurora and Fractal provers: bytes equal the oracle's."""
-    from emu_lib import emu
-    emu()
-    exe = os.path.join(ROOT, "tests", "cpp", "test_shim_emu")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(os.path.join(ROOT, "tests", "cpp", "test_shim.cpp")):
-        test_cpp_aurora_prover_on_cpu_emulation()
+    exe = _build_emu()
     r = subprocess.run([exe, "general", "7"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "general ok" in r.stdout, r.stdout + r.stderr
 
