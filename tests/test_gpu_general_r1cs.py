@@ -52,3 +52,28 @@ def test_fractal_on_general_instances(gpu, field_name, num_constraints, num_inpu
 @pytest.mark.parametrize("kind", ["constraint", "primary", "auxiliary"])
 def test_fractal_unsatisfied_bytes_are_the_oracles(gpu, field_name, num_constraints, kind, monkeypatch):
     gc.check_fractal(gpu, torch, DEV, monkeypatch, field_name, num_constraints, 15, 80, kind=kind)
+
+
+def test_aurora_general_instance_at_2p14_equals_the_oracle_prover(gpu, monkeypatch):
+    """The largest general instance the oracle prover finishes in well under a minute: byte-equality at 2^14 constraints over GF(2^192)."""
+    gc.check_aurora(gpu, torch, DEV, monkeypatch, "gf192", 1 << 14, (1 << 14) - 1, 15, 91)
+
+
+def test_aurora_general_instance_at_2p16_native_equals_python_and_the_oracle_verifier_accepts(gpu, monkeypatch):
+    """Beyond the oracle PROVER's reach in a test (minutes): at 2^16 the two independently written device provers must agree byte for byte and the
+    oracle's VERIFIER (point evaluations only) must accept the proof of the general instance; a flipped answer is rejected."""
+    import oracle
+    import r1cs_general as rg
+    from libiop_amd import aurora, domains
+    n, k = 1 << 16, 15
+    inst = rg.generate("gf192", n, n - 1, k, 92)
+    code = oracle.FIELD_GF192
+    t, prof = gc.native_aurora(gpu, 0, inst, monkeypatch, True)
+    ops = domains.DeviceOps(gpu, torch, DEV, domains.GF192())
+    cs, primary, auxiliary = gc.python_cs(ops, inst)
+    params = aurora.AuroraParameters(ops.field, n, n - 1, k)
+    assert aurora.aurora_snark_prover(ops, cs, primary, auxiliary, params).serialize() == t
+    assert oracle.aurora_verify_csr(code, inst.matrices, n - 1, k, inst.assignment[:k], t)
+    bad = bytearray(t)
+    bad[len(bad) // 2] ^= 1
+    assert not oracle.aurora_verify_csr(code, inst.matrices, n - 1, k, inst.assignment[:k], bytes(bad))
