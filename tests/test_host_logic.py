@@ -129,3 +129,32 @@ def test_bench_starts_its_own_ranks_for_several_gpus(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 0 and len(calls) == 1 and calls[0][1:3] == ["-m", "torch.distributed.run"]
+
+
+def test_bench_line_helpers():
+    """bench.py's round-5 additions that need no GPU: the kernel -> reference-block mapping of one proof's profile, the headline-size CPU figure with the digest
+    it was accepted on (the golden digest the GPU tests compare the 2^20 transcript with), and the oracle's block timers under the reference's names."""
+    import json
+    import os
+    import bench
+    import oracle
+    prof = {"k_bfly_upper_fwd": (78, 16.5, 1), "k_bfly_edge_fwd_batch": (5, 7.4, 1), "k_bfly_upper_inv": (21, 1.1, 1), "k_merkle_level": (62, 2.3, 1),
+            "k_merkle_top": (11, 0.6, 1), "k_pow_blake2b": (3, 0.85, 0), "k_pow_direct": (3, 0.1, 0), "k_fri_fold_fused_eta2": (9, 0.6, 1), "k_lincheck_add": (1, 0.2, 1),
+            "k_gather_nodes": (11, 0.07, 0)}
+    st = bench.device_stages(prof)
+    assert st["Call to additive_FFT_wrapper"]["launches"] == 78 + 5 + 3 and abs(st["Call to additive_FFT_wrapper"]["ms"] - 24.0) < 1e-9
+    assert st["Call to additive_IFFT_wrapper"]["launches"] == 21 and st["Construct Merkle tree"]["launches"] == 73 and st["pow"]["launches"] == 3
+    assert st["evaluating next FRI codeword"]["ms"] == 0.6 and st["Obtain transcript"]["launches"] == 11
+    assert st["other (virtual oracles, sparse products, uploads)"]["launches"] == 1
+    assert abs(sum(v["ms"] for v in st.values()) - sum(v[1] for v in prof.values())) < 1e-9          # every kernel is in exactly one stage
+    head = bench.headline_cpu_figure()
+    golden = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_aurora_transcript_digests_large.json")))["digests"]["20"]
+    assert head["log_n"] == 20 and head["prover_seconds"] > 1000 and head["transcript_blake2b"] == golden["transcript_blake2b"]
+    oracle.block_times()
+    oracle.aurora_prove(oracle.FIELD_GF192, 6, 15, 1)
+    blocks = oracle.block_times()
+    for name in ("Aurora SNARK prover", "Call to additive_FFT_wrapper", "Call to additive_IFFT_wrapper", "Construct Merkle tree", "Finish prover round", "evaluating next FRI codeword",
+                 "pow", "Obtain transcript"):
+        assert blocks[name][1] >= 1 and blocks[name][0] >= 0.0, name
+    assert blocks["Aurora SNARK prover"][0] >= blocks["Call to additive_FFT_wrapper"][0]
+    assert oracle.block_times() == {}                                                              # reading resets
