@@ -50,6 +50,13 @@ static int g_cur_side = -1;                 // -1: the main stream is current
 static bool g_side_dirty[IOPX_SIDE_STREAMS] = { false };      // the side stream holds work the main stream has not waited for
 static inline hipStream_t active_stream() { return g_cur_side >= 0 ? g_side_stream[g_cur_side] : g_stream; }
 
+// cached device temporaries (single-stream reuse, see runtime.h): the free list, and what was freed while a side stream was current — reusable
+// once the main stream has joined it
+struct TmpBlock { void *p; size_t cap; };
+static std::vector<TmpBlock> g_tmp_free;
+static std::mutex g_tmp_mu;
+static std::vector<TmpBlock> g_tmp_quarantine[IOPX_SIDE_STREAMS];
+
 hipStream_t stream() { std::lock_guard<std::mutex> lk(g_mu); return active_stream(); }
 int bound_device();
 
@@ -94,17 +101,21 @@ int set_stream(void *s, bool own)
     // switch under the lock, so a concurrent iopx_set_stream / iopx_use_own_stream from another host thread cannot make this
     // call drain a stream that is no longer (or not yet) the current one
     std::lock_guard<std::mutex> lk(g_mu);
-    for (int k = 0; k < IOPX_SIDE_STREAMS; ++k) if (g_side_dirty[k]) (void)hipStreamSynchronize(g_side_stream[k]);
+    for (int k = 0; k < IOPX_SIDE_STREAMS; ++k) {
+        if (!g_side_dirty[k]) continue;
+        (void)hipStreamSynchronize(g_side_stream[k]);           // drained: nothing of it is in flight, what was freed on it is reusable
+        g_side_dirty[k] = false;
+        std::lock_guard<std::mutex> lt(g_tmp_mu);
+        g_tmp_free.insert(g_tmp_free.end(), g_tmp_quarantine[k].begin(), g_tmp_quarantine[k].end());
+        g_tmp_quarantine[k].clear();
+    }
     (void)hipStreamSynchronize(g_stream);
     g_caller_stream = !own;
     g_stream = own ? g_own_stream : (hipStream_t)s;
     return IOPX_OK;
 }
 
-// ---- cached device temporaries (single-stream reuse, see runtime.h) --------------------------------
-struct TmpBlock { void *p; size_t cap; };
-static std::vector<TmpBlock> g_tmp_free;
-static std::mutex g_tmp_mu;
+// ---- cached device temporaries: allocation (the lists are declared with the streams above) ----------
 
 void *tmp_alloc(size_t bytes, size_t *cap)
 {
@@ -137,8 +148,6 @@ void *tmp_alloc(size_t bytes, size_t *cap)
     *cap = c;
     return p;
 }
-
-static std::vector<TmpBlock> g_tmp_quarantine[IOPX_SIDE_STREAMS];     // freed while a side stream was current: reusable once the main stream has joined it
 
 void tmp_free(void *p, size_t cap)
 {
