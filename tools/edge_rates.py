@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Edge-pass rate of ONE polynomial's low-degree extension (2^d coefficients -> 2^m points) over the standard basis (one- and two-word numerators at the
+"""Butterfly-pass rates of ONE polynomial's low-degree extension (2^d coefficients -> 2^m points) over the standard basis (one- and two-word numerators at the
 last two levels) and over a general basis (general product at all six levels), per kernel: cycles per wave-butterfly per SIMD at 2.4 GHz, to set
 beside the in-register product rates of tools/ubench/mul_rates.  Tuning variables are read from the environment as usual."""
 import json
@@ -30,7 +30,7 @@ for name, d, m, general in (("standard 2^20 -> 2^25", 20, 25, False), ("general 
     g.manual_seed(1)
     c = torch.randint(-2**63, 2**63 - 1, (1 << d, 3), dtype=torch.int64, device=dev, generator=g)
     o = torch.empty((1 << m, 3), dtype=torch.int64, device=dev)
-    for _ in range(2):
+    for _ in range(40):                  # half a second of work first: the shader clock ramps up over the first milliseconds of load
         lib.additive_FFT_dev(c.data_ptr(), 1 << d, basis, shift, o.data_ptr())
     lib.synchronize()
     lib.profile_begin()
