@@ -67,3 +67,19 @@ def test_fractal_on_general_instances(field_name, num_inputs, max_nnz, monkeypat
 @pytest.mark.parametrize("kind", ["constraint", "primary", "auxiliary"])
 def test_fractal_unsatisfied_bytes_are_the_oracles(field_name, kind, monkeypatch):
     gc.check_fractal(emu_lib.emu(), torch, CPU, monkeypatch, field_name, 128, 15, 44, kind=kind, python_prover=(kind == "constraint"))
+
+
+def test_recorded_general_instances_are_reproducible():
+    """tests/golden/oracle_general_r1cs_digests.json (oracle transcripts of larger general instances, compared on the GPU): the seeded generator must still build
+    the recorded instances — same entry counts per matrix — or the fixture would silently stop meaning anything."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_general_r1cs_digests.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) >= 4
+    for case in cases:
+        if case["num_constraints"] > (1 << 12):
+            continue                                                   # the large ones take the generator tens of seconds: checked by the GPU test
+        n = case["num_constraints"]
+        inst = rg.generate(case["field"], n, n - 1, case["num_inputs"], case["seed"], max_nnz=case["max_nnz"])
+        assert inst.nnz() == case["nnz"]

@@ -77,3 +77,30 @@ def test_aurora_general_instance_at_2p16_native_equals_python_and_the_oracle_ver
     bad = bytearray(t)
     bad[len(bad) // 2] ^= 1
     assert not oracle.aurora_verify_csr(code, inst.matrices, n - 1, k, inst.assignment[:k], bytes(bad))
+
+
+def _recorded_cases():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_general_r1cs_digests.json")) as f:
+        return json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("index", [0, 1, 2, 3])
+def test_general_instances_against_recorded_oracle_digests(gpu, index, monkeypatch):
+    """Sizes the oracle provers need minutes for (2^16 Aurora over both fields, 2^15 Fractal over the 181-bit field): their transcripts' digests and index
+    roots are a fixture (tools/make_general_digests.py ran the oracle on the CPU); the native provers' bytes must hash to them."""
+    import hashlib
+    import r1cs_general as rg
+    case = _recorded_cases()[index]
+    n, k = case["num_constraints"], case["num_inputs"]
+    inst = rg.generate(case["field"], n, n - 1, k, case["seed"], max_nnz=case["max_nnz"])
+    assert inst.nnz() == case["nnz"]                                  # the generator still builds the recorded instance
+    native_code = gc.FIELDS[case["field"]][1]
+    if case["protocol"] == "aurora":
+        t, _ = gc.native_aurora(gpu, native_code, inst, monkeypatch, True)
+        roots = []
+    else:
+        t, roots = gc.native_fractal(gpu, native_code, inst, monkeypatch, True)
+    assert [r.hex() for r in roots] == case["index_roots"]
+    assert len(t) == case["argument_bytes"] and hashlib.blake2b(t, digest_size=32).hexdigest() == case["transcript_blake2b"]
