@@ -35,7 +35,7 @@ namespace iopx {
 // Tile geometry.  Defaults: 2048-element phase-2 tiles (48 KiB of LDS per workgroup), 1024-element phase-1 and edge tiles.  The IOPX_TILE_BITS /
 // IOPX_P1_COLS / IOPX_P2_COLS / IOPX_P2_TOP environment variables override them (read once): used for
 // tuning, and by the tests to exercise the multi-pass schedules at small transform sizes.
-struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last, scratch_mb, p1_comb, rs_comb_cap_log2, p2_radix4, edge_lean; };
+struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last, scratch_mb, p1_comb, rs_comb_cap_log2, p2_radix4, edge_lean, edge_halves; };
 static int env_int(const char *name, int dflt, int lo, int hi)
 {
     const char *v = getenv(name);
@@ -79,6 +79,10 @@ static const Tuning &tuning()
         // bit 1: the single-polynomial edge passes, where it LOSES (3.63 -> 3.72 ms: all of their upper levels are general products, which run
         // at the same rate from four waves up — 3209 cycles, the lean form 3342 — profiles/r05_mul_rates.txt, r05_ab_edge_lean_wl.txt)
         u.edge_lean = env_int("IOPX_EDGE_LEAN", 1, 0, 3);
+        // 1: the comb product with one multiplier per half-wavefront (gf_mul_halves) where a block's butterflies fill 32 lanes of the batched last pass —
+        // pair bit 3 of four polynomials, pair bit 4 of two: k_bfly_edge_fwd_batch 7.43 -> 7.03 ms per proof (profiles/r05_ab_edge_halves.txt).  The same
+        // at pair bit 5 of the single-polynomial passes was measured too: 3.62 -> 3.58 ms at best, and only with the 54-register product beside it — not kept.
+        u.edge_halves = env_int("IOPX_EDGE_HALVES", 1, 0, 1);
         return u;
     }();
     return t;
@@ -721,6 +725,7 @@ struct BfBatchParams {
     const uint64_t *srcs[4];
     uint64_t *dsts[4];
     int batch;
+    int halves;             // 1: levels whose blocks fill half a wavefront take the comb product with one multiplier per half (gf_mul_halves)
 };
 
 template<bool LEAN>
@@ -771,6 +776,32 @@ __global__ void __launch_bounds__(512, LEAN ? 6 : 1) k_bfly_edge_fwd_batch(BfBat
                     const int b = idx >> pbit, ia = ia0 | (idx & (G - 1));
                     bf_apply<false, true>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | G, tw, true);
                 }
+            }
+        } else if (LEAN && q.halves && q.batch * G == 32 && ((half >> pbit) & 1) == 0) {
+            // two blocks per wavefront, 32 lanes each (polynomial x butterfly of the block): the comb product with one multiplier per HALF of the
+            // wavefront — the table of multiples built once, the window loop once per half (2775 modelled cycles against the general product's 3209)
+            const int groups = half >> pbit;
+            for (int x = tid; x < (groups >> 1) * 64; x += nt) {
+                const int w = __builtin_amdgcn_readfirstlane(x >> 6), lane = x & 63;
+                gf192 tw[2];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int ia0 = (2 * w + hf) << (pbit + 1);
+                    size_t unit = unit0 + (size_t)(ia0 >> tb);
+                    if (unit >= p.total_units) unit = p.total_units - 1;          // a block past the end (never with one tile per workgroup): any valid twiddle, nothing stored
+                    const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
+                    const int li = ia0 & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
+                    const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
+                    tw[hf] = bf_twiddle_uniform(p, coset, u, pbit);
+                }
+                const int g = 2 * w + (lane >> 5), idx = lane & 31;
+                const int b = idx >> pbit, ia = (g << (pbit + 1)) | (idx & (G - 1)), ib = ia | G;
+                const bool live = unit0 + (size_t)(ia >> tb) < p.total_units;
+                uint64_t *sp = iopx_smem + 3 * (size_t)E * b;
+                gf192 av = lds_get(sp, E, ia), bv = lds_get(sp, E, ib);
+                gf_add_to(av, gf_mul_halves(bv, tw[0], tw[1], lane));
+                gf_add_to(bv, av);
+                if (live) { lds_put(sp, E, ia, av); lds_put(sp, E, ib, bv); }
             }
         } else if (pbit == 0 && p.ltab_small) {
             for (int x = tid; x < q.batch * half; x += nt) {
@@ -1452,6 +1483,7 @@ static int run_phase2_fwd_batch(AddPlan &pl, const uint64_t *const *srcs, uint64
         int rc;
         p.rs_comb = rs_comb.u64() + 3 * c0 * d;
         q.batch = (int)batch;
+        q.halves = tuning().edge_halves;
         for (size_t k = 0; k < batch; ++k) { q.srcs[k] = scratch[k]->u64(); q.dsts[k] = dsts[k] + 3 * c0 * nd; }
         const size_t lds = (((size_t)24) << tb) * batch;
         if (tuning().edge_lean & 1) {

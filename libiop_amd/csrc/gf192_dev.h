@@ -365,6 +365,19 @@ __device__ __forceinline__ gf192 gf_mul_uniform(const gf192 &a, const gf192 &c_u
     return gf_reduce(r);
 }
 
+// Product by a multiplier that is uniform within each HALF of the wavefront (lanes 0..31: c_lo, lanes 32..63: c_hi; both must be wave-uniform
+// values, e.g. fetched through the scalar unit from indices computed on readfirstlane'd quantities).  `lane` = the caller's lane within its wavefront:
+// unused on the GPU (EXEC selects the half), it tells the CPU emulation — one lane at a time — which half it is in.
+__device__ __forceinline__ gf192 gf_mul_halves(const gf192 &a, const gf192 &c_lo, const gf192 &c_hi, int lane)
+{
+    uint32_t c[6], d[6], r[12];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { c[i] = __builtin_amdgcn_readfirstlane(c_lo.w[i]); d[i] = __builtin_amdgcn_readfirstlane(c_hi.w[i]); }
+    iopx_set_emu_lane(lane);
+    comb_clmul_192_halves(r, a.w, c, d);
+    return gf_reduce(r);
+}
+
 // ---- subset sums over an affine subspace --------------------------------------------------------------------------------
 // v_j = t[0] + sum_{bit k of j} t[1 + k] for the j-th element of a 2^m-point subspace (t[0] the shift term, t[1 + k] the image of
 // basis vector k).  A workgroup sweeps 256 consecutive positions, so index bits 0..7 vary across lanes (masked XORs) and the rest

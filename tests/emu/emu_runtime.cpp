@@ -4,6 +4,8 @@
 thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 namespace iopx { alignas(16) uint64_t iopx_smem[160 * 1024 / 8]; }
 
+thread_local int iopx_emu_lane = 0;
+
 void emu_launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body)
 {
     (void)block;

@@ -26,4 +26,12 @@ static inline void comb_clmul_192_uniform(uint32_t (&r)[12], const uint32_t (&a)
     }
 }
 
+// the halves form: the emulation runs one lane at a time, so the caller's lane picks the multiplier its half uses (iopx_emu_lane, set by gf_mul_halves)
+extern thread_local int iopx_emu_lane;
+static inline void iopx_set_emu_lane(int lane) { iopx_emu_lane = lane; }
+static inline void comb_clmul_192_halves(uint32_t (&r)[12], const uint32_t (&a)[6], const uint32_t (&c)[6], const uint32_t (&d)[6])
+{
+    comb_clmul_192_uniform(r, a, (iopx_emu_lane & 32) ? d : c);
+}
+
 static inline uint64_t uniform_load64(const uint64_t *p) { return *p; }

@@ -1,6 +1,7 @@
 """Round-5 switches on the CPU-compiled kernels, each in a child process (the values are read once per process):
   IOPX_DEFER_ROOTS=0   every Merkle root read back at its round end (round 4's schedule) instead of with the query phase's read-backs
   IOPX_MERKLE_STREAM=0 no side stream: every round's Merkle tree on the main stream
+  IOPX_EDGE_HALVES=0   the batched last pass's 32-lane blocks on the general product instead of the comb product with one multiplier per half-wavefront
   IOPX_EDGE_LEAN=0/2/3 the edge passes' general product in its 114- or 54-register form (batched last pass / single-polynomial passes)
 The provers must give the oracle's bytes and the transforms the oracle's values on every branch."""
 import os
@@ -69,3 +70,7 @@ def test_trees_on_the_main_stream():
 @pytest.mark.parametrize("lean", ["0", "3"])
 def test_edge_pass_product_forms(lean):
     _run(TRANSFORMS, {"IOPX_EDGE_LEAN": lean})
+
+
+def test_batched_last_pass_without_the_half_wavefront_product():
+    _run(TRANSFORMS, {"IOPX_EDGE_HALVES": "0"})
