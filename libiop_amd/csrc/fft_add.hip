@@ -35,7 +35,7 @@ namespace iopx {
 // Tile geometry.  Defaults: 2048-element phase-2 tiles (48 KiB of LDS per workgroup), 1024-element phase-1 and edge tiles.  The IOPX_TILE_BITS /
 // IOPX_P1_COLS / IOPX_P2_COLS / IOPX_P2_TOP environment variables override them (read once): used for
 // tuning, and by the tests to exercise the multi-pass schedules at small transform sizes.
-struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last, scratch_mb, p1_comb, rs_comb_cap_log2, p2_radix4, edge_lean, edge_halves; };
+struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last, scratch_mb, p1_comb, rs_comb_cap_log2, p2_radix4, edge_lean, edge_halves, edge_multi; };
 static int env_int(const char *name, int dflt, int lo, int hi)
 {
     const char *v = getenv(name);
@@ -83,6 +83,9 @@ static const Tuning &tuning()
         // pair bit 3 of four polynomials, pair bit 4 of two: k_bfly_edge_fwd_batch 7.43 -> 7.03 ms per proof (profiles/r05_ab_edge_halves.txt).  The same
         // at pair bit 5 of the single-polynomial passes was measured too: 3.62 -> 3.58 ms at best, and only with the 54-register product beside it — not kept.
         u.edge_halves = env_int("IOPX_EDGE_HALVES", 1, 0, 1);
+        // > 0: the single-polynomial edge passes take this many cosets of one tile position per workgroup (k_bfly_edge_multi): the tile's twiddles
+        // are read once into LDS, the cosets differ in one shift term per level
+        u.edge_multi = env_int("IOPX_EDGE_MULTI", 4, 0, 64);
         return u;
     }();
     return t;
@@ -357,26 +360,34 @@ struct BfParams {
     // sum of the terms of the set bits of byte g (plus the shift's own term in group 0); null = not used
     const uint64_t *rs_tab;
     int rs_tab_groups;
+    // k_bfly_edge_multi: cosets of the launch, cosets per workgroup
+    size_t ncos;
+    int cpw;
 };
+
+// shift term of level l's twiddles in coset `coset` of the launch
+__device__ __forceinline__ gf192 bf_shift_term(const BfParams &p, size_t coset, int l)
+{
+    if (p.rs_comb) return gf_load(p.rs_comb, coset * p.d + l);
+    const size_t gc = p.coset_base + coset;
+    gf192 tw = gf_zero();
+    if (p.rs_tab) {
+        for (int g = 0; g < p.rs_tab_groups; ++g) gf_add_to(tw, gf_load(p.rs_tab, ((size_t)g * 256 + ((gc >> (8 * g)) & 255)) * p.d + l));
+        return tw;
+    }
+    tw = gf_load(p.rs, (size_t)l);
+    for (int v = 0; v < p.nhi; ++v) {
+        if ((gc >> v) & 1) gf_add_to(tw, gf_load(p.rs, (size_t)(1 + v) * p.d + l));
+    }
+    return tw;
+}
 
 // twiddle of the block that contains in-coset index u at the level with pair bit pbit
 __device__ __forceinline__ gf192 bf_twiddle(const BfParams &p, size_t coset, size_t u, int pbit)
 {
     const int l = p.d - 1 - pbit;
     gf192 tw = gf_load(p.ltab, (((size_t)1) << l) - 1 + (u >> (pbit + 1)));
-    if (p.rs_comb) {
-        gf_add_to(tw, gf_load(p.rs_comb, coset * p.d + l));
-        return tw;
-    }
-    const size_t gc = p.coset_base + coset;
-    if (p.rs_tab) {
-        for (int g = 0; g < p.rs_tab_groups; ++g) gf_add_to(tw, gf_load(p.rs_tab, ((size_t)g * 256 + ((gc >> (8 * g)) & 255)) * p.d + l));
-        return tw;
-    }
-    gf_add_to(tw, gf_load(p.rs, (size_t)l));
-    for (int v = 0; v < p.nhi; ++v) {
-        if ((gc >> v) & 1) gf_add_to(tw, gf_load(p.rs, (size_t)(1 + v) * p.d + l));
-    }
+    gf_add_to(tw, bf_shift_term(p, coset, l));
     return tw;
 }
 
@@ -714,6 +725,130 @@ __global__ void __launch_bounds__(LEAN ? 256 : (COMB ? 512 : 1024), LEAN ? 6 : 1
     }
 }
 
+
+// The same pass with `cpw` cosets of one tile position per workgroup (round 5).  A twiddle is T_block + S_(coset, level): the block terms of a
+// tile position are the same in every coset, so the workgroup reads them once into LDS (2^c_top (2^a_low - 1) entries, or the numerators of
+// the small-numerator levels) and each coset adds its a_low shift terms — no per-butterfly twiddle load from memory (k_bfly_edge's were 41 %
+// of its traffic: the table of every level re-read for each coset), and tile-local index arithmetic only.  One tile per workgroup (d >= the
+// tile bits).
+template<bool INV>
+__global__ void __launch_bounds__(256) k_bfly_edge_multi(BfParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tb = p.a_low + p.c_top;
+    const int E = 1 << tb, T = 1 << p.c_top;
+    const int midbits = p.d - tb;
+    const size_t mid = blockIdx.x & (((size_t)1 << midbits) - 1);
+    const size_t c0 = (size_t)(blockIdx.x >> midbits) * p.cpw;
+    const int lomask = (1 << p.a_low) - 1, tmask = T - 1;
+    const int pmin = p.ltab_small ? (p.ltab_small1 ? 2 : 1) : 0;      // general levels: pair bits pmin .. a_low - 1
+    const int NTW = pmin < p.a_low ? T * ((1 << (p.a_low - pmin)) - 1) : 0;
+    uint64_t *s = iopx_smem;                            // the tile: 3 E words
+    uint64_t *tw = s + 3 * E;                           // block terms: 3 NTW words, level pbit at T (nblk - 1), nblk = 2^(a_low - 1 - pbit)
+    uint64_t *sh = tw + 3 * NTW;                        // shift terms of the current coset: 3 a_low words, then the two small-numerator terms
+    uint64_t *sm1 = sh + 3 * p.a_low + 2;               // numerators of pair bit 1: T 2^(a_low - 2) words
+    uint32_t *sm0 = (uint32_t *)(sm1 + (p.ltab_small1 ? (E >> 2) : 0));    // numerators of pair bit 0: T 2^(a_low - 1) half words
+
+    for (int pbit = pmin; pbit < p.a_low; ++pbit) {
+        const int nb = p.a_low - 1 - pbit, l = p.d - 1 - pbit;
+        for (int e = tid; e < (T << nb); e += nt) {
+            const size_t blk = ((size_t)(e >> nb) << (p.d - p.c_top - pbit - 1)) | (mid << nb) | (size_t)(e & ((1 << nb) - 1));
+            lds_put(tw, NTW, T * ((1 << nb) - 1) + e, gf_load(p.ltab, (((size_t)1) << l) - 1 + blk));
+        }
+    }
+    if (p.ltab_small) {
+        for (int e = tid; e < (E >> 1); e += nt) {
+            const int top = e >> (p.a_low - 1);
+            sm0[e] = p.ltab_small[((size_t)top << (p.d - p.c_top - 1)) | (mid << (p.a_low - 1)) | (size_t)(e & ((1 << (p.a_low - 1)) - 1))];
+        }
+    }
+    if (p.ltab_small1) {
+        for (int e = tid; e < (E >> 2); e += nt) {
+            const int top = e >> (p.a_low - 2);
+            sm1[e] = p.ltab_small1[((size_t)top << (p.d - p.c_top - 2)) | (mid << (p.a_low - 2)) | (size_t)(e & ((1 << (p.a_low - 2)) - 1))];
+        }
+    }
+
+    for (int j = 0; j < p.cpw; ++j) {
+        const size_t coset = c0 + j;
+        if (coset >= p.ncos) break;                     // uniform over the workgroup
+        const uint64_t *src = p.src_shared ? p.src : p.src + 3 * (coset << p.d);
+        uint64_t *dst = p.dst + 3 * (coset << p.d);
+        for (int k = pmin + tid; k <= p.a_low; k += nt) {
+            if (k < p.a_low) {                          // level with pair bit k
+                const gf192 t = bf_shift_term(p, coset, p.d - 1 - k);
+                for (int w = 0; w < 3; ++w) sh[3 * k + w] = (uint64_t)t.w[2 * w] | ((uint64_t)t.w[2 * w + 1] << 32);
+            } else {                                    // the small-numerator levels' terms
+                const size_t gc = p.coset_base + coset;
+                uint32_t y = p.rs_small[0];
+                uint64_t y1 = p.rs_small1[0];
+                for (int v = 0; v < p.nhi; ++v) {
+                    if ((gc >> v) & 1) { y ^= p.rs_small[1 + v]; y1 ^= p.rs_small1[1 + v]; }
+                }
+                sh[3 * p.a_low] = y;
+                sh[3 * p.a_low + 1] = y1;
+            }
+        }
+        if (!INV) {
+            for (int e = tid; e < E; e += nt) {
+                const int top = e >> p.a_low, lo = e & lomask;
+                lds_put(s, E, e, gf_load(src, ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo));
+            }
+        } else {
+            for (int sidx = tid; sidx < E; sidx += nt) {
+                const int tp = sidx & tmask, lo = (sidx >> p.c_top) & lomask;
+                const int top = (int)bitrev((uint32_t)tp, p.c_top);
+                const size_t v = ((size_t)bitrev((uint32_t)lo, p.a_low) << (p.d - p.a_low)) |
+                                 ((size_t)bitrev((uint32_t)mid, midbits) << p.c_top) | (size_t)tp;
+                lds_put(s, E, (top << p.a_low) | lo, gf_load(src, v));
+            }
+        }
+        __syncthreads();
+
+        for (int t = 0; t < p.a_low; ++t) {
+            const int pbit = INV ? t : p.a_low - 1 - t;
+            if (pbit == 0 && p.ltab_small) {
+                const uint32_t yc = (uint32_t)sh[3 * p.a_low];
+                for (int bf = tid; bf < (E >> 1); bf += nt) bf_apply_small<INV>(s, E, bf << 1, (bf << 1) | 1, sm0[bf] ^ yc, p.small_k);
+            } else if (pbit == 1 && p.ltab_small1) {
+                const uint64_t yc = sh[3 * p.a_low + 1];
+                for (int bf = tid; bf < (E >> 1); bf += nt) {
+                    const int ia = ((bf >> 1) << 2) | (bf & 1);
+                    bf_apply_small1<INV>(s, E, ia, ia | 2, sm1[bf >> 1] ^ yc, p.small1_k1, p.small1_k2);
+                }
+            } else {
+                const uint64_t s0 = sh[3 * pbit], s1 = sh[3 * pbit + 1], s2 = sh[3 * pbit + 2];
+                const int tbase = T * ((1 << (p.a_low - 1 - pbit)) - 1);
+                for (int bf = tid; bf < (E >> 1); bf += nt) {
+                    const int low = bf & ((1 << pbit) - 1), high = bf >> pbit;
+                    const int ia = (high << (pbit + 1)) | low;
+                    gf192 t = lds_get(tw, NTW, tbase + high);
+                    t.w[0] ^= (uint32_t)s0; t.w[1] ^= (uint32_t)(s0 >> 32); t.w[2] ^= (uint32_t)s1; t.w[3] ^= (uint32_t)(s1 >> 32);
+                    t.w[4] ^= (uint32_t)s2; t.w[5] ^= (uint32_t)(s2 >> 32);
+                    bf_apply<INV, false, false>(s, E, ia, ia | (1 << pbit), t, false);
+                }
+            }
+            __syncthreads();
+        }
+
+        if (!INV) {
+            for (int sidx = tid; sidx < E; sidx += nt) {
+                const int tp = sidx & tmask, lo = (sidx >> p.c_top) & lomask;
+                const int top = (int)bitrev((uint32_t)tp, p.c_top);
+                const size_t v = ((size_t)bitrev((uint32_t)lo, p.a_low) << (p.d - p.a_low)) |
+                                 ((size_t)bitrev((uint32_t)mid, midbits) << p.c_top) | (size_t)tp;
+                gf_store(dst, v, lds_get(s, E, (top << p.a_low) | lo));
+            }
+        } else {
+            for (int e = tid; e < E; e += nt) {
+                const int top = e >> p.a_low, lo = e & lomask;
+                gf_store(dst, ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo, lds_get(s, E, e));
+            }
+        }
+        __syncthreads();
+    }
+}
 
 // Forward last pass for a BATCH of polynomials over the same domain (the prover extends f_Az, f_Bz, f_Cz, then p_alpha' and p_alpha^ABC,
 // together: r1cs_rs_iop.tcc:459-478, basic_lincheck_aux.tcc:94-118).  The twiddle of a butterfly depends on its block and coset, not on
@@ -1337,6 +1472,18 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         p.g_bits = g_bits; p.total_units = units; p.coset_base = cbase;
         p.rs_comb = comb_count ? rs_comb_ptr + 3 * (cbase - comb_base) * d : nullptr;
         int rc;
+        const int pmin = p.ltab_small ? (p.ltab_small1 ? 2 : 1) : 0;
+        const size_t ntw = pmin < p.a_low ? ((size_t)1 << p.c_top) * (((size_t)1 << (p.a_low - pmin)) - 1) : 0;
+        const size_t lds_m = lds + 24 * ntw + 8 * (3 * (size_t)p.a_low + 2) + (p.ltab_small1 ? 8 * ((size_t)elems >> 2) : 0) + (p.ltab_small ? 4 * ((size_t)elems >> 1) : 0);
+        if (tuning().edge_multi > 0 && g_bits == 0 && tb == EDGE_TILE_BITS && threads <= 256 && lds_m <= 80 * 1024) {      // (two workgroups per CU at least)
+            size_t cpw = (size_t)tuning().edge_multi < ncos ? (size_t)tuning().edge_multi : ncos;
+            cpw = (ncos + (ncos + cpw - 1) / cpw - 1) / ((ncos + cpw - 1) / cpw);           // even shares
+            p.ncos = ncos; p.cpw = (int)cpw;
+            const size_t blocks_m = ((ncos + cpw - 1) / cpw) << (d - tb);
+            if ((rc = set_lds(k_bfly_edge_multi<INV>, lds_m)) != IOPX_OK) return rc;
+            { ProfScope ps_(INV ? "k_bfly_edge_inv" : "k_bfly_edge_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)p.a_low); hipLaunchKernelGGL((k_bfly_edge_multi<INV>), dim3((unsigned)blocks_m), dim3(threads), lds_m, stream(), p); }
+            return IOPX_OK;
+        }
         if ((tuning().edge_lean & 2) && threads <= 256) {
             if ((rc = set_lds(k_bfly_edge<INV, false, true>, lds)) != IOPX_OK) return rc;
             { ProfScope ps_(INV ? "k_bfly_edge_inv" : "k_bfly_edge_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)p.a_low); hipLaunchKernelGGL((k_bfly_edge<INV, false, true>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }

@@ -3,6 +3,8 @@
   IOPX_MERKLE_STREAM=0 no side stream: every round's Merkle tree on the main stream
   IOPX_EDGE_HALVES=0   the batched last pass's 32-lane blocks on the general product instead of the comb product with one multiplier per half-wavefront
   IOPX_EDGE_LEAN=0/2/3 the edge passes' general product in its 114- or 54-register form (batched last pass / single-polynomial passes)
+  IOPX_EDGE_MULTI=0/1/3 the single-polynomial edge passes one coset at a time (k_bfly_edge), or 1 / 3 cosets of a tile position per workgroup
+                       (k_bfly_edge_multi; default 4); with IOPX_RS_COMB_CAP_LOG2=0 the shift terms come from the byte tables
 The provers must give the oracle's bytes and the transforms the oracle's values on every branch."""
 import os
 import subprocess
@@ -51,6 +53,35 @@ for m, d, batch in ((14, 11, 4), (14, 11, 3), (13, 11, 2)):
 print("ok")
 """
 
+# extensions of one polynomial over several cosets (standard and general bases), and the batched inverse: the shapes k_bfly_edge_multi takes
+EXTENSIONS = r"""
+import numpy as np
+import torch
+import oracle
+from emu_lib import emu
+from helpers import rand_elems
+from libiop_amd import domains
+W = 3
+lib = emu()
+ops = domains.DeviceOps(lib, torch, torch.device("cpu"), domains.GF192())
+for m, d, kind in ((14, 11, "std"), (13, 10, "general"), (15, 12, "std"), (12, 11, "general")):
+    basis = oracle.standard_basis(m, W) if kind == "std" else rand_elems(60 + m, m, W)
+    shift = np.array([1 << m, 0, 0], dtype=np.uint64) if kind == "std" else rand_elems(61 + m, 1, W)[0]
+    D = domains.Domain(domains.GF192(), domains.ADDITIVE, basis=basis, shift=shift)
+    poly = rand_elems(70 + m, 1 << d, W)
+    ev = oracle.additive_fft(poly, basis, shift)
+    assert np.array_equal(ops.download(ops.FFT(ops.upload(poly), 1 << d, D)), ev), (m, d, kind)
+for m, batch, kind in ((11, 3, "std"), (12, 5, "general")):
+    basis = oracle.standard_basis(m, W) if kind == "std" else rand_elems(80 + m, m, W)
+    shift = np.array([1 << m, 0, 0], dtype=np.uint64) if kind == "std" else rand_elems(81 + m, 1, W)[0]
+    D = domains.Domain(domains.GF192(), domains.ADDITIVE, basis=basis, shift=shift)
+    polys = [rand_elems(90 + m + q, 1 << m, W) for q in range(batch)]
+    evs = [oracle.additive_fft(p, basis, shift) for p in polys]
+    for p, o in zip(polys, ops.IFFT_batch([ops.upload(e) for e in evs], D)):
+        assert np.array_equal(ops.download(o), p), (m, batch, kind)
+print("ok")
+"""
+
 
 def _run(script, extra_env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -74,3 +105,11 @@ def test_edge_pass_product_forms(lean):
 
 def test_batched_last_pass_without_the_half_wavefront_product():
     _run(TRANSFORMS, {"IOPX_EDGE_HALVES": "0"})
+
+
+@pytest.mark.parametrize("env", [{"IOPX_EDGE_MULTI": "0"}, {"IOPX_EDGE_MULTI": "1"}, {"IOPX_EDGE_MULTI": "3"}, {},
+                                 {"IOPX_EDGE_MULTI": "3", "IOPX_RS_COMB_CAP_LOG2": "0"}, {"IOPX_SMALL_LAST": "0"}],
+                         ids=["one-coset-kernel", "multi-1", "multi-3", "default", "multi-3-byte-tables", "no-small-numerators"])
+def test_edge_pass_cosets_per_workgroup(env):
+    _run(EXTENSIONS, env)
+    _run(TRANSFORMS, env)

@@ -30,6 +30,6 @@ python3 tools/rocprof_summary.py $(find gpurun_out/${P}_fr_prof -name "*.db" | h
 python3 tools/gpu_gaps.py gpurun_out/${P}_prof --min-us 30 --period-kernel k_lincheck_add --period-index 4 --histogram > gpurun_out/${P}_gpu_gaps.txt
 python3 tools/make_traffic_json.py gpurun_out/${P}_pmc_fetch gpurun_out/${P}_pmc_write 20 gpurun_out/${P}_traffic_aurora.json --bench-json gpurun_out/${P}_bench_under_rocprof.json --steps $((STEPS + WARM + 3)) > /dev/null
 python3 tools/make_traffic_json.py gpurun_out/${P}_fr_fetch gpurun_out/${P}_fr_write 20 gpurun_out/${P}_traffic_fractal.json --bench-json gpurun_out/${P}_fractal_2p20.json --steps 4 --min-ms 0.2 > /dev/null
-python3 tools/make_sq_json.py gpurun_out/${P}_pmc_sq gpurun_out/${P}_sq_aurora.json k_bfly_upperILb0 k_bfly_edgeILb0 k_bfly_edge_fwd_batch k_bfly_upperILb1 k_bfly_edgeILb1 k_ldt_combine_add_slots k_merkle_leaves_sub24ILi4 k_merkle_leaves_sub24ILi1ELi2 k_merkle_level k_lincheck_add > /dev/null
+python3 tools/make_sq_json.py gpurun_out/${P}_pmc_sq gpurun_out/${P}_sq_aurora.json k_bfly_upperILb0 k_bfly_edge_multiILb0 k_bfly_edge_fwd_batch k_bfly_upperILb1 k_bfly_edge_multiILb1 k_ldt_combine_add_slots k_merkle_leaves_sub24ILi4 k_merkle_leaves_sub24ILi1ELi2 k_merkle_level k_lincheck_add > /dev/null
 rm -rf gpurun_out/${P}_prof gpurun_out/${P}_pmc_fetch gpurun_out/${P}_pmc_write gpurun_out/${P}_pmc_sq gpurun_out/${P}_fr_prof gpurun_out/${P}_fr_fetch gpurun_out/${P}_fr_write
 head -14 gpurun_out/${P}_rocprofv3_bench_aurora2p20.txt

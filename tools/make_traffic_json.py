@@ -63,6 +63,8 @@ def profile_name(symbol):
         name = m.group(1)
         targ = (m.group(2) or "").split(",")[0].strip()
         first = "1" if targ in ("true", "1", "(bool)1") else ("0" if targ in ("false", "0", "(bool)0") else None)
+    if name == "k_bfly_edge_multi":                                            # the edge pass with several cosets per workgroup: the library's profiler names it like k_bfly_edge
+        name = "k_bfly_edge"
     if name in ("k_bfly_upper", "k_bfly_edge", "k_phase1"):
         return name + ("_inv" if first == "1" else "_fwd")
     if name == "k_merkle_leaves_sub24":                                        # template arguments: oracles, coset size (, position map)
@@ -102,6 +104,15 @@ def main():
         "log_n": a.log_n, "kernel_sources_sha256": kernel_sources_digest(), "collected": time.strftime("%Y-%m-%d"),
         "steps_in_profiled_command": steps, "kernels": {},
     }
+    # the algorithmic bytes are per PROFILE NAME: where several symbols share one (k_bfly_edge_multi for the large shapes and k_bfly_edge for the
+    # small ones are both k_bfly_edge_fwd), the ratio is taken over all of the name's launches, the short ones below --min-ms included
+    by_name = {}
+    for sym, (f_avg, n, ms) in fetch.items():
+        if sym in write:
+            t = by_name.setdefault(profile_name(sym), [0.0, 0, 0])
+            t[0] += (2 * f_avg + write[sym][0]) * 1024 * n
+            t[1] += n
+            t[2] += 1
     for sym, (f_avg, n, ms) in sorted(fetch.items(), key=lambda kv: -kv[1][2]):
         if sym not in write or ms / steps < a.min_ms:
             continue
@@ -111,7 +122,11 @@ def main():
                  "fetch_size_kib_avg": round(f_avg, 1), "write_size_kib_avg": round(write[sym][0], 1), "traffic_bytes_per_launch": traffic}
         if name in alg:
             entry["algorithmic_bytes_per_launch"] = int(round(alg[name]))
-            entry["traffic_over_algorithmic"] = round(traffic / alg[name], 3)
+            tot, launches, nsym = by_name[name]
+            entry["traffic_over_algorithmic"] = round(tot / launches / alg[name], 3)
+            if nsym > 1:
+                entry["profile_name_launches_per_step"] = launches / steps
+                entry["note"] = "%d symbols share this profile name: the ratio is over all %d launches of the name (average %d bytes per launch)" % (nsym, launches, round(tot / launches))
         if name in out["kernels"]:          # two symbols with one profile name (comb / general instantiations): keep both, the busier one under the plain key
             name = name + " [" + sym + "]"
         out["kernels"][name] = entry
