@@ -730,7 +730,8 @@ __global__ void __launch_bounds__(LEAN ? 256 : (COMB ? 512 : 1024), LEAN ? 6 : 1
 // tile position are the same in every coset, so the workgroup reads them once into LDS (2^c_top (2^a_low - 1) entries, or the numerators of
 // the small-numerator levels) and each coset adds its a_low shift terms — no per-butterfly twiddle load from memory (k_bfly_edge's were 41 %
 // of its traffic: the table of every level re-read for each coset), and tile-local index arithmetic only.  One tile per workgroup (d >= the
-// tile bits).
+// tile bits).  No register bound: the compiler takes 141 - 149 VGPRs (three wavefronts per SIMD); bounded to 128 for four, with S[a] read after
+// the product so that nothing spills in the hot loop, the pass was 2.5 % slower (profiles/r05_ab_lowlive.txt).
 template<bool INV>
 __global__ void __launch_bounds__(256) k_bfly_edge_multi(BfParams p)
 {
@@ -870,21 +871,17 @@ __global__ void __launch_bounds__(512, LEAN ? 6 : 1) k_bfly_edge_fwd_batch(BfBat
     const BfParams &p = q.p;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int tb = p.a_low + p.c_top;                   // bits of one tile
-    const int E = 1 << (tb + p.g_bits);                 // elements of ONE polynomial in LDS (2^g_bits tiles)
+    const int E = 1 << tb;                              // elements of ONE polynomial in LDS: one tile per workgroup (the host launches g_bits = 0)
     const int midbits = p.d - tb;
-    const size_t unit0 = (size_t)blockIdx.x << p.g_bits;
+    const size_t coset = (size_t)blockIdx.x >> midbits, mid = (size_t)blockIdx.x & (((size_t)1 << midbits) - 1);
     const int lomask = (1 << p.a_low) - 1, tmask = (1 << p.c_top) - 1;
+    // in-coset index of tile slot li (top, lo)
+    auto index_of = [&](int li) -> size_t { return ((size_t)(li >> p.a_low) << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)(li & lomask); };
 
     for (int b = 0; b < q.batch; ++b) {
         uint64_t *s = iopx_smem + 3 * (size_t)E * b;
-        for (int e = tid; e < E; e += nt) {
-            const size_t unit = unit0 + (size_t)(e >> tb);
-            if (unit >= p.total_units) continue;
-            const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
-            const int li = e & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
-            const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
-            lds_put(s, E, e, gf_load(q.srcs[b] + 3 * (coset << p.d), u));
-        }
+        const uint64_t *src = q.srcs[b] + 3 * (coset << p.d);
+        for (int e = tid; e < E; e += nt) lds_put(s, E, e, gf_load(src, index_of(e)));
     }
     __syncthreads();
 
@@ -894,18 +891,14 @@ __global__ void __launch_bounds__(512, LEAN ? 6 : 1) k_bfly_edge_fwd_batch(BfBat
         const int G = 1 << pbit;                        // butterflies that share a twiddle, per polynomial
         if (pbit >= 4 && q.batch * G >= 48) {
             const int groups = half >> pbit, chunks = (q.batch * G + 63) >> 6;
+            const int cshift = (chunks & (chunks - 1)) ? -1 : __builtin_ctz(chunks);       // one or two chunks with the shipped tile: no division
             // a strided loop over (work item, lane) like every other loop here; the block size is a multiple of 64, so x >> 6 is the
             // same in all lanes of a wavefront
             for (int x = tid; x < groups * chunks * 64; x += nt) {
                 const int w = __builtin_amdgcn_readfirstlane(x >> 6), lane = x & 63;
-                const int g = w / chunks, ch = w - g * chunks;
+                const int g = cshift >= 0 ? w >> cshift : w / chunks, ch = w - g * chunks;
                 const int ia0 = g << (pbit + 1);
-                const size_t unit = unit0 + (size_t)(ia0 >> tb);
-                if (unit >= p.total_units) continue;
-                const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
-                const int li = ia0 & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
-                const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
-                const gf192 tw = bf_twiddle_uniform(p, coset, u, pbit);
+                const gf192 tw = bf_twiddle_uniform(p, coset, index_of(ia0), pbit);
                 const int idx = ch * 64 + lane;
                 if (idx < q.batch * G) {
                     const int b = idx >> pbit, ia = ia0 | (idx & (G - 1));
@@ -920,56 +913,32 @@ __global__ void __launch_bounds__(512, LEAN ? 6 : 1) k_bfly_edge_fwd_batch(BfBat
                 const int w = __builtin_amdgcn_readfirstlane(x >> 6), lane = x & 63;
                 gf192 tw[2];
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int ia0 = (2 * w + hf) << (pbit + 1);
-                    size_t unit = unit0 + (size_t)(ia0 >> tb);
-                    if (unit >= p.total_units) unit = p.total_units - 1;          // a block past the end (never with one tile per workgroup): any valid twiddle, nothing stored
-                    const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
-                    const int li = ia0 & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
-                    const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
-                    tw[hf] = bf_twiddle_uniform(p, coset, u, pbit);
-                }
+                for (int hf = 0; hf < 2; ++hf) tw[hf] = bf_twiddle_uniform(p, coset, index_of((2 * w + hf) << (pbit + 1)), pbit);
                 const int g = 2 * w + (lane >> 5), idx = lane & 31;
                 const int b = idx >> pbit, ia = (g << (pbit + 1)) | (idx & (G - 1)), ib = ia | G;
-                const bool live = unit0 + (size_t)(ia >> tb) < p.total_units;
                 uint64_t *sp = iopx_smem + 3 * (size_t)E * b;
                 gf192 av = lds_get(sp, E, ia), bv = lds_get(sp, E, ib);
                 gf_add_to(av, gf_mul_halves(bv, tw[0], tw[1], lane));
                 gf_add_to(bv, av);
-                if (live) { lds_put(sp, E, ia, av); lds_put(sp, E, ib, bv); }
+                lds_put(sp, E, ia, av); lds_put(sp, E, ib, bv);
             }
         } else if (pbit == 0 && p.ltab_small) {
             for (int x = tid; x < q.batch * half; x += nt) {
-                const int b = x / half, ia = (x - b * half) << 1;
-                const size_t unit = unit0 + (size_t)(ia >> tb);
-                if (unit >= p.total_units) continue;
-                const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
-                const int li = ia & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
-                const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
-                bf_apply_small<false>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | 1, bf_twiddle_small(p, coset, u), p.small_k);
+                const int b = x >> (tb - 1), ia = (x & (half - 1)) << 1;
+                bf_apply_small<false>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | 1, bf_twiddle_small(p, coset, index_of(ia)), p.small_k);
             }
         } else if (pbit == 1 && p.ltab_small1) {
             for (int x = tid; x < q.batch * half; x += nt) {
-                const int b = x / half, bf = x - b * half;
+                const int b = x >> (tb - 1), bf = x & (half - 1);
                 const int ia = ((bf >> 1) << 2) | (bf & 1);
-                const size_t unit = unit0 + (size_t)(ia >> tb);
-                if (unit >= p.total_units) continue;
-                const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
-                const int li = ia & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
-                const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
-                bf_apply_small1<false>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | 2, bf_twiddle_small1(p, coset, u), p.small1_k1, p.small1_k2);
+                bf_apply_small1<false>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | 2, bf_twiddle_small1(p, coset, index_of(ia)), p.small1_k1, p.small1_k2);
             }
         } else {
             for (int x = tid; x < q.batch * half; x += nt) {
-                const int b = x / half, bf = x - b * half;
+                const int b = x >> (tb - 1), bf = x & (half - 1);
                 const int low = bf & (G - 1), high = bf >> pbit;
                 const int ia = (high << (pbit + 1)) | low;
-                const size_t unit = unit0 + (size_t)(ia >> tb);
-                if (unit >= p.total_units) continue;
-                const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
-                const int li = ia & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
-                const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
-                bf_apply<false, false, LEAN>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | G, bf_twiddle(p, coset, u, pbit), false);
+                bf_apply<false, false, LEAN>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | G, bf_twiddle(p, coset, index_of(ia), pbit), false);
             }
         }
         __syncthreads();
@@ -977,16 +946,13 @@ __global__ void __launch_bounds__(512, LEAN ? 6 : 1) k_bfly_edge_fwd_batch(BfBat
 
     for (int b = 0; b < q.batch; ++b) {
         const uint64_t *s = iopx_smem + 3 * (size_t)E * b;
+        uint64_t *dst = q.dsts[b] + 3 * (coset << p.d);
         for (int sidx = tid; sidx < E; sidx += nt) {
-            const size_t unit = unit0 + (size_t)(sidx >> tb);
-            if (unit >= p.total_units) continue;
-            const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
             const int tp = sidx & tmask, lo = (sidx >> p.c_top) & lomask;
             const int top = (int)bitrev((uint32_t)tp, p.c_top);
             const size_t v = ((size_t)bitrev((uint32_t)lo, p.a_low) << (p.d - p.a_low)) |
                              ((size_t)bitrev((uint32_t)mid, midbits) << p.c_top) | (size_t)tp;
-            const int e = ((sidx >> tb) << tb) | (top << p.a_low) | lo;
-            gf_store(q.dsts[b] + 3 * (coset << p.d), v, lds_get(s, E, e));
+            gf_store(dst, v, lds_get(s, E, (top << p.a_low) | lo));
         }
     }
 }
