@@ -27,8 +27,14 @@ namespace libiop_amd {
 namespace dev {
 
 template<typename FieldT> inline const uint64_t *basis_words(const field_subset<FieldT> &D) { return detail::words(D.basis().data()); }
-template<typename FieldT> inline const uint64_t *shift_words(const field_subset<FieldT> &D) { return detail::words(&D.shift()); }
-template<typename FieldT> inline const uint64_t *gen_words(const field_subset<FieldT> &D) { return detail::words(&D.generator()); }
+// shift() and generator() return BY VALUE (field_subset.hpp:65-67): the holder keeps the copy alive for the full expression of the call
+// it is an argument of.  Never store the converted pointer.
+template<typename FieldT> struct held_words {
+    FieldT v;
+    operator const uint64_t *() const { return detail::words(&v); }
+};
+template<typename FieldT> inline held_words<FieldT> shift_words(const field_subset<FieldT> &D) { return held_words<FieldT>{ D.shift() }; }
+template<typename FieldT> inline held_words<FieldT> gen_words(const field_subset<FieldT> &D) { return held_words<FieldT>{ D.generator() }; }
 template<typename FieldT> inline bool additive(const field_subset<FieldT> &D) { return D.type() == affine_subspace_type; }
 
 template<typename FieldT>
@@ -78,7 +84,7 @@ std::vector<device_vector<FieldT>> reextend_packed(const device_vector<FieldT> &
         std::vector<uint64_t *> ptrs;
         auto range = dist::coset_range(L, H.dimension());
         for (std::size_t k = 0; k < batch; ++k) outs.emplace_back(range.second << H.dimension());
-        const bool copy_first = H_is_first_coset && range.first == 0 && range.second > 1 && std::memcmp(&H.shift(), &L.shift(), sizeof(FieldT)) == 0;
+        const bool copy_first = H_is_first_coset && range.first == 0 && range.second > 1 && H.shift() == L.shift();
         for (std::size_t k = 0; k < batch; ++k) {
             if (copy_first) outs[k].slice(0, n).copy_from(packed.slice(k * n, n));
             ptrs.push_back(outs[k].words() + (copy_first ? 3 * n : 0));

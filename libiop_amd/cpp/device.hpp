@@ -68,7 +68,8 @@ struct field_host {
     {
         if (S.type() == affine_subspace_type) {
             uint64_t w[3];
-            check(iopx_gf192_vanishing_host(detail::words(S.basis().data()), S.dimension(), detail::words(&S.shift()), detail::words(&x), w, nullptr));
+            const FieldT shift = S.shift();
+            check(iopx_gf192_vanishing_host(detail::words(S.basis().data()), S.dimension(), detail::words(&shift), detail::words(&x), w, nullptr));
             return from_words(w);
         }
         return sub(pow(x, S.num_elements()), pow(S.shift(), S.num_elements()));
@@ -78,7 +79,8 @@ struct field_host {
     {
         if (S.type() == affine_subspace_type) {
             uint64_t w[3];
-            check(iopx_gf192_vanishing_host(detail::words(S.basis().data()), S.dimension(), detail::words(&S.shift()), detail::words(&x), nullptr, w));
+            const FieldT shift = S.shift();
+            check(iopx_gf192_vanishing_host(detail::words(S.basis().data()), S.dimension(), detail::words(&shift), detail::words(&x), nullptr, w));
             return from_words(w);
         }
         return mul(from_uint(S.num_elements()), pow(x, S.num_elements() - 1));

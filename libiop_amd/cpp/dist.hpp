@@ -113,7 +113,8 @@ field_subset<FieldT> local_domain(const field_subset<FieldT> &D, std::size_t ran
     if (D.type() == affine_subspace_type) {
         const std::size_t m = D.dimension(), r = c.log_world;
         uint64_t s[3];
-        std::memcpy(s, detail::words(&D.shift()), 24);
+        const FieldT D_shift = D.shift();
+        std::memcpy(s, detail::words(&D_shift), 24);
         for (std::size_t k = 0; k < r; ++k)
             if ((rank >> k) & 1) for (int w = 0; w < 3; ++w) s[w] ^= detail::words(&D.basis()[m - r + k])[w];
         return field_subset<FieldT>(affine_subspace<FieldT>(std::vector<FieldT>(D.basis().begin(), D.basis().begin() + (m - r)), field_host<FieldT>::from_words(s)));
@@ -168,7 +169,8 @@ field_subset<FieldT> window_domain(const field_subset<FieldT> &D, const window &
         const std::size_t d = detail::log2_ceil(w.count);
         if (w.stride != 1 || ((std::size_t)1 << d) != w.count || w.first % w.count || w.first + w.count > D.num_elements()) throw std::invalid_argument("not a window of this subspace");
         uint64_t s[3];                                        // element_by_index(first) (subspace.tcc:56-71)
-        std::memcpy(s, detail::words(&D.shift()), 24);
+        const FieldT D_shift = D.shift();
+        std::memcpy(s, detail::words(&D_shift), 24);
         for (std::size_t k = d; k < D.dimension(); ++k)
             if ((w.first >> k) & 1) for (int i = 0; i < 3; ++i) s[i] ^= detail::words(&D.basis()[k])[i];
         return field_subset<FieldT>(affine_subspace<FieldT>(std::vector<FieldT>(D.basis().begin(), D.basis().begin() + d), field_host<FieldT>::from_words(s)));
