@@ -172,6 +172,38 @@ def headline_cpu_figure():
         return None
 
 
+def rank_replay(lib, torch, native, params, world, rank, steps=5, warmup=2):
+    """One rank's compute path of the N-rank prover, measured on ONE GPU: iopx_aurora_prove_dist over a replay communicator
+    (iopx_comm_create_replay: rank `rank` of `world` alone, every collective completed locally on the stream — all-gathers filled from this rank's
+    own part, all-reduces and broadcasts left as they are).  Times the kernels the rank runs between its collectives; the collectives' own latency
+    over xGMI is NOT in the figure (modelled in DESIGN.md section 6), and the transcript of such a proof is meaningless.  The proof-of-work grind of a
+    replayed rank covers all ranks' candidate ranges (nobody to hear a hit from): pow_ms is reported, and ms_per_proof_pow_adjusted takes
+    (world - 1) / world of it off again."""
+    comm = lib.comm_create_replay(rank, world)
+    try:
+        for _ in range(warmup):
+            lib.aurora_prove_dist(native, comm, 128, params.RS_extra_dimensions, 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            lib.aurora_prove_dist(native, comm, 128, params.RS_extra_dimensions, 2)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        lib.comm_stats(reset=True)
+        lib.profile_begin()                           # while the profiler records, the library keeps side-stream sections on the main stream
+        lib.aurora_prove_dist(native, comm, 128, params.RS_extra_dimensions, 2)
+        prof = lib.profile_report()
+        calls, payload = lib.comm_stats()
+    finally:
+        lib.comm_destroy(comm)
+    pow_ms = sum(v[1] for k, v in prof.items() if k.startswith("k_pow_blake2b"))
+    return {"world": world, "rank": rank, "ms_per_proof": round(ms, 3), "steps": steps,
+            "pow_ms": round(pow_ms, 3), "ms_per_proof_pow_adjusted": round(ms - pow_ms * (world - 1) / world, 3),
+            "kernels_ms_total": round(sum(v[1] for v in prof.values()), 3),
+            "kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])[:14]},
+            "collectives_per_proof": calls, "collective_payload_bytes_this_rank": payload}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +219,10 @@ def main():
     ap.add_argument("--throughput", action="store_true",
                     help="with --gpus N: N independent proofs, one per rank, no collective (a labelled secondary figure: weak scaling; the default shards ONE proof over the ranks)")
     ap.add_argument("--cpu-log-n", type=int, default=12, help="size of the CPU-baseline sample (oracle prover); 2^12: about 8 s on one core, 2^13: 17 s")
+    ap.add_argument("--replay-rank", type=int, default=None,
+                    help="with --world N on ONE GPU: time rank R of the N-rank prover alone (collectives completed locally; compute path only) and print that line")
+    ap.add_argument("--world", type=int, default=8, help="the world size --replay-rank plays a rank of")
+    ap.add_argument("--no-rank-replay", action="store_true", help="skip config.rank_replay (ranks 0 and N-1 of 2, 4, 8 played alone on this GPU)")
     ap.add_argument("--cpu-all-cores", action="store_true", help="also time one independent oracle proof per host core at once (not in the reference, which is single-threaded)")
     args = ap.parse_args()
 
@@ -207,7 +243,7 @@ def main():
     # gf192, one thread — the reference is single-threaded) on a bounded sample of the same workload; its transcript is compared with the
     # device prover's for that instance further down, before the number is reported.
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.replay_rank is None:
         cpu = cpu_baseline_leg(args.cpu_log_n, args.cpu_all_cores)
 
     import torch
@@ -243,6 +279,16 @@ def main():
     # iopx_aurora_prove_dist over the communicator otherwise — the same code, libiop_amd/cpp/dist.hpp) on its own copy of the same seeded
     # instance; the Python prover (libiop_amd/aurora.py) proves it once below as a cross-check of the transcript bytes
     native = lib.aurora_example_instance(0, n, 15, n - 1, SEED)
+
+    if args.replay_rank is not None:
+        # one rank of --world played alone: its line only (no headline value: the proof's bytes are meaningless)
+        assert world == 1, "--replay-rank runs on one GPU"
+        rr = rank_replay(lib, torch, native, params, args.world, args.replay_rank, steps=args.steps, warmup=args.warmup)
+        print(json.dumps({"metric": "aurora_prover_rank_replay_ms", "value": rr["ms_per_proof"], "unit": "ms", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                          "higher_is_better": False, "data": "synthetic", "config": {"workload": "rank %d of %d of the 2^%d Aurora prover over GF(2^192), played alone on one GPU "
+                          "(compute path only: collectives completed locally, not timed)" % (args.replay_rank, args.world, args.log_n), "rank_replay": rr}}))
+        lib.aurora_instance_free(native)
+        return
 
     class _Bytes:
         def __init__(self, b):
@@ -318,9 +364,18 @@ def main():
         reference_schedule = {"ms_per_step": ref_s * 1e3, "steps": 5, "transcript_equal": True}
 
     # per-kernel durations of one more proof, live, with HIP events on the stream the kernels are launched on.  The timed loop builds every round's
-    # Merkle tree on the library's side stream, beside the next round's transforms; for THIS proof the trees stay on the main stream
-    # (IOPX_MERKLE_STREAM=0, read per round), so that every kernel is timed running alone and the durations add up
+    # Merkle tree on the library's side stream, beside the next round's transforms; while the profiler records the library keeps those sections
+    # on the main stream (iopx_side_stream_begin), so that every kernel is timed running alone and the durations add up.  The proof before it runs
+    # the same way without the profiler (IOPX_MERKLE_STREAM=0, read per round): its wall time is what the kernel sum is compared with
     lib.comm_stats(reset=True)
+    prev_merkle_stream = os.environ.get("IOPX_MERKLE_STREAM")
+
+    def restore_merkle_stream():
+        if prev_merkle_stream is None:
+            os.environ.pop("IOPX_MERKLE_STREAM", None)
+        else:
+            os.environ["IOPX_MERKLE_STREAM"] = prev_merkle_stream
+
     os.environ["IOPX_MERKLE_STREAM"] = "0"
     try:
         torch.cuda.synchronize()
@@ -332,7 +387,7 @@ def main():
         step()
         prof = lib.profile_report()
     finally:
-        del os.environ["IOPX_MERKLE_STREAM"]
+        restore_merkle_stream()
     comm_calls, comm_bytes = lib.comm_stats()
     dom_name, (dom_cnt, dom_ms, dom_bytes) = max(prof.items(), key=lambda kv: kv[1][1])
     dom_avg_s = dom_ms / dom_cnt / 1e3
@@ -445,6 +500,14 @@ def main():
                      "ms_per_proof_trees_on_main_stream": round(serial_proof_s * 1e3, 3)},
     }
 
+    if rank == 0 and world == 1 and not args.no_secondary and not args.no_rank_replay:
+        # the N-rank prover's per-rank compute path, measured on this GPU: ranks 0 (which evaluates the heads) and N - 1 of 2, 4 and 8
+        out["config"]["rank_replay"] = {
+            "what": "iopx_aurora_prove_dist over iopx_comm_create_replay: one rank of N played alone on this GPU, collectives completed locally on the stream; "
+                    "compute path only — no xGMI latency, no waiting for a slower peer; a proof's time over N GPUs is at least the max over its ranks",
+            "single_gpu_ms": prover_s * 1e3,
+            "ranks": [rank_replay(lib, torch, native, params, w, r) for w in (2, 4, 8) for r in (0, w - 1)]}
+
     if reference_schedule:
         reference_schedule["field_ops_per_s"] = (mults + adds) / (reference_schedule["ms_per_step"] / 1e3)
         reference_schedule["note"] = "IOPX_HEAD_EVAL=0: the reference's schedule on the same kernels (seven codeword extensions, virtual oracles over 2^25 points)"
@@ -517,8 +580,8 @@ def main():
             torch.cuda.synchronize()
             times5.append(time.perf_counter() - t0)
         assert tr5 == tr5_py, "native Fractal prover's transcript differs from the Python prover's"
-        lib.profile_begin()                             # one more proof under the library's HIP-event profiler, for the kernel breakdown
-        lib.fractal_prove(inst5)
+        lib.profile_begin()                             # one more proof under the library's HIP-event profiler (side-stream sections stay on the main
+        lib.fractal_prove(inst5)                        # stream while it records: every kernel timed alone), for the kernel breakdown
         prof5 = lib.profile_report()
         lib.aurora_instance_free(inst5)
         out["config"]["secondary_fractal"] = {

@@ -563,6 +563,13 @@ typedef struct iopx_comm_callbacks {
 int iopx_comm_rccl_unique_id(uint8_t *unique_id /* IOPX_COMM_UNIQUE_ID_BYTES */);
 int iopx_comm_create_rccl(int rank, int world, const uint8_t *unique_id, iopx_comm **out);
 int iopx_comm_create_callbacks(int rank, int world, const iopx_comm_callbacks *callbacks, iopx_comm **out);
+/* Rank `rank` of a `world`-rank job played ALONE on this GPU, for measuring one rank's compute path where no multi-GPU node is at hand
+ * (bench.py --replay-rank): every collective is completed locally on the library's stream — an all-gather fills every slot with this rank's
+ * part, an all-to-all and a send/receive copy the send buffer, an all-reduce and a broadcast leave the buffer as it is — so the kernels the rank
+ * would run between its collectives run, on inputs that are field elements but NOT the peers' real data: the transcript of such a proof is
+ * meaningless and must not be used.  The proof-of-work search of a replayed rank covers all ranks' candidate ranges (it has nobody to hear a hit from). */
+int iopx_comm_create_replay(int rank, int world, iopx_comm **out);
+int iopx_comm_is_replay(const iopx_comm *comm);
 int iopx_comm_destroy(iopx_comm *comm);
 int iopx_comm_rank(const iopx_comm *comm, int *rank, int *world);
 int iopx_comm_all_gather_dev(iopx_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank);

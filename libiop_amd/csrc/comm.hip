@@ -94,6 +94,9 @@ struct iopx_comm {
     ncclComm_t nccl = nullptr;
     bool use_callbacks = false;
     iopx_comm_callbacks cb{};
+    // rank `rank` of `world` played ALONE (iopx_comm_create_replay): no peer exists; every collective moves, on the library's stream, the bytes this
+    // rank would receive — from its own send buffer — so that the stream's work is what the rank's stream would carry between the collectives.
+    bool replay = false;
 };
 
 namespace iopx {
@@ -184,6 +187,20 @@ int iopx_comm_create_callbacks(int rank, int world, const iopx_comm_callbacks *c
     return IOPX_OK;
 }
 
+int iopx_comm_create_replay(int rank, int world, iopx_comm **out)
+{
+    if (!out) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
+    if (world < 1 || rank < 0 || rank >= world || (world & (world - 1))) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "rank %d of %d: the world size must be a power of two", rank, world);
+    int rc = iopx::ensure_device();
+    if (rc != IOPX_OK) return rc;
+    iopx_comm *c = new iopx_comm();
+    c->rank = rank; c->world = world; c->replay = true;
+    *out = c;
+    return IOPX_OK;
+}
+
+int iopx_comm_is_replay(const iopx_comm *comm) { return comm && comm->replay ? 1 : 0; }
+
 int iopx_comm_bind_transforms(iopx_comm *comm)
 {
     iopx::g_transform_comm = comm;
@@ -217,6 +234,13 @@ int iopx_comm_all_gather_dev(iopx_comm *comm, const void *d_send, void *d_recv, 
     if (bytes_per_rank == 0) return IOPX_OK;
     if (!d_send || !d_recv) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
     ++g_num_collectives; g_comm_bytes += bytes_per_rank;
+    if (comm->replay) {                                            // every rank's slot <- this rank's part
+        for (int r = 0; r < comm->world; ++r) {
+            void *slot = (char *)d_recv + (size_t)r * bytes_per_rank;
+            if (slot != d_send) IOPX_HIP(hipMemcpyAsync(slot, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, iopx::stream()));
+        }
+        return IOPX_OK;
+    }
     if (comm->use_callbacks) {
         if (comm->world == 1) { if (d_send != d_recv) IOPX_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, iopx::stream())); return IOPX_OK; }
         rc = comm->cb.all_gather(comm->cb.user, d_send, d_recv, bytes_per_rank, (void *)iopx::stream());
@@ -234,6 +258,7 @@ int iopx_comm_all_reduce_u64_dev(iopx_comm *comm, void *d_buf, size_t count, int
     if (!d_buf) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
     if (op != IOPX_COMM_SUM && op != IOPX_COMM_MIN) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "unknown reduction");
     ++g_num_collectives; g_comm_bytes += count * 8;
+    if (comm->replay) return IOPX_OK;                              // the peers contribute the reduction's neutral element
     if (comm->use_callbacks) {
         if (comm->world == 1) return IOPX_OK;
         rc = comm->cb.all_reduce_u64(comm->cb.user, d_buf, count, op, (void *)iopx::stream());
@@ -251,6 +276,7 @@ int iopx_comm_broadcast_dev(iopx_comm *comm, void *d_buf, size_t bytes, int root
     if (!d_buf) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
     if (root < 0 || root >= comm->world) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "broadcast root %d of %d ranks", root, comm->world);
     ++g_num_collectives; if (comm->rank == root) g_comm_bytes += bytes;
+    if (comm->replay) return IOPX_OK;                              // a receiver keeps whatever its buffer holds (timing only)
     if (comm->use_callbacks) {
         if (comm->world == 1) return IOPX_OK;
         rc = comm->cb.broadcast(comm->cb.user, d_buf, bytes, root, (void *)iopx::stream());
@@ -267,6 +293,7 @@ int iopx_comm_all_to_all_dev(iopx_comm *comm, const void *d_send, void *d_recv, 
     if (bytes_per_rank == 0) return IOPX_OK;
     if (!d_send || !d_recv || d_send == d_recv) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "all_to_all needs two distinct buffers");
     ++g_num_collectives; g_comm_bytes += bytes_per_rank * (size_t)comm->world;
+    if (comm->replay) { IOPX_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank * (size_t)comm->world, hipMemcpyDeviceToDevice, iopx::stream())); return IOPX_OK; }
     if (comm->use_callbacks) {
         if (comm->world == 1) { IOPX_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, iopx::stream())); return IOPX_OK; }
         rc = comm->cb.all_to_all(comm->cb.user, d_send, d_recv, bytes_per_rank, (void *)iopx::stream());
@@ -284,6 +311,7 @@ int iopx_comm_sendrecv_dev(iopx_comm *comm, const void *d_send, void *d_recv, si
     if (!d_send || !d_recv) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
     if (peer < 0 || peer >= comm->world || peer == comm->rank) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "peer %d (this is rank %d of %d)", peer, comm->rank, comm->world);
     ++g_num_collectives; g_comm_bytes += bytes;
+    if (comm->replay) { if (d_send != d_recv) IOPX_HIP(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, iopx::stream())); return IOPX_OK; }
     if (comm->use_callbacks) {
         rc = comm->cb.sendrecv(comm->cb.user, d_send, d_recv, bytes, peer, (void *)iopx::stream());
         return rc == 0 ? IOPX_OK : iopx::fail(IOPX_ERR_RUNTIME, "sendrecv callback failed (%d)", rc);

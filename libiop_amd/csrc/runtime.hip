@@ -1,6 +1,7 @@
 // libiop_amd runtime: device binding, stream, memory helpers, error strings (see include/libiop_amd.h).
 #include "runtime.h"
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -46,7 +47,8 @@ const char *last_error() { return g_err; }
 #define IOPX_SIDE_STREAMS 1
 static hipStream_t g_side_stream[IOPX_SIDE_STREAMS] = { nullptr };
 static hipEvent_t g_fork_event[IOPX_SIDE_STREAMS], g_join_event[IOPX_SIDE_STREAMS];
-static int g_cur_side = -1;                 // -1: the main stream is current
+static std::atomic<int> g_cur_side{ -1 };   // -1: the main stream is current (written by the driving thread under g_mu; read by pool frees of any thread)
+static bool g_side_elided = false;          // a begin/end pair that stayed on the main stream because the HIP-event profiler records (kernels timed alone)
 static bool g_side_dirty[IOPX_SIDE_STREAMS] = { false };      // the side stream holds work the main stream has not waited for
 static inline hipStream_t active_stream() { return g_cur_side >= 0 ? g_side_stream[g_cur_side] : g_stream; }
 
@@ -91,6 +93,20 @@ int ensure_device()
 
 int bound_device() { return g_ready ? g_device : -1; }
 
+// Host-waits for every side stream that holds unjoined work: nothing of it is in flight afterwards, so what was freed on it is reusable and
+// the stream is clean.  g_mu held by the caller.
+static void drain_side_streams_locked()
+{
+    for (int k = 0; k < IOPX_SIDE_STREAMS; ++k) {
+        if (!g_side_dirty[k]) continue;
+        (void)hipStreamSynchronize(g_side_stream[k]);
+        g_side_dirty[k] = false;
+        std::lock_guard<std::mutex> lt(g_tmp_mu);
+        g_tmp_free.insert(g_tmp_free.end(), g_tmp_quarantine[k].begin(), g_tmp_quarantine[k].end());
+        g_tmp_quarantine[k].clear();
+    }
+}
+
 // own = true: back to the library's private stream; otherwise the caller's handle as given, 0 included (the legacy default
 // stream, which is what torch's default stream is)
 int set_stream(void *s, bool own)
@@ -101,14 +117,8 @@ int set_stream(void *s, bool own)
     // switch under the lock, so a concurrent iopx_set_stream / iopx_use_own_stream from another host thread cannot make this
     // call drain a stream that is no longer (or not yet) the current one
     std::lock_guard<std::mutex> lk(g_mu);
-    for (int k = 0; k < IOPX_SIDE_STREAMS; ++k) {
-        if (!g_side_dirty[k]) continue;
-        (void)hipStreamSynchronize(g_side_stream[k]);           // drained: nothing of it is in flight, what was freed on it is reusable
-        g_side_dirty[k] = false;
-        std::lock_guard<std::mutex> lt(g_tmp_mu);
-        g_tmp_free.insert(g_tmp_free.end(), g_tmp_quarantine[k].begin(), g_tmp_quarantine[k].end());
-        g_tmp_quarantine[k].clear();
-    }
+    if (g_cur_side >= 0) return fail(IOPX_ERR_LOGIC, "iopx_set_stream inside a side-stream section");
+    drain_side_streams_locked();
     (void)hipStreamSynchronize(g_stream);
     g_caller_stream = !own;
     g_stream = own ? g_own_stream : (hipStream_t)s;
@@ -136,10 +146,14 @@ void *tmp_alloc(size_t bytes, size_t *cap)
     void *p = nullptr;
     const size_t c = (bytes + 255) & ~(size_t)255;
     if (hipMalloc(&p, c) != hipSuccess) {
-        // out of memory: drop the cache (after draining the streams) and retry once
+        // out of memory: drop the cache (after draining the streams: quarantined blocks become droppable too) and retry once
         (void)hipGetLastError();
-        for (int k = 0; k < IOPX_SIDE_STREAMS; ++k) if (g_side_dirty[k]) (void)hipStreamSynchronize(g_side_stream[k]);
-        (void)hipStreamSynchronize(g_stream);
+        {
+            std::lock_guard<std::mutex> lm(g_mu);
+            if (g_cur_side < 0) drain_side_streams_locked();
+            else (void)hipStreamSynchronize(g_side_stream[g_cur_side]);      // inside a section: its frees stay quarantined until the join
+            (void)hipStreamSynchronize(g_stream);
+        }
         std::lock_guard<std::mutex> lk(g_tmp_mu);
         for (auto &b : g_tmp_free) (void)hipFree(b.p);
         g_tmp_free.clear();
@@ -160,10 +174,19 @@ int side_stream_fork(int k)
     std::lock_guard<std::mutex> lk(g_mu);
     if (k < 0 || k >= IOPX_SIDE_STREAMS) return fail(IOPX_ERR_INVALID_ARGUMENT, "side stream %d", k);
     if (g_cur_side >= 0) return fail(IOPX_ERR_LOGIC, "side_stream_fork inside a side-stream section");
-    if (!g_side_stream[k]) {
-        IOPX_HIP(hipStreamCreateWithFlags(&g_side_stream[k], hipStreamNonBlocking));
-        IOPX_HIP(hipEventCreateWithFlags(&g_fork_event[k], hipEventDisableTiming));
-        IOPX_HIP(hipEventCreateWithFlags(&g_join_event[k], hipEventDisableTiming));
+    if (!g_side_stream[k]) {                                    // published only when the stream and both events exist
+        hipStream_t st = nullptr;
+        hipEvent_t ef = nullptr, ej = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ef, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ej, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            if (ej) (void)hipEventDestroy(ej);
+            if (ef) (void)hipEventDestroy(ef);
+            if (st) (void)hipStreamDestroy(st);
+            return fail(IOPX_ERR_RUNTIME, "side stream creation failed: %s", hipGetErrorString(e));
+        }
+        g_fork_event[k] = ef; g_join_event[k] = ej; g_side_stream[k] = st;
     }
     IOPX_HIP(hipEventRecord(g_fork_event[k], g_stream));
     IOPX_HIP(hipStreamWaitEvent(g_side_stream[k], g_fork_event[k], 0));
@@ -199,8 +222,11 @@ int side_stream_join(int k)
 
 void tmp_trim()
 {
-    for (int k = 0; k < IOPX_SIDE_STREAMS; ++k) if (g_side_dirty[k]) (void)hipStreamSynchronize(g_side_stream[k]);
-    (void)hipStreamSynchronize(g_stream);
+    {
+        std::lock_guard<std::mutex> lm(g_mu);
+        if (g_cur_side < 0) drain_side_streams_locked();
+        (void)hipStreamSynchronize(g_stream);
+    }
     std::lock_guard<std::mutex> lk(g_tmp_mu);
     for (auto &b : g_tmp_free) (void)hipFree(b.p);
     g_tmp_free.clear();
@@ -329,6 +355,8 @@ int defer_downloads_end()
     std::lock_guard<std::mutex> lk(g_stage_mu);
     if (!g_defer_on) return fail(IOPX_ERR_LOGIC, "iopx_defer_downloads_end without begin");
     g_defer_on = false;
+    // a deferrable read-back may have been queued inside a side-stream section: the main stream waits for the side streams, draining it covers both
+    for (int k = 0; k < IOPX_SIDE_STREAMS; ++k) if (side_stream_current() < 0) (void)side_stream_join(k);
     const hipError_t e = hipStreamSynchronize(g_stream);
     if (e == hipSuccess) for (auto &it : g_defer_items) memcpy(it.dst, it.src, it.bytes);
     g_defer_items.clear();
@@ -408,6 +436,7 @@ int iopx_profile_report(char *buf, size_t cap)
     int rc = iopx::ensure_device();
     if (rc != IOPX_OK) return rc;
     iopx::g_prof_on = false;
+    for (int k = 0; k < IOPX_SIDE_STREAMS; ++k) if (iopx::side_stream_current() < 0) (void)iopx::side_stream_join(k);     // events recorded on a side stream before the profile began
     IOPX_HIP(hipStreamSynchronize(iopx::stream()));
     struct Agg { size_t launches = 0; double ms = 0; double bytes = 0; double products = 0; };
     std::map<std::string, Agg> agg;
@@ -498,12 +527,20 @@ int iopx_side_stream_begin(void)
 {
     int rc = iopx::ensure_device();
     if (rc != IOPX_OK) return rc;
+    // while the HIP-event profiler records, the section stays on the main stream: every kernel is then timed running alone and the
+    // durations add up (what bench.py's per-kernel figures and roofline.achieved are computed from)
+    if (iopx::g_prof_on) {
+        if (iopx::g_side_elided || iopx::side_stream_current() >= 0) return iopx::fail(IOPX_ERR_LOGIC, "side_stream_begin inside a side-stream section");
+        iopx::g_side_elided = true;
+        return IOPX_OK;
+    }
     if ((rc = iopx::side_stream_fork(0)) != IOPX_OK) return rc;
     return iopx::side_stream_select(0);
 }
 
 int iopx_side_stream_end(void)
 {
+    if (iopx::g_side_elided) { iopx::g_side_elided = false; return IOPX_OK; }
     if (iopx::side_stream_current() != 0) return iopx::fail(IOPX_ERR_LOGIC, "iopx_side_stream_end without begin");
     return iopx::side_stream_select(-1);
 }
