@@ -348,8 +348,8 @@ def main():
     # the same proof by the reference's own schedule (every virtual oracle over the whole codeword domain, coefficient forms: IOPX_HEAD_EVAL=0, read per
     # proof) — a second figure beside `value`, so that the reader sees what the schedule and what the kernels contribute; same transcript bytes
     reference_schedule = None
-    if world == 1 and not args.no_secondary and os.environ.get("IOPX_HEAD_EVAL", "1")[:1] != "0":
-        os.environ["IOPX_HEAD_EVAL"] = "0"
+    if world == 1 and not args.no_secondary and lib.get_option("IOPX_HEAD_EVAL", 1) != 0:
+        lib.set_option("IOPX_HEAD_EVAL", 0)             # looked up per proof
         try:
             step()
             torch.cuda.synchronize()
@@ -359,24 +359,17 @@ def main():
             torch.cuda.synchronize()
             ref_s = (time.perf_counter() - t0) / 5
         finally:
-            del os.environ["IOPX_HEAD_EVAL"]
+            lib.clear_option("IOPX_HEAD_EVAL")
         assert t_ref.serialize() == transcript.serialize(), "the two schedules produced different transcripts"
         reference_schedule = {"ms_per_step": ref_s * 1e3, "steps": 5, "transcript_equal": True}
 
     # per-kernel durations of one more proof, live, with HIP events on the stream the kernels are launched on.  The timed loop builds every round's
     # Merkle tree on the library's side stream, beside the next round's transforms; while the profiler records the library keeps those sections
     # on the main stream (iopx_side_stream_begin), so that every kernel is timed running alone and the durations add up.  The proof before it runs
-    # the same way without the profiler (IOPX_MERKLE_STREAM=0, read per round): its wall time is what the kernel sum is compared with
+    # the same way without the profiler (option IOPX_MERKLE_STREAM = 0, looked up per round): its wall time is what the kernel sum is compared with
     lib.comm_stats(reset=True)
-    prev_merkle_stream = os.environ.get("IOPX_MERKLE_STREAM")
-
-    def restore_merkle_stream():
-        if prev_merkle_stream is None:
-            os.environ.pop("IOPX_MERKLE_STREAM", None)
-        else:
-            os.environ["IOPX_MERKLE_STREAM"] = prev_merkle_stream
-
-    os.environ["IOPX_MERKLE_STREAM"] = "0"
+    prev_merkle_stream = lib.get_option("IOPX_MERKLE_STREAM", 1)
+    lib.set_option("IOPX_MERKLE_STREAM", 0)
     try:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -387,7 +380,7 @@ def main():
         step()
         prof = lib.profile_report()
     finally:
-        restore_merkle_stream()
+        lib.set_option("IOPX_MERKLE_STREAM", prev_merkle_stream)
     comm_calls, comm_bytes = lib.comm_stats()
     dom_name, (dom_cnt, dom_ms, dom_bytes) = max(prof.items(), key=lambda kv: kv[1][1])
     dom_avg_s = dom_ms / dom_cnt / 1e3
@@ -456,7 +449,7 @@ def main():
             "prover": ("native: iopx_aurora_prove (libiop_amd/cpp/aurora.hpp behind the C ABI); transcript equal to libiop_amd/aurora.py's" if comm is None else
                        "native: iopx_aurora_prove_dist (libiop_amd/cpp/aurora.hpp + dist.hpp behind the C ABI, RCCL communicator of %d rank(s)); transcript equal to "
                        "the single-GPU prover's" % world),
-            "schedule": ("reference's: every virtual oracle over the whole codeword domain (IOPX_HEAD_EVAL=0)" if os.environ.get("IOPX_HEAD_EVAL", "1")[:1] == "0" else
+            "schedule": ("reference's: every virtual oracle over the whole codeword domain (IOPX_HEAD_EVAL=0)" if lib.get_option("IOPX_HEAD_EVAL", 1) == 0 else
                          "virtual oracles over the head of the codeword domain (as many points as their polynomial has coefficients), f_1 folded there and re-extended, "
                          "confirmed on a second window; h, f_w and f_1 re-extended without coefficient forms (DESIGN.md section 4)"),
             "reference_schedule": reference_schedule,          # field_ops_per_s filled in below

@@ -442,6 +442,19 @@ int iopx_pow_solve_poseidon_bn128(const iopx_poseidon_params *params, const uint
  * iopx_profile_begin() starts recording; iopx_profile_report() synchronises, stops recording and writes
  * one text line per kernel: "<kernel> <launches> <total_ms> <algorithmic_bytes> <field_products>\n" (used by bench.py for the roofline line;
  * algorithmic_bytes = elements swept x 24 x (read + write) summed over the launches, 0 for kernels that do not report it). */
+/* Options: named integers that select a prover schedule or a tile geometry (the names are listed in DESIGN.md).  A name's value is what
+ * iopx_set_option gave it, else the environment variable of that name (read once per process, at the name's first lookup), else the built-in
+ * default.  Schedule options (IOPX_HEAD_EVAL, IOPX_MERKLE_STREAM, IOPX_DEFER_ROOTS) are looked up per proof; tile geometries are latched by
+ * their component at its first use. */
+int iopx_set_option(const char *name, int value);
+int iopx_clear_option(const char *name);
+int iopx_get_option(const char *name, int dflt);
+
+/* One-time host-side costs since the last reset, by label — pool growth (hipMalloc), pinned staging, FFT plans and their tables, per-domain
+ * tables, matrix transpositions: "<label> <count> <total ms>\n" per label.  What a process's first proof pays beyond its kernels; after
+ * iopx_aurora_instance_warm / iopx_fractal_index the first proof adds (nearly) nothing to it. */
+int iopx_cold_stats(char *buf, size_t cap, int reset);
+int iopx_cold_add(const char *label, double ms);
 int iopx_profile_begin(void);
 int iopx_profile_report(char *buf, size_t cap);
 

@@ -59,7 +59,7 @@ EXPORTED_SYMBOLS = [
     "iopx_side_stream_begin", "iopx_side_stream_end", "iopx_side_stream_join",
     "iopx_aurora_instance_create", "iopx_aurora_example_instance_create", "iopx_aurora_prove", "iopx_aurora_instance_free", "iopx_host_free",
     "iopx_fractal_index", "iopx_fractal_prove",
-    "iopx_memcpy_d2h_deferrable", "iopx_comm_rccl_unique_id", "iopx_comm_create_rccl", "iopx_comm_create_callbacks", "iopx_comm_create_replay", "iopx_comm_is_replay", "iopx_comm_destroy", "iopx_comm_rank",
+    "iopx_memcpy_d2h_deferrable", "iopx_comm_rccl_unique_id", "iopx_comm_create_rccl", "iopx_comm_create_callbacks", "iopx_comm_create_replay", "iopx_comm_is_replay", "iopx_cold_stats", "iopx_cold_add", "iopx_set_option", "iopx_clear_option", "iopx_get_option", "iopx_comm_destroy", "iopx_comm_rank",
     "iopx_comm_all_gather_dev", "iopx_comm_all_reduce_u64_dev", "iopx_comm_broadcast_dev", "iopx_comm_all_to_all_dev", "iopx_comm_sendrecv_dev", "iopx_comm_stats", "iopx_comm_bind_transforms", "iopx_add_taylor_inv_gf192_dev", "iopx_add_combine_inv_gf192_dev",
     "iopx_interleave_dev", "iopx_gather_rows_dev", "iopx_fri_snark_prove", "iopx_fri_snark_prove_dist", "iopx_add_fft_gf192_dist_dev", "iopx_add_ifft_gf192_dist_dev", "iopx_aurora_prove_dist", "iopx_fractal_index_dist", "iopx_fractal_prove_dist",
 ]
@@ -1128,6 +1128,30 @@ class Library:
         for i, dm in enumerate(dims):
             out.append((ob[off:off + dm].copy(), osh[i].copy()))
             off += dm
+        return out
+
+    def set_option(self, name, value):
+        """A named integer option of the library (schedule switches such as IOPX_HEAD_EVAL, tile geometries): include/libiop_amd.h."""
+        self.c.iopx_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        self._check(self.c.iopx_set_option(name.encode(), int(value)))
+
+    def clear_option(self, name):
+        self.c.iopx_clear_option.argtypes = [ctypes.c_char_p]
+        self._check(self.c.iopx_clear_option(name.encode()))
+
+    def get_option(self, name, default):
+        self.c.iopx_get_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        return int(self.c.iopx_get_option(name.encode(), int(default)))
+
+    def cold_stats(self, reset=False):
+        """{label: (count, total_ms)} of one-time host-side costs (pool growth, plans, tables, transpositions) since the last reset."""
+        buf = ctypes.create_string_buffer(1 << 14)
+        self.c.iopx_cold_stats.argtypes = [ctypes.c_char_p, _sz, ctypes.c_int]
+        self._check(self.c.iopx_cold_stats(buf, len(buf), 1 if reset else 0))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            f = line.split()
+            out[f[0]] = (int(f[1]), float(f[2]))
         return out
 
     def profile_begin(self):

@@ -286,8 +286,7 @@ bool spanned_by_prefix(const field_subset<FieldT> &H, const field_subset<FieldT>
 
 inline bool head_evaluation_enabled()
 {
-    const char *e = std::getenv("IOPX_HEAD_EVAL");      // read per proof: tests prove the same instance both ways
-    return !(e && e[0] == '0');
+    return iopx_get_option("IOPX_HEAD_EVAL", 1) != 0;   // looked up per proof (iopx_set_option): tests and bench.py prove the same instance both ways
 }
 template<typename FieldT>
 bool use_head(const field_subset<FieldT> &D, std::size_t count)
@@ -747,6 +746,8 @@ public:
         const std::string key = std::to_string((int)S.type()) + ":" + std::to_string(S.dimension()) + ":" + std::to_string(V_.dimension()) + ":" + std::to_string(I_.dimension());
         auto it = cs_.lincheck_matrix_cache_.find(key);
         if (it == cs_.lincheck_matrix_cache_.end()) {
+            const auto t_cold = std::chrono::steady_clock::now();
+            struct cold_done { std::chrono::steady_clock::time_point t; ~cold_done() { (void)iopx_cold_add("transposed lincheck matrices", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count()); } } cold_{ t_cold };
             std::vector<std::size_t> col_to_summation(cs_.num_variables() + 1);
             for (std::size_t c = 0; c < col_to_summation.size(); ++c) col_to_summation[c] = S.reindex_by_subset(V_.dimension(), V_.reindex_by_subset(I_.dimension(), c));
             std::vector<sparse_matrix<FieldT>> T;
@@ -817,7 +818,7 @@ public:
             const device_vector<FieldT> fw_V0(V0.num_elements());                            // Z_I is constant on the cosets of I: one product per element
             check(iopx_div_by_vanishing_gf192_dev(fw_prime_V0.words(), dev::basis_words(V0), V0.dimension(), dev::shift_words(V0), I_.dimension(), dev::shift_words(I_),
                                                   fw_V0.words()));
-            if (V0.dimension() == C_.dimension() && std::getenv("IOPX_FW_SEPARATE") == nullptr) {
+            if (V0.dimension() == C_.dimension()) {
                 // one batch of four: at the pair bits where three polynomials leave a wavefront a quarter empty, four fill it
                 const std::vector<device_vector<FieldT>> four = dev::reextend2_packed<FieldT>(Mz, 3, C_, fw_V0, 1, V0, L_);
                 codewords = { four[3], four[0], four[1], four[2] };
@@ -1131,7 +1132,7 @@ auto run_aurora_prover(const r1cs_constraint_system<FieldT> &constraint_system, 
                        const device_vector<FieldT> *d_assignment, Finish finish) -> decltype(finish(std::declval<bcs_prover<FieldT> &>()))
 {
     // IOPX_HOST_TIMING=1: wall-clock marks of the host-side phases on stderr (registration before the first kernel, the rounds, transcript extraction)
-    const bool timing = std::getenv("IOPX_HOST_TIMING") != nullptr;
+    const bool timing = iopx_get_option("IOPX_HOST_TIMING", 0) != 0;
     const auto t0 = std::chrono::steady_clock::now();
     auto mark = [&](const char *what) {
         if (timing) std::fprintf(stderr, "[iopx host] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());

@@ -303,8 +303,8 @@ inline std::string solve_pow(const std::string &challenge, std::size_t pow_bitle
         // iopx_pow_solve_blake2b's batches (2^16 candidates, then 16 x as many each time): the short ones are waited for as before
         uint64_t found = ~(uint64_t)0, first = 0, batch = (uint64_t)1 << 16;
         bool ran = false;
-        const char *knob = std::getenv("IOPX_POW_BEHIND_LOG2");         // batches of at least 2^this candidates take the work behind them (tests: 0)
-        const uint64_t long_batch = (uint64_t)1 << (knob ? std::min(40, std::max(0, std::atoi(knob))) : 22);
+        // batches of at least 2^IOPX_POW_BEHIND_LOG2 candidates take the work behind them (tests: 0)
+        const uint64_t long_batch = (uint64_t)1 << std::min(40, std::max(0, iopx_get_option("IOPX_POW_BEHIND_LOG2", 22)));
         while (found == ~(uint64_t)0) {
             if (behind_the_grind && !ran && batch >= long_batch) {
                 check(iopx_pow_search_blake2b_begin(ch, pow_bitlen, first, batch));

@@ -595,16 +595,9 @@ public:
 private:
     std::vector<char> root_pending_;            // trees whose root has not been read back yet
     std::vector<uint8_t> root_bytes_;           // 32 bytes per tree: the target of the queued read-backs
-    static bool merkle_aside()                  // read per round (a profiling run measures its kernels one at a time with IOPX_MERKLE_STREAM=0)
-    {
-        const char *e = std::getenv("IOPX_MERKLE_STREAM");
-        return !(e && e[0] == '0');
-    }
-    static bool defer_roots()
-    {
-        static const bool on = [] { const char *e = std::getenv("IOPX_DEFER_ROOTS"); return !(e && e[0] == '0'); }();
-        return on;
-    }
+    // schedule options of the library's table (iopx_set_option / the environment, include/libiop_amd.h), looked up per round
+    static bool merkle_aside() { return iopx_get_option("IOPX_MERKLE_STREAM", 1) != 0; }      // 0: every round's tree on the main stream
+    static bool defer_roots() { return iopx_get_option("IOPX_DEFER_ROOTS", 1) != 0; }         // 0: every root read back at its round end
     // queues the read-back of every pending root (inside a defer window: delivered by its end); finish_pending_roots turns the bytes into digests
     void queue_pending_roots()
     {

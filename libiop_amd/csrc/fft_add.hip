@@ -35,14 +35,8 @@ namespace iopx {
 // Tile geometry.  Defaults: 2048-element phase-2 tiles (48 KiB of LDS per workgroup), 1024-element phase-1 and edge tiles.  The IOPX_TILE_BITS /
 // IOPX_P1_COLS / IOPX_P2_COLS / IOPX_P2_TOP environment variables override them (read once): used for
 // tuning, and by the tests to exercise the multi-pass schedules at small transform sizes.
-struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last, scratch_mb, p1_comb, rs_comb_cap_log2, p2_radix4, edge_lean, edge_halves, edge_multi; };
-static int env_int(const char *name, int dflt, int lo, int hi)
-{
-    const char *v = getenv(name);
-    if (!v || !*v) return dflt;
-    const int x = atoi(v);
-    return x < lo ? lo : (x > hi ? hi : x);
-}
+struct Tuning { int tile_bits, p1_tile_bits, edge_tile_bits, p1_cols, p2_cols, p2_top, comb, p2_threads, p1_fin_tile_bits, p1_fin_cols, small_last, scratch_mb, p1_comb, rs_comb_cap_log2, edge_multi; };
+static int env_int(const char *name, int dflt, int lo, int hi) { return opt_range(name, dflt, lo, hi); }      // runtime.h: the options table
 static const Tuning &tuning()
 {
     static const Tuning t = [] {
@@ -69,20 +63,6 @@ static const Tuning &tuning()
         u.scratch_mb = env_int("IOPX_SCRATCH_MB", 256, 1, 65536);
         u.rs_comb_cap_log2 = env_int("IOPX_RS_COMB_CAP_LOG2", 22, 0, 30);  // per-coset combined shift terms up to 2^this entries, byte tables beyond
         u.p1_comb = env_int("IOPX_P1_COMB", 1, 0, 1);                   // 1: comb product for the phase-1 twists with a wave-uniform multiplier
-        // 1: the comb upper passes take two levels per LDS round trip (four elements per lane in registers: half the LDS traffic and half the
-        // barriers).  Measured SLOWER on the MI355X — k_bfly_upper 21.9 -> 25.9 ms per proof at 6 waves per SIMD (the four live elements spill),
-        // 25.0 ms at 5 waves without spills (profiles/r04_ab_radix4*.txt): the LDS round trip and the per-level barrier are not what separates
-        // the kernel from its VALU ceiling.  Kept as an experiment, off by default.
-        u.p2_radix4 = env_int("IOPX_P2_RADIX4", 0, 0, 1);
-        // The general product in its 54-register form (gf_mul_lean), the kernel at six wavefronts per SIMD instead of four.  Bit 0: the batched last
-        // pass (k_bfly_edge_fwd_batch 8.35 -> 7.75 ms per proof: its two comb levels want the sixth wave, 1743 -> 1591 cycles per wave-product);
-        // bit 1: the single-polynomial edge passes, where it LOSES (3.63 -> 3.72 ms: all of their upper levels are general products, which run
-        // at the same rate from four waves up — 3209 cycles, the lean form 3342 — profiles/r05_mul_rates.txt, r05_ab_edge_lean_wl.txt)
-        u.edge_lean = env_int("IOPX_EDGE_LEAN", 1, 0, 3);
-        // 1: the comb product with one multiplier per half-wavefront (gf_mul_halves) where a block's butterflies fill 32 lanes of the batched last pass —
-        // pair bit 3 of four polynomials, pair bit 4 of two: k_bfly_edge_fwd_batch 7.43 -> 7.03 ms per proof (profiles/r05_ab_edge_halves.txt).  The same
-        // at pair bit 5 of the single-polynomial passes was measured too: 3.62 -> 3.58 ms at best, and only with the 54-register product beside it — not kept.
-        u.edge_halves = env_int("IOPX_EDGE_HALVES", 1, 0, 1);
         // > 0: the single-polynomial edge passes take this many cosets of one tile position per workgroup (k_bfly_edge_multi): the tile's twiddles
         // are read once into LDS, the cosets differ in one shift term per level
         u.edge_multi = env_int("IOPX_EDGE_MULTI", 4, 0, 64);
@@ -342,7 +322,6 @@ struct BfParams {
     int d, nhi;
     int c, h, A;            // upper pass tile geometry
     int p_hi, p_lo;         // pair bits handled (forward: p_hi down to p_lo)
-    int radix4;             // comb upper passes: two levels per LDS round trip
     int a_low, c_top;       // last/first pass tile: low a_low bits x top c_top bits
     int g_bits;             // last/first pass: 2^g_bits tiles per workgroup
     size_t total_units;     // cosets (of this launch) * tiles per coset
@@ -513,8 +492,8 @@ __device__ __forceinline__ void bf_apply_small1(uint64_t *s, int E, int ia, int 
     lds_put(s, E, ib, b);
 }
 
-template<bool INV, bool COMB, bool R4>
-__global__ void __launch_bounds__(COMB ? 512 : 1024, COMB ? (R4 ? 5 : 6) : 1) k_bfly_upper(BfParams p)
+template<bool INV, bool COMB>
+__global__ void __launch_bounds__(COMB ? 512 : 1024, COMB ? 6 : 1) k_bfly_upper(BfParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
     uint64_t *s = iopx_smem;
@@ -537,57 +516,7 @@ __global__ void __launch_bounds__(COMB ? 512 : 1024, COMB ? (R4 ? 5 : 6) : 1) k_
     __syncthreads();
 
     const int nlev = p.p_hi - p.p_lo + 1;
-    int t = 0;
-    if (COMB && R4) {
-        // Two levels per LDS round trip: a lane takes the four elements e[y][x] that differ in the two pair bits (A the higher), runs the
-        // two butterflies of each level in registers and writes them back — half the LDS traffic and half the barriers of the one-level
-        // loop.  The level with pair bit A has one twiddle for both of its butterflies (it depends on the bits above A only), the level
-        // with pair bit B = A - 1 one per value of bit A; all wave-uniform (the lanes of a wavefront differ in the column bits only).
-        for (; t + 1 < nlev; t += 2) {
-            const int pbA = INV ? p.p_lo + t + 1 : p.p_hi - t, pbB = pbA - 1;
-            const int plA = pbA - p.h + p.c, plB = plA - 1;
-#pragma unroll 1
-            for (int g = tid; g < (E >> 2); g += nt) {
-                const int i0 = ((g >> plB) << (plA + 1)) | (g & ((1 << plB) - 1));
-                const int i1 = i0 | (1 << plB), i2 = i0 | (1 << plA), i3 = i2 | (1 << plB);
-                const uint32_t i0_u = __builtin_amdgcn_readfirstlane((uint32_t)(i0 & ~63));
-                const size_t u0 = base | ((size_t)(i0_u >> p.c) << p.h) | (size_t)(i0_u & cmask);
-                gf192 e0 = lds_get(s, E, i0), e1 = lds_get(s, E, i1), e2 = lds_get(s, E, i2), e3 = lds_get(s, E, i3);
-                if (!INV) {
-                    {
-                        const gf192 tw = bf_twiddle_uniform(p, coset, u0, pbA);
-                        gf_add_to(e0, gf_mul_uniform(e2, tw)); gf_add_to(e2, e0);
-                        gf_add_to(e1, gf_mul_uniform(e3, tw)); gf_add_to(e3, e1);
-                    }
-                    {
-                        const gf192 tw = bf_twiddle_uniform(p, coset, u0, pbB);
-                        gf_add_to(e0, gf_mul_uniform(e1, tw)); gf_add_to(e1, e0);
-                    }
-                    {
-                        const gf192 tw = bf_twiddle_uniform(p, coset, u0 | ((size_t)1 << pbA), pbB);
-                        gf_add_to(e2, gf_mul_uniform(e3, tw)); gf_add_to(e3, e2);
-                    }
-                } else {
-                    {
-                        const gf192 tw = bf_twiddle_uniform(p, coset, u0, pbB);
-                        gf_add_to(e1, e0); gf_add_to(e0, gf_mul_uniform(e1, tw));
-                    }
-                    {
-                        const gf192 tw = bf_twiddle_uniform(p, coset, u0 | ((size_t)1 << pbA), pbB);
-                        gf_add_to(e3, e2); gf_add_to(e2, gf_mul_uniform(e3, tw));
-                    }
-                    {
-                        const gf192 tw = bf_twiddle_uniform(p, coset, u0, pbA);
-                        gf_add_to(e2, e0); gf_add_to(e0, gf_mul_uniform(e2, tw));
-                        gf_add_to(e3, e1); gf_add_to(e1, gf_mul_uniform(e3, tw));
-                    }
-                }
-                lds_put(s, E, i0, e0); lds_put(s, E, i1, e1); lds_put(s, E, i2, e2); lds_put(s, E, i3, e3);
-            }
-            __syncthreads();
-        }
-    }
-    for (; t < nlev; ++t) {
+    for (int t = 0; t < nlev; ++t) {
         const int pbit = INV ? p.p_lo + t : p.p_hi - t;
         const int pl = pbit - p.h + p.c;
         if (COMB) {
@@ -619,10 +548,8 @@ __global__ void __launch_bounds__(COMB ? 512 : 1024, COMB ? (R4 ? 5 : 6) : 1) k_
 
 // Forward: last pass — pair bits a_low-1 .. 0, then natural-order (bit-reversed) store.
 // Inverse: first pass — natural-order load, pair bits 0 .. a_low-1, block-order store.
-// LEAN (round 5): the general product in its 53-register form and a register budget of 80, so that six wavefronts per SIMD are resident
-// instead of four (launched with at most 256 threads).
-template<bool INV, bool COMB, bool LEAN>
-__global__ void __launch_bounds__(LEAN ? 256 : (COMB ? 512 : 1024), LEAN ? 6 : 1) k_bfly_edge(BfParams p)
+template<bool INV, bool COMB>
+__global__ void __launch_bounds__(COMB ? 512 : 1024, 1) k_bfly_edge(BfParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
     uint64_t *s = iopx_smem;
@@ -696,7 +623,7 @@ __global__ void __launch_bounds__(LEAN ? 256 : (COMB ? 512 : 1024), LEAN ? 6 : 1
             const size_t coset = unit >> midbits, mid = unit & (((size_t)1 << midbits) - 1);
             const int li = ia & ((1 << tb) - 1), top = li >> p.a_low, lo = li & lomask;
             const size_t u = ((size_t)top << (p.d - p.c_top)) | (mid << p.a_low) | (size_t)lo;
-            bf_apply<INV, COMB, LEAN>(s, E, ia, ib, bf_twiddle(p, coset, u, pbit), pbit >= 6);
+            bf_apply<INV, COMB>(s, E, ia, ib, bf_twiddle(p, coset, u, pbit), pbit >= 6);
         }
         __syncthreads();
     }
@@ -861,11 +788,9 @@ struct BfBatchParams {
     const uint64_t *srcs[4];
     uint64_t *dsts[4];
     int batch;
-    int halves;             // 1: levels whose blocks fill half a wavefront take the comb product with one multiplier per half (gf_mul_halves)
 };
 
-template<bool LEAN>
-__global__ void __launch_bounds__(512, LEAN ? 6 : 1) k_bfly_edge_fwd_batch(BfBatchParams q)
+__global__ void __launch_bounds__(512, 6) k_bfly_edge_fwd_batch(BfBatchParams q)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
     const BfParams &p = q.p;
@@ -905,7 +830,7 @@ __global__ void __launch_bounds__(512, LEAN ? 6 : 1) k_bfly_edge_fwd_batch(BfBat
                     bf_apply<false, true>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | G, tw, true);
                 }
             }
-        } else if (LEAN && q.halves && q.batch * G == 32 && ((half >> pbit) & 1) == 0) {
+        } else if (q.batch * G == 32 && ((half >> pbit) & 1) == 0) {
             // two blocks per wavefront, 32 lanes each (polynomial x butterfly of the block): the comb product with one multiplier per HALF of the
             // wavefront — the table of multiples built once, the window loop once per half (2775 modelled cycles against the general product's 3209)
             const int groups = half >> pbit;
@@ -938,7 +863,7 @@ __global__ void __launch_bounds__(512, LEAN ? 6 : 1) k_bfly_edge_fwd_batch(BfBat
                 const int b = x >> (tb - 1), bf = x & (half - 1);
                 const int low = bf & (G - 1), high = bf >> pbit;
                 const int ia = (high << (pbit + 1)) | low;
-                bf_apply<false, false, LEAN>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | G, bf_twiddle(p, coset, index_of(ia), pbit), false);
+                bf_apply<false, false, true>(iopx_smem + 3 * (size_t)E * b, E, ia, ia | G, bf_twiddle(p, coset, index_of(ia), pbit), false);
             }
         }
         __syncthreads();
@@ -1036,6 +961,7 @@ static int build_pow_table(uint64_t *out, const uint64_t *d_sq, int nb)
 
 static int build_pow_tables(AddPlan &pl, bool inverse)
 {
+    ColdScope cold_("additive FFT twist-power tables");
     const int d = pl.d;
     DevBuf &buf = inverse ? pl.pow_inv : pl.pow_fwd;
     int rc = buf.alloc(((((size_t)2) << d) - 2) * 24);
@@ -1073,6 +999,7 @@ static int get_plan(const uint64_t *basis, int d, AddPlan **out)
     auto it = g_plans.find(key);
     if (it != g_plans.end()) { *out = it->second.get(); return IOPX_OK; }
 
+    ColdScope cold_("additive FFT plan");
     std::unique_ptr<AddPlan> pl(new AddPlan());
     pl->d = d;
     for (int i = 0; i < d; ++i) pl->basis.push_back(hgf192::from_words(basis + 3 * i));
@@ -1247,7 +1174,7 @@ static int launch_phase1_pass(const P1Pass &ps, uint64_t *S, const uint64_t *pow
     if (rc != IOPX_OK) return rc;
     static char names[64][2][40];
     char *nm = names[ps.j0 & 63][ps.k_start == d_eff - 2 ? 1 : 0];
-    if (!nm[0]) snprintf(nm, 40, getenv("IOPX_PROFILE_LEVELS") ? "k_phase1_%s_L%02d_%s" : "k_phase1_%s", INV ? "inv" : "fwd", ps.j0, ps.k_start == d_eff - 2 ? "tw" : "x");
+    if (!nm[0]) snprintf(nm, 40, opt("IOPX_PROFILE_LEVELS", 0) ? "k_phase1_%s_L%02d_%s" : "k_phase1_%s", INV ? "inv" : "fwd", ps.j0, ps.k_start == d_eff - 2 ? "tw" : "x");
     { ProfScope ps_(nm, (batch << d_eff) * 48); hipLaunchKernelGGL(k_phase1<INV>, dim3((unsigned)blocks, (unsigned)batch), dim3(threads), lds, stream(), p); }
     return IOPX_OK;
 }
@@ -1450,20 +1377,14 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
             { ProfScope ps_(INV ? "k_bfly_edge_inv" : "k_bfly_edge_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)p.a_low); hipLaunchKernelGGL((k_bfly_edge_multi<INV>), dim3((unsigned)blocks_m), dim3(threads), lds_m, stream(), p); }
             return IOPX_OK;
         }
-        if ((tuning().edge_lean & 2) && threads <= 256) {
-            if ((rc = set_lds(k_bfly_edge<INV, false, true>, lds)) != IOPX_OK) return rc;
-            { ProfScope ps_(INV ? "k_bfly_edge_inv" : "k_bfly_edge_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)p.a_low); hipLaunchKernelGGL((k_bfly_edge<INV, false, true>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
-            return IOPX_OK;
-        }
-        if ((rc = set_lds(k_bfly_edge<INV, false, false>, lds)) != IOPX_OK) return rc;
-        { ProfScope ps_(INV ? "k_bfly_edge_inv" : "k_bfly_edge_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)p.a_low); hipLaunchKernelGGL((k_bfly_edge<INV, false, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        if ((rc = set_lds(k_bfly_edge<INV, false>, lds)) != IOPX_OK) return rc;
+        { ProfScope ps_(INV ? "k_bfly_edge_inv" : "k_bfly_edge_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)p.a_low); hipLaunchKernelGGL((k_bfly_edge<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         return IOPX_OK;
     };
     auto launch_upper = [&](const Up &u, const uint64_t *s, uint64_t *dd, int shared, size_t ncos, size_t cbase) -> int {
         p.src = s; p.dst = dd; p.src_shared = shared;
         p.c = u.c; p.h = u.h; p.A = u.A;
         p.p_hi = u.h + u.A - 1; p.p_lo = u.h;
-        p.radix4 = tuning().p2_radix4;
         const int tbits = u.c + u.A;
         const size_t lds = ((size_t)24) << tbits;
         const size_t blocks = ncos << (d - tbits);
@@ -1471,18 +1392,13 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         p.rs_comb = comb_count ? rs_comb_ptr + 3 * (cbase - comb_base) * d : nullptr;
         const int maxt = (tuning().comb && u.c < 6) ? 1024 : tuning().p2_threads;
         int threads = (1 << tbits) >= 2 * maxt ? maxt : ((1 << tbits) >= 128 ? (1 << tbits) / 2 : 64);
-        // two levels per trip: a tile has 2^tbits / 4 four-element groups; threads beyond that would idle through the paired levels
-        if (tuning().comb && u.c >= 6 && p.radix4 && u.A >= 2 && threads > (1 << tbits) / 4) threads = (1 << tbits) / 4 >= 64 ? (1 << tbits) / 4 : 64;
         int rc;
-        if (tuning().comb && u.c >= 6 && p.radix4 && u.A >= 2) {
-            if ((rc = set_lds(k_bfly_upper<INV, true, true>, lds)) != IOPX_OK) return rc;
-            { ProfScope ps_(INV ? "k_bfly_upper_inv" : "k_bfly_upper_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, true, true>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
-        } else if (tuning().comb && u.c >= 6) {
-            if ((rc = set_lds(k_bfly_upper<INV, true, false>, lds)) != IOPX_OK) return rc;
-            { ProfScope ps_(INV ? "k_bfly_upper_inv" : "k_bfly_upper_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, true, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        if (tuning().comb && u.c >= 6) {
+            if ((rc = set_lds(k_bfly_upper<INV, true>, lds)) != IOPX_OK) return rc;
+            { ProfScope ps_(INV ? "k_bfly_upper_inv" : "k_bfly_upper_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, true>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         } else {
-            if ((rc = set_lds(k_bfly_upper<INV, false, false>, lds)) != IOPX_OK) return rc;
-            { ProfScope ps_(INV ? "k_bfly_upper_inv" : "k_bfly_upper_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, false, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+            if ((rc = set_lds(k_bfly_upper<INV, false>, lds)) != IOPX_OK) return rc;
+            { ProfScope ps_(INV ? "k_bfly_upper_inv" : "k_bfly_upper_fwd", (ncos << d) * 48, ((ncos << d) >> 1) * (size_t)u.A); hipLaunchKernelGGL((k_bfly_upper<INV, false>), dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
         }
         return IOPX_OK;
     };
@@ -1596,18 +1512,11 @@ static int run_phase2_fwd_batch(AddPlan &pl, const uint64_t *const *srcs, uint64
         int rc;
         p.rs_comb = rs_comb.u64() + 3 * c0 * d;
         q.batch = (int)batch;
-        q.halves = tuning().edge_halves;
         for (size_t k = 0; k < batch; ++k) { q.srcs[k] = scratch[k]->u64(); q.dsts[k] = dsts[k] + 3 * c0 * nd; }
         const size_t lds = (((size_t)24) << tb) * batch;
-        if (tuning().edge_lean & 1) {
-            if ((rc = set_lds(k_bfly_edge_fwd_batch<true>, lds)) != IOPX_OK) return rc;
-            ProfScope ps_("k_bfly_edge_fwd_batch", batch * (nc << d) * 48, batch * ((nc << d) >> 1) * (size_t)p.a_low);
-            hipLaunchKernelGGL(k_bfly_edge_fwd_batch<true>, dim3((unsigned)p.total_units), dim3(512), lds, stream(), q);
-        } else {
-            if ((rc = set_lds(k_bfly_edge_fwd_batch<false>, lds)) != IOPX_OK) return rc;
-            ProfScope ps_("k_bfly_edge_fwd_batch", batch * (nc << d) * 48, batch * ((nc << d) >> 1) * (size_t)p.a_low);
-            hipLaunchKernelGGL(k_bfly_edge_fwd_batch<false>, dim3((unsigned)p.total_units), dim3(512), lds, stream(), q);
-        }
+        if ((rc = set_lds(k_bfly_edge_fwd_batch, lds)) != IOPX_OK) return rc;
+        ProfScope ps_("k_bfly_edge_fwd_batch", batch * (nc << d) * 48, batch * ((nc << d) >> 1) * (size_t)p.a_low);
+        hipLaunchKernelGGL(k_bfly_edge_fwd_batch, dim3((unsigned)p.total_units), dim3(512), lds, stream(), q);
     }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;

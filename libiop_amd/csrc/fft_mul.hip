@@ -30,13 +30,14 @@ namespace iopx {
 // tile geometry of k_mfft_pass (overridable for tuning runs: IOPX_MF_TILE_BITS, IOPX_MF_COLS)
 static int mf_env(const char *name, int dflt, int lo, int hi)
 {
-    const char *v = getenv(name);
-    if (!v) return dflt;
-    const int x = atoi(v);
+    const int x = opt(name, dflt);                 // runtime.h: the options table
     return x < lo || x > hi ? dflt : x;
 }
-static const int MF_TILE_BITS = mf_env("IOPX_MF_TILE_BITS", 11, 6, 12);
-static const int MF_COLS = mf_env("IOPX_MF_COLS", 4, 0, 6);
+// latched at first use (function-local: the option table of another translation unit must exist by then)
+static int mf_tile_bits() { static const int v = mf_env("IOPX_MF_TILE_BITS", 11, 6, 12); return v; }
+static int mf_cols() { static const int v = mf_env("IOPX_MF_COLS", 4, 0, 6); return v; }
+#define MF_TILE_BITS (mf_tile_bits())
+#define MF_COLS (mf_cols())
 
 __device__ __forceinline__ fp3 mlds_get(const uint64_t *s, int E, int li)
 {
@@ -302,6 +303,7 @@ static int fp_build_pow(uint64_t *out, const hfp3 &base, const hfp3 &init, int n
 
 static int build_cache(MulPlan &pl, bool inverse)
 {
+    ColdScope cold_("multiplicative FFT twiddle cache");
     const int logn = pl.logn;
     DevBuf &buf = inverse ? pl.cache_inv : pl.cache_fwd;
     const size_t n = (size_t)1 << logn;
@@ -349,7 +351,7 @@ static std::map<TableKey, std::shared_ptr<DevBuf>> g_pow_tables;        // devic
 static std::mutex g_pow_tables_mu;
 static size_t pow_table_cap()
 {
-    static const size_t cap = [] { const char *v = getenv("IOPX_POW_TABLE_CAP"); const long x = v ? atol(v) : 0; return (size_t)(x >= 1 ? x : 256); }();   // the env override exists for the eviction test
+    static const size_t cap = (size_t)opt_range("IOPX_POW_TABLE_CAP", 256, 1, 1 << 20);   // the env override exists for the eviction test
     return cap;
 }
 
@@ -630,7 +632,7 @@ int iopx_fri_fold_mul_fp3_dev(const uint64_t *d_f_i, size_t log_n, const uint64_
     if ((rc = dc.alloc(hc.size() * 8)) != IOPX_OK) return rc;
     { int urc_ = upload(dc.p, hc.data(), hc.size() * 8); if (urc_ != IOPX_OK) return urc_; }
     const uint64_t *ginv_top = pl->cache_inv.u64() + 3 * ((n >> 1) - 1);
-    if (eta <= 3 && getenv("IOPX_FOLD_UNFUSED") == nullptr) {
+    if (eta <= 3) {
         MfoldParams p;
         p.src = d_f_i; p.dst = d_next; p.ginv = ginv_top; p.consts = dc.u64(); p.half = n >> eta; p.stride_log = 0;
         const size_t bytes = (n + p.half) * 24;

@@ -155,7 +155,7 @@ int iopx_fri_fold_add_gf192_dev(const uint64_t *d_f_i, const uint64_t *basis, si
     if ((rc = dc.alloc(hc.size() * 8)) != IOPX_OK) return rc;
     { int urc_ = upload(dc.p, hc.data(), hc.size() * 8); if (urc_ != IOPX_OK) return urc_; }
 
-    if (eta <= FOLD_MAX_ETA && getenv("IOPX_FOLD_UNFUSED") == nullptr) {
+    if (eta <= FOLD_MAX_ETA) {
         FusedFoldParams fp;
         memset(&fp, 0, sizeof(fp));
         fp.src = d_f_i; fp.dst = d_next; fp.eta = eta; fp.n_out = n >> eta;

@@ -315,8 +315,7 @@ int iopx_ldt_combine_gf192_dev(const void *const *d_oracles, size_t num_oracles,
             // the slot of exponent 1, when every point of the domain is a one-word polynomial (basis vectors and shift below 2^32) and the
             // slot is a plain one (no parent, nobody's parent)
             auto one_word = [](const uint64_t *w) { return w[1] == 0 && w[2] == 0 && (w[0] >> 32) == 0; };
-            const char *knob = getenv("IOPX_LDT_SMALL_GAP1");              // 0 switches the grouping off (A/B runs, tests of the general path)
-            bool small = (!knob || atoi(knob) != 0) && m <= 32 && one_word(shift);
+            bool small = m <= 32 && one_word(shift);
             for (size_t k = 0; small && k < m; ++k) small = one_word(basis + 3 * k);
             if (small) {
                 for (size_t sidx = 0; sidx < slot_bits.size(); ++sidx)

@@ -149,6 +149,23 @@ struct hfp3;
 int build_two_level(const hfp3 &base, const hfp3 &init, int logc, TmpBuf &hi, TmpBuf &lo, bool cache_hi = true);
 
 // Per-module plan caches dropped by iopx_clear_plans() (the caller has synchronised the device).
+// Options: named integers that select a schedule or a tile geometry.  One table for the whole library: a name's value is whatever
+// iopx_set_option gave it, otherwise the environment variable of that name read ONCE (at the name's first lookup: the library's only getenv),
+// otherwise the caller's default.  Tile geometries are latched by their component at its first use; schedule options are looked up per proof
+// (a table lookup), so a test or a bench can switch them between two proofs with iopx_set_option.
+int opt(const char *name, int dflt);
+int opt_range(const char *name, int dflt, int lo, int hi);      // clamped
+
+// One-time ("cold") host-side costs — device allocations, plan and table builds, matrix transpositions — accumulated per label as wall time
+// (iopx_cold_stats): what a process's first proof pays beyond its kernels, and what iopx_aurora_instance_warm moves out of it.
+struct ColdScope {
+    const char *label;
+    long long t0_ns;
+    explicit ColdScope(const char *label);
+    ~ColdScope();
+};
+void cold_add(const char *label, double ms);
+
 // the side stream (runtime.hip): the provers' Merkle trees (C ABI iopx_side_stream_*)
 int side_stream_fork(int k);
 int side_stream_select(int k);      // -1: back to the main stream

@@ -2,6 +2,8 @@
 #include "runtime.h"
 #include <algorithm>
 #include <atomic>
+#include <ctime>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -145,6 +147,7 @@ void *tmp_alloc(size_t bytes, size_t *cap)
     }
     void *p = nullptr;
     const size_t c = (bytes + 255) & ~(size_t)255;
+    ColdScope cold_("hipMalloc (pool growth)");
     if (hipMalloc(&p, c) != hipSuccess) {
         // out of memory: drop the cache (after draining the streams: quarantined blocks become droppable too) and retry once
         (void)hipGetLastError();
@@ -257,8 +260,7 @@ __global__ void k_upload_small(UploadBlob blob, uint32_t *dst, int words, int ta
 int upload(void *dst_dev, const void *src_host, size_t bytes)
 {
     if (bytes == 0) return IOPX_OK;
-    static const bool by_kernel = [] { const char *v = getenv("IOPX_UPLOAD_KERNEL"); return !v || atoi(v) != 0; }();
-    if (by_kernel && bytes <= sizeof(UploadBlob) && ((uintptr_t)dst_dev & 3) == 0) {
+    if (bytes <= sizeof(UploadBlob) && ((uintptr_t)dst_dev & 3) == 0) {
         UploadBlob blob;
         memcpy(blob.w, src_host, bytes);
         g_bytes_h2d += bytes;
@@ -276,6 +278,7 @@ int upload(void *dst_dev, const void *src_host, size_t bytes)
         StageChunk ch;
         ch.cap = bytes < 4096 ? 4096 : bytes;
         ch.busy = false;
+        ColdScope cold_("hipHostMalloc");
         hipError_t e = hipHostMalloc(&ch.p, ch.cap, 0);
         if (e != hipSuccess) return fail(IOPX_ERR_RUNTIME, "hipHostMalloc(%zu) failed: %s", ch.cap, hipGetErrorString(e));
         e = hipEventCreateWithFlags(&ch.done, hipEventDisableTiming);
@@ -311,6 +314,7 @@ int download(void *dst_host, const void *src_dev, size_t bytes, bool deferrable)
             DeferChunk ch;
             ch.cap = need < ((size_t)1 << 20) ? ((size_t)1 << 20) : need;
             ch.used = 0;
+            ColdScope cold_("hipHostMalloc");
             hipError_t e = hipHostMalloc((void **)&ch.p, ch.cap, 0);
             if (e != hipSuccess) return fail(IOPX_ERR_RUNTIME, "hipHostMalloc(%zu) failed: %s", ch.cap, hipGetErrorString(e));
             g_defer_chunks.push_back(ch);
@@ -332,6 +336,7 @@ int download(void *dst_host, const void *src_dev, size_t bytes, bool deferrable)
         if (g_bounce) (void)hipHostFree(g_bounce);
         g_bounce = nullptr; g_bounce_cap = 0;
         const size_t cap = bytes < 65536 ? 65536 : bytes;
+        ColdScope cold_("hipHostMalloc");
         hipError_t e = hipHostMalloc(&g_bounce, cap, 0);
         if (e != hipSuccess) return fail(IOPX_ERR_RUNTIME, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
         g_bounce_cap = cap;
@@ -374,6 +379,7 @@ int cached_domain_table(const std::vector<uint64_t> &key, const std::function<in
     std::lock_guard<std::mutex> lk(g_dtab_mu);
     auto it = g_dtabs.find(key);
     if (it == g_dtabs.end()) {
+        ColdScope cold_("domain table");
         std::vector<uint64_t> words;
         int rc = build(words);
         if (rc != IOPX_OK) return rc;
@@ -392,6 +398,39 @@ void clear_domain_tables()
     std::lock_guard<std::mutex> lk(g_dtab_mu);
     g_dtabs.clear();
 }
+
+// ---- options ----------------------------------------------------------------------------------------
+static std::mutex g_opt_mu;
+static std::map<std::string, std::pair<bool, int>> g_opts;           // name -> (has a value, value); an entry without a value: the environment was asked and had none
+int opt(const char *name, int dflt)
+{
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    auto it = g_opts.find(name);
+    if (it == g_opts.end()) {
+        const char *v = getenv(name);                                  // the library's only read of the environment
+        it = g_opts.emplace(name, (v && *v) ? std::make_pair(true, atoi(v)) : std::make_pair(false, 0)).first;
+    }
+    return it->second.first ? it->second.second : dflt;
+}
+int opt_range(const char *name, int dflt, int lo, int hi)
+{
+    const int x = opt(name, dflt);
+    return x < lo ? lo : (x > hi ? hi : x);
+}
+
+// ---- one-time costs, by label ---------------------------------------------------------------------
+static std::mutex g_cold_mu;
+static std::map<std::string, std::pair<size_t, double>> g_cold;       // label -> (count, ms)
+static long long now_ns() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec; }
+void cold_add(const char *label, double ms)
+{
+    std::lock_guard<std::mutex> lk(g_cold_mu);
+    auto &e = g_cold[label];
+    e.first += 1;
+    e.second += ms;
+}
+ColdScope::ColdScope(const char *l) : label(l), t0_ns(now_ns()) {}
+ColdScope::~ColdScope() { cold_add(label, (double)(now_ns() - t0_ns) * 1e-6); }
 
 // ---- per-kernel profiling -----------------------------------------------------------------------
 struct ProfRec { const char *name; hipEvent_t a, b; size_t bytes, products; };
@@ -485,6 +524,44 @@ int iopx_profile_report(char *buf, size_t cap)
     }
     return IOPX_OK;
 }
+
+// "<label with spaces replaced by _> <count> <total ms>\n" per label of one-time host-side cost since the last reset
+int iopx_cold_stats(char *buf, size_t cap, int reset)
+{
+    std::lock_guard<std::mutex> lk(iopx::g_cold_mu);
+    std::string out;
+    for (auto &kv : iopx::g_cold) {
+        std::string l = kv.first;
+        for (char &ch : l) if (ch == ' ') ch = '_';
+        char line[256];
+        snprintf(line, sizeof(line), "%s %zu %.4f\n", l.c_str(), kv.second.first, kv.second.second);
+        out += line;
+    }
+    if (buf && cap) {
+        const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    if (reset) iopx::g_cold.clear();
+    return IOPX_OK;
+}
+int iopx_cold_add(const char *label, double ms) { if (label) iopx::cold_add(label, ms); return IOPX_OK; }
+
+int iopx_set_option(const char *name, int value)
+{
+    if (!name || !*name) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "iopx_set_option: empty name");
+    std::lock_guard<std::mutex> lk(iopx::g_opt_mu);
+    iopx::g_opts[name] = std::make_pair(true, value);
+    return IOPX_OK;
+}
+int iopx_clear_option(const char *name)          // back to the environment's value (asked again at the next lookup) or the default
+{
+    if (!name) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "iopx_clear_option: null name");
+    std::lock_guard<std::mutex> lk(iopx::g_opt_mu);
+    iopx::g_opts.erase(name);
+    return IOPX_OK;
+}
+int iopx_get_option(const char *name, int dflt) { return name ? iopx::opt(name, dflt) : dflt; }
 
 int iopx_version(void) { return 100; }
 

@@ -7,9 +7,6 @@ against the oracle in a CHILD process with the environment that takes the branch
   IOPX_EDGE_BATCH=0         every polynomial of a batch takes its own last pass
   IOPX_SMALL_LAST=0         general product at the last two levels (no one- / two-word numerators)
   IOPX_COMB=0               general product everywhere (fft.tcc:39-124 has one multiplier; every branch must agree with it)
-  IOPX_P2_RADIX4=1          two butterfly levels per LDS round trip in the upper passes (an experiment that measured slower; kept correct)
-  IOPX_EDGE_HALVES=0        the batched last pass's 32-lane blocks on the general product (default: the comb product with one multiplier per half-wavefront)
-  IOPX_EDGE_LEAN=0 / 3      the edge passes' general product in its 114- / 54-register form in both edge kernels (default 1: the batched one only)
   IOPX_EDGE_MULTI=0 / 3     the single-polynomial edge passes one coset at a time (k_bfly_edge), or three cosets of a tile position per workgroup
                             (k_bfly_edge_multi, default four), also with the byte tables of shift terms
   IOPX_DEFER_ROOTS=0        (provers) every Merkle root read back at its round end instead of with the query phase's read-backs
@@ -133,9 +130,10 @@ def _run(script, extra_env, timeout=1500):
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (extra_env, out.stdout[-2000:], out.stderr[-4000:])
 
 
-@pytest.mark.parametrize("env", [{"IOPX_RS_COMB_CAP_LOG2": "3"}, {"IOPX_P1_COMB": "0"}, {"IOPX_EDGE_BATCH": "0"}, {"IOPX_SMALL_LAST": "0"},
-                                 {"IOPX_COMB": "0"}, {"IOPX_RS_COMB_CAP_LOG2": "3", "IOPX_SMALL_LAST": "0"}, {"IOPX_P2_RADIX4": "1"}, {"IOPX_EDGE_LEAN": "0"},
-                                 {"IOPX_EDGE_LEAN": "3"}, {"IOPX_EDGE_HALVES": "0"}, {"IOPX_EDGE_MULTI": "0"}, {"IOPX_EDGE_MULTI": "3"},
+# one child process per COMBINATION (a child costs ten seconds of the driver's suite): every option appears with its non-default value at least once,
+# and the options that act on the same kernel appear separately
+@pytest.mark.parametrize("env", [{"IOPX_RS_COMB_CAP_LOG2": "3"}, {"IOPX_P1_COMB": "0", "IOPX_EDGE_BATCH": "0", "IOPX_EDGE_MULTI": "0"},
+                                 {"IOPX_COMB": "0"}, {"IOPX_RS_COMB_CAP_LOG2": "3", "IOPX_SMALL_LAST": "0"},
                                  {"IOPX_EDGE_MULTI": "3", "IOPX_RS_COMB_CAP_LOG2": "3"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_env_gated_branches_equal_the_oracle(env):

@@ -15,8 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
     (7, 2, 4, 4, "7,8,12,14"),
     (8, 0, 0, 0, "9,12"),
 ])
-@pytest.mark.parametrize("radix4", [0, 1])
-def test_schedules(tile, p1c, p2c, p2t, ms, radix4):
-    env = dict(os.environ, IOPX_TILE_BITS=str(tile), IOPX_P1_COLS=str(p1c), IOPX_P2_COLS=str(p2c), IOPX_P2_TOP=str(p2t), IOPX_P2_RADIX4=str(radix4))
+def test_schedules(tile, p1c, p2c, p2t, ms):
+    env = dict(os.environ, IOPX_TILE_BITS=str(tile), IOPX_P1_COLS=str(p1c), IOPX_P2_COLS=str(p2c), IOPX_P2_TOP=str(p2t))
     r = subprocess.run([sys.executable, os.path.join(HERE, "emu_schedule_check.py"), ms], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

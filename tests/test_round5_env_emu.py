@@ -1,8 +1,7 @@
-"""Round-5 switches on the CPU-compiled kernels, each in a child process (the values are read once per process):
+"""Options of the library on the CPU-compiled kernels, each in a child process that finds them in its environment (the library asks the environment once
+per name):
   IOPX_DEFER_ROOTS=0   every Merkle root read back at its round end (round 4's schedule) instead of with the query phase's read-backs
   IOPX_MERKLE_STREAM=0 no side stream: every round's Merkle tree on the main stream
-  IOPX_EDGE_HALVES=0   the batched last pass's 32-lane blocks on the general product instead of the comb product with one multiplier per half-wavefront
-  IOPX_EDGE_LEAN=0/2/3 the edge passes' general product in its 114- or 54-register form (batched last pass / single-polynomial passes)
   IOPX_EDGE_MULTI=0/1/3 the single-polynomial edge passes one coset at a time (k_bfly_edge), or 1 / 3 cosets of a tile position per workgroup
                        (k_bfly_edge_multi; default 4); with IOPX_RS_COMB_CAP_LOG2=0 the shift terms come from the byte tables
 The provers must give the oracle's bytes and the transforms the oracle's values on every branch."""
@@ -96,15 +95,6 @@ def test_roots_read_at_every_round_end():
 
 def test_trees_on_the_main_stream():
     _run(PROVERS, {"IOPX_MERKLE_STREAM": "0"})
-
-
-@pytest.mark.parametrize("lean", ["0", "3"])
-def test_edge_pass_product_forms(lean):
-    _run(TRANSFORMS, {"IOPX_EDGE_LEAN": lean})
-
-
-def test_batched_last_pass_without_the_half_wavefront_product():
-    _run(TRANSFORMS, {"IOPX_EDGE_HALVES": "0"})
 
 
 @pytest.mark.parametrize("env", [{"IOPX_EDGE_MULTI": "0"}, {"IOPX_EDGE_MULTI": "1"}, {"IOPX_EDGE_MULTI": "3"}, {},
