@@ -222,6 +222,7 @@ def main():
     ap.add_argument("--replay-rank", type=int, default=None,
                     help="with --world N on ONE GPU: time rank R of the N-rank prover alone (collectives completed locally; compute path only) and print that line")
     ap.add_argument("--world", type=int, default=8, help="the world size --replay-rank plays a rank of")
+    ap.add_argument("--no-warm", action="store_true", help="do not call iopx_aurora_instance_warm: config.first_proof_ms is then the cold first proof")
     ap.add_argument("--no-rank-replay", action="store_true", help="skip config.rank_replay (ranks 0 and N-1 of 2, 4, 8 played alone on this GPU)")
     ap.add_argument("--cpu-all-cores", action="store_true", help="also time one independent oracle proof per host core at once (not in the reference, which is single-threaded)")
     args = ap.parse_args()
@@ -278,7 +279,21 @@ def main():
     # Every N: the native prover behind the C ABI (libiop_amd/cpp/aurora.hpp inside the library; iopx_aurora_prove on one GPU,
     # iopx_aurora_prove_dist over the communicator otherwise — the same code, libiop_amd/cpp/dist.hpp) on its own copy of the same seeded
     # instance; the Python prover (libiop_amd/aurora.py) proves it once below as a cross-check of the transcript bytes
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     native = lib.aurora_example_instance(0, n, 15, n - 1, SEED)
+    torch.cuda.synchronize()
+    instance_create_s = time.perf_counter() - t0
+    # one-time work ahead of the first proof (iopx_aurora_instance_warm: pool, plans, tables, transposed matrices), timed on its own; --no-warm leaves it
+    # inside the first proof, as a caller that never calls it would see
+    lib.cold_stats(reset=True)
+    warm_s = None
+    if not args.no_warm and comm is None and args.replay_rank is None:
+        t0 = time.perf_counter()
+        lib.aurora_instance_warm(native)
+        torch.cuda.synchronize()
+        warm_s = time.perf_counter() - t0
+    one_time_costs = {k: {"count": v[0], "ms": round(v[1], 3)} for k, v in lib.cold_stats(reset=True).items()}
 
     if args.replay_rank is not None:
         # one rank of --world played alone: its line only (no headline value: the proof's bytes are meaningless)
@@ -311,6 +326,7 @@ def main():
     first = step()
     torch.cuda.synchronize()
     first_proof_s = time.perf_counter() - t0
+    first_proof_costs = {k: {"count": v[0], "ms": round(v[1], 3)} for k, v in lib.cold_stats(reset=True).items()}     # what the first proof still had to build
     for _ in range(args.warmup):
         transcript = step()
     if transcript is None:
@@ -444,7 +460,13 @@ def main():
                         "security 128, RS_extra_dimensions 5, FRI localization 2, non-zk, BLAKE2b: one complete proof per step, "
                         "instance and witness resident in HBM" % (args.log_n, SEED),
             "log_n": args.log_n, "field": "gf192", "prover_s": prover_s,
-            "first_proof_ms": first_proof_s * 1e3,          # cold: this process's first proof of the instance (plans, tables, caches built), before the warm-up
+            # this process's first timed proof of the instance: after iopx_aurora_instance_warm (instance_setup_ms) unless --no-warm, when it is the cold proof
+            "first_proof_ms": first_proof_s * 1e3,
+            "instance_setup_ms": (instance_create_s + (warm_s or 0.0)) * 1e3,
+            "instance_setup": {"create_ms": instance_create_s * 1e3, "warm_ms": warm_s * 1e3 if warm_s is not None else None,
+                               "what": "create: the seeded statement and witness built on the host and moved to HBM; warm: iopx_aurora_instance_warm — the device pool grown to "
+                                       "a proof's footprint, plans / twiddle tables / per-domain tables / transposed lincheck matrices built (one discarded proof)",
+                               "one_time_costs_ms": one_time_costs, "first_proof_one_time_costs_ms": first_proof_costs},
             "stages_ms": device_stages(prof),                # kernel time of one proof under the reference's profiling block names
             "prover": ("native: iopx_aurora_prove (libiop_amd/cpp/aurora.hpp behind the C ABI); transcript equal to libiop_amd/aurora.py's" if comm is None else
                        "native: iopx_aurora_prove_dist (libiop_amd/cpp/aurora.hpp + dist.hpp behind the C ABI, RCCL communicator of %d rank(s)); transcript equal to "
@@ -564,6 +586,12 @@ def main():
         lib.fractal_index(inst5)
         torch.cuda.synchronize()
         native_indexer_s = time.perf_counter() - t0
+        warm5_s = None
+        if not args.no_warm:
+            t0 = time.perf_counter()
+            lib.aurora_instance_warm(inst5, fractal=True)
+            torch.cuda.synchronize()
+            warm5_s = time.perf_counter() - t0
         times5 = []
         gc.collect()
         for it in range(8):
@@ -580,6 +608,7 @@ def main():
         out["config"]["secondary_fractal"] = {
             "workload": "configs[4] on 1 GPU: Fractal prover, 2^%d-constraint R1CS over the 181-bit field, k=0, codeword 2^%d" % (args.log_n, params5.codeword_domain_dim),
             "prover_ms": sorted(times5[1:])[len(times5[1:]) // 2] * 1e3, "prover_ms_min": min(times5[1:]) * 1e3, "prover_ms_all": [round(t * 1e3, 2) for t in times5], "indexer_ms_first_call": indexer_s * 1e3, "native_indexer_ms": native_indexer_s * 1e3,
+            "warm_ms": warm5_s * 1e3 if warm5_s is not None else None, "first_proof_ms": times5[0] * 1e3,
             "prover": "native: iopx_fractal_prove (libiop_amd/cpp/fractal.hpp behind the C ABI); transcript equal to libiop_amd/fractal.py's",
             "argument_bytes": len(tr5), "fri_query_repetitions": params5.fri_query_repetitions,
             "kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof5.items(), key=lambda kv: -kv[1][1])[:10]}}

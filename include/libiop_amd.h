@@ -522,6 +522,11 @@ int iopx_aurora_instance_create(const iopx_r1cs *r1cs, const uint64_t *assignmen
 /* generate_r1cs_example (libiop/relations/examples/r1cs_examples.tcc:23-78) seeded with SplitMix64 */
 int iopx_aurora_example_instance_create(int field, size_t num_constraints, size_t num_inputs, size_t num_variables, uint64_t seed,
                                         iopx_aurora_instance **out);
+/* One-time work of a process's first proof, done ahead of it: grows the device pool to a proof's footprint, builds the transforms' plans and
+ * tables for every domain of this parameter set, the virtual oracles' per-domain tables and the lincheck's transposed matrices, by running the
+ * prover once on the instance's own assignment and discarding the argument (protocol 0: Aurora; 1: Fractal, after iopx_fractal_index).  The
+ * proofs after it take the steady-state time (bench.py: config.first_proof_ms beside config.instance_setup_ms; iopx_cold_stats shows what was built). */
+int iopx_aurora_instance_warm(iopx_aurora_instance *instance, int protocol, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter);
 int iopx_aurora_prove(iopx_aurora_instance *instance, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter,
                       uint8_t **transcript, size_t *transcript_bytes);
 /* fractal_snark_indexer / fractal_snark_prover (libiop/snark/fractal_snark.tcc:114-162; non-zk, BLAKE2b; RS_extra_dimensions 3 and

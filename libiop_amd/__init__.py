@@ -57,7 +57,7 @@ EXPORTED_SYMBOLS = [
     "iopx_transfer_stats", "iopx_blake2b_host", "iopx_gf192_host_mul", "iopx_fp3_host_add", "iopx_fp3_host_sub", "iopx_fp3_host_inverse",
     "iopx_fp3_from_uint", "iopx_fp3_modulus", "iopx_pow_search_blake2b", "iopx_pow_search_blake2b_begin", "iopx_pow_search_blake2b_end", "iopx_pow_candidate_blake2b",
     "iopx_side_stream_begin", "iopx_side_stream_end", "iopx_side_stream_join",
-    "iopx_aurora_instance_create", "iopx_aurora_example_instance_create", "iopx_aurora_prove", "iopx_aurora_instance_free", "iopx_host_free",
+    "iopx_aurora_instance_create", "iopx_aurora_example_instance_create", "iopx_aurora_prove", "iopx_aurora_instance_warm", "iopx_aurora_instance_free", "iopx_host_free",
     "iopx_fractal_index", "iopx_fractal_prove",
     "iopx_memcpy_d2h_deferrable", "iopx_comm_rccl_unique_id", "iopx_comm_create_rccl", "iopx_comm_create_callbacks", "iopx_comm_create_replay", "iopx_comm_is_replay", "iopx_cold_stats", "iopx_cold_add", "iopx_set_option", "iopx_clear_option", "iopx_get_option", "iopx_comm_destroy", "iopx_comm_rank",
     "iopx_comm_all_gather_dev", "iopx_comm_all_reduce_u64_dev", "iopx_comm_broadcast_dev", "iopx_comm_all_to_all_dev", "iopx_comm_sendrecv_dev", "iopx_comm_stats", "iopx_comm_bind_transforms", "iopx_add_taylor_inv_gf192_dev", "iopx_add_combine_inv_gf192_dev",
@@ -828,6 +828,12 @@ class Library:
         finally:
             self.c.iopx_host_free.argtypes = [ctypes.c_void_p]
             self.c.iopx_host_free(buf)
+
+    def aurora_instance_warm(self, instance, fractal=False, security_parameter=128, RS_extra_dimensions=None, FRI_localization_parameter=2):
+        """One-time work of the first proof done ahead of it (pool, plans, tables, transposed matrices): include/libiop_amd.h."""
+        rs = RS_extra_dimensions if RS_extra_dimensions is not None else (3 if fractal else 5)
+        self.c.iopx_aurora_instance_warm.argtypes = [ctypes.c_void_p, ctypes.c_int, _sz, _sz, _sz]
+        self._check(self.c.iopx_aurora_instance_warm(instance, 1 if fractal else 0, int(security_parameter), int(rs), int(FRI_localization_parameter)))
 
     def aurora_prove_dist(self, instance, comm, security_parameter=128, RS_extra_dimensions=5, FRI_localization_parameter=2):
         """aurora_snark_prover with the codeword-domain vectors distributed over `comm`: every rank calls it and gets the same transcript."""

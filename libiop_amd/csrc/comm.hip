@@ -237,12 +237,12 @@ int iopx_comm_all_gather_dev(iopx_comm *comm, const void *d_send, void *d_recv, 
     if (comm->replay) {                                            // every rank's slot <- this rank's part
         for (int r = 0; r < comm->world; ++r) {
             void *slot = (char *)d_recv + (size_t)r * bytes_per_rank;
-            if (slot != d_send) IOPX_HIP(hipMemcpyAsync(slot, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, iopx::stream()));
+            if (slot != d_send) { const int crc_ = iopx::copy_d2d(slot, d_send, bytes_per_rank); if (crc_ != IOPX_OK) return crc_; }
         }
         return IOPX_OK;
     }
     if (comm->use_callbacks) {
-        if (comm->world == 1) { if (d_send != d_recv) IOPX_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, iopx::stream())); return IOPX_OK; }
+        if (comm->world == 1) { if (d_send != d_recv) { const int crc_ = iopx::copy_d2d(d_recv, d_send, bytes_per_rank); if (crc_ != IOPX_OK) return crc_; } return IOPX_OK; }
         rc = comm->cb.all_gather(comm->cb.user, d_send, d_recv, bytes_per_rank, (void *)iopx::stream());
         return rc == 0 ? IOPX_OK : iopx::fail(IOPX_ERR_RUNTIME, "all_gather callback failed (%d)", rc);
     }
@@ -293,9 +293,9 @@ int iopx_comm_all_to_all_dev(iopx_comm *comm, const void *d_send, void *d_recv, 
     if (bytes_per_rank == 0) return IOPX_OK;
     if (!d_send || !d_recv || d_send == d_recv) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "all_to_all needs two distinct buffers");
     ++g_num_collectives; g_comm_bytes += bytes_per_rank * (size_t)comm->world;
-    if (comm->replay) { IOPX_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank * (size_t)comm->world, hipMemcpyDeviceToDevice, iopx::stream())); return IOPX_OK; }
+    if (comm->replay) { { const int crc_ = iopx::copy_d2d(d_recv, d_send, bytes_per_rank * (size_t)comm->world); if (crc_ != IOPX_OK) return crc_; } return IOPX_OK; }
     if (comm->use_callbacks) {
-        if (comm->world == 1) { IOPX_HIP(hipMemcpyAsync(d_recv, d_send, bytes_per_rank, hipMemcpyDeviceToDevice, iopx::stream())); return IOPX_OK; }
+        if (comm->world == 1) { { const int crc_ = iopx::copy_d2d(d_recv, d_send, bytes_per_rank); if (crc_ != IOPX_OK) return crc_; } return IOPX_OK; }
         rc = comm->cb.all_to_all(comm->cb.user, d_send, d_recv, bytes_per_rank, (void *)iopx::stream());
         return rc == 0 ? IOPX_OK : iopx::fail(IOPX_ERR_RUNTIME, "all_to_all callback failed (%d)", rc);
     }
@@ -311,7 +311,7 @@ int iopx_comm_sendrecv_dev(iopx_comm *comm, const void *d_send, void *d_recv, si
     if (!d_send || !d_recv) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
     if (peer < 0 || peer >= comm->world || peer == comm->rank) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "peer %d (this is rank %d of %d)", peer, comm->rank, comm->world);
     ++g_num_collectives; g_comm_bytes += bytes;
-    if (comm->replay) { if (d_send != d_recv) IOPX_HIP(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, iopx::stream())); return IOPX_OK; }
+    if (comm->replay) { if (d_send != d_recv) { const int crc_ = iopx::copy_d2d(d_recv, d_send, bytes); if (crc_ != IOPX_OK) return crc_; } return IOPX_OK; }
     if (comm->use_callbacks) {
         rc = comm->cb.sendrecv(comm->cb.user, d_send, d_recv, bytes, peer, (void *)iopx::stream());
         return rc == 0 ? IOPX_OK : iopx::fail(IOPX_ERR_RUNTIME, "sendrecv callback failed (%d)", rc);

@@ -204,7 +204,7 @@ static int run_division(const uint64_t *d_high, size_t M, size_t min_offset, uin
     int passes = 0;
     for (size_t o = min_offset; o != 0 && o < M; o <<= 1) ++passes;         // offsets stay below 2 M <= 2^41: no overflow
     if (passes == 0) {
-        if (d_high != d_quotient) IOPX_HIP(hipMemcpyAsync(d_quotient, d_high, M * 24, hipMemcpyDeviceToDevice, stream()));
+        if (d_high != d_quotient) { const int crc_ = iopx::copy_d2d(d_quotient, d_high, M * 24); if (crc_ != IOPX_OK) return crc_; }
         return IOPX_OK;
     }
     TmpBuf ping;
@@ -223,7 +223,7 @@ static int run_division(const uint64_t *d_high, size_t M, size_t min_offset, uin
             p.off[p.nterms++] = t.off;
         }
         if (p.nterms == 0) {        // nothing reaches back into the quotient: the factor is 1 on this range
-            if (src != dst) IOPX_HIP(hipMemcpyAsync(dst, src, M * 24, hipMemcpyDeviceToDevice, stream()));
+            if (src != dst) { const int crc_ = iopx::copy_d2d(dst, src, M * 24); if (crc_ != IOPX_OK) return crc_; }
             src = dst;
             continue;
         }

@@ -1610,7 +1610,7 @@ int iopx_add_ifft_gf192_dev(const uint64_t *d_evals, const uint64_t *basis, size
     if (rc != IOPX_OK) return rc;
     if (!d_evals || !d_out) return fail(IOPX_ERR_INVALID_ARGUMENT, "null buffer");
     if (m == 0) {
-        IOPX_HIP(hipMemcpyAsync(d_out, d_evals, 24, hipMemcpyDeviceToDevice, stream()));
+        { const int crc_ = iopx::copy_d2d(d_out, d_evals, 24); if (crc_ != IOPX_OK) return crc_; }
         return IOPX_OK;
     }
     AddPlan *pl = nullptr;
@@ -1623,7 +1623,7 @@ int iopx_add_ifft_gf192_dev(const uint64_t *d_evals, const uint64_t *basis, size
     if (d_evals == d_out) {     // the first pass permutes: it cannot run in place
         rc = tmp.alloc(((size_t)24) << m);
         if (rc != IOPX_OK) return rc;
-        IOPX_HIP(hipMemcpyAsync(tmp.p, d_evals, ((size_t)24) << m, hipMemcpyDeviceToDevice, stream()));
+        { const int crc_ = iopx::copy_d2d(tmp.p, d_evals, ((size_t)24) << m); if (crc_ != IOPX_OK) return crc_; }
         src = tmp.u64();
     }
     rc = run_phase2<true>(*pl, src, d_out, 0);
@@ -1645,7 +1645,7 @@ int iopx_add_ifft_gf192_batch_dev(const uint64_t *d_evals, size_t batch, const u
     if (batch == 0 || batch > 65535) return fail(IOPX_ERR_INVALID_ARGUMENT, "batch size %zu outside 1..65535", batch);
     const size_t bytes = (batch * 24) << m;
     if (m == 0) {
-        IOPX_HIP(hipMemcpyAsync(d_out, d_evals, bytes, hipMemcpyDeviceToDevice, stream()));
+        { const int crc_ = iopx::copy_d2d(d_out, d_evals, bytes); if (crc_ != IOPX_OK) return crc_; }
         return IOPX_OK;
     }
     AddPlan *pl = nullptr;
@@ -1658,7 +1658,7 @@ int iopx_add_ifft_gf192_batch_dev(const uint64_t *d_evals, size_t batch, const u
     if (d_evals == d_out) {     // the first pass permutes: it cannot run in place
         rc = tmp.alloc(bytes);
         if (rc != IOPX_OK) return rc;
-        IOPX_HIP(hipMemcpyAsync(tmp.p, d_evals, bytes, hipMemcpyDeviceToDevice, stream()));
+        { const int crc_ = iopx::copy_d2d(tmp.p, d_evals, bytes); if (crc_ != IOPX_OK) return crc_; }
         src = tmp.u64();
     }
     rc = run_phase2<true>(*pl, src, d_out, 0, 0, batch);

@@ -460,7 +460,7 @@ int iopx_mul_fft_fp3_dev(const uint64_t *d_coeffs, size_t n_coeffs, size_t log_n
     const size_t n = (size_t)1 << log_n;
     if (n_coeffs > n) return fail(IOPX_ERR_INVALID_ARGUMENT, "multiplicative FFT: %zu coefficients exceed the domain size %zu", n_coeffs, n);
     if (n_coeffs == 0) {
-        IOPX_HIP(hipMemsetAsync(d_out, 0, n * 24, stream()));
+        { const int crc_ = iopx::fill_bytes(d_out, 0, n * 24); if (crc_ != IOPX_OK) return crc_; }
         return IOPX_OK;
     }
     MulPlan *pl = nullptr;
@@ -474,7 +474,7 @@ int iopx_mul_fft_fp3_dev(const uint64_t *d_coeffs, size_t n_coeffs, size_t log_n
     const uint64_t *src = d_coeffs;
     if (d_coeffs == d_out) {    // the first pass permutes: it cannot run in place
         if ((rc = scaled.alloc(n_coeffs * 24)) != IOPX_OK) return rc;
-        IOPX_HIP(hipMemcpyAsync(scaled.p, d_coeffs, n_coeffs * 24, hipMemcpyDeviceToDevice, stream()));
+        { const int crc_ = iopx::copy_d2d(scaled.p, d_coeffs, n_coeffs * 24); if (crc_ != IOPX_OK) return crc_; }
         src = scaled.u64();
     }
     if (!(sh == hfp3::one()) && n_coeffs > 1) {
@@ -536,7 +536,7 @@ int iopx_fp3_pow_table_dev(uint64_t *d_out, size_t count, const uint64_t *base, 
     TmpBuf full;
     if ((rc = full.alloc((((size_t)1) << nb) * 24)) != IOPX_OK) return rc;
     if ((rc = fp_build_pow(full.u64(), hfp3::from_words(base), init_d, nb)) != IOPX_OK) return rc;
-    IOPX_HIP(hipMemcpyAsync(d_out, full.p, count * 24, hipMemcpyDeviceToDevice, stream()));
+    { const int crc_ = iopx::copy_d2d(d_out, full.p, count * 24); if (crc_ != IOPX_OK) return crc_; }
     return IOPX_OK;
 }
 
@@ -548,7 +548,7 @@ int iopx_mul_ifft_fp3_dev(const uint64_t *d_evals, size_t log_n, const uint64_t 
     if (!gen || !shift || !d_out || !d_evals) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
     const size_t n = (size_t)1 << log_n;
     if (log_n == 0) {       // multiplicative_IFFT_wrapper returns {v[0]} for size 1 (fft.tcc:397-401)
-        IOPX_HIP(hipMemcpyAsync(d_out, d_evals, 24, hipMemcpyDeviceToDevice, stream()));
+        { const int crc_ = iopx::copy_d2d(d_out, d_evals, 24); if (crc_ != IOPX_OK) return crc_; }
         return IOPX_OK;
     }
     MulPlan *pl = nullptr;
@@ -571,7 +571,7 @@ int iopx_mul_ifft_fp3_dev(const uint64_t *d_evals, size_t log_n, const uint64_t 
     const uint64_t *src = d_evals;
     if (d_evals == d_out) {     // the first pass permutes: it cannot run in place
         if ((rc = tmp.alloc(n * 24)) != IOPX_OK) return rc;
-        IOPX_HIP(hipMemcpyAsync(tmp.p, d_evals, n * 24, hipMemcpyDeviceToDevice, stream()));
+        { const int crc_ = iopx::copy_d2d(tmp.p, d_evals, n * 24); if (crc_ != IOPX_OK) return crc_; }
         src = tmp.u64();
     }
     rc = run_mfft(pl->cache_inv.u64(), src, n, d_out, (int)log_n, 0, scale, hi.u64(), lo.p ? lo.u64() : nullptr);
@@ -610,7 +610,7 @@ int iopx_fri_fold_mul_fp3_dev(const uint64_t *d_f_i, size_t log_n, const uint64_
     if ((size_t)eta > log_n) return fail(IOPX_ERR_INVALID_ARGUMENT, "coset size %zu exceeds the domain size", coset_size);
     const size_t n = (size_t)1 << log_n;
     if (eta == 0) {
-        IOPX_HIP(hipMemcpyAsync(d_next, d_f_i, n * 24, hipMemcpyDeviceToDevice, stream()));
+        { const int crc_ = iopx::copy_d2d(d_next, d_f_i, n * 24); if (crc_ != IOPX_OK) return crc_; }
         return IOPX_OK;
     }
     MulPlan *pl = nullptr;

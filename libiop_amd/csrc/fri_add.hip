@@ -123,7 +123,7 @@ int iopx_fri_fold_add_gf192_dev(const uint64_t *d_f_i, const uint64_t *basis, si
     if ((size_t)eta > m) return fail(IOPX_ERR_INVALID_ARGUMENT, "coset size %zu exceeds the domain size", coset_size);
     const size_t n = (size_t)1 << m;
     if (eta == 0) {     // cosets of one element: the interpolant is the constant f(v)
-        IOPX_HIP(hipMemcpyAsync(d_next, d_f_i, n * 24, hipMemcpyDeviceToDevice, stream()));
+        { const int crc_ = iopx::copy_d2d(d_next, d_f_i, n * 24); if (crc_ != IOPX_OK) return crc_; }
         return IOPX_OK;
     }
 

@@ -226,6 +226,20 @@ static int index_entry(iopx_aurora_instance *instance, iopx_comm *comm, size_t s
     });
 }
 
+// Everything a first proof would build and later ones find: the device pool at the size one proof needs (the largest single cost: the driver maps
+// about 10 GB), the transforms' plans and twist / twiddle tables for every domain of this parameter set, the per-domain tables of the virtual oracles,
+// the lincheck's transposed matrices (per instance), pinned staging.  They are keyed by what the proof's control flow asks for, so the way to build
+// exactly them is to run that control flow once: a proof of the instance's own assignment, discarded.  protocol 1 (Fractal) needs the index.
+int iopx_aurora_instance_warm(iopx_aurora_instance *instance, int protocol, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter)
+{
+    if (protocol != 0 && protocol != 1) return iopx::fail(IOPX_ERR_INVALID_ARGUMENT, "iopx_aurora_instance_warm: protocol %d (0: Aurora, 1: Fractal)", protocol);
+    uint8_t *t = nullptr;
+    size_t n = 0;
+    const int rc = prove_entry(instance, nullptr, protocol == 1, security_parameter, RS_extra_dimensions, FRI_localization_parameter, &t, &n);
+    std::free(t);
+    return rc;
+}
+
 int iopx_aurora_prove(iopx_aurora_instance *instance, size_t security_parameter, size_t RS_extra_dimensions, size_t FRI_localization_parameter,
                       uint8_t **transcript, size_t *transcript_bytes)
 {

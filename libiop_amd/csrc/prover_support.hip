@@ -168,7 +168,7 @@ int iopx_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes)
 {
     int rc = ensure_device();
     if (rc != IOPX_OK) return rc;
-    if (bytes) IOPX_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, stream()));
+    if (bytes) { const int crc_ = iopx::copy_d2d(dst_dev, src_dev, bytes); if (crc_ != IOPX_OK) return crc_; }
     return IOPX_OK;
 }
 
@@ -176,7 +176,7 @@ int iopx_memset_dev(void *dst_dev, int value, size_t bytes)
 {
     int rc = ensure_device();
     if (rc != IOPX_OK) return rc;
-    if (bytes) IOPX_HIP(hipMemsetAsync(dst_dev, value, bytes, stream()));
+    if (bytes) { const int crc_ = iopx::fill_bytes(dst_dev, value, bytes); if (crc_ != IOPX_OK) return crc_; }
     return IOPX_OK;
 }
 

@@ -156,6 +156,11 @@ int build_two_level(const hfp3 &base, const hfp3 &init, int logc, TmpBuf &hi, Tm
 int opt(const char *name, int dflt);
 int opt_range(const char *name, int dflt, int lo, int hi);      // clamped
 
+// Device-to-device copies and fills as KERNELS on the active stream (hipMemcpyAsync / hipMemsetAsync leave the GPU idle for several microseconds
+// on both sides of the runtime's own copy kernel: profiles/r05_gpu_gaps.txt).  Any alignment, any size.
+int copy_d2d(void *dst_dev, const void *src_dev, size_t bytes);
+int fill_bytes(void *dst_dev, int value, size_t bytes);
+
 // One-time ("cold") host-side costs — device allocations, plan and table builds, matrix transpositions — accumulated per label as wall time
 // (iopx_cold_stats): what a process's first proof pays beyond its kernels, and what iopx_aurora_instance_warm moves out of it.
 struct ColdScope {

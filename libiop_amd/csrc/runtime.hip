@@ -295,36 +295,116 @@ int upload(void *dst_dev, const void *src_host, size_t bytes)
 
 static void *g_bounce = nullptr;
 static size_t g_bounce_cap = 0;
-// deferred read-backs: pinned chunks filled by asynchronous copies, delivered by iopx_defer_downloads_end
-struct DeferChunk { char *p; size_t cap, used; };
-struct DeferItem { void *dst; const char *src; size_t bytes; };
+// Deferred read-backs.  Between iopx_defer_downloads_begin and _end a deferrable read-back is a small KERNEL that copies its bytes into one device
+// arena (a kernel launch is one more packet in the compute queue; an asynchronous copy makes the queue switch to the copy path and back, several
+// microseconds of idle GPU on both sides: profiles/r05_gpu_gaps.txt counted 43 of them per proof); _end moves the arena to the host with ONE copy,
+// drains the stream once and hands every piece to its destination.  The arena and its pinned twin grow on demand and stay.
+struct DeferItem { void *dst; size_t off, bytes; };
 static bool g_defer_on = false;
-static std::vector<DeferChunk> g_defer_chunks;
+static char *g_defer_dev = nullptr, *g_defer_host = nullptr;
+static size_t g_defer_cap = 0, g_defer_used = 0;
 static std::vector<DeferItem> g_defer_items;
+
+__global__ void k_copy_small(const uint8_t *src, uint8_t *dst, size_t bytes)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 7) == 0) {
+        const size_t words = bytes >> 3;
+        for (size_t i = t; i < words; i += step) ((uint64_t *)dst)[i] = ((const uint64_t *)src)[i];
+        for (size_t i = (words << 3) + t; i < bytes; i += step) dst[i] = src[i];
+    } else {
+        for (size_t i = t; i < bytes; i += step) dst[i] = src[i];
+    }
+}
+
+__global__ void k_copy_d2d(const uint8_t *src, uint8_t *dst, size_t bytes)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const size_t quads = bytes >> 4;
+        const uint4 *s4 = (const uint4 *)src;
+        uint4 *d4 = (uint4 *)dst;
+        for (size_t i = t; i < quads; i += step) d4[i] = s4[i];
+        for (size_t i = (quads << 4) + t; i < bytes; i += step) dst[i] = src[i];
+    } else if ((((uintptr_t)src | (uintptr_t)dst) & 7) == 0) {
+        const size_t words = bytes >> 3;
+        for (size_t i = t; i < words; i += step) ((uint64_t *)dst)[i] = ((const uint64_t *)src)[i];
+        for (size_t i = (words << 3) + t; i < bytes; i += step) dst[i] = src[i];
+    } else {
+        for (size_t i = t; i < bytes; i += step) dst[i] = src[i];
+    }
+}
+
+__global__ void k_fill_bytes(uint8_t *dst, uint8_t value, size_t bytes)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    if (((uintptr_t)dst & 15) == 0) {
+        const uint32_t w = 0x01010101u * value;
+        const uint4 v = make_uint4(w, w, w, w);
+        const size_t quads = bytes >> 4;
+        for (size_t i = t; i < quads; i += step) ((uint4 *)dst)[i] = v;
+        for (size_t i = (quads << 4) + t; i < bytes; i += step) dst[i] = value;
+    } else {
+        for (size_t i = t; i < bytes; i += step) dst[i] = value;
+    }
+}
+
+static unsigned copy_grid(size_t bytes)
+{
+    const size_t blocks = (bytes + 16 * 256 * 4 - 1) / (16 * 256 * 4);          // four 16-byte accesses per thread
+    return (unsigned)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks));
+}
+
+int copy_d2d(void *dst_dev, const void *src_dev, size_t bytes)
+{
+    if (bytes == 0 || dst_dev == src_dev) return IOPX_OK;
+    { ProfScope ps_("k_copy_d2d", 2 * bytes); hipLaunchKernelGGL(k_copy_d2d, dim3(copy_grid(bytes)), dim3(256), 0, active_stream(), (const uint8_t *)src_dev, (uint8_t *)dst_dev, bytes); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+int fill_bytes(void *dst_dev, int value, size_t bytes)
+{
+    if (bytes == 0) return IOPX_OK;
+    { ProfScope ps_("k_fill_bytes", bytes); hipLaunchKernelGGL(k_fill_bytes, dim3(copy_grid(bytes)), dim3(256), 0, active_stream(), (uint8_t *)dst_dev, (uint8_t)value, bytes); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
+// g_stage_mu held.  Drains the arena's pending pieces first when it has to grow (their bytes live in the old arena).
+static int defer_reserve(size_t need)
+{
+    if (g_defer_used + need <= g_defer_cap) return IOPX_OK;
+    if (!g_defer_items.empty()) return IOPX_ERR_RUNTIME;         // caller falls back to an immediate read-back for this piece
+    ColdScope cold_("deferred read-back arena");
+    size_t cap = g_defer_cap ? g_defer_cap : ((size_t)1 << 20);
+    while (cap < need) cap <<= 1;
+    if (g_defer_dev) (void)hipFree(g_defer_dev);
+    if (g_defer_host) (void)hipHostFree(g_defer_host);
+    g_defer_dev = g_defer_host = nullptr; g_defer_cap = 0;
+    hipError_t e = hipMalloc((void **)&g_defer_dev, cap);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&g_defer_host, cap, 0);
+    if (e != hipSuccess) return fail(IOPX_ERR_RUNTIME, "deferred read-back arena of %zu bytes: %s", cap, hipGetErrorString(e));
+    g_defer_cap = cap;
+    return IOPX_OK;
+}
 
 int download(void *dst_host, const void *src_dev, size_t bytes, bool deferrable)
 {
     if (bytes == 0) return IOPX_OK;
     std::unique_lock<std::mutex> lk(g_stage_mu);
     if (deferrable && g_defer_on) {
-        DeferChunk *c = nullptr;
-        const size_t need = (bytes + 63) & ~(size_t)63;          // slots are 64-byte aligned: capacity and occupancy count whole slots
-        for (auto &ch : g_defer_chunks) if (ch.used <= ch.cap && ch.cap - ch.used >= need) { c = &ch; break; }
-        if (!c) {
-            DeferChunk ch;
-            ch.cap = need < ((size_t)1 << 20) ? ((size_t)1 << 20) : need;
-            ch.used = 0;
-            ColdScope cold_("hipHostMalloc");
-            hipError_t e = hipHostMalloc((void **)&ch.p, ch.cap, 0);
-            if (e != hipSuccess) return fail(IOPX_ERR_RUNTIME, "hipHostMalloc(%zu) failed: %s", ch.cap, hipGetErrorString(e));
-            g_defer_chunks.push_back(ch);
-            c = &g_defer_chunks.back();
+        const size_t need = (bytes + 63) & ~(size_t)63;          // 64-byte slots
+        const int rc = defer_reserve(need);
+        if (rc == IOPX_OK) {
+            const unsigned blocks = (unsigned)std::min<size_t>((bytes + 4095) / 4096, 64);
+            { ProfScope ps_("k_copy_small"); hipLaunchKernelGGL(k_copy_small, dim3(blocks ? blocks : 1), dim3(256), 0, active_stream(), (const uint8_t *)src_dev, (uint8_t *)g_defer_dev + g_defer_used, bytes); }
+            IOPX_HIP(hipGetLastError());
+            g_defer_items.push_back({dst_host, g_defer_used, bytes});
+            g_defer_used += need;
+            return IOPX_OK;
         }
-        char *slot = c->p + c->used;
-        c->used += need;
-        IOPX_HIP(copy_d2h(slot, src_dev, bytes, active_stream()));
-        g_defer_items.push_back({dst_host, slot, bytes});
-        return IOPX_OK;
+        if (!g_defer_dev) return rc;                             // the arena could not be created at all
     }
     if (bytes > ((size_t)4 << 20)) {                    // large read-backs (test helpers): the plain path
         lk.unlock();
@@ -352,6 +432,7 @@ int defer_downloads_begin()
     std::lock_guard<std::mutex> lk(g_stage_mu);
     if (g_defer_on) return fail(IOPX_ERR_LOGIC, "iopx_defer_downloads_begin: already deferring");
     g_defer_on = true;
+    g_defer_used = 0;
     return IOPX_OK;
 }
 
@@ -362,10 +443,12 @@ int defer_downloads_end()
     g_defer_on = false;
     // a deferrable read-back may have been queued inside a side-stream section: the main stream waits for the side streams, draining it covers both
     for (int k = 0; k < IOPX_SIDE_STREAMS; ++k) if (side_stream_current() < 0) (void)side_stream_join(k);
-    const hipError_t e = hipStreamSynchronize(g_stream);
-    if (e == hipSuccess) for (auto &it : g_defer_items) memcpy(it.dst, it.src, it.bytes);
+    hipError_t e = hipSuccess;
+    if (g_defer_used) e = copy_d2h(g_defer_host, g_defer_dev, g_defer_used, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    if (e == hipSuccess) for (auto &it : g_defer_items) memcpy(it.dst, g_defer_host + it.off, it.bytes);
     g_defer_items.clear();
-    for (auto &ch : g_defer_chunks) ch.used = 0;
+    g_defer_used = 0;
     IOPX_HIP(e);
     return IOPX_OK;
 }

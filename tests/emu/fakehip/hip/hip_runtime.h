@@ -26,6 +26,8 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 v = { x, y, z, w }; return v; }
 
 static inline void __syncthreads() {}
 static inline void __threadfence_block() {}

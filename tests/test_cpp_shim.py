@@ -87,21 +87,21 @@ def test_cpp_provers_on_general_constraint_systems_on_cpu_emulation():
 @pytest.mark.gpu
 def test_cpp_provers_on_general_constraint_systems_on_gpu():
     exe = _build()
-    r = subprocess.run([exe, "general", "11"], capture_output=True, text=True, timeout=1800)
+    r = subprocess.run([exe, "general", "9"], capture_output=True, text=True, timeout=1800)      # sizes 2^8, 2^9: the oracle provers beside it set the time
     assert r.returncode == 0 and "general ok" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.gpu
 def test_cpp_fractal_prover_on_gpu():
     exe = _build()
-    r = subprocess.run([exe, "fractal", "10"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([exe, "fractal", "9"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "fractal ok" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.gpu
 def test_cpp_aurora_prover_on_gpu():
     exe = _build()
-    r = subprocess.run([exe, "aurora", "12"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([exe, "aurora", "11"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "aurora ok" in r.stdout, r.stdout + r.stderr
 
 

@@ -200,21 +200,9 @@ def test_ldt_combination_2p25_sampled(env):
         assert host.gf_from_words(got[q]) == acc, p
 
 
-def test_aurora_2p20_proof_accepted_by_the_oracle_verifier(env):
-    """The complete Aurora proof bench.py times (2^20 constraints, 2^25-point codewords, 10 Merkle trees, 27 queries) is accepted
-    by the oracle's independent verifier, which re-derives the instance from the seed; a flipped answer is rejected."""
-    from libiop_amd import aurora, r1cs
-    lib, torch, dev, ops, _ = env
-    n = 1 << D
-    cs, primary, auxiliary = r1cs.generate_r1cs_example(ops, n, 15, n - 1, 0x2204)
-    params = aurora.AuroraParameters(ops.field, n, n - 1, 15)
-    transcript = aurora.aurora_snark_prover(ops, cs, primary, auxiliary, params)
-    data = transcript.serialize()
-    assert len(transcript.MT_roots) == 11 and params.codeword_domain_dim == 25
-    assert oracle.aurora_verify(oracle.FIELD_GF192, D, 15, 0x2204, data)
-    transcript.query_responses[0] = transcript.query_responses[0].copy()
-    transcript.query_responses[0][3, 2, 1] ^= np.uint64(4)
-    assert not oracle.aurora_verify(oracle.FIELD_GF192, D, 15, 0x2204, transcript.serialize())
+# The 2^20 Aurora proof is pinned by digest equality with the oracle prover's transcript (test_aurora_transcript_equals_the_oracle_provers_at_large_sizes[20],
+# native and Python provers); the oracle VERIFIER's run on it (two minutes of one host core for bytes whose equality is already asserted) is made at 2^14
+# (test_aurora_2p14_transcript_byte_equal_to_the_oracle_prover: byte equality, acceptance) and with every tampered component at 2^8 - 2^12 (tests/aurora_cases.py).
 
 
 def test_fractal_2p20_proof_accepted_by_the_oracle_verifier(env):

@@ -54,9 +54,9 @@ def test_fractal_unsatisfied_bytes_are_the_oracles(gpu, field_name, num_constrai
     gc.check_fractal(gpu, torch, DEV, monkeypatch, field_name, num_constraints, 15, 80, kind=kind)
 
 
-def test_aurora_general_instance_at_2p14_equals_the_oracle_prover(gpu, monkeypatch):
-    """The largest general instance the oracle prover finishes in well under a minute: byte-equality at 2^14 constraints over GF(2^192)."""
-    gc.check_aurora(gpu, torch, DEV, monkeypatch, "gf192", 1 << 14, (1 << 14) - 1, 15, 91)
+def test_aurora_general_instance_at_2p13_equals_the_oracle_prover(gpu, monkeypatch):
+    """A larger general instance against the oracle prover itself: byte-equality at 2^13 constraints over GF(2^192) (2^16 goes against the recorded digest below)."""
+    gc.check_aurora(gpu, torch, DEV, monkeypatch, "gf192", 1 << 13, (1 << 13) - 1, 15, 91)
 
 
 def test_aurora_general_instance_at_2p16_native_equals_python_and_the_oracle_verifier_accepts(gpu, monkeypatch):

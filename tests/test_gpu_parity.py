@@ -536,7 +536,7 @@ def test_aurora_other_rates(gpu, field_name):
     ac.check_transcript_equals_oracle(gpu, torch, torch.device("cuda:0"), field_name, 9, 7, 5, rs_extra=3, localization=3)
 
 
-@pytest.mark.parametrize("m,d,batch", [(9, 5, 3), (14, 9, 2), (18, 14, 3), (20, 16, 1)])
+@pytest.mark.parametrize("m,d,batch", [(9, 5, 3), (14, 9, 2), (18, 14, 3), (19, 16, 1)])
 def test_reextend_equals_ifft_then_fft(gpu, m, d, batch):
     import torch
     gpu.set_stream(torch.cuda.current_stream().cuda_stream)
