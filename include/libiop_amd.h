@@ -163,6 +163,11 @@ int iopx_add_combine_gf192_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_
  *                         (cosets {j + k * n / coset_size}, subgroup.tcc:175-197) */
 int iopx_mul_fft_fp3_dev(const uint64_t *d_coeffs, size_t n_coeffs, size_t log_n, const uint64_t *gen,
                          const uint64_t *shift, uint64_t *d_out);
+/* ... and, from the same last pass, up to two WINDOWS of the output: d_windows[w][k] = d_out[window_first[w] + (k << window_log_stride[w])] for
+ * k < 2^(log_n - window_log_stride[w]) (window_first[w] < 2^window_log_stride[w]) — the coset of order 2^(log_n - log_stride) through element `first`,
+ * e.g. the positions IFFT_of_known_degree_over_field_subset reads (fft.tcc:435-456).  Saves the strided sweep over the finished codeword. */
+int iopx_mul_fft_fp3_windows_dev(const uint64_t *d_coeffs, size_t n_coeffs, size_t log_n, const uint64_t *gen, const uint64_t *shift, uint64_t *d_out,
+                                 size_t num_windows, const size_t *window_first, const size_t *window_log_stride, uint64_t *const *d_windows);
 int iopx_mul_fft_fp3(const uint64_t *coeffs, size_t n_coeffs, size_t log_n, const uint64_t *gen,
                      const uint64_t *shift, uint64_t *out);
 int iopx_mul_ifft_fp3_dev(const uint64_t *d_evals, size_t log_n, const uint64_t *gen, const uint64_t *shift,
@@ -463,6 +468,10 @@ int iopx_profile_report(char *buf, size_t cap);
 int iopx_gf192_mul_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count);
 /* d_out[i] = d_a[i] * d_c[0]: the wave-uniform-multiplier path the butterfly kernels use. */
 int iopx_gf192_mul_uniform_dev(const uint64_t *d_a, const uint64_t *d_c, uint64_t *d_out, size_t count);
+/* Test entry for the half-wavefront comb product (one multiplier per 32 lanes: d_c2[0] for lanes 0..31 of a wavefront, d_c2[1] for lanes 32..63):
+ * element i is multiplied when (i & lane_mask) != 0 and copied otherwise — a divergent branch around the product when lane_mask has bits below 6 —
+ * and d_active[i / 64] receives the number of lanes a ballot placed right after the product sees active.  count: a multiple of 64. */
+int iopx_gf192_mul_halves_dev(const uint64_t *d_a, const uint64_t *d_c2, uint64_t *d_out, uint32_t *d_active, size_t count, uint32_t lane_mask);
 
 /* ---- support for a native prover built on this ABI (libiop_amd/cpp/{iop,aurora}.hpp; libiop_amd/csrc/prover_support.hip) ---- */
 /* Pooled device allocations for oracles, trees and scratch vectors: blocks are recycled in the order of the library's stream (all

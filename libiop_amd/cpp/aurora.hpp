@@ -53,8 +53,26 @@ device_vector<FieldT> FFT(const device_vector<FieldT> &coeffs, std::size_t n_coe
         return out;
     }
     device_vector<FieldT> out(D.num_elements());
-    if (additive(D)) check(iopx_add_fft_gf192_dev(coeffs.words(), n_coeffs, basis_words(D), D.dimension(), shift_words(D), out.words()));
-    else check(iopx_mul_fft_fp3_dev(coeffs.words(), n_coeffs, D.dimension(), gen_words(D), shift_words(D), out.words()));
+    if (additive(D)) { check(iopx_add_fft_gf192_dev(coeffs.words(), n_coeffs, basis_words(D), D.dimension(), shift_words(D), out.words())); return out; }
+    // the windows the prover will ask for (dist::window_collector) leave the transform's last pass together with the codeword
+    dist::window_collector<FieldT> *col = dist::active_collector<FieldT>();
+    if (col && col->domain_elements == D.num_elements() && !col->wanted.empty()) {
+        typename dist::window_collector<FieldT>::entry e;
+        std::size_t firsts[2], log_strides[2];
+        uint64_t *ptrs[2];
+        std::size_t nw = 0;
+        for (const dist::window &w : col->wanted) {
+            if (nw == 2) break;
+            e.windows.emplace_back(w, device_vector<FieldT>(w.count));
+            firsts[nw] = w.first; log_strides[nw] = detail::log2_ceil(w.stride); ptrs[nw] = e.windows.back().second.words();
+            ++nw;
+        }
+        check(iopx_mul_fft_fp3_windows_dev(coeffs.words(), n_coeffs, D.dimension(), gen_words(D), shift_words(D), out.words(), nw, firsts, log_strides, ptrs));
+        e.codeword = out;
+        col->produced.push_back(std::move(e));
+        return out;
+    }
+    check(iopx_mul_fft_fp3_dev(coeffs.words(), n_coeffs, D.dimension(), gen_words(D), shift_words(D), out.words()));
     return out;
 }
 
@@ -946,8 +964,28 @@ public:
     {
         compute_domains();
     }
+    // the head of L^(0) and the confirmation window beside it: the two windows first_round_from_head evaluates every oracle of the LDT over
+    bool head_windows(dist::window &h0, dist::window &c0, std::size_t &confirm_out)
+    {
+        if (num_reductions_ < 2) return false;
+        const field_subset<FieldT> &L0 = domains_[0];
+        const std::size_t head = (std::size_t)1 << detail::log2_ceil(poly_degree_bound_), cs0 = (std::size_t)1 << localization_[0];
+        if (head * 4 > L0.num_elements() || L0.num_elements() % head || head / cs0 < 2) return false;
+        std::size_t confirm = 2 * cs0;
+        for (auto &h : poly_handles_) confirm = std::max(confirm, IOP_.smallest_window(h));
+        confirm = std::min(head, (std::size_t)1 << detail::log2_ceil(confirm));
+        h0 = dist::head_window(L0, head);
+        c0 = dist::beside_head_window(L0, head, confirm);
+        confirm_out = confirm;
+        return true;
+    }
     void register_interactions()                                                             // :342-398
     {
+        {
+            dist::window h0, c0;
+            std::size_t confirm;
+            if (dev::head_evaluation_enabled() && head_windows(h0, c0, confirm)) { IOP_.want_window(codeword_domain_handle_, h0); IOP_.want_window(codeword_domain_handle_, c0); }
+        }
         std::size_t total = localization_[0];
         domain_handles_.assign(num_reductions_, codeword_domain_handle_);
         oracle_handles_.assign(num_reductions_, {});

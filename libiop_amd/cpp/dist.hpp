@@ -231,6 +231,21 @@ bool window_from_window(const device_vector<FieldT> &have, const window &held, c
     return true;
 }
 
+// ---- windows produced by the transform that makes the codeword.  Over a multiplicative coset a window is a strided set of positions; gathering it
+// from the finished 2^25-point codeword reads a whole 128-byte line for every 24 useful bytes (3.2 x the useful traffic, profiles/r05_traffic_fractal.json).
+// The prover that will ask for windows of its codeword-domain oracles says so at registration (bcs_prover::want_window); the forward transform
+// (dev::FFT, aurora.hpp) then writes the wanted windows from its last pass (iopx_mul_fft_fp3_windows_dev) and leaves them here, keyed by the codeword
+// it made; bcs_prover::submit_oracle adopts them into the oracle's window cache, a round end drops what nobody adopted. ----
+template<typename FieldT>
+struct window_collector {
+    std::size_t domain_elements = 0;                  // the (whole, multiplicative) domain the wanted windows are windows of
+    std::vector<window> wanted;                       // at most two (a transform's last pass carries two extra outputs)
+    struct entry { device_vector<FieldT> codeword; std::vector<std::pair<window, device_vector<FieldT>>> windows; };
+    std::vector<entry> produced;
+};
+template<typename FieldT>
+inline window_collector<FieldT> *&active_collector() { static thread_local window_collector<FieldT> *c = nullptr; return c; }
+
 // ---- collectives on device vectors (enqueued on the library's stream) ------------------------------------------------------------
 template<typename T>
 device_array<T> all_gather(const device_array<T> &local)                                     // rank-major concatenation

@@ -360,6 +360,7 @@ private:
     std::map<std::size_t, std::vector<FieldT>> verifier_random_messages_;
     std::map<std::size_t, device_vector<FieldT>> virtual_contents_cache_;
     std::size_t head_hint_ = 0;
+    dist::window_collector<FieldT> collector_, *outer_collector_ = nullptr;
     std::map<std::size_t, std::vector<std::pair<dist::window, device_vector<FieldT>>>> window_cache_, real_window_cache_;
     hash_digest pow_answer_;
 
@@ -436,8 +437,18 @@ private:
     }
 
 public:
-    explicit bcs_prover(std::size_t pow_work_parameter, const bcs_prover_index<FieldT> *index = nullptr) : pow_bitlen_(pow_work_parameter), index_(index) {}
-    ~bcs_prover() { (void)iopx_side_stream_join(); }            // trees still being built beside the rounds read this object's oracles (an unwinding proof)
+    explicit bcs_prover(std::size_t pow_work_parameter, const bcs_prover_index<FieldT> *index = nullptr) : pow_bitlen_(pow_work_parameter), index_(index)
+    {
+        outer_collector_ = dist::active_collector<FieldT>();          // this prover's transforms leave their wanted windows with it (dist::window_collector)
+        dist::active_collector<FieldT>() = &collector_;
+    }
+    bcs_prover(const bcs_prover &) = delete;                          // (the user-declared destructor suppressed the moves; copies were never meant)
+    bcs_prover &operator=(const bcs_prover &) = delete;
+    ~bcs_prover()
+    {
+        dist::active_collector<FieldT>() = outer_collector_;
+        (void)iopx_side_stream_join();                                // trees still being built beside the rounds read this object's oracles (an unwinding proof)
+    }
 
     // ---- registration ----
     domain_handle register_domain(const field_subset<FieldT> &S) { domains_.push_back(S); return domain_handle{ domains_.size() - 1 }; }
@@ -547,6 +558,13 @@ public:
         if (dist::local_size(domains_[oracle_regs_[oid].domain]) != contents.size()) throw std::invalid_argument("oracle evaluations don't match the domain size");
         oracles_[oid] = contents.device_contents();
         oracle_submitted_[oid] = true;
+        for (std::size_t k = 0; k < collector_.produced.size(); ++k)                             // windows its transform already wrote
+            if (collector_.produced[k].codeword.data() == oracles_[oid].data() && collector_.produced[k].codeword.size() == oracles_[oid].size()) {
+                auto &cache = real_window_cache_[oid];
+                for (auto &w : collector_.produced[k].windows) cache.push_back(std::move(w));
+                collector_.produced.erase(collector_.produced.begin() + k);
+                break;
+            }
     }
     void submit_prover_message(const prover_message_handle &handle, const std::vector<FieldT> &contents)
     {
@@ -629,6 +647,7 @@ private:
         for (std::size_t mid = mbegin; mid < num_prover_messages_at_end_of_round_[ended]; ++mid)
             if (!message_submitted_[mid]) throw std::logic_error("signaling end of round without submitting all prover messages in the round");
         ++num_prover_rounds_done_;
+        collector_.produced.clear();                                  // windows of transforms whose output was not submitted as an oracle of this round
         // one tree per (round, domain) over every oracle of that domain, leaves serialised by cosets (bcs_prover.tcc:36-47); the
         // reference indexes Merkle_trees_[processed_MTs_] for each domain of the round: every shipped protocol has one
         const auto mapping = oracles_in_round_by_domain(ended);
@@ -708,6 +727,17 @@ public:
     // the head a later stage of the protocol will ask for (the LDT's): an earlier stage that needs a smaller head of a cached oracle evaluates
     // the larger one once instead of both
     void set_head_hint(std::size_t count) { head_hint_ = std::max(head_hint_, count); }
+    // A protocol that will ask for window w of the real oracles over this domain (get_oracle_evaluations_over_window) says so while it registers: over
+    // a multiplicative coset held whole the forward transform then writes w beside the codeword (dist::window_collector) instead of a strided sweep later.
+    void want_window(const domain_handle &h, const dist::window &w)
+    {
+        const field_subset<FieldT> &D = domains_[h.id];
+        if (D.type() == affine_subspace_type || D.distributed() || w.stride == 1 || (w.stride & (w.stride - 1)) || w.count * w.stride != D.num_elements()) return;
+        if (collector_.domain_elements && collector_.domain_elements != D.num_elements()) return;       // one codeword domain per proof
+        collector_.domain_elements = D.num_elements();
+        for (auto &have : collector_.wanted) if (have == w) return;
+        if (collector_.wanted.size() < 2) collector_.wanted.push_back(w);
+    }
     std::size_t head_hint() const { return head_hint_; }
     std::size_t smallest_window(const oracle_handle &h) const
     {

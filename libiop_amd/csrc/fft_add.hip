@@ -2043,6 +2043,36 @@ int iopx_gf192_pow_table_dev(uint64_t *d_out, size_t count, const uint64_t *base
     return IOPX_OK;
 }
 
+// The half-wavefront product (gf_mul_halves: lanes 0..31 of a wavefront by c[0], lanes 32..63 by c[1]) in a context that depends on EXEC, which the
+// asm block narrows and restores: only the lanes with (i & lane_mask) != 0 take the branch that holds the product, a ballot right after the
+// product counts the lanes still active, and the lanes outside the branch store their input.  d_active[wave] = that count (popcount of the ballot).
+__global__ void __launch_bounds__(256) k_gf192_mul_halves(const uint64_t *a, const uint64_t *c, uint64_t *out, uint32_t *active, size_t count, uint32_t lane_mask)
+{
+    const gf192 c0 = gf_load(c, 0), c1 = gf_load(c, 1);
+    // whole wavefronts per trip (count, the block size and the stride are multiples of 64): element i sits in lane i % 64
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        gf192 v = gf_load(a, i);
+        if ((uint32_t)i & lane_mask) {                 // divergent when lane_mask has bits below 6
+            v = gf_mul_halves(v, c0, c1, lane);
+            const unsigned long long live = __ballot(1);
+            if ((live & ((1ull << lane) - 1)) == 0) active[i >> 6] = (uint32_t)__popcll(live);       // the lowest active lane reports
+        }
+        gf_store(out, i, v);
+    }
+}
+
+int iopx_gf192_mul_halves_dev(const uint64_t *d_a, const uint64_t *d_c2, uint64_t *d_out, uint32_t *d_active, size_t count, uint32_t lane_mask)
+{
+    int rc = ensure_device();
+    if (rc != IOPX_OK) return rc;
+    if (count == 0) return IOPX_OK;
+    if (count % 64) return fail(IOPX_ERR_INVALID_ARGUMENT, "iopx_gf192_mul_halves_dev: whole wavefronts only");
+    { ProfScope ps_("k_gf192_mul_halves"); hipLaunchKernelGGL(k_gf192_mul_halves, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream(), d_a, d_c2, d_out, d_active, count, lane_mask); }
+    IOPX_HIP(hipGetLastError());
+    return IOPX_OK;
+}
+
 int iopx_gf192_mul_dev(const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t count)
 {
     int rc = ensure_device();

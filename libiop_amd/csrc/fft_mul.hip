@@ -113,6 +113,13 @@ struct MfParams {
     int b_lo, b_hi;         // butterfly bits of this pass (ascending)
     int scale;              // 0 none, 1 sc_hi[0] only (n^-1), 2 two-level table
     int final;              // last pass of a transform: store canonical values (earlier passes store lazily reduced ones)
+    // last pass: windows of the output written beside it — window w holds out[first + k << log_stride], k < 2^(logn - log_stride) — so that a caller
+    // that needs the strided head of the codeword (the positions a known-degree interpolation reads, fft.tcc:435-456) does not sweep the codeword
+    // again with 24 useful bytes per 128-byte line (k_gather_stride_words moved 3.2 x its useful bytes)
+    int num_win;
+    uint64_t *win_dst[2];
+    uint32_t win_first[2];
+    int win_log_stride[2];
 };
 
 // R levels starting at global index bit b on 2^R elements per lane (local indices i0 | k << bl).  Level b + lev pairs k with
@@ -187,6 +194,10 @@ __global__ void __launch_bounds__(512) k_mfft_pass(MfParams p)
         else if (p.scale == 2) v = fp_mul(fp_mul(v, fp_load(p.sc_hi, gi >> 12)), fp_load(p.sc_lo, gi & 4095));
         else if (p.final) v = fp7_canonical(fp7_unpack(v));
         fp_store(p.dst, gi, v);
+        for (int w = 0; w < p.num_win; ++w) {
+            const size_t rel = gi - p.win_first[w];
+            if (gi >= p.win_first[w] && (rel & ((((size_t)1) << p.win_log_stride[w]) - 1)) == 0) fp_store(p.win_dst[w], rel >> p.win_log_stride[w], v);
+        }
     }
 }
 
@@ -398,8 +409,10 @@ int build_two_level(const hfp3 &base, const hfp3 &init, int logc, TmpBuf &hi, Tm
 }
 
 // runs the radix-2 levels on index bits [logrho, logn) (first pass gathers src bit-reversed), natural-order dst
+struct MfWindows { int num = 0; uint64_t *dst[2] = { nullptr, nullptr }; uint32_t first[2] = { 0, 0 }; int log_stride[2] = { 0, 0 }; };
+
 static int run_mfft(const uint64_t *cache, const uint64_t *src, size_t n_src, uint64_t *dst, int logn, int logrho,
-                    int scale, const uint64_t *sc_hi, const uint64_t *sc_lo)
+                    int scale, const uint64_t *sc_hi, const uint64_t *sc_lo, const MfWindows *windows = nullptr)
 {
     struct Pass { int c, h, A, b_lo, b_hi; };
     std::vector<Pass> passes;
@@ -431,7 +444,10 @@ static int run_mfft(const uint64_t *cache, const uint64_t *src, size_t n_src, ui
         p.logn = logn; p.logrho = logrho;
         p.gather = (i == 0);
         p.c = ps.c; p.h = ps.h; p.A = ps.A; p.b_lo = ps.b_lo; p.b_hi = ps.b_hi;
-        if (i + 1 == passes.size()) { p.scale = scale; p.sc_hi = sc_hi; p.sc_lo = sc_lo; p.final = 1; }
+        if (i + 1 == passes.size()) {
+            p.scale = scale; p.sc_hi = sc_hi; p.sc_lo = sc_lo; p.final = 1;
+            if (windows) { p.num_win = windows->num; for (int w = 0; w < windows->num; ++w) { p.win_dst[w] = windows->dst[w]; p.win_first[w] = windows->first[w]; p.win_log_stride[w] = windows->log_stride[w]; } }
+        }
         const int tbits = ps.c + ps.A;
         const size_t lds = ((size_t)24) << tbits;
         const size_t blocks = (size_t)1 << (logn - tbits);
@@ -453,14 +469,30 @@ extern "C" {
 int iopx_mul_fft_fp3_dev(const uint64_t *d_coeffs, size_t n_coeffs, size_t log_n, const uint64_t *gen,
                          const uint64_t *shift, uint64_t *d_out)
 {
+    return iopx_mul_fft_fp3_windows_dev(d_coeffs, n_coeffs, log_n, gen, shift, d_out, 0, nullptr, nullptr, nullptr);
+}
+
+int iopx_mul_fft_fp3_windows_dev(const uint64_t *d_coeffs, size_t n_coeffs, size_t log_n, const uint64_t *gen, const uint64_t *shift, uint64_t *d_out,
+                                 size_t num_windows, const size_t *window_first, const size_t *window_log_stride, uint64_t *const *d_windows)
+{
     int rc = ensure_device();
     if (rc != IOPX_OK) return rc;
     if (log_n > 31) return fail(IOPX_ERR_INVALID_ARGUMENT, "log_n %zu exceeds the 2-adicity of the field", log_n);
     if (!gen || !shift || !d_out || (n_coeffs && !d_coeffs)) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
     const size_t n = (size_t)1 << log_n;
     if (n_coeffs > n) return fail(IOPX_ERR_INVALID_ARGUMENT, "multiplicative FFT: %zu coefficients exceed the domain size %zu", n_coeffs, n);
+    if (num_windows > 2) return fail(IOPX_ERR_INVALID_ARGUMENT, "at most two windows per transform");
+    MfWindows wins;
+    for (size_t w = 0; w < num_windows; ++w) {
+        if (!window_first || !window_log_stride || !d_windows || !d_windows[w]) return fail(IOPX_ERR_INVALID_ARGUMENT, "null window argument");
+        if (window_log_stride[w] > log_n || window_first[w] >= ((size_t)1 << window_log_stride[w])) return fail(IOPX_ERR_INVALID_ARGUMENT, "window %zu: first %zu, stride 2^%zu of a 2^%zu-point domain", w, window_first[w], window_log_stride[w], log_n);
+        if (d_windows[w] == d_out) return fail(IOPX_ERR_INVALID_ARGUMENT, "a window may not alias the output");
+        wins.dst[w] = d_windows[w]; wins.first[w] = (uint32_t)window_first[w]; wins.log_stride[w] = (int)window_log_stride[w];
+    }
+    wins.num = (int)num_windows;
     if (n_coeffs == 0) {
         { const int crc_ = iopx::fill_bytes(d_out, 0, n * 24); if (crc_ != IOPX_OK) return crc_; }
+        for (size_t w = 0; w < num_windows; ++w) { const int crc_ = iopx::fill_bytes(d_windows[w], 0, (n >> window_log_stride[w]) * 24); if (crc_ != IOPX_OK) return crc_; }
         return IOPX_OK;
     }
     MulPlan *pl = nullptr;
@@ -483,7 +515,7 @@ int iopx_mul_fft_fp3_dev(const uint64_t *d_coeffs, size_t n_coeffs, size_t log_n
         { ProfScope ps_("k_fp_scale_pow"); hipLaunchKernelGGL(k_fp_scale_pow, dim3(mgrid(n_coeffs, 256)), dim3(256), 0, stream(), scaled.u64(), src, (const uint64_t *)hi.u64(), (const uint64_t *)lo.u64(), n_coeffs); }
         src = scaled.u64();
     }
-    rc = run_mfft(pl->cache_fwd.u64(), src, n_coeffs, d_out, (int)log_n, (int)log_n - logd, 0, nullptr, nullptr);
+    rc = run_mfft(pl->cache_fwd.u64(), src, n_coeffs, d_out, (int)log_n, (int)log_n - logd, 0, nullptr, nullptr, &wins);
     if (rc != IOPX_OK) return rc;
     return IOPX_OK;                                     // per-call tables are released in stream order
 }

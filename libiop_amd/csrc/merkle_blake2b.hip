@@ -409,16 +409,20 @@ int iopx_merkle_inner_blake2b_dev(uint8_t *d_nodes, size_t num_leaves)
     if (!d_nodes) return fail(IOPX_ERR_INVALID_ARGUMENT, "null argument");
     const size_t L = num_leaves;
     if (L < 2 || (L & (L - 1))) return fail(IOPX_ERR_INVALID_ARGUMENT, "Merkle tree size must be a power of two, and at least 2.");
-    // inner levels: L/2, L/4, ... nodes; the last levels (<= 1024 nodes) in one workgroup
+    // inner levels: L/2, L/4, ... nodes; the last levels (<= 256 nodes: one wavefront per SIMD of one CU, a level then costs one compression's
+    // latency) in one workgroup.  Wider levels take more time inside that workgroup (1024 nodes: four wavefronts per SIMD in turn) than as a launch of their own
     static const bool vec_ok = opt("IOPX_MERKLE_FIXED", 1) != 0;
     const bool vec = vec_ok && ((uintptr_t)d_nodes & 15) == 0;
     size_t count = L / 2;
-    while (count > 1024) {
-        size_t g = (count + 255) / 256;
+    while (count > 256) {
+        size_t g = (count + 63) / 64;                   // 64 nodes per workgroup at the narrow levels: 1024 nodes spread over 16 CUs
         if (g > 65536) g = 65536;
         { ProfScope ps_("k_merkle_level", count * 96);
-          if (vec) hipLaunchKernelGGL(k_merkle_level<true>, dim3((unsigned)g), dim3(256), 0, stream(), (uint64_t *)d_nodes, count - 1, count);
-          else hipLaunchKernelGGL(k_merkle_level<false>, dim3((unsigned)g), dim3(256), 0, stream(), (uint64_t *)d_nodes, count - 1, count); }
+          const unsigned tb = count >= 65536 ? 256 : 64;
+          if (tb == 256) g = (count + 255) / 256;
+          if (g > 65536) g = 65536;
+          if (vec) hipLaunchKernelGGL(k_merkle_level<true>, dim3((unsigned)g), dim3(tb), 0, stream(), (uint64_t *)d_nodes, count - 1, count);
+          else hipLaunchKernelGGL(k_merkle_level<false>, dim3((unsigned)g), dim3(tb), 0, stream(), (uint64_t *)d_nodes, count - 1, count); }
         count >>= 1;
     }
     { ProfScope ps_("k_merkle_top", count * 96);

@@ -30,6 +30,9 @@ struct uint4 { unsigned x, y, z, w; };
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 v = { x, y, z, w }; return v; }
 
 static inline void __syncthreads() {}
+// one thread at a time: a ballot sees the calling lane only
+static inline unsigned long long __ballot(int pred) { return pred ? ~0ull : 0ull; }      // (the emulated thread stands for every lane of its wavefront)
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline void __threadfence_block() {}
 static inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v)
 {

@@ -87,7 +87,7 @@ def test_cpp_provers_on_general_constraint_systems_on_cpu_emulation():
 @pytest.mark.gpu
 def test_cpp_provers_on_general_constraint_systems_on_gpu():
     exe = _build()
-    r = subprocess.run([exe, "general", "9"], capture_output=True, text=True, timeout=1800)      # sizes 2^8, 2^9: the oracle provers beside it set the time
+    r = subprocess.run([exe, "general", "8"], capture_output=True, text=True, timeout=1800)      # the oracle provers beside it set the time (2^9 - 2^12: tests/test_gpu_general_r1cs.py)
     assert r.returncode == 0 and "general ok" in r.stdout, r.stdout + r.stderr
 
 

@@ -132,9 +132,8 @@ def _run(script, extra_env, timeout=1500):
 
 # one child process per COMBINATION (a child costs ten seconds of the driver's suite): every option appears with its non-default value at least once,
 # and the options that act on the same kernel appear separately
-@pytest.mark.parametrize("env", [{"IOPX_RS_COMB_CAP_LOG2": "3"}, {"IOPX_P1_COMB": "0", "IOPX_EDGE_BATCH": "0", "IOPX_EDGE_MULTI": "0"},
-                                 {"IOPX_COMB": "0"}, {"IOPX_RS_COMB_CAP_LOG2": "3", "IOPX_SMALL_LAST": "0"},
-                                 {"IOPX_EDGE_MULTI": "3", "IOPX_RS_COMB_CAP_LOG2": "3"}],
+@pytest.mark.parametrize("env", [{"IOPX_RS_COMB_CAP_LOG2": "3"}, {"IOPX_P1_COMB": "0", "IOPX_EDGE_BATCH": "0", "IOPX_EDGE_MULTI": "0", "IOPX_SMALL_LAST": "0"},
+                                 {"IOPX_COMB": "0"}, {"IOPX_EDGE_MULTI": "3", "IOPX_RS_COMB_CAP_LOG2": "3"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_env_gated_branches_equal_the_oracle(env):
     _run(SHAPES, env)
@@ -158,7 +157,7 @@ print("ok")
 """
 
 
-@pytest.mark.parametrize("env", [{"IOPX_DEFER_ROOTS": "0"}, {"IOPX_DEFER_ROOTS": "1"}, {"IOPX_MERKLE_STREAM": "0"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+@pytest.mark.parametrize("env", [{"IOPX_DEFER_ROOTS": "0"}, {"IOPX_MERKLE_STREAM": "0"}], ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_provers_with_roots_read_at_round_ends_or_with_the_queries(env):
     _run(PROVERS, env)
 

@@ -583,3 +583,11 @@ def test_fractal_domain_kernels(gpu, field_name, log_l, log_h):
     import torch
     gpu.set_stream(torch.cuda.current_stream().cuda_stream)
     frc.check_domain_kernels(gpu, torch, torch.device("cuda:0"), field_name, log_l, log_h, samples=(0, 1, 255, 256, 4095, 4096, 70001))
+
+
+def test_half_wavefront_product_keeps_exec(gpu):
+    """gf_mul_halves narrows EXEC to one half of the wavefront at a time inside its asm block and restores it (the block no longer names EXEC on its
+    clobber list): under a divergent branch the products are right, untaken lanes keep their input, and a ballot right after the product sees
+    exactly the lanes that took the branch."""
+    import halves_cases
+    halves_cases.check(gpu, None, count_active=True)

@@ -241,3 +241,10 @@ def test_batched_lde_standard_basis(m, ncoef, batch, cb, cc):
     lib.additive_LDE_batch_dev([p.ctypes.data for p in polys], ncoef, basis, shift, cb, cc, [o.ctypes.data for o in outs])
     for k in range(batch):
         assert np.array_equal(outs[k], oracle.additive_fft(polys[k], basis, shift)[cb << d:(cb + cc) << d]), k
+
+
+def test_half_wavefront_product_under_a_divergent_branch():
+    """gf_mul_halves through its test entry on the CPU build: lanes 0..31 of a wavefront by the first multiplier, lanes 32..63 by the second, only
+    where the branch around the product is taken (the EXEC part of the story is the GPU test's: tests/test_gpu_parity.py)."""
+    import halves_cases
+    halves_cases.check(emu(), None, count_active=False)

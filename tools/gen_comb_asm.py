@@ -185,15 +185,18 @@ __device__ __forceinline__ void comb_clmul_192_uniform(uint32_t (&r)[12], const 
 
 // The product for a wavefront whose HALVES share a multiplier each (lanes 0..31: c, lanes 32..63: d, both in SGPRs): the table of multiples of a is
 // built once for all 64 lanes, the window loop runs twice, under EXEC = the low half with c's windows and under EXEC = the high half with d's
-// (modelled 155 + 2 x 1240 + 140 = 2775 cycles per wave against 3209 for the general product with per-lane multipliers).  Scalar scratch s[%d:%d];
-// EXEC is restored.  Used where a block's butterflies fill half a wavefront: pair bit 3 of the four-polynomial last pass.
+// (modelled 155 + 2 x 1240 + 140 = 2775 cycles per wave against 3209 for the general product with per-lane multipliers).  Scalar scratch s[%d:%d].
+// EXEC: saved on entry, narrowed to one half at a time (an AND with the half: lanes that were inactive on entry stay inactive), restored before the
+// block ends — it holds the same value after the statement as before it, so it is NOT on the clobber list (the compiler, which keeps EXEC reserved,
+// warns about any asm that names it there); tests/test_gpu_parity.py::test_half_wavefront_product_keeps_exec calls the product under a divergent
+// branch with a ballot right after it.  Used where a block's butterflies fill half a wavefront: pair bit 3 of the four-polynomial last pass.
 __device__ __forceinline__ void comb_clmul_192_halves(uint32_t (&r)[12], const uint32_t (&a)[6], const uint32_t (&c)[6], const uint32_t (&d)[6])
 {
     asm volatile(
 %s
         : %s
         : %s
-        : %s, "exec");
+        : %s);
 }
 
 // the CPU emulation of comb_clmul_192_halves runs one lane at a time and must be told which half the lane is in; on the GPU EXEC does that
