@@ -405,13 +405,15 @@ def main():
     # HBM bytes per launch of that kernel: NOT measured in this run (PMC counters need rocprofv3 passes of their own) — taken from the
     # committed PMC run of the same kernels and labelled with its file; null when that run covered other kernel sources
     traffic, traffic_source = None, None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r05_traffic_aurora.json")))
-        if tj.get("log_n") == args.log_n and dom_name in tj.get("kernels", {}) and tj.get("kernel_sources_sha256") == kernel_sources_digest():
-            traffic = tj["kernels"][dom_name]["traffic_bytes_per_launch"]
-            traffic_source = "profiles/r05_traffic_aurora.json (rocprofv3 --pmc passes of this command, collected %s)" % tj.get("collected", "?")
-    except (OSError, ValueError):
-        pass
+    for tname in ("r06_traffic_aurora.json", "r05_traffic_aurora.json"):         # the newest collection whose sources are the ones that run now
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
+            if tj.get("log_n") == args.log_n and dom_name in tj.get("kernels", {}) and tj.get("kernel_sources_sha256") == kernel_sources_digest():
+                traffic = tj["kernels"][dom_name]["traffic_bytes_per_launch"]
+                traffic_source = "profiles/%s (rocprofv3 --pmc passes of this command, collected %s)" % (tname, tj.get("collected", "?"))
+                break
+        except (OSError, ValueError):
+            pass
     # ALU ceiling: the rate measured live in this run (field products of the launches / their HIP-event time) against the VALU-issue
     # ceiling of the kernel's instruction mix (tools/alu_model.py: ISA histogram x per-class cycles measured by tools/ubench/valu_rates)
     products = getattr(lib, "last_profile_products", {})
@@ -614,13 +616,15 @@ def main():
             "kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof5.items(), key=lambda kv: -kv[1][1])[:10]}}
         d5, (c5, ms5, b5) = max(prof5.items(), key=lambda kv: kv[1][1])
         traffic5, traffic5_source = None, None
-        try:          # PMC passes of tools/fractal_bench.py at this size (tools/collect_profiles.sh), quoted only for the kernel sources they ran on
-            tj5 = json.load(open(os.path.join(ROOT, "profiles", "r05_traffic_fractal.json")))
-            if tj5.get("log_n") == args.log_n and d5 in tj5.get("kernels", {}) and tj5.get("kernel_sources_sha256") == kernel_sources_digest():
-                traffic5 = tj5["kernels"][d5]["traffic_bytes_per_launch"]
-                traffic5_source = "profiles/r05_traffic_fractal.json (rocprofv3 --pmc passes of tools/fractal_bench.py --log-n %d, collected %s; averaged over the indexer's and the prover's launches)" % (args.log_n, tj5.get("collected", "?"))
-        except (OSError, ValueError):
-            pass
+        for tname in ("r06_traffic_fractal.json", "r05_traffic_fractal.json"):
+            try:      # PMC passes of tools/fractal_bench.py at this size (tools/collect_profiles.sh), quoted only for the kernel sources they ran on
+                tj5 = json.load(open(os.path.join(ROOT, "profiles", tname)))
+                if tj5.get("log_n") == args.log_n and d5 in tj5.get("kernels", {}) and tj5.get("kernel_sources_sha256") == kernel_sources_digest():
+                    traffic5 = tj5["kernels"][d5]["traffic_bytes_per_launch"]
+                    traffic5_source = "profiles/%s (rocprofv3 --pmc passes of tools/fractal_bench.py --log-n %d, collected %s; averaged over the indexer's and the prover's launches)" % (tname, args.log_n, tj5.get("collected", "?"))
+                    break
+            except (OSError, ValueError):
+                pass
         out["config"]["secondary_fractal"]["roofline"] = {
             "bound": "hbm", "kernel": d5, "launches_per_proof": c5, "avg_launch_ms": ms5 / c5, "algorithmic_bytes_per_launch": b5 / c5 if b5 else None,
             "achieved": (b5 / (ms5 / 1e3) / 1e9) if b5 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (b5 / (ms5 / 1e3) / 1e9 / HBM_PEAK_GBS) if b5 else None,

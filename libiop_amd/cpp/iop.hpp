@@ -76,6 +76,10 @@ class blake2b_hashchain {
     uint8_t state_[32];
     uint64_t squeeze_index_ = 0;
 public:
+    // absorb() never mixes its input in (reference quirk F8), so a challenge is a function of the round structure alone.  bcs_prover relies on that:
+    // it queues the roots' read-backs and builds trees beside the next round (defer_roots / merkle_aside).  A hashchain that really absorbs — the
+    // reference's algebraic sponge chain — must set this to true, which switches both off (bcs_prover::finish_round).
+    static const bool absorbs_input = false;
     blake2b_hashchain() { std::memset(state_, ' ', 32); }                                     // blake2b.tcc:17
     // :50-61 — hashes the first digest_len bytes of state || input: the state advances to BLAKE2b-256(state) whatever is absorbed
     // (reference behaviour F8 of SURVEY.md, reproduced because the verifier does the same)
@@ -661,7 +665,8 @@ private:
                 // ... and nothing else in the next round reads the tree, so its kernels (leaves, levels and the single-workgroup top: 5.7 ms of a
                 // 2^20 proof, 0.9 ms of it latency-bound) go to the library's side stream and run beside the next round's transforms; the query
                 // phase joins.  Not when distributed: the tree's collectives stay in the communicator's one stream order.  IOPX_MERKLE_STREAM=0: main stream.
-                const bool aside = defer_roots() && merkle_aside() && !dist::ctx().active();
+                const bool deferring = defer_roots() && !blake2b_hashchain<FieldT>::absorbs_input;      // a chain that absorbs needs every root before its round's challenges
+                const bool aside = deferring && merkle_aside() && !dist::ctx().active();
                 if (aside) check(iopx_side_stream_begin());
                 struct back_to_main { bool on; ~back_to_main() { if (on) (void)iopx_side_stream_end(); } } section{ aside };
                 MT_trees_[processed_MTs_] = device_merkle_tree(round_oracles, domains_[kv.first], cs);
@@ -669,7 +674,7 @@ private:
                 // bcs/hashing/blake2b.tcc:51-66), so every challenge is a function of the round structure and the prover may go on enqueuing the
                 // next round without waiting for this tree.  The read-back is queued with the query phase's (one drain of the stream for all of
                 // them); IOPX_DEFER_ROOTS=0 reads each root at its round end, as round 4 did (11 drains of about 40 us per 2^20 proof).
-                if (defer_roots()) root_pending_[processed_MTs_] = 1;
+                if (deferring) root_pending_[processed_MTs_] = 1;
                 else MT_roots_[processed_MTs_] = MT_trees_[processed_MTs_].get_root();
             } else {                                                                         // "The Merkle trees are already filled in by the preprocessor."
                 MT_trees_[processed_MTs_] = index_->trees[processed_MTs_];

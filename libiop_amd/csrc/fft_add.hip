@@ -707,12 +707,12 @@ __global__ void __launch_bounds__(256) k_bfly_edge_multi(BfParams p)
             if (k < p.a_low) {                          // level with pair bit k
                 const gf192 t = bf_shift_term(p, coset, p.d - 1 - k);
                 for (int w = 0; w < 3; ++w) sh[3 * k + w] = (uint64_t)t.w[2 * w] | ((uint64_t)t.w[2 * w + 1] << 32);
-            } else {                                    // the small-numerator levels' terms
+            } else if (p.ltab_small) {                  // the small-numerator levels' terms (the host fills rs_small only with the tables: nhi <= 24 then)
                 const size_t gc = p.coset_base + coset;
                 uint32_t y = p.rs_small[0];
-                uint64_t y1 = p.rs_small1[0];
-                for (int v = 0; v < p.nhi; ++v) {
-                    if ((gc >> v) & 1) { y ^= p.rs_small[1 + v]; y1 ^= p.rs_small1[1 + v]; }
+                uint64_t y1 = p.ltab_small1 ? p.rs_small1[0] : 0;
+                for (int v = 0; v < p.nhi && v < 24; ++v) {
+                    if ((gc >> v) & 1) { y ^= p.rs_small[1 + v]; if (p.ltab_small1) y1 ^= p.rs_small1[1 + v]; }
                 }
                 sh[3 * p.a_low] = y;
                 sh[3 * p.a_low + 1] = y1;

@@ -116,10 +116,10 @@ struct MfParams {
     // last pass: windows of the output written beside it — window w holds out[first + k << log_stride], k < 2^(logn - log_stride) — so that a caller
     // that needs the strided head of the codeword (the positions a known-degree interpolation reads, fft.tcc:435-456) does not sweep the codeword
     // again with 24 useful bytes per 128-byte line (k_gather_stride_words moved 3.2 x its useful bytes)
-    int num_win;
-    uint64_t *win_dst[2];
-    uint32_t win_first[2];
-    int win_log_stride[2];
+    // (scalar fields, not arrays: a dynamically indexed member would move the argument block out of SGPRs)
+    uint64_t *win0_dst, *win1_dst;       // null: no such window
+    uint32_t win0_first, win1_first;
+    int win0_log_stride, win1_log_stride;
 };
 
 // R levels starting at global index bit b on 2^R elements per lane (local indices i0 | k << bl).  Level b + lev pairs k with
@@ -153,6 +153,8 @@ __device__ __forceinline__ void mfft_step(uint64_t *s, int E, const MfParams &p,
     }
 }
 
+// WIN: the last pass of a transform that also writes windows of its output (a separate instantiation: the passes without windows keep their registers)
+template<bool WIN>
 __global__ void __launch_bounds__(512) k_mfft_pass(MfParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t iopx_smem[];
@@ -194,9 +196,9 @@ __global__ void __launch_bounds__(512) k_mfft_pass(MfParams p)
         else if (p.scale == 2) v = fp_mul(fp_mul(v, fp_load(p.sc_hi, gi >> 12)), fp_load(p.sc_lo, gi & 4095));
         else if (p.final) v = fp7_canonical(fp7_unpack(v));
         fp_store(p.dst, gi, v);
-        for (int w = 0; w < p.num_win; ++w) {
-            const size_t rel = gi - p.win_first[w];
-            if (gi >= p.win_first[w] && (rel & ((((size_t)1) << p.win_log_stride[w]) - 1)) == 0) fp_store(p.win_dst[w], rel >> p.win_log_stride[w], v);
+        if (WIN) {
+            if (p.win0_dst && (gi & ((((size_t)1) << p.win0_log_stride) - 1)) == p.win0_first) fp_store(p.win0_dst, gi >> p.win0_log_stride, v);
+            if (p.win1_dst && (gi & ((((size_t)1) << p.win1_log_stride) - 1)) == p.win1_first) fp_store(p.win1_dst, gi >> p.win1_log_stride, v);
         }
     }
 }
@@ -446,15 +448,19 @@ static int run_mfft(const uint64_t *cache, const uint64_t *src, size_t n_src, ui
         p.c = ps.c; p.h = ps.h; p.A = ps.A; p.b_lo = ps.b_lo; p.b_hi = ps.b_hi;
         if (i + 1 == passes.size()) {
             p.scale = scale; p.sc_hi = sc_hi; p.sc_lo = sc_lo; p.final = 1;
-            if (windows) { p.num_win = windows->num; for (int w = 0; w < windows->num; ++w) { p.win_dst[w] = windows->dst[w]; p.win_first[w] = windows->first[w]; p.win_log_stride[w] = windows->log_stride[w]; } }
+            if (windows && windows->num > 0) { p.win0_dst = windows->dst[0]; p.win0_first = windows->first[0]; p.win0_log_stride = windows->log_stride[0]; }
+            if (windows && windows->num > 1) { p.win1_dst = windows->dst[1]; p.win1_first = windows->first[1]; p.win1_log_stride = windows->log_stride[1]; }
         }
         const int tbits = ps.c + ps.A;
         const size_t lds = ((size_t)24) << tbits;
         const size_t blocks = (size_t)1 << (logn - tbits);
         const int threads = (1 << tbits) >= 512 ? (1 << tbits) / 8 : 64;          // one radix-8 group per lane and step
-        if (lds > 64 * 1024) IOPX_HIP(hipFuncSetAttribute((const void *)k_mfft_pass, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const bool win = p.win0_dst != nullptr;
+        if (lds > 64 * 1024) IOPX_HIP(hipFuncSetAttribute(win ? (const void *)k_mfft_pass<true> : (const void *)k_mfft_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // algorithmic bytes: the pass reads and writes the 2^logn-element vector once; products: one per radix-2 butterfly of its levels
-        { ProfScope ps_("k_mfft_pass", ((size_t)48) << logn, (((size_t)1 << logn) >> 1) * (size_t)(ps.b_hi >= ps.b_lo ? ps.b_hi - ps.b_lo + 1 : 0)); hipLaunchKernelGGL(k_mfft_pass, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
+        { ProfScope ps_("k_mfft_pass", ((size_t)48) << logn, (((size_t)1 << logn) >> 1) * (size_t)(ps.b_hi >= ps.b_lo ? ps.b_hi - ps.b_lo + 1 : 0));
+          if (win) hipLaunchKernelGGL(k_mfft_pass<true>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p);
+          else hipLaunchKernelGGL(k_mfft_pass<false>, dim3((unsigned)blocks), dim3(threads), lds, stream(), p); }
     }
     IOPX_HIP(hipGetLastError());
     return IOPX_OK;

@@ -32,6 +32,15 @@ def test_integer_only_golden_vectors(gpu):
     golden_cases.check(gpu.additive_FFT, gpu.additive_IFFT, gpu.evaluate_next_f_i_over_entire_domain, gpu.merkle_tree)
 
 
+def test_integer_only_golden_vectors_prime_field(gpu):
+    """tests/golden/edwards_tiny.json: multiplicative FFT / IFFT / known-degree IFFT / folds / a Merkle tree over multiplicative cosets for the 181-bit
+    field, computed with Python integers and hashlib only (tests/golden/make_edwards_tiny.py) — the HIP path against vectors that share no code with the oracle."""
+    import golden_cases_edwards
+    import libiop_amd
+    golden_cases_edwards.check(gpu.multiplicative_FFT, gpu.multiplicative_IFFT, gpu.multiplicative_IFFT_of_known_degree, gpu.multiplicative_evaluate_next_f_i,
+                               lambda o, cs: gpu.merkle_tree(o, cs, domain_type=libiop_amd.DOMAIN_MULTIPLICATIVE))
+
+
 def test_field_mul(gpu):
     a, b = rand_elems(1, 1 << 16, W), rand_elems(2, 1 << 16, W)
     a[0] = 0xFFFFFFFFFFFFFFFF

@@ -2,7 +2,7 @@
 # One GPU-box call for a round's final numbers: the rocprofv3 passes (tools/collect_profiles.sh), their summaries copied into profiles/ so that
 # bench.py quotes the PMC traffic of the sources it runs, then the benches.  Outputs under gpurun_out/ (copy what is to be judged into profiles/).
 set -u
-P=${1:-r05}
+P=${1:-r06}
 bash tools/collect_profiles.sh $P > gpurun_out/${P}_collect.log 2>&1
 for f in traffic_aurora.json traffic_fractal.json sq_aurora.json rocprofv3_bench_aurora2p20.txt rocprofv3_fractal2p20.txt gpu_gaps.txt bench_under_rocprof.json fractal_2p20.json; do
     cp gpurun_out/${P}_$f profiles/${P}_$f

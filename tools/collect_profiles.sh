@@ -5,7 +5,7 @@
 # The profiled commands keep every round's Merkle tree on the main stream (IOPX_MERKLE_STREAM=0, exported here — rocprofv3's own command line stays the
 # program itself): with the trees on the side stream two kernels run at once, and a per-kernel duration or counter would be the pair's.
 set -u
-P=${1:-r05}
+P=${1:-r06}
 R=$PWD
 export TMPDIR=/tmp
 export IOPX_MERKLE_STREAM=0
@@ -22,13 +22,14 @@ rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${P}_fr_prof -- $FR --out $R/g
 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${P}_fr_fetch -- $FR > /dev/null 2> $R/gpurun_out/${P}_fr_fetch.err
 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${P}_fr_write -- $FR > /dev/null 2> $R/gpurun_out/${P}_fr_write.err
 cd $R
-# bench.py also proves a cold first proof, one with the trees on the main stream and one under its own profiler: STEPS + WARM + 3 proofs per command
+# bench.py also proves the warm-up proof of iopx_aurora_instance_warm, a first timed proof, one with the trees on the main stream and one under its own
+# profiler: STEPS + WARM + 4 proofs per command
 python3 tools/rocprof_summary.py $(find gpurun_out/${P}_prof -name "*.db" | head -1) > gpurun_out/${P}_rocprofv3_bench_aurora2p20.txt
 python3 tools/rocprof_summary.py $(find gpurun_out/${P}_fr_prof -name "*.db" | head -1) > gpurun_out/${P}_rocprofv3_fractal2p20.txt
 # GPU idle gaps inside the last proof of the traced run (under the tracer's own per-launch overhead: an upper bound on the unprofiled gaps)
 # (one proof period of the timed loop: from the 4th proof's lincheck kernel to the 5th's)
-python3 tools/gpu_gaps.py gpurun_out/${P}_prof --min-us 30 --period-kernel k_lincheck_add --period-index 4 --histogram > gpurun_out/${P}_gpu_gaps.txt
-python3 tools/make_traffic_json.py gpurun_out/${P}_pmc_fetch gpurun_out/${P}_pmc_write 20 gpurun_out/${P}_traffic_aurora.json --bench-json gpurun_out/${P}_bench_under_rocprof.json --steps $((STEPS + WARM + 3)) > /dev/null
+python3 tools/gpu_gaps.py gpurun_out/${P}_prof --min-us 30 --period-kernel k_lincheck_add --period-index 5 --histogram > gpurun_out/${P}_gpu_gaps.txt
+python3 tools/make_traffic_json.py gpurun_out/${P}_pmc_fetch gpurun_out/${P}_pmc_write 20 gpurun_out/${P}_traffic_aurora.json --bench-json gpurun_out/${P}_bench_under_rocprof.json --steps $((STEPS + WARM + 4)) > /dev/null
 python3 tools/make_traffic_json.py gpurun_out/${P}_fr_fetch gpurun_out/${P}_fr_write 20 gpurun_out/${P}_traffic_fractal.json --bench-json gpurun_out/${P}_fractal_2p20.json --steps 4 --min-ms 0.2 > /dev/null
 python3 tools/make_sq_json.py gpurun_out/${P}_pmc_sq gpurun_out/${P}_sq_aurora.json k_bfly_upperILb0 k_bfly_edge_multiILb0 k_bfly_edge_fwd_batch k_bfly_upperILb1 k_bfly_edge_multiILb1 k_ldt_combine_add_slots k_merkle_leaves_sub24ILi4 k_merkle_leaves_sub24ILi1ELi2 k_merkle_level k_lincheck_add > /dev/null
 rm -rf gpurun_out/${P}_prof gpurun_out/${P}_pmc_fetch gpurun_out/${P}_pmc_write gpurun_out/${P}_pmc_sq gpurun_out/${P}_fr_prof gpurun_out/${P}_fr_fetch gpurun_out/${P}_fr_write
