@@ -102,14 +102,20 @@ def _oracle_prove(k):
     return time.perf_counter() - t0
 
 
-def cpu_baseline_leg(k, all_cores):
-    """Times the oracle prover (test infrastructure: used here as the reported CPU baseline only) on the 2^k-constraint sample."""
+def cpu_baseline_leg(k, all_cores, reps=5):
+    """Times the oracle prover (test infrastructure: used here as the reported CPU baseline only) on the 2^k-constraint sample: one warm-up run, then
+    `reps` timed runs, the median reported."""
     import oracle
-    oracle.block_times()                 # reset
-    t0 = time.perf_counter()
-    ref = oracle.aurora_prove(oracle.FIELD_GF192, k, 15, SEED)
-    cpu_s = time.perf_counter() - t0
-    out = {"transcript": ref, "seconds": cpu_s, "log_n": k, "host": host_description(), "blocks": oracle.block_times()}
+    oracle.aurora_prove(oracle.FIELD_GF192, k, 15, SEED)          # warm-up (page cache, tables)
+    times, ref, blocks = [], None, None
+    for _ in range(max(reps, 1)):
+        oracle.block_times()                 # reset
+        t0 = time.perf_counter()
+        ref = oracle.aurora_prove(oracle.FIELD_GF192, k, 15, SEED)
+        times.append(time.perf_counter() - t0)
+        blocks = oracle.block_times()
+    cpu_s = sorted(times)[len(times) // 2]
+    out = {"transcript": ref, "seconds": cpu_s, "runs_s": [round(t, 4) for t in times], "log_n": k, "host": host_description(), "blocks": blocks}
     if all_cores:
         # not in the reference (it is single-threaded): one independent proof per logical core, all at once — a throughput figure
         import multiprocessing as mp
@@ -218,7 +224,8 @@ def main():
                     help="use the multi-GPU operator set even with one rank (exercises the RCCL calls on a 1-GPU box; run under torch.distributed.run)")
     ap.add_argument("--throughput", action="store_true",
                     help="with --gpus N: N independent proofs, one per rank, no collective (a labelled secondary figure: weak scaling; the default shards ONE proof over the ranks)")
-    ap.add_argument("--cpu-log-n", type=int, default=12, help="size of the CPU-baseline sample (oracle prover); 2^12: about 8 s on one core, 2^13: 17 s")
+    ap.add_argument("--cpu-log-n", type=int, default=11, help="size of the CPU-baseline sample (oracle prover); 2^11: about 4 s per run on one core, 2^12: 8 s")
+    ap.add_argument("--cpu-reps", type=int, default=5, help="timed runs of the CPU-baseline sample after one warm-up run (the median is reported)")
     ap.add_argument("--replay-rank", type=int, default=None,
                     help="with --world N on ONE GPU: time rank R of the N-rank prover alone (collectives completed locally; compute path only) and print that line")
     ap.add_argument("--world", type=int, default=8, help="the world size --replay-rank plays a rank of")
@@ -245,7 +252,7 @@ def main():
     # device prover's for that instance further down, before the number is reported.
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.replay_rank is None:
-        cpu = cpu_baseline_leg(args.cpu_log_n, args.cpu_all_cores)
+        cpu = cpu_baseline_leg(args.cpu_log_n, args.cpu_all_cores, args.cpu_reps)
 
     import torch
     import torch.distributed as dist
@@ -642,9 +649,10 @@ def main():
         inv_k = aurora_transform_inventory(k, params_k.RS_extra_dimensions, params_k.codeword_domain_dim - sum(params_k.localization_parameters))
         ops_k = sum(sum(ref_fft_ops(m)) for _, m in inv_k)
         out["cpu_baseline"] = {"value": ops_k / cpu["seconds"], "unit": "field-ops/s", "cores": 1, "kind": "port",
-                               "sample": "the same prover on a 2^%d-constraint instance (same protocol, rate 1/32, seed): %.2f s on one core, run before the "
-                                         "GPU loop; its transcript equals the device prover's byte for byte (headline_size: the 2^20 instance itself, measured once)" % (k, cpu["seconds"]),
-                               "seconds": cpu["seconds"], "sample_log_n": k, "host": cpu["host"],
+                               "sample": "the same prover on a 2^%d-constraint instance (same protocol, rate 1/32, seed): median %.2f s of %d runs after one warm-up, on one "
+                                         "core, run before the GPU loop; its transcript equals the device prover's byte for byte (headline_size: the 2^20 instance itself, "
+                                         "measured once)" % (k, cpu["seconds"], len(cpu["runs_s"])),
+                               "seconds": cpu["seconds"], "runs_s": cpu["runs_s"], "sample_log_n": k, "host": cpu["host"],
                                # inclusive seconds / calls of the sample under the reference's block names (nested: the FFT wrappers run inside other blocks)
                                "stages_s": {name: {"seconds": round(v[0], 6), "calls": v[1]} for name, v in sorted(cpu["blocks"].items())},
                                # the same prover at the headline size, measured once on this pool's host (not re-run here: 42 minutes of one core)

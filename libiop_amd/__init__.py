@@ -59,7 +59,7 @@ EXPORTED_SYMBOLS = [
     "iopx_side_stream_begin", "iopx_side_stream_end", "iopx_side_stream_join",
     "iopx_aurora_instance_create", "iopx_aurora_example_instance_create", "iopx_aurora_prove", "iopx_aurora_instance_warm", "iopx_aurora_instance_free", "iopx_host_free",
     "iopx_fractal_index", "iopx_fractal_prove",
-    "iopx_memcpy_d2h_deferrable", "iopx_comm_rccl_unique_id", "iopx_comm_create_rccl", "iopx_comm_create_callbacks", "iopx_comm_create_replay", "iopx_comm_is_replay", "iopx_cold_stats", "iopx_cold_add", "iopx_gf192_mul_halves_dev", "iopx_set_option", "iopx_clear_option", "iopx_get_option", "iopx_comm_destroy", "iopx_comm_rank",
+    "iopx_memcpy_d2h_deferrable", "iopx_comm_rccl_unique_id", "iopx_comm_create_rccl", "iopx_comm_create_callbacks", "iopx_comm_create_replay", "iopx_comm_is_replay", "iopx_cold_stats", "iopx_cold_add", "iopx_gf192_mul_halves_dev", "iopx_mul_fft_fp3_windows_dev", "iopx_set_option", "iopx_clear_option", "iopx_get_option", "iopx_comm_destroy", "iopx_comm_rank",
     "iopx_comm_all_gather_dev", "iopx_comm_all_reduce_u64_dev", "iopx_comm_broadcast_dev", "iopx_comm_all_to_all_dev", "iopx_comm_sendrecv_dev", "iopx_comm_stats", "iopx_comm_bind_transforms", "iopx_add_taylor_inv_gf192_dev", "iopx_add_combine_inv_gf192_dev",
     "iopx_interleave_dev", "iopx_gather_rows_dev", "iopx_fri_snark_prove", "iopx_fri_snark_prove_dist", "iopx_add_fft_gf192_dist_dev", "iopx_add_ifft_gf192_dist_dev", "iopx_aurora_prove_dist", "iopx_fractal_index_dist", "iopx_fractal_prove_dist",
 ]

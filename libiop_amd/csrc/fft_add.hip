@@ -42,25 +42,24 @@ static const Tuning &tuning()
     static const Tuning t = [] {
         Tuning u;
         u.tile_bits = env_int("IOPX_TILE_BITS", 11, 4, 12);   // 2048-element tiles: two comb workgroups per CU overlap their load / compute phases
-        u.p1_tile_bits = env_int("IOPX_P1_TILE_BITS", u.tile_bits < 10 ? u.tile_bits : 10, 4, 12);   // phase 1 is latency-bound: smaller tiles, more workgroups per CU
+        u.p1_tile_bits = (u.tile_bits < 10 ? u.tile_bits : 10);   // phase 1 is latency-bound: smaller tiles, more workgroups per CU
         u.p1_cols = env_int("IOPX_P1_COLS", 3, 0, u.p1_tile_bits - 3);  // strided phase-1 tiles: 2^c contiguous columns
         // the last phase-1 pass runs every remaining level inside its tile (multiplier-bound): it may use a larger, narrower tile
         // (2^11 rows since the top levels' twists run on the comb product: five wave-uniform levels instead of four, k_phase1 4.24 -> 4.11 ms per proof)
-        u.p1_fin_tile_bits = env_int("IOPX_P1_FIN_TILE_BITS", u.tile_bits > u.p1_tile_bits ? u.p1_tile_bits + 1 : u.p1_tile_bits, u.p1_tile_bits,
-                                     u.tile_bits > u.p1_tile_bits ? u.tile_bits : u.p1_tile_bits);
-        u.p1_fin_cols = env_int("IOPX_P1_FIN_COLS", 0, 0, u.p1_fin_tile_bits - 3);   // measured: 4.74 -> 4.59 ms at 2^22 with single-element columns
+        u.p1_fin_tile_bits = (u.tile_bits > u.p1_tile_bits ? u.p1_tile_bits + 1 : u.p1_tile_bits);
+        u.p1_fin_cols = (0);   // measured: 4.74 -> 4.59 ms at 2^22 with single-element columns
         // phase-2 upper passes: 2^c contiguous columns.  With c = 6 every row bit of a tile sits at local bit >= 6, so all of a pass's
         // butterflies have wave-uniform twiddles (comb product); c = 4 left the two lowest row bits of each pass on the general product
         // (k_bfly_upper 36.2 -> 33.0 ms per Aurora 2^20 proof, with 96 instead of 65 launches)
         u.p2_cols = env_int("IOPX_P2_COLS", u.tile_bits - 2 < 6 ? u.tile_bits - 2 : 6, 0, u.tile_bits - 2);
         // the edge pass holds the levels whose twiddles are not wave-uniform (pair bits < 6): general multiplier,
         // small tiles for occupancy; 2^p2_top natural-order runs
-        u.edge_tile_bits = env_int("IOPX_EDGE_TILE_BITS", u.tile_bits < 10 ? u.tile_bits : 10, 4, u.tile_bits);
+        u.edge_tile_bits = (u.tile_bits < 10 ? u.tile_bits : 10);
         u.p2_top = env_int("IOPX_P2_TOP", 4, 0, u.edge_tile_bits - 2);
         u.comb = env_int("IOPX_COMB", 1, 0, 1);                         // 1: asm comb multiplier where the twiddle is wave-uniform
-        u.p2_threads = env_int("IOPX_P2_THREADS", u.comb ? 512 : 1024, 64, u.comb ? 512 : 1024);
+        u.p2_threads = (u.comb ? 512 : 1024);
         u.small_last = env_int("IOPX_SMALL_LAST", 1, 0, 1);             // 1: one-word twiddle numerators at the last level where the basis allows
-        u.scratch_mb = env_int("IOPX_SCRATCH_MB", 256, 1, 65536);
+        u.scratch_mb = (256);
         u.rs_comb_cap_log2 = env_int("IOPX_RS_COMB_CAP_LOG2", 22, 0, 30);  // per-coset combined shift terms up to 2^this entries, byte tables beyond
         u.p1_comb = env_int("IOPX_P1_COMB", 1, 0, 1);                   // 1: comb product for the phase-1 twists with a wave-uniform multiplier
         // > 0: the single-polynomial edge passes take this many cosets of one tile position per workgroup (k_bfly_edge_multi): the tile's twiddles
@@ -1163,7 +1162,7 @@ static int launch_phase1_pass(const P1Pass &ps, uint64_t *S, const uint64_t *pow
     p.pow = pow;
     p.d = d_eff; p.c = ps.c; p.h = ps.h; p.A = ps.A;
     p.j0 = ps.j0; p.j1 = ps.j1; p.k_start = ps.k_start; p.k_end = ps.k_end;
-    p.xcd_remap = env_int("IOPX_XCD_REMAP", 1, 0, 1);
+    p.xcd_remap = (1);
     p.comb = tuning().comb && tuning().p1_comb;
     p.extra = ps.extra; p.skip_j0 = ps.skip_j0;
     const int tbits = ps.c + ps.A;
@@ -1359,7 +1358,7 @@ static int run_phase2(AddPlan &pl, const uint64_t *src, uint64_t *dst, int nhi, 
         const size_t lds = ((size_t)24) << (tb + g_bits);
         const size_t blocks = (units + ((size_t)1 << g_bits) - 1) >> g_bits;
         const int elems = 1 << (tb + g_bits);
-        const int maxt = env_int("IOPX_EDGE_THREADS", 256, 64, 1024);
+        const int maxt = (256);
         const int threads = elems >= 4 * maxt ? maxt : (elems >= 256 ? elems / 4 : 64);
         p.src = s; p.dst = dd; p.src_shared = shared;
         p.g_bits = g_bits; p.total_units = units; p.coset_base = cbase;

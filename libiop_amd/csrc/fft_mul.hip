@@ -27,17 +27,9 @@
 
 namespace iopx {
 
-// tile geometry of k_mfft_pass (overridable for tuning runs: IOPX_MF_TILE_BITS, IOPX_MF_COLS)
-static int mf_env(const char *name, int dflt, int lo, int hi)
-{
-    const int x = opt(name, dflt);                 // runtime.h: the options table
-    return x < lo || x > hi ? dflt : x;
-}
-// latched at first use (function-local: the option table of another translation unit must exist by then)
-static int mf_tile_bits() { static const int v = mf_env("IOPX_MF_TILE_BITS", 11, 6, 12); return v; }
-static int mf_cols() { static const int v = mf_env("IOPX_MF_COLS", 4, 0, 6); return v; }
-#define MF_TILE_BITS (mf_tile_bits())
-#define MF_COLS (mf_cols())
+// tile geometry of k_mfft_pass: 2048-element tiles, 16 contiguous columns in the strided passes
+static const int MF_TILE_BITS = 11;
+static const int MF_COLS = 4;
 
 __device__ __forceinline__ fp3 mlds_get(const uint64_t *s, int E, int li)
 {

@@ -364,7 +364,7 @@ static int merkle_blake2b_impl(const void *const *d_oracles, size_t num_oracles,
     if (grid > 65536) grid = 65536;
     {
         // the fixed-shape kernel where it applies (IOPX_MERKLE_FIXED=0: the general one everywhere, for A/B runs and tests of the general path)
-        static const bool fixed_ok = opt("IOPX_MERKLE_FIXED", 1) != 0;         // 0: the general leaf kernel for every shape (tests)
+        const bool fixed_ok = true;
         bool fixed = fixed_ok && elem_bytes == 24 && !d_salts && num_oracles <= 4 && (coset_size == 2 || coset_size == 4) && ((uintptr_t)d_nodes & 15) == 0;
         for (size_t k = 0; fixed && p.additive && k < num_oracles; ++k) fixed = ((uintptr_t)d_oracles[k] & 15) == 0;
         // profile names per shape (oracles x coset size), as tools/make_traffic_json.py derives them from the kernel symbols
@@ -411,8 +411,7 @@ int iopx_merkle_inner_blake2b_dev(uint8_t *d_nodes, size_t num_leaves)
     if (L < 2 || (L & (L - 1))) return fail(IOPX_ERR_INVALID_ARGUMENT, "Merkle tree size must be a power of two, and at least 2.");
     // inner levels: L/2, L/4, ... nodes; the last levels (<= 256 nodes: one wavefront per SIMD of one CU, a level then costs one compression's
     // latency) in one workgroup.  Wider levels take more time inside that workgroup (1024 nodes: four wavefronts per SIMD in turn) than as a launch of their own
-    static const bool vec_ok = opt("IOPX_MERKLE_FIXED", 1) != 0;
-    const bool vec = vec_ok && ((uintptr_t)d_nodes & 15) == 0;
+    const bool vec = ((uintptr_t)d_nodes & 15) == 0;
     size_t count = L / 2;
     while (count > 256) {
         size_t g = (count + 63) / 64;                   // 64 nodes per workgroup at the narrow levels: 1024 nodes spread over 16 CUs

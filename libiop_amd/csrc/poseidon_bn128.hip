@@ -705,7 +705,7 @@ int iopx_merkle_poseidon_bn128_dev(const iopx_poseidon_params *params, const voi
     { ProfScope ps_("k_poseidon_leaves"); if (P.t == 3) hipLaunchKernelGGL(k_poseidon_leaves<3>, dim3(pgrid(L, 64)), dim3(64), 0, stream(), P, p);
       else hipLaunchKernelGGL(k_poseidon_leaves<4>, dim3(pgrid(L, 64)), dim3(64), 0, stream(), P, p); }
     // large levels: one lane per node (throughput); levels of at most 2^14 nodes: one permutation over t lanes (latency)
-    static const int par_from = opt("IOPX_POSEIDON_PAR_BELOW", 1 << 14);
+    static const int par_from = 1 << 14;
     const size_t par_lds = (size_t)2 * P.t * 9 * POSEIDON_PAR_NODES * 4;
     if (P.t == 3) { IOPX_HIP(hipFuncSetAttribute((const void *)k_poseidon_level_par<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)par_lds));
                     IOPX_HIP(hipFuncSetAttribute((const void *)k_poseidon_top_par<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)par_lds)); }
