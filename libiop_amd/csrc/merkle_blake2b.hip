@@ -153,7 +153,7 @@ __global__ void k_merkle_leaves(LeafParams p)
 // The provers' own leaf shapes — NO <= 4 oracles of 24-byte elements, cosets of CS = 2 or 4 positions, no salts — with the
 // serialisation order fixed at compile time: over a subspace a leaf's slice of an oracle is 24 CS contiguous bytes, 16-byte aligned, fetched as
 // 16-byte loads instead of 3 CS strided 8-byte ones; in both cases the cursor arithmetic of the general kernel is gone.  Same bytes into the same
-// compressions (k_merkle_leaves 3.8 -> 2.8 ms per Aurora 2^20 proof; IOPX_MERKLE_FIXED=0 keeps the general kernel).
+// compressions (k_merkle_leaves 3.8 -> 2.8 ms per Aurora 2^20 proof; other shapes — three oracles, cosets of one or eight, salted leaves — take the general kernel).
 typedef uint64_t b2b_u64x2 __attribute__((vector_size(16)));
 
 // ADD = false: cosets of a multiplicative domain, position j of leaf i at i + j L (subgroup.tcc:191-197): 24-byte elements on their own, 8-byte loads.
@@ -363,7 +363,7 @@ static int merkle_blake2b_impl(const void *const *d_oracles, size_t num_oracles,
     size_t grid = (L + 255) / 256;
     if (grid > 65536) grid = 65536;
     {
-        // the fixed-shape kernel where it applies (IOPX_MERKLE_FIXED=0: the general one everywhere, for A/B runs and tests of the general path)
+        // the fixed-shape kernel where it applies
         const bool fixed_ok = true;
         bool fixed = fixed_ok && elem_bytes == 24 && !d_salts && num_oracles <= 4 && (coset_size == 2 || coset_size == 4) && ((uintptr_t)d_nodes & 15) == 0;
         for (size_t k = 0; fixed && p.additive && k < num_oracles; ++k) fixed = ((uintptr_t)d_oracles[k] & 15) == 0;

@@ -600,3 +600,10 @@ def test_half_wavefront_product_keeps_exec(gpu):
     exactly the lanes that took the branch."""
     import halves_cases
     halves_cases.check(gpu, None, count_active=True)
+
+
+def test_membership_proofs_validate_with_hashlib_only(gpu):
+    """tests/bcs/test_merkle_tree.cpp:117-167 on the HIP library: an 8-leaf tree over two oracles and the pruned multi-membership proof of EVERY subset of its
+    leaves, validated by a pure-Python verifier over hashlib (tests/test_independent_pins.py) — no oracle code involved."""
+    import test_independent_pins as pins
+    pins.check_every_subset_validates(gpu)

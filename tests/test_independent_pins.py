@@ -92,7 +92,11 @@ def _validate(root, num_leaves, positions, leaf_digests, aux):
 def test_every_subset_of_an_eight_leaf_tree_validates_independently():
     """tests/bcs/test_merkle_tree.cpp:117-167 (run_multi_test): tree.construct({vec1, vec2}) over 8 positions, every subset of the
     leaves; the tree and the proofs come from the product kernels (CPU build), the leaf digests and the validation from hashlib."""
-    lib = emu()
+    check_every_subset_validates(emu())
+
+
+def check_every_subset_validates(lib):
+    """(also run on the HIP library: tests/test_gpu_parity.py::test_membership_proofs_validate_with_hashlib_only)"""
     L = 8
     vec1, vec2 = rand_elems(11, L, 3), rand_elems(12, L, 3)
     nodes = lib.merkle_tree([vec1, vec2], 1)
