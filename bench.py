@@ -133,10 +133,10 @@ def cpu_baseline_leg(k, all_cores, reps=5):
 
 
 def alu_model():
-    """profiles/r03_alu_model.json (tools/alu_model.py): the VALU-issue ceiling of the butterfly kernels from their ISA and the measured
+    """profiles/r06_alu_model.json (tools/alu_model.py): the VALU-issue ceiling of the butterfly kernels from their ISA and the measured
     per-class instruction costs; None when the file is missing."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r03_alu_model.json")))
+        return json.load(open(os.path.join(ROOT, "profiles", "r06_alu_model.json")))
     except (OSError, ValueError):
         return None
 
@@ -510,7 +510,7 @@ def main():
                      "alu": alu,
                      "note": "frac = algorithmic bytes / HBM peak as the contract asks; the kernel is bound by VALU issue, for which alu_ceiling_frac is the "
                              "figure: measured products/s over the ceiling of the kernel's instruction mix at the per-class issue costs measured on this GPU "
-                             "(profiles/r03_alu_model.json, profiles/r03_valu_rates.txt)",
+                             "(profiles/r06_alu_model.json, profiles/r05_valu_rates.txt)",
                      "kernels_ms_per_step": {k: round(v[1], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
                      "kernel_launches_per_step": {k: v[0] for k, v in prof.items()},
                      "kernel_algorithmic_bytes_per_launch": {k: round(v[2] / v[0]) for k, v in prof.items() if v[2]},

@@ -4,12 +4,12 @@
 For each kernel: the VALU instructions one butterfly executes, by issue class, taken from the compiler's assembly of the hot loop
 (hipcc -S of libiop_amd/csrc/fft_add.hip; instructions inside the comb product's inline-asm block are replaced by the block's
 DYNAMIC count — one of its sixteen window blocks runs per window, so a static count would be 16x too high), priced with the
-per-class issue cost measured by tools/ubench/valu_rates (profiles/r03_valu_rates.txt, 8 waves per SIMD):
+per-class issue cost measured by tools/ubench/valu_rates (profiles/r05_valu_rates.txt, 8 waves per SIMD):
 
     ceiling [products/s] = SIMDs x clock / sum_class(count_class x cycles_class) x 64 lanes
 
 bench.py divides the rate it measures live (field products per launch / HIP-event time) by this ceiling: roofline.alu_ceiling_frac.
-Writes profiles/r03_alu_model.json.  Needs hipcc (cross-compiles without a GPU)."""
+Writes profiles/r06_alu_model.json.  Needs hipcc (cross-compiles without a GPU)."""
 import json
 import os
 import re
@@ -18,8 +18,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIMDS, CLOCK = 1024, 2.4e9
+RATES_FILE = "r05_valu_rates.txt"          # tools/ubench/valu_rates on the MI355X (the newest collection)
 
-# mnemonic -> micro-benchmark line it is priced by (profiles/r03_valu_rates.txt); anything else that starts with v_ is priced as the
+# mnemonic -> micro-benchmark line it is priced by (profiles/r05_valu_rates.txt); anything else that starts with v_ is priced as the
 # slow class and listed under "unmeasured" in the output
 CLASS_OF = {
     "v_xor_b32": "v_xor_b32 (VOP2)", "v_and_b32": "v_and_b32 (VOP2)", "v_or_b32": "v_and_b32 (VOP2)", "v_not_b32": "v_and_b32 (VOP2)",
@@ -35,7 +36,7 @@ SLOW_DEFAULT = "v_alignbit_b32"
 
 def measured_rates():
     rates = {}
-    for line in open(os.path.join(ROOT, "profiles", "r03_valu_rates.txt")):
+    for line in open(os.path.join(ROOT, "profiles", RATES_FILE)):
         m = re.match(r"(.+?)\s+[\d.]+ ms\s+([\d.]+) T lane-ops/s", line)
         if m:
             rates[m.group(1).strip()] = float(m.group(2)) * 1e12
@@ -112,7 +113,7 @@ def classify(body, rates):
         base = re.sub(r"_e32$|_e64$|_sdwa$|_dpp$", "", op)
         if base.startswith("v_"):
             if base == "v_bitop3_b32" and re.search(r",\s*s\d+|,\s*0x", l):
-                # Back to back, an op with an SGPR operand issues at the slow rate (profiles/r03_valu_rates.txt: 37.8 T against 61.9 T).
+                # Back to back, an op with an SGPR operand issues at the slow rate (tools/ubench/valu_rates: 37.8 T against 61.9 T).
                 # Inside the general product it does not: moving every mask into VGPRs (no SGPR operand left, checked in the ISA) changed
                 # the measured product rate by -1.5 % (tools/ubench/comb_rates "general": 4.45e10 -> 4.38e10/s).  So these are priced at
                 # the three-VGPR rate, which makes the ceiling higher (the reported fraction lower) than the pessimistic reading would.
@@ -161,7 +162,7 @@ def main():
     asm = assembly("fft_add.hip")
     out = {"source": "tools/alu_model.py", "clock_hz": CLOCK, "simds": SIMDS,
            "class_cycles_per_wave_instruction": {k: round(cycles_of(v), 3) for k, v in rates.items()},
-           "rates_file": "profiles/r03_valu_rates.txt", "kernels": {}}
+           "rates_file": "profiles/" + RATES_FILE, "kernels": {}}
     comb = comb_dynamic(rates)
     for name, prefix, want_asm in (("k_bfly_upper", "_ZN4iopx12k_bfly_upperILb0ELb1EEE", True), ("k_bfly_edge", "_ZN4iopx11k_bfly_edgeILb0ELb0EEE", False)):
         sym, lines = kernel_body(asm, prefix)
@@ -191,7 +192,7 @@ def main():
         entry["alu_ceiling_products_per_s"] = SIMDS * CLOCK / total_cycles * 64
         out["kernels"][name] = entry
         print(name, "cycles per wave-butterfly %.0f" % total_cycles, "ceiling %.3e products/s" % entry["alu_ceiling_products_per_s"], "unmeasured:", unmeasured)
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r03_alu_model.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", "r06_alu_model.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
