@@ -614,13 +614,47 @@ def main():
         lib.fractal_prove(inst5)                        # stream while it records: every kernel timed alone), for the kernel breakdown
         prof5 = lib.profile_report()
         lib.aurora_instance_free(inst5)
+        # configs[4] names 8 GPUs: ranks 0 and 7 of the residue-class distribution played alone on this GPU (compute path only, as config.rank_replay)
+        fractal_replay = []
+        if not args.no_rank_replay:
+            for w, r in ((8, 0), (8, 7)):
+                rinst = lib.aurora_example_instance(1, n, 0, n - 1, 0x2205)
+                rcomm = lib.comm_create_replay(r, w)
+                try:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    lib.fractal_index_dist(rinst, rcomm)
+                    torch.cuda.synchronize()
+                    index_ms = (time.perf_counter() - t0) * 1e3
+                    for _ in range(2):
+                        lib.fractal_prove_dist(rinst, rcomm)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(4):
+                        lib.fractal_prove_dist(rinst, rcomm)
+                    torch.cuda.synchronize()
+                    ms = (time.perf_counter() - t0) / 4 * 1e3
+                    lib.comm_stats(reset=True)
+                    lib.profile_begin()
+                    lib.fractal_prove_dist(rinst, rcomm)
+                    rprof = lib.profile_report()
+                    calls, payload = lib.comm_stats()
+                    pow_ms = sum(v[1] for k, v in rprof.items() if k.startswith("k_pow_blake2b"))
+                    fractal_replay.append({"world": w, "rank": r, "ms_per_proof": round(ms, 3), "ms_per_proof_pow_adjusted": round(ms - pow_ms * (w - 1) / w, 3),
+                                           "indexer_ms_first_call": round(index_ms, 2), "kernels_ms_total": round(sum(v[1] for v in rprof.values()), 3),
+                                           "kernels_ms": {k: round(v[1], 3) for k, v in sorted(rprof.items(), key=lambda kv: -kv[1][1])[:10]},
+                                           "collectives_per_proof": calls, "collective_payload_bytes_this_rank": payload})
+                finally:
+                    lib.comm_destroy(rcomm)
+                    lib.aurora_instance_free(rinst)
         out["config"]["secondary_fractal"] = {
             "workload": "configs[4] on 1 GPU: Fractal prover, 2^%d-constraint R1CS over the 181-bit field, k=0, codeword 2^%d" % (args.log_n, params5.codeword_domain_dim),
             "prover_ms": sorted(times5[1:])[len(times5[1:]) // 2] * 1e3, "prover_ms_min": min(times5[1:]) * 1e3, "prover_ms_all": [round(t * 1e3, 2) for t in times5], "indexer_ms_first_call": indexer_s * 1e3, "native_indexer_ms": native_indexer_s * 1e3,
             "warm_ms": warm5_s * 1e3 if warm5_s is not None else None, "first_proof_ms": times5[0] * 1e3,
             "prover": "native: iopx_fractal_prove (libiop_amd/cpp/fractal.hpp behind the C ABI); transcript equal to libiop_amd/fractal.py's",
             "argument_bytes": len(tr5), "fri_query_repetitions": params5.fri_query_repetitions,
-            "kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof5.items(), key=lambda kv: -kv[1][1])[:10]}}
+            "kernels_ms": {k: round(v[1], 3) for k, v in sorted(prof5.items(), key=lambda kv: -kv[1][1])[:10]},
+            "rank_replay": fractal_replay}
         d5, (c5, ms5, b5) = max(prof5.items(), key=lambda kv: kv[1][1])
         traffic5, traffic5_source = None, None
         for tname in ("r06_traffic_fractal.json", "r05_traffic_fractal.json"):
