@@ -167,15 +167,18 @@ def device_stages(prof):
 
 
 def headline_cpu_figure():
-    """The oracle prover at the HEADLINE size, measured once on the GPU box's host (tools/cpu_baseline_sizes.py, hours of one core: not repeated per run):
-    profiles/r04_cpu_baseline_sizes.json, with the transcript digest its time was accepted on — the digest the device prover's transcript must hash to."""
-    try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_baseline_sizes.json")))
-        e = next(x for x in j["sizes"] if x["log_n"] == 20)
-        return {"log_n": 20, "prover_seconds": e["prover_seconds"], "field_ops_per_s": e["field_ops_per_s"], "cores": j["cores"], "kind": j["kind"],
-                "host": j["host"], "transcript_blake2b": e["transcript_blake2b"], "source": "profiles/r04_cpu_baseline_sizes.json (tools/cpu_baseline_sizes.py --log-n 20)"}
-    except (OSError, ValueError, KeyError, StopIteration):
-        return None
+    """The oracle prover at the HEADLINE size, measured once per round on the GPU box's host (tools/cpu_baseline_sizes.py, 40 minutes of one core: not repeated per
+    run): profiles/r06_cpu_baseline_sizes.json (r04's when that is missing), with the transcript digest its time was accepted on — the digest the device
+    prover's transcript must hash to."""
+    for name in ("r06_cpu_baseline_sizes.json", "r04_cpu_baseline_sizes.json"):
+        try:
+            j = json.load(open(os.path.join(ROOT, "profiles", name)))
+            e = next(x for x in j["sizes"] if x["log_n"] == 20)
+            return {"log_n": 20, "prover_seconds": e["prover_seconds"], "field_ops_per_s": e["field_ops_per_s"], "cores": j["cores"], "kind": j["kind"],
+                    "host": j["host"], "transcript_blake2b": e["transcript_blake2b"], "source": "profiles/%s (tools/cpu_baseline_sizes.py --log-n 20)" % name}
+        except (OSError, ValueError, KeyError, StopIteration):
+            continue
+    return None
 
 
 def rank_replay(lib, torch, native, params, world, rank, steps=5, warmup=2):
