@@ -1,0 +1,35 @@
+"""Generates tests/golden/reference_over_shim.json (run in the build container: needs /root/reference, libsodium, GMP).
+
+Each entry is what the REFERENCE'S OWN prover — libiop's sources compiled unmodified by tests/harness over a stand-in libff whose field arithmetic
+is this repository's host code — produced for one seeded instance: the BLAKE2b-256 digest and length of its transcript (in the byte form of
+oracle::bcs_transcript::serialize), the index roots of a Fractal run, and that the reference's own verifier accepted.  The oracle and the HIP provers
+are compared with these digests.  What they pin: libiop's protocol logic, run from its own code.  What they do not pin: libff's bytes (the shim is a stand-in)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "tests", "harness"))
+import harness  # noqa: E402
+
+
+def main():
+    why = harness.available()
+    if why:
+        sys.exit(why)
+    harness.build(stubbed=False)
+    entries = []
+    for protocol, field, log_n, k, seed, rs_extra in harness.CASES:
+        r = harness.run("plain", protocol, field, log_n, k, seed, rs_extra)
+        assert r["verifier_accepts"], (protocol, field, log_n)
+        entries.append({"protocol": protocol, "field": field, "log_n": log_n, "num_inputs": k, "seed": seed, "rs_extra": rs_extra, "localization": 2,
+                        "reference_verifier_accepts": True, "transcript_bytes": len(r["transcript"]), "transcript_blake2b": harness.digest(r["transcript"]),
+                        "index_roots": [x.hex() for x in r["index_roots"]]})
+        print(protocol, field, log_n, len(r["transcript"]), entries[-1]["transcript_blake2b"][:16])
+    with open(os.path.join(ROOT, "tests", "golden", "reference_over_shim.json"), "w") as f:
+        json.dump({"generated_by": "tests/golden/make_reference_over_shim.py", "program": "tests/harness/run_reference.cpp over tests/harness/shim",
+                   "entries": entries}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
