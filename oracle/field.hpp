@@ -14,7 +14,9 @@
 // libiop/algebra/fft.tcc:62-70, libiop/algebra/field_subset/subspace.tcc:93-108).
 // Pinning: irreducibility of every modulus and the field axioms are checked in
 // tests/test_oracle_field.py; byte-identity with libff itself is NOT checkable in this image
-// ("parity unpinned" for the libff constants).
+// ("parity unpinned" for the libff constants).  The protocol logic above the fields IS checked against the reference's
+// own code: tests/harness compiles libiop's unmodified sources over a stand-in libff and tests/test_reference_harness.py compares this oracle's
+// Aurora / Fractal transcripts with theirs byte for byte (container only; digests: tests/golden/reference_over_shim.json).
 #pragma once
 #include <chrono>
 #include <cstdint>

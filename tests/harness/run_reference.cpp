@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE ONLY — container-only harness (SURVEY §8(b) last row).
 // Compiles the reference's OWN Aurora prover and verifier straight from /root/reference (nothing copied) over the stand-in libff of tests/harness/shim,
-// runs prover -> verifier (Aurora; Fractal with its indexer) on the seeded instances the parity tests use, and writes the transcript in
+// runs prover -> verifier (Aurora; Fractal with its indexer; Ligero) on the seeded instances the parity tests use, and writes the transcript in
 // the byte form of oracle::bcs_transcript::serialize.  Not the FRI-only SNARK: the reference's dummy_oracle::evaluated_contents returns an EMPTY vector
 // (protocols/encoded/dummy_protocol.tcc:24-29 reserves, then loops to size()), so FRI_snark_prover folds out of bounds — it crashes here.
 #include <cstdio>
@@ -10,6 +10,7 @@
 #include <libff/algebra/curves/edwards/edwards_pp.hpp>
 #include "libiop/snark/aurora_snark.hpp"
 #include "libiop/snark/fractal_snark.hpp"
+#include "libiop/snark/ligero_snark.hpp"
 #include "libiop/relations/examples/r1cs_examples.hpp"
 #include "libiop/bcs/common_bcs_parameters.hpp"
 
@@ -61,7 +62,7 @@ static std::string hex(const std::string &bytes)
 }
 
 struct job {
-    std::string protocol;                 // aurora | fractal
+    std::string protocol;                 // aurora | fractal | ligero
     size_t log_n, k, rs_extra, localization;
     uint64_t seed;
     const char *out_path;
@@ -123,6 +124,22 @@ static int run(const field_subset_type domain_type, const job &j)
         ok = fractal_snark_verifier<FieldT, binary_hash_digest>(index.second, example.primary_input_, proof, parameters);
         bytes = canonical_bytes<FieldT>(proof);
         for (auto &r : index.second.index_MT_roots_) roots += (roots.size() > 1 ? ", \"" : "\"") + hex(r) + "\"";
+    } else if (j.protocol == "ligero") {                                                 // instrument_ligero_snark.cpp:65-130, non-zk; no oracle restates Ligero:
+        r1cs_example<FieldT> example = generate_r1cs_example<FieldT>(n, j.k, m);         // the plain and the stubbed program must agree with each other
+        ligero_snark_parameters<FieldT, binary_hash_digest> parameters;
+        parameters.security_level_ = 128;
+        parameters.LDT_reducer_soundness_type_ = ldt;
+        parameters.height_width_ratio_ = 0.1;
+        parameters.RS_extra_dimensions_ = j.rs_extra;
+        parameters.make_zk_ = false;
+        parameters.domain_type_ = domain_type;
+        parameters.bcs_params_ = default_bcs_params<FieldT, binary_hash_digest>(blake2b_type, 128, j.log_n);
+        begin_kernel_count();
+        const ligero_snark_argument<FieldT, binary_hash_digest> proof =
+            ligero_snark_prover<FieldT, binary_hash_digest>(example.constraint_system_, example.primary_input_, example.auxiliary_input_, parameters);
+        launches = end_kernel_count();
+        ok = ligero_snark_verifier<FieldT, binary_hash_digest>(example.constraint_system_, example.primary_input_, proof, parameters);
+        bytes = canonical_bytes<FieldT>(proof);
     } else {
         fprintf(stderr, "unknown protocol %s\n", j.protocol.c_str());
         return 2;
@@ -135,7 +152,7 @@ static int run(const field_subset_type domain_type, const job &j)
 
 int main(int argc, char **argv)
 {
-    if (argc < 9) { fprintf(stderr, "usage: %s aurora|fractal gf192|edwards_Fr log_n num_inputs seed rs_extra localization out.bin\n", argv[0]); return 2; }
+    if (argc < 9) { fprintf(stderr, "usage: %s aurora|fractal|ligero gf192|edwards_Fr log_n num_inputs seed rs_extra localization out.bin\n", argv[0]); return 2; }
     job j;
     j.protocol = argv[1];
     const std::string field = argv[2];

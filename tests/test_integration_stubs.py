@@ -1,13 +1,14 @@
 """The reference-side stubs of INTEGRATION.md, compiled and run.
 
-libiop itself cannot be compiled here (its headers include libff, an empty submodule; no stand-ins are written), so the stubs — explicit specialisations
+This file needs nothing of the reference tree (it runs wherever the CPU suite runs; tests/test_reference_harness.py compiles the same text into libiop itself
+where /root/reference exists).  The stubs — explicit specialisations
 of libiop's function templates for libff::gf192 / libff::edwards_Fr — are compiled VERBATIM (code blocks cut out of INTEGRATION.md, minus the two
 #include lines) against the nearest thing that can be: `namespace libiop` holding the mirror classes of libiop_amd/cpp/libiop_amd.hpp, whose member
 declarations tests/test_reference_signatures.py compares with the reference's header text, and the reference's primary templates DECLARED with the
 reference's signatures (fft.hpp:28-52, fri_aux.tcc:36-41,106-111); libff::gf192 / edwards_Fr = the plain 24-byte types of cpp/fields.hpp.  The program
 then calls every stub and compares with the mirror's own functions on the CPU build of the kernels.  What this shows: the documented binding is
 well-formed against classes with the reference's declarations (an `&domain.shift()` does not compile here: shift() is a prvalue) and forwards correctly.
-What it does not show: libiop's own code compiled against it."""
+libiop's own code compiled against the stubs: tests/harness."""
 import os
 import re
 import subprocess

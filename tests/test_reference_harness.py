@@ -73,6 +73,21 @@ def test_the_references_prover_calls_the_kernels_through_the_documented_stubs(ca
         assert ran.get(k, 0) > 0, (k, ran)
 
 
+@pytest.mark.parametrize("field,log_n", [("gf192", 8), ("edwards_Fr", 9)])
+def test_ligero_calls_the_kernels_unchanged_too(field, log_n, built):
+    """north_star: "Aurora/Fractal/Ligero call it unchanged".  No oracle restates Ligero, so the two programs are compared with each other: the reference's
+    Ligero prover (instrument_ligero_snark.cpp's settings, non-zk) with the stubs compiled in produces the transcript the plain one does, its transforms,
+    tree, combination and proof of work having run in the kernel library, and the reference's verifier accepts."""
+    plain = harness.run("plain", "ligero", field, log_n, 15, 0x2206, 2)
+    stubbed = harness.run("stubbed", "ligero", field, log_n, 15, 0x2206, 2)
+    assert plain["verifier_accepts"] and stubbed["verifier_accepts"]
+    assert plain["transcript"] == stubbed["transcript"] and len(plain["transcript"]) > 10000
+    ran = stubbed["kernel_launches_in_prover"]
+    for k in (("k_phase1_fwd", "k_phase1_inv") if field == "gf192" else ("k_mfft_pass",)) + ("k_merkle_leaves", "k_pow_blake2b"):
+        assert ran.get(k, 0) > 0, (k, ran)
+    assert plain["kernel_launches_in_prover"] == {}
+
+
 def test_the_compiled_stub_text_is_integration_md(built):
     with open(os.path.join(harness.ROOT, "INTEGRATION.md")) as f:
         md = f.read()
