@@ -29,7 +29,24 @@ def main():
     with open(os.path.join(ROOT, "tests", "golden", "reference_over_shim.json"), "w") as f:
         json.dump({"generated_by": "tests/golden/make_reference_over_shim.py", "program": "tests/harness/run_reference.cpp over tests/harness/shim",
                    "entries": entries}, f, indent=1)
+    functions()
+
+
+def functions():
+    """tests/golden/reference_functions.json: tests/harness/reference_vectors.cpp's lines (the reference's own functions on seeded inputs)."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-j4", "-C", harness.HERE, "_build/reference_vectors"])
+    out = subprocess.run([os.path.join(harness.HERE, "_build", "reference_vectors")], capture_output=True, text=True, check=True).stdout
+    entries = [json.loads(line) for line in out.splitlines() if line.startswith("{")]
+    with open(os.path.join(ROOT, "tests", "golden", "reference_functions.json"), "w") as f:
+        f.write('{"generated_by": "tests/golden/make_reference_over_shim.py", "program": "tests/harness/reference_vectors.cpp over tests/harness/shim",\n "entries": [\n')
+        f.write(",\n".join(json.dumps(e) for e in entries))
+        f.write("\n]}\n")
+    print(len(entries), "function-level vectors")
 
 
 if __name__ == "__main__":
+    if "--functions-only" in sys.argv:
+        functions()
+        sys.exit(0)
     main()

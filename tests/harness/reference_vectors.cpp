@@ -1,0 +1,207 @@
+// TEST INFRASTRUCTURE ONLY — container-only (tests/harness).  Calls the REFERENCE'S OWN functions (compiled from /root/reference over the stand-in libff of
+// shim/) on seeded inputs and prints one JSON object per line: the case's parameters and the BLAKE2b-256 digest of the output bytes.  The lines become
+// tests/golden/reference_functions.json (tests/golden/make_reference_over_shim.py); the oracle, the CPU build of the kernels and the HIP kernels are
+// checked against them (tests/reference_function_cases.py).  Inputs: element i of the stream seeded with s = SplitMix64 outputs 3 i .. 3 i + 2
+// (libiop_amd/r1cs.py seeded_elements), so both sides build them from the seed alone.
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include <sodium.h>
+#include <libff/algebra/fields/binary/gf192.hpp>
+#include <libff/algebra/curves/edwards/edwards_pp.hpp>
+#include "libiop/algebra/fft.hpp"
+#include "libiop/protocols/ldt/fri/fri_aux.hpp"
+#include "libiop/protocols/ldt/ldt_reducer_aux.hpp"
+#include "libiop/bcs/merkle_tree.hpp"
+#include "libiop/bcs/hashing/hash_enum.hpp"
+#include "libiop/bcs/pow.hpp"
+
+using namespace libiop;
+
+namespace libff {
+gf192 gf192::multiplicative_generator = gf192(2);
+bigint<3> edwards_Fr::mod;
+edwards_Fr edwards_Fr::multiplicative_generator, edwards_Fr::root_of_unity;
+bool inhibit_profiling_info = true, inhibit_profiling_counters = true;
+}
+
+template<typename FieldT> static std::vector<FieldT> seeded(uint64_t seed, size_t n)
+{
+    FieldT::seed_random(seed);
+    std::vector<FieldT> v;
+    for (size_t i = 0; i < n; ++i) v.push_back(FieldT::random_element());
+    return v;
+}
+static std::string digest(const void *p, size_t n)
+{
+    unsigned char d[32];
+    crypto_generichash_blake2b(d, 32, (const unsigned char *)p, n, nullptr, 0);
+    static const char *hx = "0123456789abcdef";
+    std::string s;
+    for (unsigned char c : d) { s.push_back(hx[c >> 4]); s.push_back(hx[c & 15]); }
+    return s;
+}
+template<typename FieldT> static std::string digest(const std::vector<FieldT> &v) { return digest(v.data(), v.size() * sizeof(FieldT)); }
+
+// ---- GF(2^192) over affine subspaces.  kind: 0 standard basis, shift 0; 1 standard basis, shift x^m (Aurora's codeword domain); 2 standard basis, seeded
+// shift; 3 seeded basis and shift.  Basis = seeded(seed + 1, m), shift = seeded(seed + 2, 1)[0].
+static affine_subspace<libff::gf192> subspace(size_t m, int kind, uint64_t seed)
+{
+    typedef libff::gf192 F;
+    std::vector<F> basis;
+    for (size_t i = 0; i < m; ++i) basis.push_back(i < 64 ? F((uint64_t)1 << i) : F(0));
+    F shift = F(0);
+    if (kind == 1) shift = F((uint64_t)1 << m);
+    if (kind >= 2) shift = seeded<F>(seed + 2, 1)[0];
+    if (kind == 3) basis = seeded<F>(seed + 1, m);
+    return affine_subspace<F>(basis, shift);
+}
+
+static void additive_cases()
+{
+    typedef libff::gf192 F;
+    uint64_t seed = 0x5100;
+    for (size_t m = 1; m <= 11; ++m)
+        for (int kind = 0; kind < 4; ++kind) {
+            const affine_subspace<F> S = subspace(m, kind, seed);
+            const size_t n = (size_t)1 << m;
+            for (size_t ncoeffs : { n, n - (n > 2 ? 3 : 1), (size_t)1 }) {
+                if (ncoeffs == 0 || (ncoeffs != n && (m % 3) != 1)) continue;
+                const std::vector<F> out = additive_FFT<F>(seeded<F>(seed, ncoeffs), S);
+                printf("{\"case\": \"additive_fft\", \"m\": %zu, \"kind\": %d, \"ncoeffs\": %zu, \"seed\": %llu, \"digest\": \"%s\"}\n", m, kind, ncoeffs, (unsigned long long)seed, digest(out).c_str());
+            }
+            const std::vector<F> back = additive_IFFT<F>(seeded<F>(seed, n), S);
+            printf("{\"case\": \"additive_ifft\", \"m\": %zu, \"kind\": %d, \"seed\": %llu, \"digest\": \"%s\"}\n", m, kind, (unsigned long long)seed, digest(back).c_str());
+            if (m >= 3 && kind != 2) {                                              // evaluations of a polynomial of degree < 2^(m-2), then the known-degree inverse
+                const size_t degree = n >> 2;
+                const std::vector<F> evals = additive_FFT<F>(seeded<F>(seed, degree), S);
+                const std::vector<F> coeffs = IFFT_of_known_degree_over_field_subset<F>(evals, degree, field_subset<F>(S));
+                printf("{\"case\": \"additive_ifft_known_degree\", \"m\": %zu, \"kind\": %d, \"degree\": %zu, \"seed\": %llu, \"digest\": \"%s\"}\n", m, kind, degree, (unsigned long long)seed, digest(coeffs).c_str());
+            }
+            for (size_t c : { (size_t)2, (size_t)4, (size_t)8 }) {                 // FRI folds; x_in = 1: the challenge is a point of the domain
+                if (c >= n || (kind == 2 && c != 4)) continue;
+                for (int x_in = 0; x_in < 2; ++x_in) {
+                    if (x_in && (m % 2)) continue;
+                    const auto f = std::make_shared<std::vector<F>>(seeded<F>(seed, n));
+                    const F x = x_in ? S.element_by_index(n / 3) : seeded<F>(seed + 3, 1)[0];
+                    const auto next = evaluate_next_f_i_over_entire_domain<F>(f, field_subset<F>(S), c, x);
+                    printf("{\"case\": \"additive_fold\", \"m\": %zu, \"kind\": %d, \"coset_size\": %zu, \"x_in_domain\": %d, \"seed\": %llu, \"digest\": \"%s\"}\n", m, kind, c, x_in,
+                           (unsigned long long)seed, digest(*next).c_str());
+                }
+            }
+            ++seed;
+        }
+    // combined_LDT_virtual_oracle::evaluated_contents: oracles of maximal and submaximal degree over Aurora-style and seeded domains
+    for (size_t m : { (size_t)6, (size_t)9 })
+        for (int kind : { 1, 3 }) {
+            const affine_subspace<F> S = subspace(m, kind, seed);
+            const size_t n = (size_t)1 << m;
+            const std::vector<size_t> degrees = { n / 4, n / 8, n / 4 - 3, 5, n / 4 };
+            combined_LDT_virtual_oracle<F> combined(field_subset<F>(S), degrees);
+            combined.set_random_coefficients(seeded<F>(seed + 4, 2 * degrees.size()));
+            std::vector<std::shared_ptr<std::vector<F>>> constituents;
+            for (size_t k = 0; k < degrees.size(); ++k) constituents.push_back(std::make_shared<std::vector<F>>(seeded<F>(seed + 10 + k, n)));
+            const auto out = combined.evaluated_contents(constituents);
+            printf("{\"case\": \"additive_ldt_combine\", \"m\": %zu, \"kind\": %d, \"seed\": %llu, \"digest\": \"%s\"}\n", m, kind, (unsigned long long)seed, digest(*out).c_str());
+            ++seed;
+        }
+}
+
+// ---- edwards_Fr over multiplicative cosets.  kind: 0 the subgroup (shift 1); 1 shift = the field's generator (Aurora's codeword domain); 2 seeded shift.
+static libff::edwards_Fr coset_shift(int kind, uint64_t seed)
+{
+    typedef libff::edwards_Fr F;
+    return kind == 0 ? F::one() : kind == 1 ? F::multiplicative_generator : seeded<F>(seed + 2, 1)[0];
+}
+
+static void multiplicative_cases()
+{
+    typedef libff::edwards_Fr F;
+    uint64_t seed = 0x5200;
+    for (size_t m = 1; m <= 11; ++m)
+        for (int kind = 0; kind < 3; ++kind) {
+            const size_t n = (size_t)1 << m;
+            const F shift = coset_shift(kind, seed);
+            const multiplicative_coset<F> C(n, shift);
+            for (size_t ncoeffs : { n, n - (n > 2 ? 3 : 1), n / 2 + 1, (size_t)1 }) {
+                if (ncoeffs == 0 || ncoeffs > n || (ncoeffs != n && (m % 3) != 1)) continue;
+                const std::vector<F> out = multiplicative_FFT<F>(seeded<F>(seed, ncoeffs), C);
+                printf("{\"case\": \"multiplicative_fft\", \"m\": %zu, \"kind\": %d, \"ncoeffs\": %zu, \"seed\": %llu, \"digest\": \"%s\"}\n", m, kind, ncoeffs, (unsigned long long)seed, digest(out).c_str());
+            }
+            const std::vector<F> back = multiplicative_IFFT<F>(seeded<F>(seed, n), C);
+            printf("{\"case\": \"multiplicative_ifft\", \"m\": %zu, \"kind\": %d, \"seed\": %llu, \"digest\": \"%s\"}\n", m, kind, (unsigned long long)seed, digest(back).c_str());
+            if (m >= 3) {
+                const size_t degree = n >> 2;
+                const std::vector<F> evals = multiplicative_FFT<F>(seeded<F>(seed, degree), C);
+                const std::vector<F> coeffs = IFFT_of_known_degree_over_field_subset<F>(evals, degree, field_subset<F>(C));
+                printf("{\"case\": \"multiplicative_ifft_known_degree\", \"m\": %zu, \"kind\": %d, \"degree\": %zu, \"seed\": %llu, \"digest\": \"%s\"}\n", m, kind, degree, (unsigned long long)seed, digest(coeffs).c_str());
+            }
+            for (size_t c : { (size_t)2, (size_t)4, (size_t)8 }) {
+                if (c >= n) continue;
+                const auto f = std::make_shared<std::vector<F>>(seeded<F>(seed, n));
+                const F x = seeded<F>(seed + 3, 1)[0];
+                const auto next = evaluate_next_f_i_over_entire_domain<F>(f, field_subset<F>(C), c, x);
+                printf("{\"case\": \"multiplicative_fold\", \"m\": %zu, \"kind\": %d, \"coset_size\": %zu, \"seed\": %llu, \"digest\": \"%s\"}\n", m, kind, c, (unsigned long long)seed, digest(*next).c_str());
+            }
+            ++seed;
+        }
+    for (size_t m : { (size_t)6, (size_t)9 })
+        for (int kind : { 1, 2 }) {
+            const size_t n = (size_t)1 << m;
+            const multiplicative_coset<F> C(n, coset_shift(kind, seed));
+            const std::vector<size_t> degrees = { n / 4, n / 8, n / 4 - 3, 5, n / 4 };
+            combined_LDT_virtual_oracle<F> combined(field_subset<F>(C), degrees);
+            combined.set_random_coefficients(seeded<F>(seed + 4, 2 * degrees.size()));
+            std::vector<std::shared_ptr<std::vector<F>>> constituents;
+            for (size_t k = 0; k < degrees.size(); ++k) constituents.push_back(std::make_shared<std::vector<F>>(seeded<F>(seed + 10 + k, n)));
+            const auto out = combined.evaluated_contents(constituents);
+            printf("{\"case\": \"multiplicative_ldt_combine\", \"m\": %zu, \"kind\": %d, \"seed\": %llu, \"digest\": \"%s\"}\n", m, kind, (unsigned long long)seed, digest(*out).c_str());
+            ++seed;
+        }
+}
+
+// ---- BLAKE2b Merkle trees with leaves serialised by cosets (non-zk: the salts of a zk tree are libsodium's), and the proof-of-work grind
+template<typename FieldT>
+static void tree_and_pow_cases(const char *field, uint64_t seed)
+{
+    for (size_t log_n : { (size_t)5, (size_t)10 })
+        for (size_t r : { (size_t)1, (size_t)3, (size_t)4 })
+            for (size_t c : { (size_t)1, (size_t)2, (size_t)4, (size_t)8 }) {
+                if (r == 3 && c == 8) continue;
+                const size_t n = (size_t)1 << log_n, L = n / c;
+                merkle_tree<FieldT, binary_hash_digest> tree(L, get_leafhash<FieldT, binary_hash_digest>(blake2b_type, 128, r * c),
+                                                             get_two_to_one_hash<binary_hash_digest, FieldT>(blake2b_type, 128), 32, false, 128);
+                std::vector<std::shared_ptr<std::vector<FieldT>>> columns;
+                for (size_t k = 0; k < r; ++k) columns.push_back(std::make_shared<std::vector<FieldT>>(seeded<FieldT>(seed + k, n)));
+                tree.construct_with_leaves_serialized_by_cosets(columns, c);
+                const binary_hash_digest root = tree.get_root();
+                std::string hexroot;
+                static const char *hx = "0123456789abcdef";
+                for (unsigned char ch : root) { hexroot.push_back(hx[ch >> 4]); hexroot.push_back(hx[ch & 15]); }
+                printf("{\"case\": \"merkle_root\", \"field\": \"%s\", \"log_n\": %zu, \"oracles\": %zu, \"coset_size\": %zu, \"seed\": %llu, \"digest\": \"%s\"}\n", field, log_n, r, c,
+                       (unsigned long long)seed, hexroot.c_str());
+                seed += 8;
+            }
+    for (size_t work : { (size_t)4, (size_t)9, (size_t)14 }) {
+        const pow_parameters params(work, 1);
+        const libiop::pow<FieldT, binary_hash_digest> grinder(params, 32);
+        const two_to_one_hash_function<binary_hash_digest> node_hasher = get_two_to_one_hash<binary_hash_digest, FieldT>(blake2b_type, 128);
+        const std::vector<libff::gf192> words = seeded<libff::gf192>(seed, 2);
+        const binary_hash_digest challenge((const char *)words.data(), 32);
+        const binary_hash_digest answer = grinder.solve_pow(node_hasher, challenge);
+        printf("{\"case\": \"pow\", \"field\": \"%s\", \"work_parameter\": %zu, \"bitlen\": %zu, \"seed\": %llu, \"digest\": \"%s\"}\n", field, work, params.pow_bitlen(), (unsigned long long)seed,
+               digest(answer.data(), answer.size()).c_str());
+        ++seed;
+    }
+}
+
+int main()
+{
+    libff::edwards_pp::init_public_params();
+    additive_cases();
+    multiplicative_cases();
+    tree_and_pow_cases<libff::gf192>("gf192", 0x5300);
+    tree_and_pow_cases<libff::edwards_Fr>("edwards_Fr", 0x5400);
+    return 0;
+}

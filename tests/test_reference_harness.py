@@ -109,3 +109,15 @@ def test_the_committed_digests_are_what_the_reference_program_produces(built):
     for e in entries[:3] + entries[7:8]:
         r = harness.run("plain", e["protocol"], e["field"], e["log_n"], e["num_inputs"], e["seed"], e["rs_extra"])
         assert harness.digest(r["transcript"]) == e["transcript_blake2b"] and len(r["transcript"]) == e["transcript_bytes"]
+
+
+def test_the_committed_function_vectors_are_what_the_references_functions_produce(built):
+    """tests/golden/reference_functions.json == the lines tests/harness/reference_vectors.cpp prints today (libiop's own FFTs, folds, trees, ... on the seeds)."""
+    import json
+    import subprocess
+    subprocess.check_call(["make", "-s", "-j4", "-C", harness.HERE, "_build/reference_vectors"])
+    out = subprocess.run([os.path.join(harness.HERE, "_build", "reference_vectors")], capture_output=True, text=True, check=True).stdout
+    now = [json.loads(line) for line in out.splitlines() if line.startswith("{")]
+    with open(os.path.join(harness.ROOT, "tests", "golden", "reference_functions.json")) as f:
+        committed = json.load(f)["entries"]
+    assert now == committed and len(now) > 500
