@@ -55,3 +55,35 @@ def run(variant, protocol, field, log_n, num_inputs, seed, rs_extra, localizatio
 
 def digest(b):
     return hashlib.blake2b(b, digest_size=32).hexdigest()
+
+
+# libiop's own test files run as programs (tests/harness/Makefile REFTESTS); the default subset keeps the CPU suite short, IOPX_REFTESTS=all runs the 34
+REFTESTS_DEFAULT = ["algebra/test_fft", "protocols/test_fri_aux", "protocols/test_aurora_protocol", "protocols/test_direct_ldt", "bcs/test_merkle_tree"]
+
+
+def reftests():
+    if os.environ.get("IOPX_REFTESTS") == "all":
+        out = subprocess.run(["make", "-s", "-C", HERE, "-pn"], capture_output=True, text=True).stdout
+        for line in out.splitlines():
+            if line.startswith("REFTESTS :="):
+                return line.split(":=")[1].split()
+    return list(REFTESTS_DEFAULT)
+
+
+def build_reftest(name, variant="stubbed"):
+    subprocess.check_call(["make", "-s", "-C", HERE, "_build/reftests/%s/%s" % (variant, name)])
+
+
+def run_reftest(name, variant="stubbed"):
+    """-> (tests run, tests passed, {kernel: launches}, tail of the output)"""
+    r = subprocess.run([os.path.join(HERE, "_build", "reftests", variant, name)], capture_output=True, text=True, timeout=1800)
+    lines = r.stdout.splitlines()
+    ran = sum(1 for l in lines if l.startswith("[ RUN "))
+    ok = sum(1 for l in lines if l.startswith("[       OK ]"))
+    kernels = {}
+    if "[ KERNELS  ]" in r.stdout:
+        for l in r.stdout.split("[ KERNELS  ]")[1].split("[ /KERNELS ]")[0].splitlines():
+            parts = l.split()
+            if len(parts) >= 2 and parts[0].startswith("k_"):
+                kernels[parts[0]] = int(parts[1])
+    return ran, ok, kernels, (r.stdout[-600:] + r.stderr[-600:]) if r.returncode else ""

@@ -22,12 +22,6 @@
 
 using namespace libiop;
 
-namespace libff {
-gf192 gf192::multiplicative_generator = gf192(2);
-bigint<3> edwards_Fr::mod;
-edwards_Fr edwards_Fr::multiplicative_generator, edwards_Fr::root_of_unity;
-bool inhibit_profiling_info = true, inhibit_profiling_counters = true;
-}
 
 template<typename FieldT>
 static std::vector<uint8_t> canonical_bytes(const bcs_transformation_transcript<FieldT, binary_hash_digest> &t)

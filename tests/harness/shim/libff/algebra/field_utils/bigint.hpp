@@ -14,6 +14,15 @@ public:
     mp_limb_t data[n];
     bigint() { std::memset(data, 0, sizeof(data)); }
     bigint(const unsigned long x) { std::memset(data, 0, sizeof(data)); data[0] = x; }
+    bigint(const char *decimal)                              // libff: a decimal string (Poseidon's constants)
+    {
+        std::memset(data, 0, sizeof(data));
+        mpz_t v;
+        mpz_init_set_str(v, decimal, 10);
+        size_t count = 0;
+        mpz_export(data, &count, -1, sizeof(mp_limb_t), 0, 0, v);
+        mpz_clear(v);
+    }
     bool operator==(const bigint<n> &o) const { return std::memcmp(data, o.data, sizeof(data)) == 0; }
     bool operator!=(const bigint<n> &o) const { return !(*this == o); }
     void clear() { std::memset(data, 0, sizeof(data)); }

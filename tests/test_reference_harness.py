@@ -121,3 +121,18 @@ def test_the_committed_function_vectors_are_what_the_references_functions_produc
     with open(os.path.join(harness.ROOT, "tests", "golden", "reference_functions.json")) as f:
         committed = json.load(f)["entries"]
     assert now == committed and len(now) > 500
+
+
+@pytest.mark.parametrize("name", harness.reftests())
+def test_the_references_own_test_files_pass_with_the_kernels_underneath(name, built):
+    """libiop's own test files (libiop/tests/*/test_*.cpp), unmodified, compiled as programs with the stubs of INTEGRATION.md in force (googletest replaced by
+    tests/harness/shim/gtest/gtest.h, tests_prelude.hpp force-included ahead of the test's text): every TEST passes, and the multiplicative ones ran their
+    transforms in the kernel library.  Default: five programs; IOPX_REFTESTS=all: the 34 of tests/harness/Makefile (145 tests, recorded in
+    profiles/r06_reference_own_tests_{plain,stubbed}.json)."""
+    harness.build_reftest(name)
+    ran, ok, kernels, tail = harness.run_reftest(name)
+    assert ran > 0 and ok == ran, (name, ran, ok, tail)
+    if name in ("algebra/test_fft", "protocols/test_aurora_protocol", "protocols/test_direct_ldt"):
+        assert kernels.get("k_mfft_pass", 0) > 0, kernels
+    if name == "protocols/test_fri_aux":
+        assert kernels.get("k_fri_fold_fused_mul_eta2", 0) > 0, kernels
