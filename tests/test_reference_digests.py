@@ -23,7 +23,7 @@ def test_the_references_own_prover_at_baseline_sizes_equals_the_oracle_goldens()
     import json
     import os
     large = {(e["protocol"], e["field"], e["log_n"]): e for e in __import__("json").load(open(os.path.join(rc.ROOT, "tests", "golden", "reference_over_shim.json")))["large_entries"]}
-    assert ("fractal", "edwards_Fr", 20) in large and ("aurora", "gf192", 18) in large
+    assert ("fractal", "edwards_Fr", 20) in large and ("aurora", "gf192", 20) in large        # BASELINE configs[4] and configs[3] (the headline), one process
     with open(os.path.join(rc.ROOT, "tests", "golden", "oracle_aurora_transcript_digests_large.json")) as f:
         aurora = json.load(f)["digests"]
     with open(os.path.join(rc.ROOT, "tests", "golden", "oracle_fractal_transcript_digests_large.json")) as f:
