@@ -20,6 +20,15 @@
 using namespace libiop;
 
 
+// libsodium's randombytes_buf, interposed (this program's definition is the one libiop's code in this program binds to): the zk salts of a Merkle tree become
+// the bytes of the SplitMix64 stream seeded with g_salt_seed — word j little endian at bytes 8 j .. 8 j + 7 — so that a zk tree is reproducible from a seed
+static uint64_t g_salt_seed = 0, g_salt_pos = 0;
+extern "C" void randombytes_buf(void *const buf, const size_t size)
+{
+    for (size_t i = 0; i < size; ++i, ++g_salt_pos)
+        ((unsigned char *)buf)[i] = (unsigned char)(libff::gf192::splitmix64_at(g_salt_seed, g_salt_pos / 8) >> (8 * (g_salt_pos % 8)));
+}
+
 template<typename FieldT> static std::vector<FieldT> seeded(uint64_t seed, size_t n)
 {
     FieldT::seed_random(seed);
@@ -177,6 +186,24 @@ static void tree_and_pow_cases(const char *field, uint64_t seed)
                        (unsigned long long)seed, hexroot.c_str());
                 seed += 8;
             }
+    // zk trees: leaf = H(H(slice) || salt) (blake2b.tcc:126-136), salt i = bytes 32 i .. 32 i + 31 of the interposed stream seeded with seed + 100
+    for (size_t r : { (size_t)1, (size_t)4 })
+        for (size_t c : { (size_t)1, (size_t)2, (size_t)4 }) {
+            const size_t log_n = 8, n = (size_t)1 << log_n, L = n / c;
+            merkle_tree<FieldT, binary_hash_digest> tree(L, get_leafhash<FieldT, binary_hash_digest>(blake2b_type, 128, r * c),
+                                                         get_two_to_one_hash<binary_hash_digest, FieldT>(blake2b_type, 128), 32, true, 128);
+            std::vector<std::shared_ptr<std::vector<FieldT>>> columns;
+            for (size_t k = 0; k < r; ++k) columns.push_back(std::make_shared<std::vector<FieldT>>(seeded<FieldT>(seed + k, n)));
+            g_salt_seed = seed + 100; g_salt_pos = 0;
+            tree.construct_with_leaves_serialized_by_cosets(columns, c);
+            const binary_hash_digest root = tree.get_root();
+            std::string hexroot;
+            static const char *hx = "0123456789abcdef";
+            for (unsigned char ch : root) { hexroot.push_back(hx[ch >> 4]); hexroot.push_back(hx[ch & 15]); }
+            printf("{\"case\": \"merkle_root_zk\", \"field\": \"%s\", \"log_n\": %zu, \"oracles\": %zu, \"coset_size\": %zu, \"salt_bytes\": 32, \"seed\": %llu, \"digest\": \"%s\"}\n", field, log_n, r, c,
+                   (unsigned long long)seed, hexroot.c_str());
+            seed += 8;
+        }
     for (size_t work : { (size_t)4, (size_t)9, (size_t)14 }) {
         const pow_parameters params(work, 1);
         const libiop::pow<FieldT, binary_hash_digest> grinder(params, 32);

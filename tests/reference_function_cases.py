@@ -134,6 +134,17 @@ def compute(e, lib=None):
         if lib:
             return lib.merkle_tree(cols, e["coset_size"], libiop_amd.DOMAIN_ADDITIVE if additive else libiop_amd.DOMAIN_MULTIPLICATIVE)[0]
         return oracle.merkle_build(cols, e["coset_size"], additive=additive)[0]
+    if case == "merkle_root_zk":
+        additive = e["field"] == "gf192"
+        gen = _gf if additive else _fp
+        n, cs = 1 << e["log_n"], e["coset_size"]
+        cols = [gen(seed + k, n) for k in range(e["oracles"])]
+        leaves = n // cs
+        words = r1cs._splitmix64(seed + 100, np.arange(leaves * e["salt_bytes"] // 8, dtype=np.uint64))       # the interposed randombytes_buf of reference_vectors.cpp
+        salts = np.frombuffer(words.astype("<u8").tobytes(), dtype=np.uint8).reshape(leaves, e["salt_bytes"])
+        if lib:
+            return lib.merkle_tree(cols, cs, libiop_amd.DOMAIN_ADDITIVE if additive else libiop_amd.DOMAIN_MULTIPLICATIVE, salts=salts)[0]
+        return oracle.merkle_build(cols, cs, additive=additive, salts=salts)[0]
     if case == "pow":
         challenge = _gf(seed, 2).tobytes()[:32]
         answer = lib.solve_pow(challenge, e["bitlen"]) if lib else oracle.pow_solve_blake2b(challenge, e["bitlen"])[0]
@@ -143,5 +154,5 @@ def compute(e, lib=None):
 
 def check(e, lib=None):
     out = compute(e, lib)
-    got = bytes(np.ascontiguousarray(out).tobytes()).hex() if e["case"] == "merkle_root" else _digest(out)
+    got = bytes(np.ascontiguousarray(out).tobytes()).hex() if e["case"].startswith("merkle_root") else _digest(out)
     assert got == e["digest"], (ident(e), "differs from what libiop's own function produced")
