@@ -10,6 +10,7 @@
 #include <sodium.h>
 #include <libff/algebra/fields/binary/gf192.hpp>
 #include <libff/algebra/curves/edwards/edwards_pp.hpp>
+#include <libff/algebra/curves/alt_bn128/alt_bn128_pp.hpp>
 #include "libiop/algebra/fft.hpp"
 #include "libiop/protocols/ldt/fri/fri_aux.hpp"
 #include "libiop/protocols/ldt/ldt_reducer_aux.hpp"
@@ -217,12 +218,54 @@ static void tree_and_pow_cases(const char *field, uint64_t seed)
     }
 }
 
+// ---- alt_bn128_Fr with the algebraic hashes (Poseidon, hash_enum.tcc:73-165): trees whose leaves, nodes and root are field elements, and the grind over them.
+// Elements: four SplitMix64 words of the stream, reduced mod r, Montgomery form (R = 2^256); the root / answer are printed as their 32 Montgomery bytes.
+static std::string hex32(const libff::alt_bn128_Fr &x)
+{
+    static const char *hx = "0123456789abcdef";
+    std::string out;
+    const unsigned char *b = (const unsigned char *)x.mont_repr.data;
+    for (int i = 0; i < 32; ++i) { out.push_back(hx[b[i] >> 4]); out.push_back(hx[b[i] & 15]); }
+    return out;
+}
+static void poseidon_cases()
+{
+    typedef libff::alt_bn128_Fr F;
+    uint64_t seed = 0x5500;
+    for (int which = 0; which < 2; ++which) {
+        const bcs_hash_type hash_enum = which ? high_alpha_poseidon_type : starkware_poseidon_type;
+        const char *set = which ? "high_alpha17_t3" : "starkware_alpha5_t3";
+        for (size_t r : { (size_t)1, (size_t)3 })
+            for (size_t c : { (size_t)1, (size_t)2, (size_t)4 }) {
+                const size_t log_n = 6, n = (size_t)1 << log_n, L = n / c;
+                merkle_tree<F, F> tree(L, get_leafhash<F, F>(hash_enum, 128, r * c), get_two_to_one_hash<F, F>(hash_enum, 128), 32, false, 128);
+                std::vector<std::shared_ptr<std::vector<F>>> columns;
+                for (size_t k = 0; k < r; ++k) columns.push_back(std::make_shared<std::vector<F>>(seeded<F>(seed + k, n)));
+                tree.construct_with_leaves_serialized_by_cosets(columns, c);
+                printf("{\"case\": \"poseidon_merkle_root\", \"set\": \"%s\", \"log_n\": %zu, \"oracles\": %zu, \"coset_size\": %zu, \"seed\": %llu, \"digest\": \"%s\"}\n", set, log_n, r, c,
+                       (unsigned long long)seed, hex32(tree.get_root()).c_str());
+                seed += 8;
+            }
+        for (size_t work : { (size_t)3, (size_t)8 }) {
+            const pow_parameters params(work, 1);
+            const libiop::pow<F, F> grinder(params, 32);
+            const F challenge = seeded<F>(seed, 1)[0];
+            const F answer = grinder.solve_pow(get_two_to_one_hash<F, F>(hash_enum, 128), challenge);
+            printf("{\"case\": \"poseidon_pow\", \"set\": \"%s\", \"work_parameter\": %zu, \"bitlen\": %zu, \"seed\": %llu, \"digest\": \"%s\"}\n", set, work, params.pow_bitlen(),
+                   (unsigned long long)seed, hex32(answer).c_str());
+            ++seed;
+        }
+    }
+}
+
 int main()
 {
     libff::edwards_pp::init_public_params();
+    libff::alt_bn128_pp::init_public_params();
     additive_cases();
     multiplicative_cases();
     tree_and_pow_cases<libff::gf192>("gf192", 0x5300);
     tree_and_pow_cases<libff::edwards_Fr>("edwards_Fr", 0x5400);
+    poseidon_cases();
     return 0;
 }

@@ -25,7 +25,7 @@ def entries(cases=None):
 
 
 def ident(e):
-    return "-".join(str(e[k]) for k in ("case", "field", "m", "log_n", "kind", "ncoeffs", "degree", "oracles", "coset_size", "x_in_domain", "work_parameter") if k in e)
+    return "-".join(str(e[k]) for k in ("case", "field", "set", "m", "log_n", "kind", "ncoeffs", "degree", "oracles", "coset_size", "x_in_domain", "work_parameter") if k in e)
 
 
 def _digest(a):
@@ -145,6 +145,23 @@ def compute(e, lib=None):
         if lib:
             return lib.merkle_tree(cols, cs, libiop_amd.DOMAIN_ADDITIVE if additive else libiop_amd.DOMAIN_MULTIPLICATIVE, salts=salts)[0]
         return oracle.merkle_build(cols, cs, additive=additive, salts=salts)[0]
+    if case.startswith("poseidon"):
+        import json as _json
+        with open(os.path.join(ROOT, "libiop_amd", "data", "poseidon_alt_bn128.json")) as f:
+            d = _json.load(f)["sets"][e["set"]]
+        params = libiop_amd.PoseidonParams.from_dict(d) if lib else oracle.PoseidonParams(d)
+
+        def bn(sd, count):                  # four stream words per element, reduced mod r, Montgomery form
+            w = r1cs._splitmix64(sd, np.arange(4 * count, dtype=np.uint64)).reshape(count, 4)
+            return oracle.bn_from_ints([(int(a) | (int(b) << 64) | (int(c) << 128) | (int(dd) << 192)) % oracle.BN128_R for a, b, c, dd in w])
+        if case == "poseidon_merkle_root":
+            cols = [bn(seed + k, 1 << e["log_n"]) for k in range(e["oracles"])]
+            if lib:
+                return lib.merkle_tree_poseidon(params, cols, e["coset_size"], libiop_amd.DOMAIN_MULTIPLICATIVE, None)[0]
+            return oracle.poseidon_merkle(params, cols, e["coset_size"], False, None)[0]
+        if case == "poseidon_pow":
+            challenge = bn(seed, 1)[0]
+            return lib.solve_pow(challenge, e["bitlen"], params) if lib else oracle.pow_solve_poseidon(params, challenge, e["bitlen"])[0]
     if case == "pow":
         challenge = _gf(seed, 2).tobytes()[:32]
         answer = lib.solve_pow(challenge, e["bitlen"]) if lib else oracle.pow_solve_blake2b(challenge, e["bitlen"])[0]
@@ -154,5 +171,5 @@ def compute(e, lib=None):
 
 def check(e, lib=None):
     out = compute(e, lib)
-    got = bytes(np.ascontiguousarray(out).tobytes()).hex() if e["case"].startswith("merkle_root") else _digest(out)
+    got = bytes(np.ascontiguousarray(out).tobytes()).hex() if (e["case"].startswith("merkle_root") or e["case"].startswith("poseidon")) else _digest(out)
     assert got == e["digest"], (ident(e), "differs from what libiop's own function produced")
