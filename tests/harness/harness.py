@@ -57,8 +57,8 @@ def digest(b):
     return hashlib.blake2b(b, digest_size=32).hexdigest()
 
 
-# libiop's own test files run as programs (tests/harness/Makefile REFTESTS); the default subset keeps the CPU suite short, IOPX_REFTESTS=all runs the 34
-REFTESTS_DEFAULT = ["algebra/test_fft", "protocols/test_fri_aux", "protocols/test_aurora_protocol", "protocols/test_direct_ldt", "bcs/test_merkle_tree"]
+# libiop's own test files run as programs (tests/harness/Makefile REFTESTS); the default subset (three programs, seconds each) keeps the CPU suite short, IOPX_REFTESTS=all runs the 34
+REFTESTS_DEFAULT = ["protocols/test_fri_aux", "protocols/test_aurora_protocol", "protocols/test_direct_ldt"]
 
 
 def reftests():
