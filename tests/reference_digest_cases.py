@@ -11,9 +11,11 @@ CODES = {"gf192": oracle.FIELD_GF192, "edwards_Fr": oracle.FIELD_EDWARDS}
 NAMES = {"gf192": "gf192", "edwards_Fr": "edwards_Fr"}
 
 
-def entries():
+def entries(large_up_to=0):
+    """The small cases (2^6 - 2^12), plus the "large_entries" up to 2^large_up_to (2^14: about 25 s of the oracle prover)."""
     with open(os.path.join(ROOT, "tests", "golden", "reference_over_shim.json")) as f:
-        return json.load(f)["entries"]
+        doc = json.load(f)
+    return doc["entries"] + [e for e in doc["large_entries"] if e["log_n"] <= large_up_to]
 
 
 def ident(e):

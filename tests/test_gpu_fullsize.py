@@ -258,17 +258,39 @@ def test_fri_snark_cfg3_full_size_accepted_by_the_oracle_verifier(env):
     assert not oracle.fri_snark_verify(*args, t.serialize())
 
 
-def test_aurora_2p14_transcript_byte_equal_to_the_oracle_prover(env):
-    """the largest byte-equal case (the oracle prover needs about a minute for it on one host core)."""
+def _reference_own_entry(protocol, field, log_n):
+    import reference_digest_cases as rc
+    import json
+    import os
+    with open(os.path.join(rc.ROOT, "tests", "golden", "reference_over_shim.json")) as f:
+        doc = json.load(f)
+    return next(e for e in doc["large_entries"] + doc["entries"] if (e["protocol"], e["field"], e["log_n"]) == (protocol, field, log_n))
+
+
+def test_aurora_2p14_transcript_byte_equal_to_the_references_own_prover(env):
+    """the largest case whose verifier run stays in the suite.  The Python device prover's transcript against the digest of what libiop's OWN
+    prover produced for the instance (tests/golden/reference_over_shim.json, 49 s of one core in the build container; until round 6 the oracle prover was run here
+    instead: 25 s of this test), and the oracle's verifier accepts it."""
+    import hashlib
     import aurora_cases
     lib, torch, dev, _, _ = env
-    aurora_cases.check_transcript_equals_oracle(lib, torch, dev, "gf192", 14, 15, 0x2204)
+    e = _reference_own_entry("aurora", "gf192", 14)
+    transcript, _, _ = aurora_cases.device_prove(lib, torch, dev, "gf192", 14, 15, 0x2204, 5, 2)
+    mine = transcript.serialize()
+    assert len(mine) == e["transcript_bytes"] and hashlib.blake2b(mine, digest_size=32).hexdigest() == e["transcript_blake2b"]
+    assert oracle.aurora_verify(oracle.FIELD_GF192, 14, 15, 0x2204, mine, rs_extra=5, localization=2)
 
 
-def test_fractal_2p14_transcript_byte_equal_to_the_oracle_prover(env):
+def test_fractal_2p14_transcript_byte_equal_to_the_references_own_prover(env):
+    import hashlib
     import fractal_cases
     lib, torch, dev, _, _ = env
-    fractal_cases.check_transcript_equals_oracle(lib, torch, dev, "edwards_Fr", 14, 0, 0x2205)
+    e = _reference_own_entry("fractal", "edwards_Fr", 14)
+    transcript, (roots, messages), _, _, _ = fractal_cases.device_index_and_prove(lib, torch, dev, "edwards_Fr", 14, 0, 0x2205, 3, 2)
+    assert messages == [] and [bytes(r).hex() for r in roots] == e["index_roots"]
+    mine = transcript.serialize()
+    assert len(mine) == e["transcript_bytes"] and hashlib.blake2b(mine, digest_size=32).hexdigest() == e["transcript_blake2b"]
+    assert oracle.fractal_verify(oracle.FIELD_EDWARDS, 14, 0, 0x2205, mine, [bytes(r) for r in roots], rs_extra=3, localization=2)
 
 
 def test_cpp_prover_transcripts_equal_the_python_provers_at_2p20(env):

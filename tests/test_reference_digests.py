@@ -6,7 +6,7 @@ import emu_lib
 import reference_digest_cases as rc
 
 
-@pytest.mark.parametrize("e", rc.entries(), ids=rc.ident)
+@pytest.mark.parametrize("e", rc.entries(large_up_to=14), ids=rc.ident)
 def test_oracle_equals_the_references_own_prover(e):
     rc.check_oracle(e)
 
@@ -30,6 +30,8 @@ def test_the_references_own_prover_at_baseline_sizes_equals_the_oracle_goldens()
         fractal = json.load(f)["digests"]
     for (protocol, field, log_n), e in large.items():
         assert e["reference_verifier_accepts"]
+        if log_n < 16:
+            continue                        # 2^14: the oracle prover itself is run against it above
         gold = (aurora if protocol == "aurora" else fractal)[str(log_n)]
         assert e["transcript_blake2b"] == gold["transcript_blake2b"], (protocol, log_n)
         if protocol == "fractal":
