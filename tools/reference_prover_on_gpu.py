@@ -31,15 +31,18 @@ def expected():
 
 def main():
     want = expected()
-    cases = [("aurora", "gf192", 12, 15, 0x2204, 5), ("aurora", "gf192", 14, 15, 0x2204, 5), ("aurora", "gf192", 16, 15, 0x2204, 5),
-             ("aurora", "edwards_Fr", 12, 15, 0x2204, 5), ("fractal", "gf192", 10, 15, 0x2205, 3), ("fractal", "edwards_Fr", 16, 0, 0x2205, 3),
-             ("ligero", "gf192", 10, 15, 0x2206, 2)]
+    if "--headline" in sys.argv:            # BASELINE's headline instance through the reference's own prover: minutes of the reference's host code around the kernels
+        cases = [("aurora", "gf192", 18, 15, 0x2204, 5), ("aurora", "gf192", 20, 15, 0x2204, 5)]
+    else:
+        cases = [("aurora", "gf192", 12, 15, 0x2204, 5), ("aurora", "gf192", 14, 15, 0x2204, 5), ("aurora", "gf192", 16, 15, 0x2204, 5),
+                 ("aurora", "edwards_Fr", 12, 15, 0x2204, 5), ("fractal", "gf192", 10, 15, 0x2205, 3), ("fractal", "edwards_Fr", 16, 0, 0x2205, 3),
+                 ("ligero", "gf192", 10, 15, 0x2206, 2)]
     ok = True
     for proto, field, log_n, k, seed, rs in cases:
         with tempfile.TemporaryDirectory() as d:
             out = os.path.join(d, "t.bin")
             t = time.time()
-            r = subprocess.run([EXE, proto, field, str(log_n), str(k), hex(seed), str(rs), "2", out], capture_output=True, text=True, timeout=3000)
+            r = subprocess.run([EXE, proto, field, str(log_n), str(k), hex(seed), str(rs), "2", out], capture_output=True, text=True, timeout=5000)
             dt = time.time() - t
             if r.returncode not in (0, 1):
                 print(json.dumps({"case": [proto, field, log_n], "error": r.stderr[-400:]}))
