@@ -17,6 +17,10 @@
 #ifdef HARNESS_STUBS
 #include "libiop/bcs/pow.hpp"
 #include "libiop/protocols/ldt/ldt_reducer_aux.hpp"
+#include "libiop/protocols/encoded/common/rowcheck.hpp"
+#include "libiop/protocols/encoded/r1cs_rs_iop/r1cs_rs_iop.hpp"
+#include "libiop/protocols/encoded/sumcheck/sumcheck.hpp"
+#include "libiop/protocols/encoded/lincheck/basic_lincheck_aux.hpp"
 #include "stubs.inc"                    // the stub definitions of INTEGRATION.md, verbatim (tests/harness/make_shadow.py)
 #endif
 

@@ -8,4 +8,8 @@
 #include "libiop/protocols/ldt/ldt_reducer_aux.hpp"
 #include "libiop/bcs/merkle_tree.hpp"
 #include "libiop/bcs/pow.hpp"
+#include "libiop/protocols/encoded/common/rowcheck.hpp"
+#include "libiop/protocols/encoded/r1cs_rs_iop/r1cs_rs_iop.hpp"
+#include "libiop/protocols/encoded/sumcheck/sumcheck.hpp"
+#include "libiop/protocols/encoded/lincheck/basic_lincheck_aux.hpp"
 #include "stubs.inc"

@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "harness", "_hip", "reference_stubbed_hip")
 
-EXPECTED_KERNELS = {("aurora", "gf192"): ("k_bfly_edge_fwd", "k_fri_fold_fused_eta2", "k_ldt_combine_add_slots", "k_merkle_level", "k_pow_blake2b"),
-                    ("aurora", "edwards_Fr"): ("k_mfft_pass", "k_fri_fold_fused_mul_eta2", "k_ldt_combine_fp", "k_merkle_level", "k_pow_blake2b"),
+EXPECTED_KERNELS = {("aurora", "gf192"): ("k_bfly_edge_fwd", "k_rowcheck_add", "k_fz_add", "k_lincheck_add", "k_sumcheck_g_add_zero_sum", "k_fri_fold_fused_eta2", "k_ldt_combine_add_slots", "k_merkle_level", "k_pow_blake2b"),
+                    ("aurora", "edwards_Fr"): ("k_mfft_pass", "k_rowcheck_fp", "k_fz_fp", "k_lincheck_fp", "k_sumcheck_g_fp", "k_fri_fold_fused_mul_eta2", "k_ldt_combine_fp", "k_merkle_level", "k_pow_blake2b"),
                     ("fractal", "gf192"): ("k_bfly_edge_fwd", "k_ldt_combine_add_slots", "k_merkle_level", "k_pow_blake2b"),
                     ("fractal", "edwards_Fr"): ("k_mfft_pass", "k_ldt_combine_fp", "k_merkle_level", "k_pow_blake2b")}
 

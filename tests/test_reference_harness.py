@@ -53,8 +53,8 @@ def test_the_references_own_prover_over_the_shim_equals_the_oracle(case, built):
 
 
 EXPECTED_KERNELS = {
-    ("aurora", "gf192"): ("k_phase1_fwd", "k_phase1_inv", "k_fri_fold_fused_eta2", "k_ldt_combine_add_slots", "k_merkle_leaves_4x2", "k_merkle_level", "k_pow_blake2b"),
-    ("aurora", "edwards_Fr"): ("k_mfft_pass", "k_fri_fold_fused_mul_eta2", "k_ldt_combine_fp", "k_merkle_leaves_4x2", "k_merkle_level", "k_pow_blake2b"),
+    ("aurora", "gf192"): ("k_phase1_fwd", "k_phase1_inv", "k_rowcheck_add", "k_fz_add", "k_lincheck_add", "k_sumcheck_g_add_zero_sum", "k_fri_fold_fused_eta2", "k_ldt_combine_add_slots", "k_merkle_leaves_4x2", "k_merkle_level", "k_pow_blake2b"),
+    ("aurora", "edwards_Fr"): ("k_mfft_pass", "k_rowcheck_fp", "k_fz_fp", "k_lincheck_fp", "k_sumcheck_g_fp", "k_fri_fold_fused_mul_eta2", "k_ldt_combine_fp", "k_merkle_leaves_4x2", "k_merkle_level", "k_pow_blake2b"),
     ("fractal", "gf192"): ("k_phase1_fwd", "k_phase1_inv", "k_ldt_combine_add_slots", "k_merkle_level", "k_pow_blake2b"),
     ("fractal", "edwards_Fr"): ("k_mfft_pass", "k_ldt_combine_fp", "k_merkle_level", "k_pow_blake2b"),
 }
