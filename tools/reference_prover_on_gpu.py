@@ -32,11 +32,13 @@ def expected():
 def main():
     want = expected()
     if "--headline" in sys.argv:            # BASELINE's headline instance through the reference's own prover: minutes of the reference's host code around the kernels
-        cases = [("aurora", "gf192", 18, 15, 0x2204, 5), ("aurora", "gf192", 20, 15, 0x2204, 5)]
+        cases = [("aurora", "gf192", 18, 15, 0x2204, 5), ("aurora", "gf192", 20, 15, 0x2204, 5), ("fractal", "edwards_Fr", 20, 0, 0x2205, 3)]
     else:
         cases = [("aurora", "gf192", 12, 15, 0x2204, 5), ("aurora", "gf192", 14, 15, 0x2204, 5), ("aurora", "gf192", 16, 15, 0x2204, 5),
                  ("aurora", "edwards_Fr", 12, 15, 0x2204, 5), ("fractal", "gf192", 10, 15, 0x2205, 3), ("fractal", "edwards_Fr", 16, 0, 0x2205, 3),
                  ("ligero", "gf192", 10, 15, 0x2206, 2)]
+    if "--fractal-only" in sys.argv:
+        cases = [c for c in cases if c[0] == "fractal"]
     ok = True
     for proto, field, log_n, k, seed, rs in cases:
         with tempfile.TemporaryDirectory() as d:
