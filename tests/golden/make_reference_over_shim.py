@@ -40,7 +40,7 @@ def main():
 def functions():
     """tests/golden/reference_functions.json: tests/harness/reference_vectors.cpp's lines (the reference's own functions on seeded inputs)."""
     import subprocess
-    subprocess.check_call(["make", "-s", "-j4", "-C", harness.HERE, "_build/reference_vectors"])
+    harness._make(["_build/reference_vectors"])
     out = subprocess.run([os.path.join(harness.HERE, "_build", "reference_vectors")], capture_output=True, text=True, check=True).stdout
     entries = [json.loads(line) for line in out.splitlines() if line.startswith("{")]
     with open(os.path.join(ROOT, "tests", "golden", "reference_functions.json"), "w") as f:

@@ -34,9 +34,17 @@ def available():
     return None
 
 
+def _make(targets):
+    """xdist workers start together: one make at a time in this directory"""
+    import fcntl
+    os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+    with open(os.path.join(HERE, "_build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-s", "-j4", "-C", HERE] + list(targets))
+
+
 def build(stubbed=True):
-    targets = ["_build/reference_plain"] + (["_build/reference_stubbed"] if stubbed else [])
-    subprocess.check_call(["make", "-s", "-j4", "-C", HERE] + targets)
+    _make(["_build/reference_plain"] + (["_build/reference_stubbed"] if stubbed else []))
 
 
 def run(variant, protocol, field, log_n, num_inputs, seed, rs_extra, localization=2):
@@ -71,7 +79,7 @@ def reftests():
 
 
 def build_reftest(name, variant="stubbed"):
-    subprocess.check_call(["make", "-s", "-C", HERE, "_build/reftests/%s/%s" % (variant, name)])
+    _make(["_build/reftests/%s/%s" % (variant, name)])
 
 
 def run_reftest(name, variant="stubbed"):

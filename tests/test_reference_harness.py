@@ -115,7 +115,7 @@ def test_the_committed_function_vectors_are_what_the_references_functions_produc
     """tests/golden/reference_functions.json == the lines tests/harness/reference_vectors.cpp prints today (libiop's own FFTs, folds, trees, ... on the seeds)."""
     import json
     import subprocess
-    subprocess.check_call(["make", "-s", "-j4", "-C", harness.HERE, "_build/reference_vectors"])
+    harness._make(["_build/reference_vectors"])
     out = subprocess.run([os.path.join(harness.HERE, "_build", "reference_vectors")], capture_output=True, text=True, check=True).stdout
     now = [json.loads(line) for line in out.splitlines() if line.startswith("{")]
     with open(os.path.join(harness.ROOT, "tests", "golden", "reference_functions.json")) as f:
