@@ -17,6 +17,7 @@
 #include "libiop/bcs/merkle_tree.hpp"
 #include "libiop/bcs/hashing/hash_enum.hpp"
 #include "libiop/bcs/pow.hpp"
+#include "libiop/bcs/hashing/blake2b.hpp"
 
 using namespace libiop;
 
@@ -258,6 +259,30 @@ static void poseidon_cases()
     }
 }
 
+// ---- the BLAKE2b hashchain (blake2b.tcc:10-110): a fixed script of absorbs and squeezes — field elements (for edwards_Fr with the rejection sampling of :187-257),
+// query positions, a root-type squeeze — the outputs concatenated and hashed.  (absorb ignores its input, quirk F8: the script absorbs all the same.)
+template<typename FieldT>
+static void hashchain_case(const char *field, uint64_t seed)
+{
+    blake2b_hashchain<FieldT, binary_hash_digest> chain(128);
+    std::vector<unsigned char> out;
+    auto put = [&](const void *p, size_t n) { out.insert(out.end(), (const unsigned char *)p, (const unsigned char *)p + n); };
+    auto elems = [&](const std::vector<FieldT> &v) { put(v.data(), v.size() * sizeof(FieldT)); };
+    auto positions = [&](const std::vector<size_t> &v) { for (size_t p : v) { const uint64_t w = p; put(&w, 8); } };
+    elems(chain.squeeze(3));
+    const std::vector<libff::gf192> words = seeded<libff::gf192>(seed, 2);
+    chain.absorb(binary_hash_digest((const char *)words.data(), 32));
+    elems(chain.squeeze(1));
+    elems(chain.squeeze(40));                       // enough draws for the prime field's rejection sampling to retry
+    chain.absorb(seeded<FieldT>(seed + 1, 5));
+    positions(chain.squeeze_query_positions(6, (size_t)1 << 12));
+    const binary_hash_digest r = chain.squeeze_root_type();
+    put(r.data(), r.size());
+    positions(chain.squeeze_query_positions(3, (size_t)1 << 25));
+    elems(chain.squeeze(2));
+    printf("{\"case\": \"hashchain\", \"field\": \"%s\", \"seed\": %llu, \"digest\": \"%s\"}\n", field, (unsigned long long)seed, digest(out.data(), out.size()).c_str());
+}
+
 int main()
 {
     libff::edwards_pp::init_public_params();
@@ -267,5 +292,7 @@ int main()
     tree_and_pow_cases<libff::gf192>("gf192", 0x5300);
     tree_and_pow_cases<libff::edwards_Fr>("edwards_Fr", 0x5400);
     poseidon_cases();
+    hashchain_case<libff::gf192>("gf192", 0x5600);
+    hashchain_case<libff::edwards_Fr>("edwards_Fr", 0x5610);
     return 0;
 }
