@@ -82,9 +82,15 @@ def build_reftest(name, variant="stubbed"):
     _make(["_build/reftests/%s/%s" % (variant, name)])
 
 
+# the two tests that feed raw random bytes as edwards_Fr elements (tests/harness/run_reftests.py FILTER)
+REFTEST_FILTER = {"protocols/test_ligero_interleaved_lincheck_et": "--gtest_filter=-InterleavedLincheckETTrueMultiplicativeTest.*",
+                  "protocols/test_ligero_interleaved_lincheck_ot": "--gtest_filter=-InterleavedLincheckOTTrueMultiplicativeTest.*"}
+
+
 def run_reftest(name, variant="stubbed"):
     """-> (tests run, tests passed, {kernel: launches}, tail of the output)"""
-    r = subprocess.run([os.path.join(HERE, "_build", "reftests", variant, name)], capture_output=True, text=True, timeout=1800)
+    r = subprocess.run([os.path.join(HERE, "_build", "reftests", variant, name)] + ([REFTEST_FILTER[name]] if name in REFTEST_FILTER and variant != "plain" else []),
+                       capture_output=True, text=True, timeout=1800)
     lines = r.stdout.splitlines()
     ran = sum(1 for l in lines if l.startswith("[ RUN "))
     ok = sum(1 for l in lines if l.startswith("[       OK ]"))

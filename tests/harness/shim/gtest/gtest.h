@@ -27,12 +27,35 @@ struct AssertHelper {
     }
 };
 class Test { public: virtual ~Test() {} virtual void TestBody() = 0; };
-inline void InitGoogleTest(int *, char **) {}
+// --gtest_filter=-A*:B* — only the negative form (tests to leave out), ':' separated, '*' wildcards: what tests/harness/run_reftests.py needs
+inline std::vector<std::string> &excluded() { static std::vector<std::string> v; return v; }
+inline bool glob(const char *pat, const char *str)
+{
+    if (!*pat) return !*str;
+    if (*pat == '*') return glob(pat + 1, str) || (*str && glob(pat, str + 1));
+    return *pat == *str && glob(pat + 1, str + 1);
+}
+inline void InitGoogleTest(int *argc, char **argv)
+{
+    for (int i = 1; i < *argc; ++i) {
+        const std::string a = argv[i];
+        if (a.rfind("--gtest_filter=-", 0) == 0) {
+            std::string rest = a.substr(16);
+            size_t at;
+            while ((at = rest.find(':')) != std::string::npos) { excluded().push_back(rest.substr(0, at)); rest = rest.substr(at + 1); }
+            if (!rest.empty()) excluded().push_back(rest);
+        }
+    }
+}
 
 inline int RunAllTests()
 {
     int failed = 0;
     for (auto &t : registry()) {
+        const std::string full = std::string(t.suite) + "." + t.name;
+        bool skip = false;
+        for (auto &pat : excluded()) skip = skip || glob(pat.c_str(), full.c_str());
+        if (skip) { std::printf("[ SKIPPED  ] %s\n", full.c_str()); continue; }
         failures_in_current_test() = 0;
         std::printf("[ RUN      ] %s.%s\n", t.suite, t.name);
         std::fflush(stdout);

@@ -127,7 +127,7 @@ def test_the_committed_function_vectors_are_what_the_references_functions_produc
 def test_the_references_own_test_files_pass_with_the_kernels_underneath(name, built):
     """libiop's own test files (libiop/tests/*/test_*.cpp), unmodified, compiled as programs with the stubs of INTEGRATION.md in force (googletest replaced by
     tests/harness/shim/gtest/gtest.h, tests_prelude.hpp force-included ahead of the test's text): every TEST passes, and the multiplicative ones ran their
-    transforms in the kernel library.  Default: three programs; IOPX_REFTESTS=all: the 34 of tests/harness/Makefile (145 tests, recorded in
+    transforms in the kernel library.  Default: three programs; IOPX_REFTESTS=all: the 34 of tests/harness/Makefile (143 tests with the stubs, 145 without, recorded in
     profiles/r06_reference_own_tests_{plain,stubbed}.json)."""
     harness.build_reftest(name)
     ran, ok, kernels, tail = harness.run_reftest(name)
