@@ -13,7 +13,15 @@ for exe in sorted(glob.glob(os.path.join(base, "*", "*"))):
     name = os.path.relpath(exe, base)
     t = time.time()
     try:
+        # Some of libiop's negative tests pick WHAT to corrupt with std::rand() (e.g. test_holographic_lincheck.cpp:321) and pass only if the pick matters; the
+        # process's rand() sequence is fixed on the CPU builds (0 failures in 200 runs) but the HIP runtime's start-up draws from it, so on the GPU box about one
+        # run in thirty of such a program fails — the additive (gf64) case, which no kernel serves, as often as the others.  A failing program is run again (twice
+        # at most) and the count recorded.
+        attempts = 1
         r = subprocess.run([exe] + ([FILTER[name]] if name in FILTER and variant != "plain" else []), capture_output=True, text=True, timeout=float(os.environ.get("REFTEST_TIMEOUT", "1500")))
+        while r.returncode == 1 and variant == "hip" and attempts < 3:
+            attempts += 1
+            r = subprocess.run([exe] + ([FILTER[name]] if name in FILTER else []), capture_output=True, text=True, timeout=float(os.environ.get("REFTEST_TIMEOUT", "1500")))
         lines = r.stdout.splitlines()
         ran = [l for l in lines if l.startswith("[ RUN ")]
         skipped = [l.split("]")[1].strip() for l in lines if l.startswith("[ SKIPPED  ]")]
@@ -26,6 +34,7 @@ for exe in sorted(glob.glob(os.path.join(base, "*", "*"))):
                 if len(parts) >= 2 and parts[0].startswith("k_"): kernels[parts[0]] = int(parts[1])
         out[name] = {"rc": r.returncode, "tests": len(ran), "passed": len(ok), "failed": failed, "seconds": round(time.time() - t, 1), "kernel_launches": kernels}
         if skipped: out[name]["left_out"] = skipped
+        if attempts > 1: out[name]["attempts"] = attempts
         if r.returncode not in (0, 1): out[name]["stderr"] = r.stderr[-300:]
     except subprocess.TimeoutExpired:
         out[name] = {"rc": "timeout", "seconds": round(time.time() - t, 1)}
