@@ -607,3 +607,8 @@ def test_membership_proofs_validate_with_hashlib_only(gpu):
     leaves, validated by a pure-Python verifier over hashlib (tests/test_independent_pins.py) — no oracle code involved."""
     import test_independent_pins as pins
     pins.check_every_subset_validates(gpu)
+
+
+def test_noncanonical_prime_field_inputs_give_canonical_congruent_outputs(gpu):
+    import noncanonical_cases
+    noncanonical_cases.check(gpu)

@@ -248,3 +248,8 @@ def test_half_wavefront_product_under_a_divergent_branch():
     where the branch around the product is taken (the EXEC part of the story is the GPU test's: tests/test_gpu_parity.py)."""
     import halves_cases
     halves_cases.check(emu(), None, count_active=False)
+
+
+def test_noncanonical_prime_field_inputs_give_canonical_congruent_outputs():
+    import noncanonical_cases
+    noncanonical_cases.check(emu())
