@@ -20,7 +20,7 @@ CONDA = "/opt/conda"
 # k = 15; instrument_fractal_snark.cpp:93-110: 3, k = 15 over subspaces and 0 over cosets), localization parameter 2
 CASES = [("aurora", "gf192", 6, 15, 0x2204, 5), ("aurora", "gf192", 8, 15, 0x2204, 5), ("aurora", "gf192", 10, 15, 0x2204, 5), ("aurora", "gf192", 12, 15, 0x2204, 5),
          ("aurora", "edwards_Fr", 8, 15, 0x2204, 5), ("aurora", "edwards_Fr", 10, 15, 0x2204, 5), ("aurora", "edwards_Fr", 12, 15, 0x2204, 5),
-         ("fractal", "gf192", 7, 15, 0x2205, 3), ("fractal", "gf192", 10, 15, 0x2205, 3),
+         ("fractal", "gf192", 7, 15, 0x2205, 3), ("fractal", "gf192", 9, 15, 0x2205, 3),
          ("fractal", "edwards_Fr", 8, 0, 0x2205, 3), ("fractal", "edwards_Fr", 11, 0, 0x2205, 3)]
 
 
